@@ -1,0 +1,183 @@
+"""Deterministic synthetic inputs for the hyperedge-classifier path (numpy only).
+
+Used by bench.py (there is no network for real 4DN data), by the parity tests and by
+tests/golden/make_golden.py, so that golden fixtures only need to store *outputs*: inputs and
+weights are regenerated from a seed with ``np.random.default_rng`` (bit-stable across numpy
+versions).  Layouts follow SURVEY.md §8(d2) / BASELINE.json ``configs``.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List
+
+import numpy as np
+
+# hg38, 1 Mb bins: ceil(size/res)+1 bins per chromosome (reference process.py:23-31), chr1..22 + chrX
+HG38_1MB = [250, 244, 200, 192, 183, 172, 161, 147, 140, 135, 137, 135, 116, 109, 103, 92, 85, 82,
+            60, 66, 48, 52, 158]
+# hg38 chromosome sizes (Mb, rounded up to 0.1) -> 100 kb bins
+_HG38_MB = [248.96, 242.20, 198.30, 190.22, 181.54, 170.81, 159.35, 145.14, 138.40, 133.80, 135.09,
+            133.28, 114.37, 107.05, 101.99, 90.34, 83.26, 80.38, 58.62, 64.45, 46.71, 50.82, 156.05]
+HG38_100KB = [int(np.ceil(mb * 10)) + 1 for mb in _HG38_MB]
+
+LAYOUTS = {
+    "tiny": [16, 16, 16, 16],          # golden-fixture size
+    "c1": [128, 128, 128, 128],        # BASELINE.json configs[0]: 512 bins
+    "hg38_1mb": HG38_1MB,              # configs[1], configs[2]: N = 3067
+    "hg38_100kb": HG38_100KB,          # configs[3]: N ~ 30.4 k
+}
+
+
+def chrom_range(num: List[int]) -> np.ndarray:
+    """[C,2] int64, 1-based [start,end) node ids per chromosome (reference temp_dir/chrom_range.npy)."""
+    b = np.concatenate([[0], np.cumsum(num)])
+    return np.stack([b[:-1] + 1, b[1:] + 1], axis=1).astype(np.int64)
+
+
+def bounds(num: List[int]) -> List[int]:
+    return [0] + [int(v) for v in np.cumsum(num)]
+
+
+def node2chrom(num: List[int]) -> np.ndarray:
+    """int32 [N+1]; entry 0 (pad) = -1."""
+    out = np.full(int(np.sum(num)) + 1, -1, dtype=np.int32)
+    b = bounds(num)
+    for c in range(len(num)):
+        out[b[c] + 1:b[c + 1] + 1] = c
+    return out
+
+
+def make_edges(rng: np.random.Generator, n_nodes: int, k: int, m: int) -> np.ndarray:
+    """m distinct hyperedges of k distinct nodes (ids 1..n_nodes), each row ascending; int64 [m,k]."""
+    seen, rows = set(), []
+    while len(rows) < m:
+        cand = rng.integers(1, n_nodes + 1, size=(2 * (m - len(rows)) + 16, k))
+        cand.sort(axis=1)
+        ok = (np.diff(cand, axis=1) > 0).all(axis=1)
+        for r in cand[ok]:
+            t = tuple(int(v) for v in r)
+            if t not in seen:
+                seen.add(t)
+                rows.append(t)
+                if len(rows) == m:
+                    break
+    return np.asarray(rows, dtype=np.int64)
+
+
+def make_edges_fast(rng: np.random.Generator, n_nodes: int, k: int, m: int) -> np.ndarray:
+    """Vectorised variant for large m (bench sizes): rows ascending and duplicate-free within a row;
+    duplicate rows are removed with np.unique and topped up."""
+    out = np.zeros((0, k), dtype=np.int64)
+    while len(out) < m:
+        cand = rng.integers(1, n_nodes + 1, size=(int(1.3 * (m - len(out))) + 64, k))
+        cand.sort(axis=1)
+        cand = cand[(np.diff(cand, axis=1) > 0).all(axis=1)]
+        out = np.unique(np.concatenate([out, cand]), axis=0)
+    sel = rng.permutation(len(out))[:m]
+    return out[np.sort(sel)]
+
+
+def make_freq(rng: np.random.Generator, m: int) -> np.ndarray:
+    """Occurrence counts as generate_kmers.py would store them: integers U[2,50)."""
+    return rng.integers(2, 50, size=m).astype(np.float32)
+
+
+def make_adjacency(rng: np.random.Generator, num: List[int]):
+    """(intra_adj, inter_adj) float32 [N,N] symmetric contact maps:
+    intra = Gamma(2,1)/(|i-j|+1) inside a chromosome, inter = Gamma(2,0.05) between chromosomes."""
+    n = int(np.sum(num))
+    b = bounds(num)
+    g = rng.gamma(2.0, 1.0, size=(n, n)).astype(np.float32)
+    g = (g + g.T) * 0.5
+    idx = np.arange(n)
+    intra = np.zeros((n, n), dtype=np.float32)
+    inter = (g * 0.05).astype(np.float32)
+    for c in range(len(num)):
+        lo, hi = b[c], b[c + 1]
+        dist = np.abs(idx[lo:hi, None] - idx[None, lo:hi]) + 1
+        intra[lo:hi, lo:hi] = g[lo:hi, lo:hi] / dist
+        inter[lo:hi, lo:hi] = 0.0
+    return intra, inter
+
+
+def _uniform(rng, shape, bound):
+    return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def _ln(rng, d):
+    return (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+
+
+def make_state_dict(rng: np.random.Generator, num: List[int], d: int, mode: str,
+                    attr_table: np.ndarray, n_head: int = 8) -> "OrderedDict[str, np.ndarray]":
+    """Weights for every key of the reference ``Classifier.state_dict()`` (same names, shapes and
+    registration order; scales close to the reference's initialisers, LayerNorm affine made
+    non-trivial so that parity tests exercise it).  mode: 'adj' (MultipleEmbedding) | 'table'."""
+    C = len(num)
+    N = int(np.sum(num))
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def linear(prefix, out_f, in_f, bias=True):
+        sd[prefix + ".weight"] = _uniform(rng, (out_f, in_f), 1.0 / np.sqrt(in_f))
+        if bias:
+            sd[prefix + ".bias"] = _uniform(rng, (out_f,), 1.0 / np.sqrt(in_f))
+
+    def conv(prefix, out_f, in_f):
+        sd[prefix + ".weight"] = _uniform(rng, (out_f, in_f, 1), 1.0 / np.sqrt(in_f))
+        sd[prefix + ".bias"] = _uniform(rng, (out_f,), 1.0 / np.sqrt(in_f))
+
+    def lnorm(prefix, n):
+        sd[prefix + ".weight"], sd[prefix + ".bias"] = _ln(rng, n)
+
+    conv("pff_classifier.PWF_Conv0", 1, d)
+    lnorm("pff_classifier.layer_norm", 1)
+    if mode == "adj":
+        linear("node_embedding.next_w.FF_Linear0", d, d)
+        for i, n in enumerate(num):
+            p = f"node_embedding.Embedding_Linear{i}."
+            sd[p + "tied weight_0"] = _uniform(rng, (d, n), 1.0 / np.sqrt(n))
+            sd[p + "tied bias1"] = _uniform(rng, (d,), 1.0 / np.sqrt(d))
+            sd[p + "tied bias2"] = _uniform(rng, (n,), 1.0 / np.sqrt(d))
+            sd[p + "tied weight_1"] = _uniform(rng, (d, d), 1.0 / np.sqrt(d))
+            linear(f"node_embedding.Embedding_recon{i}.FF_Linear0", n, d)
+    elif mode == "table":
+        w = rng.standard_normal((N + 1, d)).astype(np.float32)
+        w[0] = 0.0                                    # nn.Embedding(padding_idx=0)
+        sd["node_embedding.weight"] = w
+    else:
+        raise ValueError(mode)
+    for enc in ("encode1", "encode2"):
+        a = enc + ".mul_head_attn."
+        std = np.sqrt(2.0 / (d + d))
+        for nm in ("w_qs", "w_ks", "w_vs"):
+            sd[a + nm + ".weight"] = (std * rng.standard_normal((n_head * d, d))).astype(np.float32)
+        linear(a + "fc1", d, n_head * d)
+        linear(a + "fc2", d, n_head * d)
+        for nm in ("layer_norm1", "layer_norm2", "layer_norm3"):
+            lnorm(a + nm, d)
+        for pff in ("pff_n1", "pff_n2"):
+            conv(f"{enc}.{pff}.PWF_Conv0", d, d)
+            conv(f"{enc}.{pff}.PWF_Conv1", d, d)
+            lnorm(f"{enc}.{pff}.layer_norm", d)
+    lnorm("layer_norm1", d)
+    lnorm("layer_norm2", d)
+    linear("next_w.FF_Linear0", d, d)
+    sd["attribute_dict_embedding.weight"] = attr_table.astype(np.float32)
+    linear("attribute_nn", d, C + 1)
+    sd["attribute_dict.weight"] = sd["attribute_dict_embedding.weight"]
+    return sd
+
+
+def make_batch(rng: np.random.Generator, n_nodes: int, ks: List[int], rows_per_k: int, L: int = 0):
+    """A zero-padded mixed-k batch: x int64 [B,L] (rows ascending, 0 = pad), y, w float32 [B,1]."""
+    L = max(L, max(ks))
+    xs = []
+    for k in ks:
+        e = make_edges(rng, n_nodes, k, rows_per_k)
+        xs.append(np.pad(e, ((0, 0), (0, L - k))))
+    x = np.concatenate(xs, axis=0)
+    perm = rng.permutation(len(x))
+    x = x[perm]
+    y = (rng.random((len(x), 1)) < 0.25).astype(np.float32)
+    w = np.where(y > 0, rng.uniform(0.5, 4.0, size=y.shape), 1.0).astype(np.float32)
+    return x, y, w

@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU box).
+Nothing here is imported by the tests; they read the .npz / model2load files this writes.
+
+What it does
+  * puts two dev-only shims in a temp dir on sys.path: a set-backed ``pybloom_live`` stand-in
+    (the package is a third-party dependency of the reference that is not installed and not
+    installable here -- parity at that boundary is UNPINNED) and nothing else;
+  * imports /root/reference/Code/Modules.py unmodified, builds the reference ``Classifier`` in
+    'adj' (MultipleEmbedding) and 'table' (Wrap_Embedding) modes;
+  * loads the deterministic synthetic weights of matcha_amd/synth.py (so fixtures store outputs
+    only), runs eval forwards, dropout-free training steps with torch.optim.AdamW exactly as
+    main.py:630 builds it, and the reference's own save_embeddings / get_attributes /
+    generate_negative (function bodies exec'd out of main.py's AST, because main.py has no
+    __main__ guard and cannot be imported);
+  * writes G1..G5 of SURVEY.md §8(c2) + sampler statistics.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import ast
+import io
+import math
+import os
+import random
+import sys
+import tempfile
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/Code"
+sys.path.insert(0, ROOT)
+from matcha_amd import synth  # noqa: E402
+
+_SHIM = '''
+class BloomFilter:
+    """exact-set stand-in (dev only): same surface the reference uses (utils.py:83-91, main.py:346)"""
+    def __init__(self, capacity, error_rate=1e-3):
+        self.capacity = capacity
+        self._s = set()
+    def add(self, k):
+        self._s.add(k)
+    def __contains__(self, k):
+        return k in self._s
+    def __len__(self):
+        return len(self._s)
+'''
+
+
+def import_reference():
+    shim = tempfile.mkdtemp(prefix="matcha_shim_")
+    with open(os.path.join(shim, "pybloom_live.py"), "w") as f:
+        f.write(_SHIM)
+    sys.path[:0] = [shim, REF]
+    with redirect_stdout(io.StringIO()):
+        import Modules  # noqa
+        import utils  # noqa
+    return Modules, utils
+
+
+def main_functions(names, glb):
+    """exec selected top-level function definitions of main.py (it cannot be imported)."""
+    src = open(os.path.join(REF, "main.py")).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=body, type_ignores=[])
+    exec(compile(mod, os.path.join(REF, "main.py"), "exec"), glb)
+    return glb
+
+
+def build_ref(M, num, d, mode, seed_weights, set_weights=True):
+    rng = np.random.default_rng(seed_weights)
+    cr = synth.chrom_range(num)
+    N = int(np.sum(num))
+    glb = dict(num=num, chrom_list=list(range(len(num))), np=np, print=lambda *a, **k: None)
+    main_functions({"get_attributes"}, glb)
+    attr = glb["get_attributes"]()
+    feats = inter_z = None
+    with redirect_stdout(io.StringIO()), redirect_stderr_null():
+        if mode == "adj":
+            arng = np.random.default_rng(seed_weights + 1000)
+            intra, inter = synth.make_adjacency(arng, num)
+            # main.py:571-577 (script body, restated call-for-call on the reference's numpy)
+            feats = []
+            for v in cr:
+                t = np.corrcoef(intra[v[0] - 1:v[1] - 1, v[0] - 1:v[1] - 1]).astype("float32")
+                t[np.isnan(t)] = 0.0
+                feats.append(t)
+            inter_in = inter.copy()
+            ne = M.MultipleEmbedding(feats, d, False, torch.as_tensor(np.cumsum(num)), cr, inter_in)
+            inter_z = ne.inter_initial.embedding.numpy().copy()
+        else:
+            ne = M.Wrap_Embedding(N + 1, d, padding_idx=0)
+        clf = M.Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True,
+                           bottle_neck=d, attribute_dict=attr)
+    sd = synth.make_state_dict(rng, num, d, mode, attr)
+    if set_weights:
+        missing = clf.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    return clf, attr, feats, inter_z, sd
+
+
+class redirect_stderr_null:
+    def __enter__(self):
+        self._old = sys.stderr
+        sys.stderr = io.StringIO()
+
+    def __exit__(self, *a):
+        sys.stderr = self._old
+
+
+def set_dropout(model, p=None):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout) and p is not None:
+            m.p = p
+
+
+def eval_logits(clf, x, C, seed=7):
+    clf.eval()
+    np.random.seed(seed)
+    with torch.no_grad():
+        out, recon = clf(torch.from_numpy(x), return_recon=True)
+    return out.numpy().copy(), recon.numpy().copy()
+
+
+def predraw_chroms(C, n, seed):
+    np.random.seed(seed)
+    seq = [int(np.random.choice(np.arange(C), 1)[0]) for _ in range(n)]
+    np.random.seed(seed)
+    return seq
+
+
+def g2_eval(M, name, num, d, mode, seed):
+    """G2: eval-mode logits, uniform k, mixed k, and the same rows at L=k vs L=5 (headline fact 7)."""
+    clf, *_ = build_ref(M, num, d, mode, seed)
+    C, N = len(num), int(np.sum(num))
+    out = {}
+    rng = np.random.default_rng(seed + 1)
+    for k in (2, 3, 4, 5):
+        e = synth.make_edges(rng, N, k, 12)
+        out[f"x_k{k}"] = e
+        chrom = predraw_chroms(C, 1, 7)[0]
+        lg, rc = eval_logits(clf, e, C)
+        out[f"logits_k{k}"], out[f"recon_k{k}"], out[f"chrom_k{k}"] = lg, rc, np.int64(chrom)
+        pad = np.pad(e, ((0, 0), (0, 5 - k)))
+        lg5, rc5 = eval_logits(clf, pad, C)
+        out[f"logits_k{k}_L5"], out[f"recon_k{k}_L5"] = lg5, rc5
+    xm, _, _ = synth.make_batch(np.random.default_rng(seed + 2), N, [2, 3, 4, 5], 6)
+    out["x_mixed"] = xm
+    out["chrom_mixed"] = np.int64(predraw_chroms(C, 1, 7)[0])
+    out["logits_mixed"], out["recon_mixed"] = eval_logits(clf, xm, C)
+    np.savez_compressed(os.path.join(HERE, f"g2_{name}.npz"), **out)
+    print("G2", name, {k: v.shape for k, v in out.items() if k.startswith("logits")})
+
+
+def g3_train(M, name, num, d, mode, seed, alpha, beta, tag, n_steps=10, full=True):
+    """G3/G4: dropout-free training steps with the reference model + torch.optim.AdamW (main.py:630)."""
+    clf, attr, feats, inter_z, sd = build_ref(M, num, d, mode, seed)
+    C, N = len(num), int(np.sum(num))
+    set_dropout(clf, 0.0)
+    clf.train()
+    opt = torch.optim.AdamW(list(clf.parameters()), lr=1e-3, amsgrad=False)    # main.py:630
+    glb = dict(num_list=torch.as_tensor(np.cumsum(num)), batch_size=96, device=torch.device("cpu"),
+               np=np, torch=torch, math=math)
+    main_functions({"save_embeddings"}, glb)
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="matcha_gold_")
+    os.makedirs(os.path.join(tmp, "run"))
+    os.chdir(os.path.join(tmp, "run"))
+    try:
+        np.random.seed(99)
+        out["emb_before"] = glb["save_embeddings"](clf, True)                 # G4 (main.py:462-479)
+        clf.train()
+        chroms = predraw_chroms(C, n_steps, 1234)
+        out["chroms"] = np.asarray(chroms, dtype=np.int64)
+        brng = np.random.default_rng(seed + 3)
+        for step in range(n_steps):
+            x, y, w = synth.make_batch(brng, N, [2, 3, 4, 5] if step % 2 == 0 else [3], 6 if step % 2 == 0 else 24)
+            out[f"x{step}"], out[f"y{step}"], out[f"w{step}"] = x, y, w
+            pred, recon = clf(torch.from_numpy(x), return_recon=True)        # main.py:54
+            bce = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.from_numpy(y), weight=torch.from_numpy(w))
+            loss = bce * alpha + recon * beta                                  # main.py:166
+            opt.zero_grad()
+            loss.backward()
+            out[f"bce{step}"], out[f"recon{step}"] = bce.detach().numpy().copy(), recon.detach().numpy().copy()
+            out[f"logits{step}"] = pred.detach().numpy().copy()
+            if step == 0:
+                none = []
+                for n_, p in clf.named_parameters():
+                    if p.grad is None:
+                        none.append(n_)
+                    elif full:
+                        out["grad0/" + n_] = p.grad.numpy().copy()
+                    else:
+                        out["gradnorm0/" + n_] = np.float64(p.grad.double().norm().item())
+                out["grad_none"] = np.asarray(none)
+            opt.step()
+            if step in (0, n_steps - 1):
+                for n_, p in clf.named_parameters():
+                    if p.grad is not None or step == n_steps - 1:
+                        changed = not np.array_equal(p.detach().numpy(), np.asarray(sd[n_]))
+                        if changed and full:
+                            out[f"param{step}/" + n_] = p.detach().numpy().copy()
+                        elif changed:
+                            out[f"paramnorm{step}/" + n_] = np.float64(p.detach().double().norm().item())
+        np.random.seed(99)
+        out["emb_after"] = glb["save_embeddings"](clf, True)
+        if not full:   # keep the fixture small: every 16th node
+            out["emb_before"], out["emb_after"] = out["emb_before"][::16], out["emb_after"][::16]
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, f"g3_{name}_{tag}.npz"), **out)
+    print("G3", name, tag, "bce0", out["bce0"], "recon0", out["recon0"], "none", len(out["grad_none"]))
+
+
+def g1_g5(M):
+    """G1 reference-initialised state_dict (tiny); G5 preprocessing pins; reference-pickled model2load."""
+    num = synth.LAYOUTS["tiny"]
+    for mode in ("adj", "table"):
+        torch.manual_seed(0)
+        clf, attr, feats, inter_z, _ = build_ref(M, num, 16, mode, 11, set_weights=False)
+        sd = {k: v.numpy().copy() for k, v in clf.state_dict().items()}
+        np.savez_compressed(os.path.join(HERE, f"g1_tiny_{mode}_refinit.npz"), **sd)
+        x = synth.make_batch(np.random.default_rng(5), int(np.sum(num)), [2, 3, 4], 5)[0]
+        chrom = predraw_chroms(len(num), 1, 7)[0]
+        lg, rc = eval_logits(clf, x, len(num))
+        np.savez_compressed(os.path.join(HERE, f"g1_tiny_{mode}_refinit_out.npz"), x=x, logits=lg, recon=rc, chrom=np.int64(chrom))
+        # what main.py:322/:685 writes: the whole pickled module (class refs to `Modules.*` + tensors)
+        torch.save(clf, os.path.join(HERE, f"ref_model2load_tiny_{mode}"))
+        torch.save({"model_link": clf.state_dict(), "epoch": 0}, os.path.join(HERE, f"ref_model_chkpt_tiny_{mode}"))
+        if mode == "adj":
+            g5 = {"attr": attr, "inter_z": inter_z}
+            for i, f in enumerate(feats):
+                g5[f"feat{i}"] = f
+            np.savez_compressed(os.path.join(HERE, "g5_tiny_preproc.npz"), **g5)
+        print("G1", mode, len(sd), "keys")
+
+
+def sampler_stats(M, U):
+    """Run the reference's own generate_negative (main.py:361-459) on synthetic k=3 / mixed data with the
+    exact-set stand-in and record the invariants of SURVEY.md §8(c3) + the differing-node histogram."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    cr = synth.chrom_range(num)
+    n2c = synth.node2chrom(num)
+    rng = np.random.default_rng(3)
+    out = {}
+    for k in (2, 3, 5):
+        pos = synth.make_edges_fast(rng, N, k, 3000)
+        from pybloom_live import BloomFilter
+        dicts = [BloomFilter(10) for _ in range(k + 1)]
+        for r in pos:
+            dicts[k].add(tuple(int(v) for v in r))
+        glb = dict(train_dict=dicts, test_dict=dicts, max_size=k, min_size=k, node2chrom={i: int(n2c[i]) for i in range(1, N + 1)},
+                   chrom_range=cr, min_dis=0, task_mode="class", device=torch.device("cpu"), np=np, torch=torch,
+                   math=math, random=random, np2tensor_hyper=U.np2tensor_hyper,
+                   pad_sequence=torch.nn.utils.rnn.pad_sequence)
+        main_functions({"generate_negative", "neighbor_check"}, glb)
+        np.random.seed(5)
+        random.seed(5)
+        batch = pos[:1500]
+        x, y, w, s = glb["generate_negative"](batch, "train_dict", np.ones(len(batch), dtype=np.float32), neg_num=3)
+        x = x.numpy()
+        neg = x[len(batch):]
+        assert len(neg) == 3 * len(batch)
+        posset = {tuple(r) for r in pos.tolist()}
+        diff_hist = np.zeros(k + 1, dtype=np.int64)
+        for j, r in enumerate(neg):
+            p = batch[j // 3]
+            assert (np.diff(r) > 0).all() and tuple(r.tolist()) not in posset
+            assert sorted(n2c[r].tolist()) == sorted(n2c[p].tolist())
+            diff_hist[len(set(r.tolist()) - set(p.tolist()))] += 1
+        out[f"diff_hist_k{k}"] = diff_hist
+        print("sampler k", k, "diff histogram", diff_hist)
+    np.savez_compressed(os.path.join(HERE, "sampler_stats.npz"), **out)
+
+
+def main():
+    torch.set_num_threads(4)
+    M, U = import_reference()
+    g1_g5(M)
+    g2_eval(M, "tiny_adj", synth.LAYOUTS["tiny"], 16, "adj", 21)
+    g2_eval(M, "tiny_table", synth.LAYOUTS["tiny"], 16, "table", 22)
+    g2_eval(M, "c1_adj", synth.LAYOUTS["c1"], 16, "adj", 23)
+    g2_eval(M, "hg38_table_d64", synth.LAYOUTS["hg38_1mb"], 64, "table", 24)
+    g2_eval(M, "hg38_adj_d64", synth.LAYOUTS["hg38_1mb"], 64, "adj", 25)
+    for mode in ("adj", "table"):
+        g3_train(M, f"tiny_{mode}", synth.LAYOUTS["tiny"], 16, mode, 31, 0.0, 1.0, "phase1")    # main.py:637-638
+        g3_train(M, f"tiny_{mode}", synth.LAYOUTS["tiny"], 16, mode, 31, 1.0, 0.001, "phase2")  # main.py:672-673
+    g3_train(M, "hg38_table_d64", synth.LAYOUTS["hg38_1mb"], 64, "table", 41, 1.0, 0.001, "phase2", n_steps=3, full=False)
+    g3_train(M, "hg38_adj_d64", synth.LAYOUTS["hg38_1mb"], 64, "adj", 42, 1.0, 0.001, "phase2", n_steps=3, full=False)
+    sampler_stats(M, U)
+
+
+if __name__ == "__main__":
+    main()

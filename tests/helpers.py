@@ -1,0 +1,42 @@
+"""Shared test helpers: synthetic model state for the oracle and for the HIP path."""
+import os
+
+import numpy as np
+import torch
+
+from matcha_amd import synth
+from oracle import hypersagnn as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def oracle_state(num, d, mode, seed, requires_grad=False):
+    """(P, fe, sd_numpy): the same deterministic weights/features make_golden.py loaded into the reference."""
+    attr = O.attribute_table(num)
+    sd = synth.make_state_dict(np.random.default_rng(seed), num, d, mode, attr)
+    P = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(np.array(v))
+        if requires_grad and not k.startswith("attribute_dict"):
+            t.requires_grad_(True)
+        P[k] = t
+    fe = front_end(num, mode, seed)
+    return P, fe, sd
+
+
+def front_end(num, mode, seed):
+    if mode == "table":
+        return O.FrontEnd(mode="table", bounds=synth.bounds(num))
+    intra, inter = synth.make_adjacency(np.random.default_rng(seed + 1000), num)
+    feats = [torch.from_numpy(f) for f in O.corrcoef_features(intra, synth.chrom_range(num))]
+    return O.FrontEnd(mode="adj", bounds=synth.bounds(num), feats=feats, inter=torch.from_numpy(O.zscore_inter(inter)))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
