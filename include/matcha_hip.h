@@ -1,0 +1,242 @@
+/*
+ * matcha_hip.h -- C ABI of the MI355X (gfx950) hot path of MATCHA's hyperedge-classifier
+ * training loop.  One shared library, libmatcha_hip.so; plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every buffer is a caller-owned DEVICE pointer (hipMalloc / torch .data_ptr()), contiguous,
+ *     row-major; fp32 data, int64 node ids at the boundary (the reference's dtype, main.py:433);
+ *   - no allocation, no ownership transfer, no hidden synchronisation: every call enqueues work
+ *     on `stream` (a hipStream_t passed as void*) and returns; scratch comes from the caller via
+ *     matcha_workspace_bytes();
+ *   - return 0 on success, a negative errno-style code otherwise; matcha_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - reentrant across streams; one process per GPU.
+ *
+ * The reference (ma-compbio/MATCHA, Code/) is pure Python/PyTorch and has no FFI of its own; each
+ * entry point cites the reference lines whose ATen call sites it replaces.  The reference-side
+ * binding (a ctypes stub for Code/Modules.py) is in INTEGRATION.md.
+ */
+#ifndef MATCHA_HIP_H
+#define MATCHA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MATCHA_ABI_VERSION 1
+
+#define MATCHA_OK 0
+#define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
+#define MATCHA_EHIP (-5)    /* a HIP runtime call or kernel launch failed    */
+#define MATCHA_ENOMEM (-12) /* workspace too small                             */
+
+#define MATCHA_MAX_L 8      /* widest hyperedge (BASELINE.json configs[4]: k in 2..8) */
+#define MATCHA_N_HEAD 8     /* main.py:616 */
+
+typedef void* matcha_stream_t; /* hipStream_t */
+
+int matcha_abi_version(void);
+const char* matcha_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only box; never fails) */
+int matcha_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Model description: shapes + one pointer per LIVE tensor of the reference's
+ * Classifier.state_dict() (Modules.py:204-249).  The same struct type carries parameters
+ * (`matcha_tensors` of weights) and gradients (`matcha_tensors` of grads; same shapes).
+ * Dead tensors of the reference (encode2.*, fc2, pff_n2, decoder biases, node_embedding.next_w;
+ * SURVEY.md headline fact 3) are never read and have no slot.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct matcha_shape {
+  int32_t d;        /* embed_dim = d_model = d_k = d_v = bottle_neck (main.py:517); multiple of 16, <= 256 */
+  int32_t n_attr;   /* C+1 columns of the attribute table (main.py:497-512) */
+  int32_t n_nodes;  /* N; node ids are 1..N, 0 = padding */
+  int32_t n_chrom;  /* C (adj mode); may be 0 in table mode */
+  int32_t mode;     /* 0 = table (Wrap_Embedding, Modules.py:29-34); 1 = adj (MultipleEmbedding :125-201) */
+  int32_t max_bins; /* adj: max_i n_i */
+} matcha_shape;
+
+typedef struct matcha_tensors {
+  /* front end -- table mode */
+  float* table;      /* [N+1, d]       node_embedding.weight                                    */
+  /* front end -- adj mode: per-chromosome tensors packed back to back, chromosome i at bounds[i] */
+  float* adj_w0;     /* sum_i [d, n_i] node_embedding.Embedding_Linear{i}."tied weight_0"; offset d*bounds[i] */
+  float* adj_w1;     /* [C, d, d]      node_embedding.Embedding_Linear{i}."tied weight_1"         */
+  float* recon_w;    /* sum_i [n_i, d] node_embedding.Embedding_recon{i}.FF_Linear0.weight; offset d*bounds[i] */
+  float* recon_b;    /* [N]            node_embedding.Embedding_recon{i}.FF_Linear0.bias; offset bounds[i]     */
+  /* attribute path (Modules.py:243-249, :263-264) */
+  float* attr_w;     /* [d, n_attr]    attribute_nn.weight */
+  float* attr_b;     /* [d]            attribute_nn.bias   */
+  float* next_w;     /* [d, d]         next_w.FF_Linear0.weight (Modules.py:270) */
+  float* next_b;     /* [d] */
+  /* encode1.mul_head_attn (Modules.py:463-575) */
+  float* ln_q_g; float* ln_q_b;   /* layer_norm1 */
+  float* ln_k_g; float* ln_k_b;   /* layer_norm2 */
+  float* ln_v_g; float* ln_v_b;   /* layer_norm3 */
+  float* w_q;        /* [8d, d] w_qs.weight */
+  float* w_k;        /* [8d, d] w_ks.weight */
+  float* w_v;        /* [8d, d] w_vs.weight */
+  float* fc1_w;      /* [d, 8d] fc1.weight  */
+  float* fc1_b;      /* [d] */
+  /* encode1.pff_n1 (Modules.py:604-605, :353-376); Conv1d(k=1) weight [d,d,1] == [d,d] */
+  float* pff0_w; float* pff0_b;
+  float* pff1_w; float* pff1_b;
+  float* pff_ln_g; float* pff_ln_b;
+  /* Classifier tail (Modules.py:290-299) */
+  float* ln1_g; float* ln1_b;     /* layer_norm1 (dynamic) */
+  float* ln2_g; float* ln2_b;     /* layer_norm2 (static)  */
+  float* cls_w;      /* [d]  pff_classifier.PWF_Conv0.weight [1,d,1] */
+  float* cls_b;      /* [1] */
+} matcha_tensors;
+
+/* Frozen (non-trainable) inputs of the front end. */
+typedef struct matcha_frozen {
+  const float* attr_table;   /* [N+1, n_attr] attribute_dict_embedding.weight, row 0 zeros (main.py:508) */
+  const int32_t* bounds;     /* [C+1] Modules.py:138 num_list = [0, n_0, n_0+n_1, ...] (adj; device)     */
+  const float* feats;        /* adj: sum_i [n_i, n_i] feature matrices (main.py:571-577), chrom i at feat_off[i] */
+  const int64_t* feat_off;   /* [C+1] element offsets into feats (HOST pointer)                           */
+  const float* inter;        /* adj: [N, N] z-scored inter-chromosome matrix (Modules.py:146-154)         */
+  const int32_t* bounds_host;/* [C+1] same as bounds, HOST pointer                                         */
+} matcha_frozen;
+
+/* Per-call options of the fused step. */
+typedef struct matcha_step_opts {
+  int32_t training;          /* 0: eval (no dropout); 1: train (dropout with the seeds below)            */
+  int32_t random_chrom;      /* adj: the chromosome drawn at Modules.py:192 (caller draws it)             */
+  float p_drop_adj;          /* Modules.py:174  (0.2) */
+  float p_drop_fc1;          /* Modules.py:226  (0.3) */
+  float p_drop_pff;          /* Modules.py:227  (0.4) */
+  float alpha;               /* main.py:166 loss = bce*alpha + recon*beta */
+  float beta;
+  const uint64_t* seed;      /* DEVICE pointer to the 64-bit dropout seed of this step (graph-replay safe) */
+} matcha_step_opts;
+
+/* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */
+size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L);
+
+/* Classifier.forward(x, return_recon=True) (Modules.py:278-318) + the weighted BCE of main.py:56.
+ *   x      int64 [B,L], 0 = padding
+ *   y, w   float [B] labels / BCE weights, may be NULL (then no loss is computed)
+ *   logits float [B]  (the reference returns [B,1] logits; callers apply sigmoid themselves)
+ *   losses float [2]  {bce (mean over B), recon_loss}
+ * Activations needed by matcha_backward stay in `ws`. */
+int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                   const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L,
+                   const float* y, const float* w, float* logits, float* losses,
+                   void* ws, size_t ws_bytes, matcha_stream_t stream);
+
+/* loss.backward() of main.py:179 for loss = bce*alpha + recon*beta, or, when `dlogits` is not NULL,
+ * the vector-Jacobian product for an arbitrary upstream gradient on the logits (autograd glue).
+ * Gradients are ACCUMULATED into `grads` (same layout as params; caller zeroes them -- the fused AdamW
+ * does).  `touched` (device int32 [2+2C], may be NULL) receives 1 for each tensor group that received a
+ * gradient this step: [0] always 1, [1] table, [2+i] adj encoder of chromosome i, [2+C+i] recon head i --
+ * these are the tensors whose grad is not None in the reference (SURVEY.md §7 "AdamW semantics"). */
+int matcha_backward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                    const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L,
+                    const float* y, const float* w, const float* dlogits, const float* drecon,
+                    matcha_tensors* grads, int32_t* touched,
+                    void* ws, size_t ws_bytes, matcha_stream_t stream);
+
+/* model.get_node_embeddings(x) (Modules.py:252-259), eval mode: rows float [T,d] for ids int64 [T]. */
+int matcha_node_embeddings(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                           const int64_t* ids, int64_t T, float* rows, void* ws, size_t ws_bytes,
+                           matcha_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * torch.optim.AdamW(lr=1e-3) as main.py:630/:671 builds it, fused over one flat buffer.
+ * Segment s covers elements [seg_off[s], seg_off[s+1]) (device int64 [n_seg+1]) and is one tensor of the
+ * reference: it has its own step count `seg_step[s]` (device int32, incremented here) and is skipped
+ * entirely -- no decay, no step -- unless touched[seg_group[s]] != 0 (device int32 arrays; `touched` is what
+ * matcha_backward wrote; NULL = every segment is active), which is how tensors with grad None behave.
+ * Gradients are zeroed after use (opt.zero_grad of main.py:175-176).  `grad_scale` multiplies the gradient
+ * first (1/world_size after an all-reduce SUM).  `seg_coef` is device scratch, 3*n_seg floats.
+ * ------------------------------------------------------------------------------------------ */
+int matcha_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const int64_t* seg_off, int32_t n_seg, const int32_t* seg_group, const int32_t* touched,
+                      int32_t* seg_step, float* seg_coef, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, double grad_scale, matcha_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Negative sampling (main.py:361-459) against an exact device hash set of the positive hyperedges
+ * (the reference uses a Bloom filter per size, utils.py:75-97; an exact set is strictly stronger).
+ * ------------------------------------------------------------------------------------------ */
+/* bytes for a set holding `n_edges` hyperedges */
+size_t matcha_hashset_bytes(int64_t n_edges);
+/* build: edges int64 [n_edges, L] zero-padded rows (k = number of non-zero entries, ascending) */
+int matcha_hashset_build(void* set, size_t set_bytes, const int64_t* edges, int64_t n_edges, int32_t L,
+                         matcha_stream_t stream);
+/* out[i] = 1 if row i of `rows` [n,L] is in the set */
+int matcha_hashset_contains(const void* set, const int64_t* edges, int32_t L_set, const int64_t* rows,
+                            int64_t n, int32_t L, int32_t* out, matcha_stream_t stream);
+/* generate_negative: for each positive row (int64 [P,L], zero-padded) emit `neg_num` corrupted copies into
+ * neg int64 [P*neg_num, L] (row P*? layout: negatives of positive j at rows neg_num*j .. neg_num*j+neg_num-1,
+ * main.py:383-428).  node2chrom int32 [N+1]; chrom_range int32 [C,2] = [start,end) ids; an EMPTY set
+ * (n_set_edges == 0) reproduces the reference's phase-1 quirk: negatives == positives (main.py:589). */
+int matcha_neg_sample(const void* set, const int64_t* set_edges, int64_t n_set_edges, int32_t L_set,
+                      const int64_t* pos, int64_t P, int32_t L, int32_t neg_num, int32_t min_dis,
+                      const int32_t* node2chrom, const int32_t* chrom_range, const uint64_t* seed,
+                      int64_t* neg, matcha_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Op-level entry points (the kernels behind matcha_forward/backward, exposed so that each one is
+ * parity-tested on its own against the oracle).
+ * ------------------------------------------------------------------------------------------ */
+#define MATCHA_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T   (F.linear, Modules.py:111/:392/:481-483/:340)   */
+#define MATCHA_GEMM_NN 1 /* C[M,N] = A[M,K] . B[K,N]     (input gradient of a Linear)                     */
+#define MATCHA_GEMM_TN 2 /* C[M,N] = A[R,M]^T . B[R,N]   (weight gradient; reduction over R rows/tokens)  */
+
+/* epilogue steps, applied in THIS order: */
+#define MATCHA_EPI_BIAS 1        /* + bias[n]                                                         */
+#define MATCHA_EPI_TANH 2        /* tanh()                                                            */
+#define MATCHA_EPI_RESIDUAL 16   /* + residual[m,n]                                                   */
+#define MATCHA_EPI_DROPOUT 4     /* * keep/(1-p); keep = rand_u32(key(seed,stream), m, n) >= p*2^32   */
+#define MATCHA_EPI_ROWMASK 8     /* * (row_ids[m] != 0)                                               */
+#define MATCHA_EPI_DTANH 32      /* * (1 - (aux[m,n]*aux_scale)^2)   aux = saved tanh output          */
+#define MATCHA_EPI_ACCUM 64      /* C += result instead of C = result                                 */
+
+typedef struct matcha_gemm_epilogue {
+  int32_t flags;
+  const float* bias;        /* [N] */
+  const float* residual;    /* [M,N] */
+  const float* aux;         /* [M,N] */
+  const int64_t* row_ids;   /* [M] node ids (row mask) */
+  const uint64_t* seed;     /* device */
+  int32_t stream_id;        /* RNG stream (oracle/rng.py) */
+  float p_drop;
+  float aux_scale;          /* (1-p) when aux holds dropout(tanh(.)), else 1 */
+} matcha_gemm_epilogue;
+
+/* f32 MFMA GEMM. For TN, `ws` must hold matcha_gemm_tn_workspace_bytes(M,N,R) bytes; `colsum` (may be
+ * NULL) additionally receives sum_r A[r,m] (bias gradient), accumulated like C. */
+size_t matcha_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
+int matcha_gemm(int32_t op, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K,
+                const matcha_gemm_epilogue* epi, float* colsum, const int64_t* b_row_gather,
+                void* ws, size_t ws_bytes, matcha_stream_t stream);
+
+/* K1 + K6: x0[t] = rows[t] + attr_table[x[t]] . attr_w^T + attr_b, rows[t] = table[x[t]] (table != NULL) or
+ * dense[t] (Modules.py:34, :263-269).  Backward: scatter-add into dtable (row 0 skipped, padding_idx=0). */
+int matcha_embed_fwd(const int64_t* x, int64_t T, int32_t d, const float* table, const float* dense,
+                     const float* attr_table, int32_t n_attr, const float* attr_w, const float* attr_b,
+                     float* x0, matcha_stream_t stream);
+int matcha_embed_scatter_bwd(const int64_t* x, int64_t T, int32_t d, const float* dx0, float* dtable,
+                             matcha_stream_t stream);
+
+/* K8 (LayerNorm part): xhat-normalise X once, emit the three affine variants (Modules.py:519-521). */
+int matcha_ln3_fwd(const float* X, int64_t T, int32_t d, const float* gq, const float* bq, const float* gk,
+                   const float* bk, const float* gv, const float* bv, float* qin, float* kin, float* vin,
+                   float* stats /* [T,2] mean,rstd */, matcha_stream_t stream);
+
+/* K9: per (hyperedge, head) attention with the diagonal masked and pad slots attended (Modules.py:449-458;
+ * SURVEY.md headline fact 7).  Q,K,V,O: [B*L, 8d]; P: [B, 8, L, L]. */
+int matcha_attn_fwd(const float* Q, const float* K, const float* V, int64_t B, int32_t L, int32_t d,
+                    float* O, float* P, matcha_stream_t stream);
+int matcha_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO,
+                    int64_t B, int32_t L, int32_t d, float* dQ, float* dK, float* dV, matcha_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATCHA_HIP_H */

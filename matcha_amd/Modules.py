@@ -1,0 +1,585 @@
+"""Host-side mirror of the reference's ``Modules`` interface for the hyperedge-classifier path.
+
+Same class names, constructor arguments, sub-module / parameter names (hence identical ``state_dict()`` keys,
+including the odd ``'tied weight_0'`` names) and the same call surface --
+``model(x)``, ``model(x, return_recon=True)``, ``model.get_node_embeddings(x)``,
+``model.get_embedding(...)``, ``torch.save(model)`` / ``torch.load`` -- as
+``/root/reference/Code/Modules.py`` (cited per class below).  What differs is everything underneath: the
+sub-modules are parameter containers only, and ``Classifier.forward`` runs the hand-written gfx950 kernels
+of ``libmatcha_hip.so`` through the C ABI in ``include/matcha_hip.h``.  There is no PyTorch-op fallback: on a
+machine without the library or without a GPU tensor the call raises.
+
+A model pickled by the *reference* (``torch.save(model, "model2load")``, main.py:322/:685) unpickles into these
+classes when this module is importable as ``Modules`` (see the top-level ``Modules.py`` shim) and runs on the
+HIP path unchanged: the runtime state is rebuilt lazily from the module tree.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ["Classifier", "MultipleEmbedding", "Wrap_Embedding", "SparseEmbedding", "TiedAutoEncoder",
+           "EncoderLayer", "MultiHeadAttention", "ScaledDotProductAttention", "PositionwiseFeedForward",
+           "FeedForward", "DataGenerator", "get_non_pad_mask", "get_attn_key_pad_mask"]
+
+_PUBLIC_MODULE = "Modules"   # pickles refer to `Modules.<Class>` exactly like the reference's (main.py:322)
+
+
+def _default_device() -> torch.device:
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def _no_submodule_forward(self, *a, **k):
+    raise RuntimeError(
+        f"{type(self).__name__} is a parameter container in matcha_amd; the computation runs fused inside "
+        "Classifier.forward / get_node_embeddings on the HIP path")
+
+
+# ----------------------------------------------------------------------------------------------------
+# small helpers on the reference's surface
+# ----------------------------------------------------------------------------------------------------
+def get_non_pad_mask(seq: torch.Tensor) -> torch.Tensor:
+    """x != 0 as float [B,L,1] (reference Modules.py:12-14)."""
+    if seq.dim() != 2:
+        raise AssertionError("expected a [B, L] tensor")
+    return (seq != 0).to(torch.float32).unsqueeze(-1)
+
+
+def get_attn_key_pad_mask(seq_k: torch.Tensor, seq_q: torch.Tensor) -> torch.Tensor:
+    """x == 0 expanded to [B, Lq, Lk] (reference Modules.py:17-26).  The reference computes it and then never
+    applies it (SURVEY.md headline fact 7); kept for surface compatibility only."""
+    return (seq_k == 0).unsqueeze(1).expand(-1, seq_q.size(1), -1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter containers (same registration names and initialisers as the reference)
+# ----------------------------------------------------------------------------------------------------
+class Wrap_Embedding(nn.Embedding):
+    """Trainable bin-embedding table (reference Modules.py:29-34).  Used as ``node_embedding``; its lookup
+    (+ zero recon loss) happens inside the fused kernels."""
+
+    def forward(self, *input):
+        x = input[0]
+        rows = _gather_rows(self.weight, x)
+        return rows, torch.zeros(1, dtype=self.weight.dtype, device=self.weight.device)
+
+
+class SparseEmbedding(nn.Module):
+    """Frozen feature matrix holder (reference Modules.py:38-67): ``.embedding`` is a plain tensor attribute
+    (not a buffer), so it travels inside the pickle but not in the state_dict."""
+
+    def __init__(self, embedding_weight, sparse=False):
+        super().__init__()
+        if sparse:
+            raise NotImplementedError("sparse (scipy) feature matrices are not supported on the HIP path")
+        w = embedding_weight.todense() if hasattr(embedding_weight, "todense") else embedding_weight
+        self.sparse = False
+        self.embedding = torch.from_numpy(np.ascontiguousarray(np.asarray(w))).to(_default_device())
+
+    forward = _no_submodule_forward
+
+
+class TiedAutoEncoder(nn.Module):
+    """Per-chromosome encoder weights (reference Modules.py:70-122): parameters ``'tied weight_%d'``,
+    ``'tied bias1'``, ``'tied bias2'`` with the reference's (quirky) registration: for shape_list [n,d,d] the
+    surviving biases are bias_list[1] [d] and recon_bias_list[1] [n].  Only the weights are live (use_bias=False
+    at Modules.py:163; the decoder output is discarded at :187)."""
+
+    def __init__(self, shape_list, use_bias=True):
+        super().__init__()
+        dev = _default_device()
+        self.use_bias = use_bias
+        self.weight_list, self.bias_list, self.recon_bias_list = [], [], []
+        for i in range(len(shape_list) - 1):
+            self.weight_list.append(nn.Parameter(torch.empty(shape_list[i + 1], shape_list[i], device=dev)))
+            self.bias_list.append(nn.Parameter(torch.empty(shape_list[i + 1], device=dev)))
+            self.recon_bias_list.append(nn.Parameter(torch.empty(shape_list[i], device=dev)))
+        self.recon_bias_list = self.recon_bias_list[::-1]
+        for i, w in enumerate(self.weight_list):
+            self.register_parameter("tied weight_%d" % i, w)
+            self.register_parameter("tied bias1", self.bias_list[i])
+            self.register_parameter("tied bias2", self.recon_bias_list[i])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for w in self.weight_list:
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        for w, b in zip(self.weight_list, self.bias_list):
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(w)
+            nn.init.uniform_(b, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        for w, b in zip(self.weight_list[::-1], self.recon_bias_list):
+            _, fan_out = nn.init._calculate_fan_in_and_fan_out(w)
+            nn.init.uniform_(b, -1 / math.sqrt(fan_out), 1 / math.sqrt(fan_out))
+
+    forward = _no_submodule_forward
+
+
+class FeedForward(nn.Module):
+    """Linear stack ``FF_Linear%d`` (reference Modules.py:385-414)."""
+
+    def __init__(self, dims, dropout=None, reshape=False, use_bias=True):
+        super().__init__()
+        self.w_stack = []
+        for i in range(len(dims) - 1):
+            self.w_stack.append(nn.Linear(dims[i], dims[i + 1], use_bias))
+            self.add_module("FF_Linear%d" % i, self.w_stack[-1])
+        self.dropout = nn.Dropout(dropout) if dropout is not None else None
+        self.reshape = reshape
+
+    forward = _no_submodule_forward
+
+
+class PositionwiseFeedForward(nn.Module):
+    """Conv1d(k=1) stack ``PWF_Conv%d`` + LayerNorm (reference Modules.py:327-376)."""
+
+    def __init__(self, dims, dropout=None, reshape=False, use_bias=True, residual=False, layer_norm=False):
+        super().__init__()
+        self.w_stack = []
+        self.dims = dims
+        for i in range(len(dims) - 1):
+            self.w_stack.append(nn.Conv1d(dims[i], dims[i + 1], 1, bias=use_bias))
+            self.add_module("PWF_Conv%d" % i, self.w_stack[-1])
+        self.reshape = reshape
+        self.layer_norm = nn.LayerNorm(dims[-1])
+        self.dropout = nn.Dropout(dropout) if dropout is not None else None
+        self.residual = residual
+        self.layer_norm_flag = layer_norm
+
+    forward = _no_submodule_forward
+
+
+class ScaledDotProductAttention(nn.Module):
+    """Holds the temperature only (reference Modules.py:417-460)."""
+
+    def __init__(self, temperature):
+        super().__init__()
+        self.temperature = temperature
+
+    forward = _no_submodule_forward
+
+
+class MultiHeadAttention(nn.Module):
+    """w_qs / w_ks / w_vs / fc1 / fc2 / layer_norm1-3 (reference Modules.py:463-575)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout, diag_mask, input_dim):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.w_qs = nn.Linear(input_dim, n_head * d_k, bias=False)
+        self.w_ks = nn.Linear(input_dim, n_head * d_k, bias=False)
+        self.w_vs = nn.Linear(input_dim, n_head * d_v, bias=False)
+        nn.init.normal_(self.w_qs.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_ks.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_vs.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_v)))
+        self.attention = ScaledDotProductAttention(temperature=np.power(d_k, 0.5))
+        self.fc1 = nn.Linear(n_head * d_v, d_model)
+        self.fc2 = nn.Linear(n_head * d_v, d_model)      # dead in the reference's forward (Modules.py:573, :617)
+        self.layer_norm1 = nn.LayerNorm(input_dim)
+        self.layer_norm2 = nn.LayerNorm(input_dim)
+        self.layer_norm3 = nn.LayerNorm(input_dim)
+        self.dropout = nn.Dropout(dropout) if dropout is not None else dropout
+        self.diag_mask_flag = diag_mask
+        self.diag_mask = None
+
+    forward = _no_submodule_forward
+
+
+class EncoderLayer(nn.Module):
+    """mul_head_attn + pff_n1 (+ dead pff_n2) (reference Modules.py:578-617)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout_mul, dropout_pff, diag_mask, bottle_neck):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.mul_head_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout_mul, diag_mask=diag_mask,
+                                                input_dim=bottle_neck)
+        self.pff_n1 = PositionwiseFeedForward([d_model, d_model, d_model], dropout=dropout_pff, residual=True, layer_norm=True)
+        self.pff_n2 = PositionwiseFeedForward([bottle_neck, d_model, d_model], dropout=dropout_pff, residual=False, layer_norm=True)
+
+    forward = _no_submodule_forward
+
+
+class MultipleEmbedding(nn.Module):
+    """adj-mode front end (reference Modules.py:125-201): per-chromosome feature matrices + 2-layer encoders
+    ``Embedding_Linear{i}`` and reconstruction heads ``Embedding_recon{i}``; ``inter_initial`` rows are
+    z-scored over their positive entries at construction (Modules.py:146-152), in place like the reference."""
+
+    def __init__(self, embedding_weights, dim, sparse=True, num_list=None, chrom_range=None, inter_initial=None):
+        super().__init__()
+        dev = _default_device()
+        self.chrom_range = chrom_range
+        self.num_list = torch.tensor([0] + [int(v) for v in list(num_list)]).to(dev)
+        self.dim = dim
+        self.embeddings = [SparseEmbedding(w, sparse) for w in embedding_weights]
+        if inter_initial is not None:
+            for i in range(len(inter_initial)):
+                row = inter_initial[i, :]
+                pos = row > 0
+                v = row[pos]
+                if v.size:
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        inter_initial[i, pos] = ((v - v.mean()) / v.std()).astype("float32")
+            inter_initial[np.isnan(inter_initial)] = 0.0
+            self.inter_initial = SparseEmbedding(inter_initial, sparse)
+        else:
+            self.inter_initial = SparseEmbedding(embedding_weights[-1], sparse)
+        self.input_size = [int(e.embedding.shape[-1]) for e in self.embeddings]
+        self.wstack = [TiedAutoEncoder([self.input_size[i], self.dim, self.dim], use_bias=False).to(dev)
+                       for i in range(len(self.embeddings))]
+        self.next_w = FeedForward([self.dim, self.dim]).to(dev)     # dead in the reference's forward
+        self.recon = [FeedForward([self.dim, int(v[1] - v[0])]).to(dev) for v in self.chrom_range]
+        for i, w in enumerate(self.wstack):
+            self.add_module("Embedding_Linear%d" % i, w)
+            self.add_module("Embedding_recon%d" % i, self.recon[i])
+        self.dropout = nn.Dropout(0.2)
+
+    forward = _no_submodule_forward
+
+
+# ----------------------------------------------------------------------------------------------------
+# runtime: flat parameter storage + C-ABI descriptors, rebuilt lazily from the module tree
+# ----------------------------------------------------------------------------------------------------
+def _gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    if not table.is_cuda:
+        raise _lib.MatchaHipError("matcha_amd runs on the GPU only: move the model with .to('cuda') (no CPU fallback)")
+    lib = _lib.load()
+    ids = ids.to(device=table.device, dtype=torch.long).contiguous()
+    d = table.shape[1]
+    out = torch.empty(ids.numel(), d, dtype=torch.float32, device=table.device)
+    shp = _lib.Shape(d, 1, table.shape[0] - 1, 0, 0, 0)
+    ten = _lib.Tensors()
+    ten.table = table.data_ptr()
+    fro = _lib.Frozen()
+    _lib.check(lib.matcha_node_embeddings(C.byref(shp), C.byref(ten), C.byref(fro), _lib.ptr(ids), ids.numel(), _lib.ptr(out),
+                                          None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "matcha_node_embeddings")
+    return out.view(*ids.shape, d)
+
+
+class _Runtime:
+    """Flat storage for the LIVE parameters (one buffer -> one AdamW launch, one all-reduce bucket) plus the
+    ctypes descriptors handed to the C ABI.  Rebuilt whenever a parameter's storage moved (``.to()``,
+    ``load_state_dict`` into fresh tensors, unpickling)."""
+
+    def __init__(self, model: "Classifier"):
+        self.lib = _lib.load()
+        dev = model.layer_norm1.weight.device
+        if dev.type != "cuda":
+            raise _lib.MatchaHipError("matcha_amd runs on the GPU only: move the model with .to('cuda') (no CPU fallback)")
+        self.device = dev
+        ne = model.node_embedding
+        self.mode = 1 if isinstance(ne, MultipleEmbedding) or hasattr(ne, "wstack") else 0
+        enc, mha, pff = model.encode1, model.encode1.mul_head_attn, model.encode1.pff_n1
+        d = int(model.layer_norm1.weight.shape[0])
+        self.d = d
+        attr_mod = model.attribute_dict_embedding
+        self.n_attr = int(attr_mod.weight.shape[1])
+        # (field, [params...], group)  -- group indexes the `touched` flags of matcha_backward
+        entries = []
+        if self.mode == 0:
+            self.n_nodes = int(ne.weight.shape[0]) - 1
+            self.n_chrom = 0
+            self.max_bins = 0
+            entries.append(("table", [ne.weight], 1))
+        else:
+            bounds = [int(v) for v in ne.num_list.tolist()]
+            self.bounds_list = bounds
+            self.n_chrom = len(bounds) - 1
+            self.n_nodes = bounds[-1]
+            self.max_bins = max(bounds[i + 1] - bounds[i] for i in range(self.n_chrom))
+            Cn = self.n_chrom
+            entries.append(("adj_w0", [getattr(ne.wstack[i], "tied weight_0") for i in range(Cn)], [2 + i for i in range(Cn)]))
+            entries.append(("adj_w1", [getattr(ne.wstack[i], "tied weight_1") for i in range(Cn)], [2 + i for i in range(Cn)]))
+            entries.append(("recon_w", [ne.recon[i].FF_Linear0.weight for i in range(Cn)], [2 + Cn + i for i in range(Cn)]))
+            entries.append(("recon_b", [ne.recon[i].FF_Linear0.bias for i in range(Cn)], [2 + Cn + i for i in range(Cn)]))
+        ff = model.next_w.FF_Linear0
+        entries += [
+            ("attr_w", [model.attribute_nn.weight], 0), ("attr_b", [model.attribute_nn.bias], 0),
+            ("next_w", [ff.weight], 0), ("next_b", [ff.bias], 0),
+            ("ln_q_g", [mha.layer_norm1.weight], 0), ("ln_q_b", [mha.layer_norm1.bias], 0),
+            ("ln_k_g", [mha.layer_norm2.weight], 0), ("ln_k_b", [mha.layer_norm2.bias], 0),
+            ("ln_v_g", [mha.layer_norm3.weight], 0), ("ln_v_b", [mha.layer_norm3.bias], 0),
+            ("w_q", [mha.w_qs.weight], 0), ("w_k", [mha.w_ks.weight], 0), ("w_v", [mha.w_vs.weight], 0),
+            ("fc1_w", [mha.fc1.weight], 0), ("fc1_b", [mha.fc1.bias], 0),
+            ("pff0_w", [pff.PWF_Conv0.weight], 0), ("pff0_b", [pff.PWF_Conv0.bias], 0),
+            ("pff1_w", [pff.PWF_Conv1.weight], 0), ("pff1_b", [pff.PWF_Conv1.bias], 0),
+            ("pff_ln_g", [pff.layer_norm.weight], 0), ("pff_ln_b", [pff.layer_norm.bias], 0),
+            ("ln1_g", [model.layer_norm1.weight], 0), ("ln1_b", [model.layer_norm1.bias], 0),
+            ("ln2_g", [model.layer_norm2.weight], 0), ("ln2_b", [model.layer_norm2.bias], 0),
+            ("cls_w", [model.pff_classifier.PWF_Conv0.weight], 0), ("cls_b", [model.pff_classifier.PWF_Conv0.bias], 0),
+        ]
+        # flat layout: every ABI field starts on a 16-byte boundary; tensors of one field are back to back
+        self.live: List[nn.Parameter] = []
+        self.field_off: Dict[str, int] = {}
+        seg_off, seg_group = [], []
+        off = 0
+        for field, plist, group in entries:
+            off = (off + 3) // 4 * 4
+            self.field_off[field] = off
+            for j, p in enumerate(plist):
+                seg_off.append(off)
+                seg_group.append(group[j] if isinstance(group, list) else group)
+                self.live.append(p)
+                off += p.numel()
+        self.n_flat = (off + 3) // 4 * 4
+        seg_off.append(self.n_flat)
+        self.seg_off_list, self.seg_group_list = seg_off, seg_group
+        self.flat = torch.zeros(self.n_flat, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.live, seg_off[:-1]):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.detach().to(device=dev, dtype=torch.float32))
+                p.data = view
+        self.expected_ptrs = [p.data_ptr() for p in self.live]
+        self.seg_off = torch.tensor(seg_off, dtype=torch.int64, device=dev)
+        self.seg_group = torch.tensor(seg_group, dtype=torch.int32, device=dev)
+        self.n_touched = 2 + 2 * self.n_chrom
+        # frozen inputs
+        self.attr_table = attr_mod.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self._keep = [self.attr_table]
+        self.frozen = _lib.Frozen()
+        self.frozen.attr_table = self.attr_table.data_ptr()
+        if self.mode == 1:
+            feats = [e.embedding.detach().to(device=dev, dtype=torch.float32).contiguous() for e in ne.embeddings]
+            offs = np.zeros(self.n_chrom + 1, dtype=np.int64)
+            for i, f in enumerate(feats):
+                if tuple(f.shape) != (self.bounds_list[i + 1] - self.bounds_list[i],) * 2:
+                    raise ValueError("adj mode expects square [n_i, n_i] feature matrices (main.py:571-577)")
+                offs[i + 1] = offs[i] + f.numel()
+            self.feat_pack = torch.cat([f.reshape(-1) for f in feats])
+            self.feat_off_host = offs
+            self.inter = ne.inter_initial.embedding.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self.bounds_dev = torch.tensor(self.bounds_list, dtype=torch.int32, device=dev)
+            self.bounds_host = np.asarray(self.bounds_list, dtype=np.int32)
+            self.frozen.bounds = self.bounds_dev.data_ptr()
+            self.frozen.feats = self.feat_pack.data_ptr()
+            self.frozen.feat_off = self.feat_off_host.ctypes.data
+            self.frozen.inter = self.inter.data_ptr()
+            self.frozen.bounds_host = self.bounds_host.ctypes.data
+            self._keep += [self.feat_pack, self.inter, self.bounds_dev]
+        self.shape = _lib.Shape(d, self.n_attr, self.n_nodes, self.n_chrom, self.mode, self.max_bins)
+        self.params = self.tensors_for(self.flat)
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed_counter = 0
+
+    def tensors_for(self, flat: torch.Tensor) -> "_lib.Tensors":
+        t = _lib.Tensors()
+        base = flat.data_ptr()
+        for field, off in self.field_off.items():
+            setattr(t, field, base + 4 * off)
+        return t
+
+    def still_packed(self) -> bool:
+        return all(p.data_ptr() == e for p, e in zip(self.live, self.expected_ptrs))
+
+    def workspace(self, B: int, L: int) -> torch.Tensor:
+        n = self.lib.matcha_workspace_bytes(C.byref(self.shape), B, L)
+        if n == 0:
+            raise _lib.MatchaHipError(self.lib.matcha_last_error().decode())
+        return torch.empty(n, dtype=torch.uint8, device=self.device)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+
+class _ClassifierFn(torch.autograd.Function):
+    """Autograd glue around matcha_forward / matcha_backward (one node for the whole model)."""
+
+    @staticmethod
+    def forward(ctx, x, rt: _Runtime, opts: "_lib.StepOpts", seed_t, *live):
+        B, L = x.shape
+        ws = rt.workspace(B, L)
+        logits = torch.empty(B, dtype=torch.float32, device=rt.device)
+        losses = torch.zeros(2, dtype=torch.float32, device=rt.device)
+        _lib.check(rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
+                                         None, None, _lib.ptr(logits), _lib.ptr(losses), _lib.ptr(ws), ws.numel(), rt.stream()),
+                   "matcha_forward")
+        ctx.rt, ctx.opts, ctx.ws, ctx.x, ctx.seed_t = rt, opts, ws, x, seed_t
+        return logits.view(B, 1), losses[1:2]
+
+    @staticmethod
+    def backward(ctx, dlogits, drecon):
+        rt, opts, x = ctx.rt, ctx.opts, ctx.x
+        B, L = x.shape
+        gflat = torch.zeros(rt.n_flat, dtype=torch.float32, device=rt.device)
+        grads = rt.tensors_for(gflat)
+        touched = torch.zeros(rt.n_touched, dtype=torch.int32, device=rt.device)
+        dl = dlogits.reshape(-1).to(torch.float32).contiguous()
+        dr = drecon.reshape(-1).to(torch.float32).contiguous() if drecon is not None else None
+        _lib.check(rt.lib.matcha_backward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
+                                          None, None, _lib.ptr(dl), _lib.ptr(dr), C.byref(grads), _lib.ptr(touched), _lib.ptr(ctx.ws),
+                                          ctx.ws.numel(), rt.stream()), "matcha_backward")
+        outs = []
+        tl = touched.tolist() if rt.mode == 1 else None      # adj: which per-chromosome tensors have grad None
+        for p, o, g in zip(rt.live, rt.seg_off_list[:-1], rt.seg_group_list):
+            if tl is not None and g >= 2 and tl[g] == 0:
+                outs.append(None)
+            else:
+                outs.append(gflat[o:o + p.numel()].view(p.shape))
+        return (None, None, None, None, *outs)
+
+
+class Classifier(nn.Module):
+    """Hyper-SAGNN hyperedge classifier (reference Modules.py:204-318): same constructor, parameters and call
+    surface; forward = fused gfx950 kernels.  ``model(x)`` returns LOGITS [B,1] (callers apply sigmoid, as in
+    main.py:58 / predict_multiway.py:113)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, node_embedding, diag_mask, bottle_neck, attribute_dict=None, **args):
+        super().__init__()
+        if n_head != _lib.N_HEAD or not (d_model == d_k == d_v == bottle_neck) or not diag_mask:
+            raise NotImplementedError("the HIP path implements the configuration main.py:615-623 builds: "
+                                      "n_head=8, d_model=d_k=d_v=bottle_neck, diag_mask=True")
+        if attribute_dict is None:
+            raise NotImplementedError("attribute_dict is required (main.py:580, :623)")
+        dev = _default_device()
+        self.pff_classifier = PositionwiseFeedForward([d_model, 1], reshape=True, use_bias=True)
+        self.node_embedding = node_embedding
+        self.encode1 = EncoderLayer(n_head, d_model, d_k, d_v, dropout_mul=0.3, dropout_pff=0.4, diag_mask=diag_mask,
+                                    bottle_neck=bottle_neck)
+        self.encode2 = EncoderLayer(n_head, d_model, d_k, d_v, dropout_mul=0.3, dropout_pff=0.4, diag_mask=diag_mask,
+                                    bottle_neck=bottle_neck)       # dead (Modules.py:272 is commented out)
+        self.diag_mask_flag = diag_mask
+        self.layer_norm1 = nn.LayerNorm(d_model)
+        self.layer_norm2 = nn.LayerNorm(d_model)
+        self.next_w = FeedForward([bottle_neck, bottle_neck]).to(dev)
+        table = torch.from_numpy(np.asarray(attribute_dict, dtype=np.float32)).to(dev)
+        self.attribute_dict_embedding = nn.Embedding(len(table), 1, padding_idx=0)
+        self.attribute_dict_embedding.weight = nn.Parameter(table)
+        self.attribute_dict_embedding.weight.requires_grad = False
+        self.attribute_nn = nn.Linear(table.shape[-1], bottle_neck)
+        self.attribute_dict = self.attribute_dict_embedding
+
+    # ---- runtime plumbing ---------------------------------------------------------------------------
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_rt", None)
+        return st
+
+    def _runtime(self) -> _Runtime:
+        rt = self.__dict__.get("_rt")
+        if rt is None or not rt.still_packed() or rt.device != self.layer_norm1.weight.device:
+            rt = _Runtime(self)
+            self.__dict__["_rt"] = rt
+        return rt
+
+    def _dropout_p(self):
+        ne = self.node_embedding
+        p_adj = float(ne.dropout.p) if hasattr(ne, "dropout") and ne.dropout is not None else 0.0
+        mha, pff = self.encode1.mul_head_attn, self.encode1.pff_n1
+        p_fc1 = float(mha.dropout.p) if mha.dropout is not None else 0.0
+        p_pff = float(pff.dropout.p) if pff.dropout is not None else 0.0
+        return p_adj, p_fc1, p_pff
+
+    def _opts(self, rt: _Runtime, return_recon: bool):
+        o = _lib.StepOpts()
+        o.training = 1 if self.training else 0
+        o.p_drop_adj, o.p_drop_fc1, o.p_drop_pff = self._dropout_p()
+        o.alpha, o.beta = 1.0, 1.0
+        o.random_chrom = 0
+        if rt.mode == 1:
+            # the reference draws this from numpy's global generator on EVERY forward, train and eval (Modules.py:192)
+            o.random_chrom = int(np.random.choice(np.arange(rt.n_chrom), 1)[0])
+        seed_t = None
+        if self.training and (o.p_drop_adj > 0 or o.p_drop_fc1 > 0 or o.p_drop_pff > 0):
+            rt.seed_counter += 1
+            seed_t = torch.full((1,), (int(torch.initial_seed()) * 1000003 + rt.seed_counter) & 0x7FFFFFFFFFFFFFFF,
+                                dtype=torch.int64, device=rt.device)
+            o.seed = seed_t.data_ptr()
+        return o, seed_t
+
+    # ---- the reference's call surface -----------------------------------------------------------------
+    def forward(self, x, mask=None, get_outlier=None, return_recon=False):
+        rt = self._runtime()
+        x = torch.as_tensor(x).to(device=rt.device, dtype=torch.long)
+        if x.dim() != 2:
+            raise ValueError("x must be [B, L] node ids (0 = padding)")
+        x = x.contiguous()
+        if x.shape[1] > _lib.MAX_L:
+            raise ValueError(f"hyperedges wider than {_lib.MAX_L} are not supported")
+        opts, seed_t = self._opts(rt, return_recon)
+        logits, recon = _ClassifierFn.apply(x, rt, opts, seed_t, *rt.live)
+        return (logits, recon) if return_recon else logits
+
+    def get_node_embeddings(self, x, return_recon=False):
+        """Rows of the node-embedding front end, [B, L, d] (reference Modules.py:252-259).  Inference surface
+        (main.py:471 save_embeddings); not differentiable here -- training goes through forward()."""
+        rt = self._runtime()
+        x = torch.as_tensor(x).to(device=rt.device, dtype=torch.long).contiguous()
+        sz_b, len_seq = x.shape
+        ids = x.view(-1)
+        out = torch.empty(ids.numel(), rt.d, dtype=torch.float32, device=rt.device)
+        recon = torch.zeros(1, dtype=torch.float32, device=rt.device)
+        ws = None
+        if rt.mode == 1:
+            np.random.choice(np.arange(rt.n_chrom), 1)      # keep numpy's global stream in step with Modules.py:192
+            ws = rt.workspace(sz_b, len_seq)
+        _lib.check(rt.lib.matcha_node_embeddings(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), _lib.ptr(ids), ids.numel(),
+                                                 _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), rt.stream()),
+                   "matcha_node_embeddings")
+        out = out.view(sz_b, len_seq, -1)
+        return (out, recon) if return_recon else out
+
+    def get_embedding(self, x, slf_attn_mask=None, non_pad_mask=None, return_recon=False):
+        raise NotImplementedError("get_embedding's intermediates (dynamic, static, attn) stay on chip in the fused path; "
+                                  "use forward() / get_node_embeddings()")
+
+
+class DataGenerator:
+    """Epoch batch server (reference Modules.py:620-681): bucket hyperedges by size, duplicate each bucket until it
+    holds more than num_batch_per_iter*batch_size rows, shuffle, and hand out that many rows per size per call,
+    wrapping around with a reshuffle.  Host-side numpy, as in the reference; mixed sizes are returned as a
+    zero-padded [M, max_size] int64 array instead of a ragged object array (which numpy >= 1.24 rejects)."""
+
+    def __init__(self, edges, edge_weight, batch_size, num_batch_per_iter, min_size=2, max_size=2, flag=False):
+        self.batch_size, self.num_batch_per_iter = batch_size, num_batch_per_iter
+        self.min_size, self.max_size, self.flag = min_size, max_size, flag
+        per = [[] for _ in range(max_size + 1)]
+        wts = [[] for _ in range(max_size + 1)]
+        for e, w in zip(edges, edge_weight):
+            e = np.asarray(e)
+            e = e[e != 0]
+            per[len(e)].append(e)
+            wts[len(e)].append(w)
+        self.edges = [None] * (max_size + 1)
+        self.edge_weight = [None] * (max_size + 1)
+        need = num_batch_per_iter * batch_size
+        for k in range(min_size, max_size + 1):
+            e = np.asarray(per[k], dtype=np.int64).reshape(-1, k)
+            w = np.asarray(wts[k], dtype=np.float32)
+            while 0 < len(e) <= need:
+                e, w = np.concatenate([e, e]), np.concatenate([w, w])
+            self.edges[k], self.edge_weight[k] = e, w
+            self.shuffle(k)
+        self.pointer = np.zeros(max_size + 1, dtype="int")
+
+    def shuffle(self, k):
+        idx = np.random.permutation(len(self.edges[k]))
+        self.edges[k], self.edge_weight[k] = self.edges[k][idx], self.edge_weight[k][idx]
+
+    def next_iter(self):
+        need = self.num_batch_per_iter * self.batch_size
+        out_e, out_w = [], []
+        for k in range(self.min_size, self.max_size + 1):
+            if len(self.edges[k]) == 0:
+                continue
+            lo = self.pointer[k]
+            self.pointer[k] += need
+            e, w = self.edges[k][lo:self.pointer[k]], self.edge_weight[k][lo:self.pointer[k]]
+            if self.pointer[k] > len(self.edges[k]):
+                self.shuffle(k)
+                left = need - len(e)
+                self.pointer[k] = left
+                e = np.concatenate([e, self.edges[k][:left]])
+                w = np.concatenate([w, self.edge_weight[k][:left]])
+            out_e.append(np.pad(e, ((0, 0), (0, self.max_size - k))))
+            out_w.append(w)
+        return np.concatenate(out_e), np.concatenate(out_w)
+
+
+for _cls in (Classifier, MultipleEmbedding, Wrap_Embedding, SparseEmbedding, TiedAutoEncoder, EncoderLayer, MultiHeadAttention,
+             ScaledDotProductAttention, PositionwiseFeedForward, FeedForward, DataGenerator):
+    _cls.__module__ = _PUBLIC_MODULE

@@ -1,0 +1,115 @@
+"""ctypes binding of libmatcha_hip.so (the C ABI declared in include/matcha_hip.h).
+
+There is no CPU fallback: if the library is missing, every entry point raises.  PyTorch is used by the
+callers only for device memory (``tensor.data_ptr()``) and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmatcha_hip.so")
+
+MAX_L = 8
+N_HEAD = 8
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_TANH, EPI_DROPOUT, EPI_ROWMASK, EPI_RESIDUAL, EPI_DTANH, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+
+_fp = C.c_void_p  # device pointers travel as void*
+
+
+class Shape(C.Structure):
+    _fields_ = [("d", C.c_int32), ("n_attr", C.c_int32), ("n_nodes", C.c_int32), ("n_chrom", C.c_int32),
+                ("mode", C.c_int32), ("max_bins", C.c_int32)]
+
+
+TENSOR_FIELDS = ["table", "adj_w0", "adj_w1", "recon_w", "recon_b", "attr_w", "attr_b", "next_w", "next_b",
+                 "ln_q_g", "ln_q_b", "ln_k_g", "ln_k_b", "ln_v_g", "ln_v_b", "w_q", "w_k", "w_v", "fc1_w", "fc1_b",
+                 "pff0_w", "pff0_b", "pff1_w", "pff1_b", "pff_ln_g", "pff_ln_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                 "cls_w", "cls_b"]
+
+
+class Tensors(C.Structure):
+    _fields_ = [(n, _fp) for n in TENSOR_FIELDS]
+
+
+class Frozen(C.Structure):
+    _fields_ = [("attr_table", _fp), ("bounds", _fp), ("feats", _fp), ("feat_off", _fp), ("inter", _fp),
+                ("bounds_host", _fp)]
+
+
+class StepOpts(C.Structure):
+    _fields_ = [("training", C.c_int32), ("random_chrom", C.c_int32), ("p_drop_adj", C.c_float),
+                ("p_drop_fc1", C.c_float), ("p_drop_pff", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+                ("seed", _fp)]
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("flags", C.c_int32), ("bias", _fp), ("residual", _fp), ("aux", _fp), ("row_ids", _fp), ("seed", _fp),
+                ("stream_id", C.c_int32), ("p_drop", C.c_float), ("aux_scale", C.c_float)]
+
+
+# name -> (restype, argtypes)   -- every symbol include/matcha_hip.h declares
+_I64, _I32, _SZ, _D = C.c_int64, C.c_int32, C.c_size_t, C.c_double
+SIGNATURES = {
+    "matcha_abi_version": (C.c_int, []),
+    "matcha_last_error": (C.c_char_p, []),
+    "matcha_device_count": (C.c_int, []),
+    "matcha_workspace_bytes": (_SZ, [C.POINTER(Shape), _I64, _I32]),
+    "matcha_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,
+                                 _I32, _fp, _fp, _fp, _fp, _fp, _SZ, _fp]),
+    "matcha_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,
+                                  _I32, _fp, _fp, _fp, _fp, C.POINTER(Tensors), _fp, _fp, _SZ, _fp]),
+    "matcha_node_embeddings": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), _fp, _I64, _fp, _fp, _SZ, _fp]),
+    "matcha_adamw_step": (C.c_int, [_fp, _fp, _fp, _fp, _I64, _fp, _I32, _fp, _fp, _fp, _fp, _D, _D, _D, _D, _D, _D, _fp]),
+    "matcha_hashset_bytes": (_SZ, [_I64]),
+    "matcha_hashset_build": (C.c_int, [_fp, _SZ, _fp, _I64, _I32, _fp]),
+    "matcha_hashset_contains": (C.c_int, [_fp, _fp, _I32, _fp, _I64, _I32, _fp, _fp]),
+    "matcha_neg_sample": (C.c_int, [_fp, _fp, _I64, _I32, _fp, _I64, _I32, _I32, _I32, _fp, _fp, _fp, _fp, _fp]),
+    "matcha_gemm_tn_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "matcha_gemm": (C.c_int, [_I32, _fp, _fp, _fp, _I64, _I64, _I64, C.POINTER(GemmEpilogue), _fp, _fp, _fp, _SZ, _fp]),
+    "matcha_embed_fwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _I32, _fp, _fp, _fp, _fp]),
+    "matcha_embed_scatter_bwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp]),
+    "matcha_ln3_fwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "matcha_attn_fwd": (C.c_int, [_fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp]),
+    "matcha_attn_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp, _fp]),
+}
+
+_lib = None
+
+
+class MatchaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmatcha_hip.so once; raise (loudly) when it is absent -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MatchaHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  matcha_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.matcha_abi_version() != 1:
+        raise MatchaHipError("libmatcha_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().matcha_last_error().decode("utf-8", "replace")
+        raise MatchaHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,76 @@
+// Shared device/host helpers for the gfx950 kernels. CDNA4 only: 64-lane wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/matcha_hip.h"
+
+namespace matcha {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define MATCHA_CHECK_ARG(cond, ...)              \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::matcha::set_error(__VA_ARGS__);          \
+      return MATCHA_EINVAL;                      \
+    }                                            \
+  } while (0)
+
+#define MATCHA_CHECK_LAUNCH(name)                                                       \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      ::matcha::set_error("launch of %s failed: %s", name, hipGetErrorString(e__));     \
+      return MATCHA_EHIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define MATCHA_TRY(expr)          \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != MATCHA_OK) return rc__; \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- counter-based RNG: the specification is oracle/rng.py (bit-identical) ---------------------
+__host__ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t rng_key(uint64_t seed, uint32_t stream) {
+  uint32_t k = lowbias32(stream + 0x9E3779B9u);
+  k = lowbias32((uint32_t)(seed >> 32) ^ k);
+  k = lowbias32((uint32_t)(seed & 0xFFFFFFFFu) ^ k);
+  return k;
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint32_t key, uint32_t hi, uint32_t lo) {
+  return lowbias32(lo ^ lowbias32(hi ^ key));
+}
+__host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+constexpr uint32_t kStreamDropAdj = 1, kStreamDropFc1 = 2, kStreamDropPff = 3, kStreamNeg = 16;
+
+// ---- wave-level reductions over groups of 2^k adjacent lanes -----------------------------------
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+}  // namespace matcha

@@ -1,0 +1,59 @@
+// Internal launcher prototypes shared by the translation units of libmatcha_hip.so.
+#pragma once
+#include "common.hpp"
+
+namespace matcha {
+
+struct GemmArgs {
+  const float* A[3];
+  const float* B[3];
+  float* C[3];
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int batch;
+  // epilogue (applied in the order documented in include/matcha_hip.h)
+  int flags;
+  const float* bias[3];
+  const float* residual;
+  const float* aux;
+  const int64_t* row_ids;
+  const uint64_t* seed;
+  uint32_t stream_id;
+  float p_drop;
+  float aux_scale;
+};
+
+struct HeadParams {
+  const float *gp, *bp, *g1, *b1, *g2, *b2, *wc, *bc;
+};
+
+// gemm_f32.hip
+int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st);
+size_t gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t R);
+int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int64_t M, int64_t N, int64_t R, int64_t lda,
+                   int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
+// token_kernels.hip
+int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
+                     int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st);
+int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st);
+int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, float* rows, hipStream_t st);
+int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
+int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const float* bq, const float* gk, const float* bk,
+                   const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st);
+int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const float* dvin, const float* dXs, int64_t T, int d,
+                   const float* gq, const float* gk, const float* gv, float* dZ0, float* slab, float* dgq, float* dbq,
+                   float* dgk, float* dbk, float* dgv, float* dbv, hipStream_t st);
+int launch_head_fwd(const int64_t* x, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
+                    const float* y, const float* w, float* logits, float* row_loss, float* bce_out, hipStream_t st);
+int launch_head_bwd(const int64_t* x, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
+                    const float* y, const float* w, const float* logits, const float* dlogits, float alpha, float* dH2,
+                    float* dXs, float* slab, const HeadParams& ghp, hipStream_t st);
+size_t colsum_slab_bytes(int64_t n, int nv, int d);
+
+// attention.hip
+int launch_attn_fwd(const float* Q, const float* K, const float* V, int64_t B, int L, int d, float* O, float* P, hipStream_t st);
+int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, int64_t B, int L, int d,
+                    float* dQ, float* dK, float* dV, hipStream_t st);
+
+}  // namespace matcha

@@ -1,0 +1,285 @@
+// Orchestration of one classifier step behind the C ABI: Classifier.forward (Modules.py:278-318) and its
+// backward as a fixed sequence of kernel launches on the caller's stream -- no allocation, no host
+// synchronisation, so the whole step is hipGraph-capturable.
+#include <string.h>
+
+#include "kernels.hpp"
+
+namespace matcha {
+
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// adj_frontend.hip
+int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
+                const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st);
+int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
+                 const int64_t* x, int64_t T, const float* dnode, const float* drecon, matcha_tensors& g, int32_t* touched,
+                 void* ws, size_t ws_bytes, hipStream_t st);
+size_t adj_workspace_bytes(const matcha_shape& s, int64_t T);
+
+struct Workspace {
+  // saved by forward
+  float *x0, *X, *qin, *kin, *vin, *stats, *Q, *K, *V, *P, *O, *Y, *H1, *H2, *row_loss, *logits, *node;
+  // backward temporaries
+  float *dH2, *dXs, *dZ1, *ddyn0, *dO, *dQ, *dK, *dV, *dqin, *dkin, *dvin, *dZ0, *dX0;
+  float* slab;      size_t slab_bytes;    // column-sum slabs (LayerNorm / tail parameter gradients)
+  float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
+  void* adj_ws;     size_t adj_ws_bytes;
+  size_t total;
+};
+
+static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
+  const int64_t T = B * L, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
+  size_t off = 0;
+  auto take = [&](size_t n_floats) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += align_up(n_floats * sizeof(float), 256);
+    return p;
+  };
+  w.x0 = take(T * d); w.X = take(T * d);
+  w.qin = take(T * d); w.kin = take(T * d); w.vin = take(T * d);
+  w.stats = take(T * 2);
+  w.Q = take(T * hd); w.K = take(T * hd); w.V = take(T * hd);
+  w.P = take(B * MATCHA_N_HEAD * L * L);
+  w.O = take(T * hd);
+  w.Y = take(T * d); w.H1 = take(T * d); w.H2 = take(T * d);
+  w.row_loss = take(B); w.logits = take(B);
+  w.node = take(s.mode == 1 ? T * d : 0);
+  w.dH2 = take(T * d); w.dXs = take(T * d); w.dZ1 = take(T * d); w.ddyn0 = take(T * d);
+  w.dO = take(T * hd); w.dQ = take(T * hd); w.dK = take(T * hd); w.dV = take(T * hd);
+  w.dqin = take(T * d); w.dkin = take(T * d); w.dvin = take(T * d);
+  w.dZ0 = take(T * d); w.dX0 = take(T * d);
+  size_t sb = colsum_slab_bytes(T, 6, (int)d);
+  const size_t sb2 = colsum_slab_bytes(B, 7, (int)d);
+  if (sb2 > sb) sb = sb2;
+  w.slab_bytes = sb; w.slab = take(sb / sizeof(float));
+  size_t gb = gemm_tn_ws_bytes(hd, d, T);                       // dWq/dWk/dWv
+  size_t g2 = gemm_tn_ws_bytes(d, hd, T); if (g2 > gb) gb = g2; // dfc1
+  g2 = gemm_tn_ws_bytes(d, d, T); if (g2 > gb) gb = g2;
+  g2 = gemm_tn_ws_bytes(d, s.n_attr, T); if (g2 > gb) gb = g2;
+  w.gemm_ws_bytes = gb; w.gemm_ws = take(gb / sizeof(float));
+  w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, T) : 0;
+  w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
+  w.total = off;
+  return off;
+}
+
+static int check_shape(const matcha_shape* s, int64_t B, int32_t L) {
+  MATCHA_CHECK_ARG(s, "null shape");
+  MATCHA_CHECK_ARG(s->d >= 8 && s->d <= 256 && s->d % 8 == 0 && (s->d <= 64 || s->d % 64 == 0),
+                   "embed_dim d=%d unsupported (multiples of 8 up to 64, then 128, 192, 256)", s->d);
+  MATCHA_CHECK_ARG(s->d % 4 == 0, "d must be a multiple of 4");
+  MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L, "L=%d outside 1..%d", L, MATCHA_MAX_L);
+  MATCHA_CHECK_ARG(B >= 1, "B=%lld must be >= 1", (long long)B);
+  MATCHA_CHECK_ARG(s->mode == 0 || s->mode == 1, "mode=%d must be 0 (table) or 1 (adj)", s->mode);
+  MATCHA_CHECK_ARG(s->n_attr >= 1, "n_attr=%d", s->n_attr);
+  return MATCHA_OK;
+}
+
+static GemmArgs gemm1(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, bool b_kn) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A[0] = A; g.B[0] = B; g.C[0] = C; g.batch = 1;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = b_kn ? N : K; g.ldc = N;
+  g.aux_scale = 1.f;
+  return g;
+}
+
+}  // namespace matcha
+
+using namespace matcha;
+
+extern "C" int matcha_abi_version(void) { return MATCHA_ABI_VERSION; }
+extern "C" const char* matcha_last_error(void) { return g_err; }
+extern "C" int matcha_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+extern "C" size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L) {
+  if (check_shape(shp, B, L) != MATCHA_OK) return 0;
+  Workspace w;
+  return carve(*shp, B, L, nullptr, w);
+}
+
+extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                              const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, const float* y,
+                              const float* w_bce, float* logits, float* losses, void* ws, size_t ws_bytes,
+                              matcha_stream_t stream) {
+  MATCHA_TRY(check_shape(shp, B, L));
+  MATCHA_CHECK_ARG(params && frozen && opts && x && ws, "matcha_forward: null pointer");
+  MATCHA_CHECK_ARG(((uintptr_t)ws) % 256 == 0, "matcha_forward: workspace must be 256-byte aligned");
+  const matcha_shape& s = *shp;
+  const matcha_tensors& p = *params;
+  hipStream_t st = (hipStream_t)stream;
+  Workspace w;
+  const size_t need = carve(s, B, L, (char*)ws, w);
+  if (ws_bytes < need) { set_error("matcha_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
+  const int64_t T = B * L;
+  const int d = s.d;
+  const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
+  const bool train = opts->training != 0;
+  MATCHA_CHECK_ARG(!train || opts->seed || (opts->p_drop_adj <= 0 && opts->p_drop_fc1 <= 0 && opts->p_drop_pff <= 0),
+                   "matcha_forward: training with dropout needs opts->seed");
+  MATCHA_CHECK_ARG(frozen->attr_table && p.attr_w && p.attr_b && p.next_w && p.next_b && p.w_q && p.w_k && p.w_v && p.fc1_w &&
+                       p.fc1_b && p.pff0_w && p.pff0_b && p.pff1_w && p.pff1_b && p.pff_ln_g && p.pff_ln_b && p.ln1_g && p.ln1_b &&
+                       p.ln2_g && p.ln2_b && p.cls_w && p.cls_b && p.ln_q_g && p.ln_q_b && p.ln_k_g && p.ln_k_b && p.ln_v_g && p.ln_v_b,
+                   "matcha_forward: a parameter pointer is null");
+
+  // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
+  float* recon_out = losses ? losses + 1 : nullptr;
+  if (s.mode == 0) {
+    MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
+    MATCHA_TRY(launch_embed_fwd(x, T, d, p.table, nullptr, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st));
+    if (recon_out && hipMemsetAsync(recon_out, 0, sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+  } else {
+    MATCHA_TRY(adj_forward(s, p, *frozen, *opts, x, T, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st));
+    MATCHA_TRY(launch_embed_fwd(x, T, d, nullptr, w.node, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st));
+  }
+  // X = tanh(next_w(x0))   (Modules.py:270)
+  {
+    GemmArgs g = gemm1(w.x0, p.next_w, w.X, T, d, d, false);
+    g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
+  MATCHA_TRY(launch_ln3_fwd(w.X, T, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st));
+  {
+    GemmArgs g = gemm1(w.qin, p.w_q, w.Q, T, hd, d, false);
+    g.A[1] = w.kin; g.B[1] = p.w_k; g.C[1] = w.K;
+    g.A[2] = w.vin; g.B[2] = p.w_v; g.C[2] = w.V;
+    g.batch = 3;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  MATCHA_TRY(launch_attn_fwd(w.Q, w.K, w.V, B, L, d, w.O, w.P, st));
+  // Y = (dropout(fc1(O))) * non_pad_mask    (Modules.py:572, :614)
+  {
+    GemmArgs g = gemm1(w.O, p.fc1_w, w.Y, T, d, hd, false);
+    g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_ROWMASK; g.bias[0] = p.fc1_b; g.row_ids = x;
+    if (train && opts->p_drop_fc1 > 0.f) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  // pff_n1: H1 = dropout(tanh(conv0(Y)));  H2 = conv1(H1) + Y      (Modules.py:353-371)
+  {
+    GemmArgs g = gemm1(w.Y, p.pff0_w, w.H1, T, d, d, false);
+    g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.pff0_b;
+    if (train && opts->p_drop_pff > 0.f) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropPff; g.p_drop = opts->p_drop_pff; }
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  {
+    GemmArgs g = gemm1(w.H1, p.pff1_w, w.H2, T, d, d, false);
+    g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_RESIDUAL; g.bias[0] = p.pff1_b; g.residual = w.Y;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  // LayerNorms, (dynamic-static)^2, Conv1d(d->1), masked mean, weighted BCE   (Modules.py:373-374, :290-311; main.py:56)
+  HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
+  MATCHA_TRY(launch_head_fwd(x, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, w.row_loss, losses, st));
+  if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    set_error("logits copy failed"); return MATCHA_EHIP;
+  }
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                               const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, const float* y,
+                               const float* w_bce, const float* dlogits, const float* drecon, matcha_tensors* grads,
+                               int32_t* touched, void* ws, size_t ws_bytes, matcha_stream_t stream) {
+  MATCHA_TRY(check_shape(shp, B, L));
+  MATCHA_CHECK_ARG(params && frozen && opts && x && ws && grads, "matcha_backward: null pointer");
+  MATCHA_CHECK_ARG(dlogits || (y && w_bce), "matcha_backward: need dlogits or (y, w)");
+  const matcha_shape& s = *shp;
+  const matcha_tensors& p = *params;
+  matcha_tensors& g_ = *grads;
+  hipStream_t st = (hipStream_t)stream;
+  Workspace w;
+  const size_t need = carve(s, B, L, (char*)ws, w);
+  if (ws_bytes < need) { set_error("matcha_backward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
+  const int64_t T = B * L;
+  const int d = s.d;
+  const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
+  const bool train = opts->training != 0;
+  const bool drop_fc1 = train && opts->p_drop_fc1 > 0.f, drop_pff = train && opts->p_drop_pff > 0.f;
+
+  // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
+  HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
+  HeadParams ghp = {g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.cls_b};
+  MATCHA_TRY(launch_head_bwd(x, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, dlogits, opts->alpha, w.dH2, w.dXs, w.slab, ghp, st));
+  // pff_n1 conv1: dW1 += dH2^T H1 ; db1 += colsum(dH2) ; dZ1 = (dH2 W1) * dropmask * (1 - tanh^2)
+  MATCHA_TRY(launch_gemm_tn(w.dH2, w.H1, g_.pff1_w, g_.pff1_b, d, d, T, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  {
+    GemmArgs g = gemm1(w.dH2, p.pff1_w, w.dZ1, T, d, d, true);
+    g.flags = MATCHA_EPI_DTANH; g.aux = w.H1;
+    if (drop_pff) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropPff; g.p_drop = opts->p_drop_pff; g.aux_scale = 1.f - opts->p_drop_pff; }
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  // pff_n1 conv0: dW0 += dZ1^T Y ; ddyn0 = (dZ1 W0 + dH2[residual]) * dropmask_fc1 * non_pad
+  MATCHA_TRY(launch_gemm_tn(w.dZ1, w.Y, g_.pff0_w, g_.pff0_b, d, d, T, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  {
+    GemmArgs g = gemm1(w.dZ1, p.pff0_w, w.ddyn0, T, d, d, true);
+    g.flags = MATCHA_EPI_RESIDUAL | MATCHA_EPI_ROWMASK; g.residual = w.dH2; g.row_ids = x;
+    if (drop_fc1) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  // fc1: dW += ddyn0^T O ; db += colsum ; dO = ddyn0 Wfc1
+  MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, g_.fc1_w, g_.fc1_b, d, hd, T, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  {
+    GemmArgs g = gemm1(w.ddyn0, p.fc1_w, w.dO, T, hd, d, true);
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  MATCHA_TRY(launch_attn_bwd(w.Q, w.K, w.V, w.P, w.dO, B, L, d, w.dQ, w.dK, w.dV, st));
+  // Q/K/V projections: dW += dQ^T qin ; dqin = dQ Wq  (batched x3)
+  MATCHA_TRY(launch_gemm_tn(w.dQ, w.qin, g_.w_q, nullptr, hd, d, T, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.dK, w.kin, g_.w_k, nullptr, hd, d, T, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.dV, w.vin, g_.w_v, nullptr, hd, d, T, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  {
+    GemmArgs g = gemm1(w.dQ, p.w_q, w.dqin, T, d, hd, true);
+    g.A[1] = w.dK; g.B[1] = p.w_k; g.C[1] = w.dkin;
+    g.A[2] = w.dV; g.B[2] = p.w_v; g.C[2] = w.dvin;
+    g.batch = 3;
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  // LayerNorm x3 backward + static-branch gradient + tanh'
+  MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, T, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
+                            g_.ln_q_b, g_.ln_k_g, g_.ln_k_b, g_.ln_v_g, g_.ln_v_b, st));
+  // next_w: dW += dZ0^T x0 ; db += colsum ; dX0 = dZ0 Wn
+  MATCHA_TRY(launch_gemm_tn(w.dZ0, w.x0, g_.next_w, g_.next_b, d, d, T, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  {
+    GemmArgs g = gemm1(w.dZ0, p.next_w, w.dX0, T, d, d, true);
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  // attribute_nn: dWa += dX0^T attr_table[x] ; dba += colsum(dX0)
+  MATCHA_TRY(launch_gemm_tn(w.dX0, frozen->attr_table, g_.attr_w, g_.attr_b, d, s.n_attr, T, d, s.n_attr, x, true, w.gemm_ws,
+                            w.gemm_ws_bytes, st));
+  // node embedding
+  if (s.mode == 0) {
+    MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
+    MATCHA_TRY(launch_embed_scatter(x, T, d, w.dX0, g_.table, st));
+    if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
+  } else {
+    MATCHA_TRY(adj_backward(s, p, *frozen, *opts, x, T, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, st));
+  }
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_node_embeddings(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                                      const int64_t* ids, int64_t T, float* rows, void* ws, size_t ws_bytes,
+                                      matcha_stream_t stream) {
+  MATCHA_CHECK_ARG(shp && params && frozen && ids && rows, "matcha_node_embeddings: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (shp->mode == 0) {
+    // Wrap_Embedding: plain row gather (Modules.py:33-34); implemented as embed_fwd with a zero attribute path
+    MATCHA_CHECK_ARG(params->table, "matcha_node_embeddings: null table");
+    return launch_gather_rows(ids, T, shp->d, params->table, rows, st);
+  }
+  matcha_step_opts o;
+  memset(&o, 0, sizeof(o));
+  o.random_chrom = -1;   // no reconstruction branch
+  return adj_forward(*shp, *params, *frozen, o, ids, T, rows, nullptr, ws, ws_bytes, st);
+}

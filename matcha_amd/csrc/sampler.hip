@@ -1,0 +1,196 @@
+// K16: negative sampling (main.py:361-459) on the GPU against an EXACT hash set of the known hyperedges.
+//
+// The reference keeps one Bloom filter per hyperedge size (utils.py:75-97, pybloom_live) and rejects a
+// candidate when `tuple(temp) in filter`.  Here membership is exact: an open-addressing table of int32
+// indices into the (immutable) edge list; a probe compares the candidate with the stored row itself.
+// A zero-padded ascending row [a,b,c,0,...] identifies (k, tuple) uniquely because node ids are >= 1.
+//
+// Randomness is the counter RNG of oracle/rng.py, stream STREAM_NEG; negative n = neg_num*j + i of positive j
+// draws   mask bits   : rand(key, n, 0xFFFF0000 + attempt)  -> low k bits, redrawn while zero
+//                       (each position chosen with prob 1/2, conditioned on >= 1 chosen  ==  the reference's
+//                        Binomial(k, 1/2) != 0 count (main.py:371-372) + uniform choice of positions (:389))
+//         replacement : rand(key, n, 8*trial + position)     -> start + floor(u * (end - start))    (:405-407)
+#include "kernels.hpp"
+
+namespace matcha {
+
+constexpr int kSetHeader = 64;         // int32 words reserved in front of the slots (word 0..1 = capacity)
+constexpr int kMaxTrials = 1 << 16;
+
+__device__ __forceinline__ uint64_t row_hash(const int64_t* __restrict__ row, int L) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < L; ++i) {
+    const uint64_t v = (uint64_t)row[i];
+    if (v == 0) break;
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
+  }
+  return h;
+}
+// rows equal as zero-padded tuples of possibly different widths
+__device__ __forceinline__ bool rows_equal(const int64_t* __restrict__ a, int La, const int64_t* __restrict__ b, int Lb) {
+  const int L = La > Lb ? La : Lb;
+  for (int i = 0; i < L; ++i) {
+    const int64_t va = i < La ? a[i] : 0, vb = i < Lb ? b[i] : 0;
+    if (va != vb) return false;
+    if (va == 0) return true;
+  }
+  return true;
+}
+
+__global__ void hashset_clear_kernel(int32_t* set, int64_t cap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { reinterpret_cast<int64_t*>(set)[0] = cap; }
+  if (i < cap) set[kSetHeader + i] = -1;
+}
+
+__global__ void hashset_insert_kernel(int32_t* set, const int64_t* __restrict__ edges, int64_t n, int L) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t cap = reinterpret_cast<const int64_t*>(set)[0];
+  int32_t* slots = set + kSetHeader;
+  const int64_t* row = edges + i * L;
+  uint64_t pos = row_hash(row, L) & (uint64_t)(cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    const int32_t old = atomicCAS(&slots[pos], -1, (int32_t)i);
+    if (old == -1) return;                                         // inserted
+    if (rows_equal(edges + (int64_t)old * L, L, row, L)) return;   // duplicate row already present
+    pos = (pos + 1) & (uint64_t)(cap - 1);
+  }
+}
+
+__device__ __forceinline__ bool set_contains(const int32_t* __restrict__ set, const int64_t* __restrict__ edges, int L_set,
+                                             const int64_t* row, int L) {
+  const int64_t cap = reinterpret_cast<const int64_t*>(set)[0];
+  const int32_t* slots = set + kSetHeader;
+  uint64_t pos = row_hash(row, L) & (uint64_t)(cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    const int32_t idx = slots[pos];
+    if (idx < 0) return false;
+    if (rows_equal(edges + (int64_t)idx * L_set, L_set, row, L)) return true;
+    pos = (pos + 1) & (uint64_t)(cap - 1);
+  }
+  return false;
+}
+
+__global__ void hashset_contains_kernel(const int32_t* __restrict__ set, const int64_t* __restrict__ edges, int L_set,
+                                        const int64_t* __restrict__ rows, int64_t n, int L, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = set_contains(set, edges, L_set, rows + i * L, L) ? 1 : 0;
+}
+
+// one thread per negative
+__global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restrict__ set, const int64_t* __restrict__ set_edges,
+                                                         int64_t n_set, int L_set, const int64_t* __restrict__ pos, int64_t P,
+                                                         int L, int neg_num, int min_dis, const int32_t* __restrict__ node2chrom,
+                                                         const int32_t* __restrict__ chrom_range, const uint64_t* __restrict__ seed,
+                                                         int64_t* __restrict__ neg) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P * neg_num) return;
+  const int64_t j = n / neg_num;
+  int64_t orig[MATCHA_MAX_L], cand[MATCHA_MAX_L];
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < MATCHA_MAX_L; ++i) {
+    orig[i] = (i < L) ? pos[j * L + i] : 0;
+    if (orig[i] != 0) k = i + 1;
+  }
+  int64_t* out = neg + n * L;
+  // `while neighbor_check(temp, dict)` with temp == the positive on entry (main.py:390-392): if the positive is
+  // not a member (in particular: empty set, the reference's phase 1, main.py:589) the loop never runs.
+  bool resample = (n_set > 0) && (k > 0) && set_contains(set, set_edges, L_set, orig, L);
+  bool done = false;
+  if (resample) {
+    const uint32_t key = rng_key(*seed, kStreamNeg);
+    uint32_t mask = 0;
+    for (uint32_t a = 0; mask == 0; ++a) mask = rng_u32(key, (uint32_t)n, 0xFFFF0000u + a) & ((1u << k) - 1u);
+    for (int trial = 0; trial < kMaxTrials && !done; ++trial) {
+#pragma unroll
+      for (int i = 0; i < MATCHA_MAX_L; ++i) {
+        cand[i] = orig[i];
+        if (i < k && ((mask >> i) & 1u)) {
+          const int c = node2chrom[orig[i]];
+          const int64_t start = chrom_range[2 * c], end = chrom_range[2 * c + 1];
+          const uint32_t r = rng_u32(key, (uint32_t)n, (uint32_t)(8 * trial + i));
+          cand[i] = start + (int64_t)(((uint64_t)r * (uint64_t)(end - start)) >> 32);
+        }
+      }
+      // sort ascending (k <= 8), then reject duplicates / close neighbours / known hyperedges (main.py:410-421, :392)
+#pragma unroll
+      for (int a = 1; a < MATCHA_MAX_L; ++a) {
+        if (a < k) {
+          const int64_t v = cand[a];
+          int b = a - 1;
+          while (b >= 0 && cand[b] > v) { cand[b + 1] = cand[b]; --b; }
+          cand[b + 1] = v;
+        }
+      }
+      bool ok = true;
+      for (int a = 0; a + 1 < k; ++a) {
+        const int64_t gap = cand[a + 1] - cand[a];
+        if (gap == 0 || gap <= min_dis) ok = false;
+      }
+      if (ok && !set_contains(set, set_edges, L_set, cand, L)) done = true;
+    }
+  }
+  for (int i = 0; i < L; ++i) out[i] = done ? cand[i] : orig[i];
+}
+
+}  // namespace matcha
+
+using namespace matcha;
+
+static int64_t set_capacity(int64_t n_edges) {
+  int64_t cap = 1024;
+  while (cap < 2 * n_edges) cap <<= 1;
+  return cap;
+}
+
+extern "C" size_t matcha_hashset_bytes(int64_t n_edges) {
+  return (size_t)(kSetHeader + set_capacity(n_edges < 0 ? 0 : n_edges)) * sizeof(int32_t);
+}
+
+extern "C" int matcha_hashset_build(void* set, size_t set_bytes, const int64_t* edges, int64_t n_edges, int32_t L,
+                                    matcha_stream_t stream) {
+  MATCHA_CHECK_ARG(set && (edges || n_edges == 0), "matcha_hashset_build: null pointer");
+  MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L, "matcha_hashset_build: L=%d", L);
+  MATCHA_CHECK_ARG(n_edges >= 0 && n_edges < (1ll << 31), "matcha_hashset_build: n_edges=%lld", (long long)n_edges);
+  MATCHA_CHECK_ARG(set_bytes >= matcha_hashset_bytes(n_edges), "matcha_hashset_build: set buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t cap = set_capacity(n_edges);
+  hipLaunchKernelGGL(hashset_clear_kernel, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, st, (int32_t*)set, cap);
+  MATCHA_CHECK_LAUNCH("hashset_clear_kernel");
+  if (n_edges > 0) {
+    hipLaunchKernelGGL(hashset_insert_kernel, dim3((unsigned)cdiv(n_edges, 256)), dim3(256), 0, st, (int32_t*)set, edges, n_edges, L);
+    MATCHA_CHECK_LAUNCH("hashset_insert_kernel");
+  }
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_hashset_contains(const void* set, const int64_t* edges, int32_t L_set, const int64_t* rows, int64_t n,
+                                       int32_t L, int32_t* out, matcha_stream_t stream) {
+  MATCHA_CHECK_ARG(set && rows && out, "matcha_hashset_contains: null pointer");
+  MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L && L_set >= 1 && L_set <= MATCHA_MAX_L, "matcha_hashset_contains: bad width");
+  if (n <= 0) return MATCHA_OK;
+  hipLaunchKernelGGL(hashset_contains_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const int32_t*)set,
+                     edges, L_set, rows, n, L, out);
+  MATCHA_CHECK_LAUNCH("hashset_contains_kernel");
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_neg_sample(const void* set, const int64_t* set_edges, int64_t n_set_edges, int32_t L_set,
+                                 const int64_t* pos, int64_t P, int32_t L, int32_t neg_num, int32_t min_dis,
+                                 const int32_t* node2chrom, const int32_t* chrom_range, const uint64_t* seed, int64_t* neg,
+                                 matcha_stream_t stream) {
+  MATCHA_CHECK_ARG(pos && neg && node2chrom && chrom_range && seed, "matcha_neg_sample: null pointer");
+  MATCHA_CHECK_ARG(n_set_edges == 0 || (set && set_edges), "matcha_neg_sample: non-empty set without buffers");
+  MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L && neg_num >= 1, "matcha_neg_sample: L=%d neg_num=%d", L, neg_num);
+  if (P <= 0) return MATCHA_OK;
+  hipLaunchKernelGGL(neg_sample_kernel, dim3((unsigned)cdiv(P * neg_num, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const int32_t*)set, set_edges, n_set_edges, L_set > 0 ? L_set : L, pos, P, L, neg_num, min_dis, node2chrom,
+                     chrom_range, seed, neg);
+  MATCHA_CHECK_LAUNCH("neg_sample_kernel");
+  return MATCHA_OK;
+}

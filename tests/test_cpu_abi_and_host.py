@@ -1,0 +1,159 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/matcha_hip.h declares, the host-side
+mirror keeps the reference's surface (state_dict keys, pickles), and the product path fails loudly -- instead of
+falling back to a CPU implementation -- when there is no GPU tensor.  No compute calls are made here."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import _lib, synth
+from oracle import hypersagnn as O
+from oracle import rng as R
+from tests.helpers import GOLD, gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "matcha_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(matcha_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"libmatcha_hip.so does not export {name}"
+        assert name in _lib.SIGNATURES, f"ctypes binding missing for {name}"
+    assert sorted(_lib.SIGNATURES) == declared
+    assert lib.matcha_abi_version() == 1
+    assert lib.matcha_device_count() >= 0
+
+
+def test_ctypes_structs_match_header_field_order():
+    src = open(os.path.join(ROOT, "include", "matcha_hip.h")).read()
+    body = src[src.index("typedef struct matcha_tensors {"):src.index("} matcha_tensors;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"float\*\s+([a-z0-9_]+);", body)
+    assert fields == _lib.TENSOR_FIELDS
+    import ctypes as C
+    assert C.sizeof(_lib.Shape) == 24 and C.sizeof(_lib.Tensors) == 8 * len(fields)
+
+
+def test_workspace_query_and_argument_errors():
+    lib = _lib.load()
+    import ctypes as C
+    shp = _lib.Shape(64, 24, 3067, 23, 0, 250)
+    small, big = lib.matcha_workspace_bytes(C.byref(shp), 384, 5), lib.matcha_workspace_bytes(C.byref(shp), 768, 5)
+    assert 0 < small < big
+    bad = _lib.Shape(20, 24, 10, 0, 0, 0)          # d=20: unsupported
+    assert lib.matcha_workspace_bytes(C.byref(bad), 4, 3) == 0
+    assert b"embed_dim" in lib.matcha_last_error()
+    assert lib.matcha_workspace_bytes(C.byref(shp), 4, 9) == 0      # L > 8
+    assert lib.matcha_hashset_bytes(1000) >= 4 * 2000
+
+
+def _build(mode):
+    import Modules as M
+    num, d = synth.LAYOUTS["tiny"], 16
+    attr = O.attribute_table(num)
+    N = int(np.sum(num))
+    if mode == "table":
+        ne = M.Wrap_Embedding(N + 1, d, padding_idx=0)
+    else:
+        intra, inter = synth.make_adjacency(np.random.default_rng(1), num)
+        ne = M.MultipleEmbedding(O.corrcoef_features(intra, synth.chrom_range(num)), d, False, torch.as_tensor(np.cumsum(num)),
+                                 synth.chrom_range(num), inter.copy())
+    return M.Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True, bottle_neck=d, attribute_dict=attr)
+
+
+@pytest.mark.parametrize("mode", ["adj", "table"])
+def test_state_dict_surface_matches_reference(mode):
+    ref = gold(f"g1_tiny_{mode}_refinit.npz")
+    clf = _build(mode)
+    sd = clf.state_dict()
+    assert list(sd.keys()) == list(ref.files)                  # names AND registration order
+    for k in ref.files:
+        assert tuple(sd[k].shape) == ref[k].shape, k
+    frozen = [n for n, p in clf.named_parameters() if not p.requires_grad]
+    assert frozen == ["attribute_dict_embedding.weight"]        # Modules.py:247
+    clf.load_state_dict({k: torch.from_numpy(ref[k]) for k in ref.files})      # reference checkpoint keys load
+
+
+def test_inter_zscore_matches_reference_preprocessing():
+    g = gold("g5_tiny_preproc.npz")
+    import Modules as M
+    num = synth.LAYOUTS["tiny"]
+    intra, inter = synth.make_adjacency(np.random.default_rng(11 + 1000), num)
+    ne = M.MultipleEmbedding(O.corrcoef_features(intra, synth.chrom_range(num)), 16, False, torch.as_tensor(np.cumsum(num)),
+                             synth.chrom_range(num), inter.copy())
+    np.testing.assert_allclose(ne.inter_initial.embedding.cpu().numpy(), g["inter_z"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["adj", "table"])
+def test_reference_pickle_unpickles_into_our_classes(mode):
+    import Modules  # noqa: F401
+    clf = torch.load(os.path.join(GOLD, f"ref_model2load_tiny_{mode}"), map_location="cpu", weights_only=False)
+    assert type(clf).__module__ == "Modules" and type(clf).__name__ == "Classifier"
+    from matcha_amd.Modules import Classifier
+    assert isinstance(clf, Classifier)
+    buf = io.BytesIO()
+    torch.save(clf, buf)                                        # and pickles back out under the same GLOBAL names
+    assert b"Modules" in buf.getvalue() and b"matcha_amd" not in buf.getvalue()
+
+
+def test_no_cpu_fallback():
+    """A CPU model must raise, not silently compute on the host."""
+    clf = _build("table").to("cpu")
+    with pytest.raises(_lib.MatchaHipError):
+        clf(torch.tensor([[1, 2, 3]]))
+    with pytest.raises(_lib.MatchaHipError):
+        clf.get_node_embeddings(torch.tensor([[1], [2]]))
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "matcha_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "/root/reference" not in txt or f == "Modules.py", f
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(ROOT, "Modules.py")).read(), flags=re.M)
+
+
+def test_data_generator_contract():
+    """Modules.py:620-681: > num_batch*batch rows per size after duplication, exactly that many per call, wrap."""
+    import Modules as M
+    rng = np.random.default_rng(0)
+    e2, e3 = synth.make_edges(rng, 64, 2, 50), synth.make_edges(rng, 64, 3, 70)
+    edges = [r for r in e2] + [r for r in e3]
+    w = np.arange(len(edges), dtype=np.float32)
+    np.random.seed(0)
+    gen = M.DataGenerator(edges, w, batch_size=8, num_batch_per_iter=10, min_size=2, max_size=3)
+    assert len(gen.edges[2]) > 80 and len(gen.edges[3]) > 80
+    for _ in range(5):
+        e, ww = gen.next_iter()
+        assert e.shape == (160, 3) and ww.shape == (160,)
+        k = (e != 0).sum(1)
+        assert (k[:80] == 2).all() and (k[80:] == 3).all()
+        # weights stay attached to their edges
+        lut = {tuple(r.tolist()): i for i, r in enumerate(edges)}
+        for row, wi in zip(e, ww):
+            assert lut[tuple(row[row != 0].tolist())] == int(wi)
+
+
+def test_rng_spec_is_stable():
+    """Known-answer vectors of the counter RNG (oracle/rng.py == matcha_amd/csrc/common.hpp)."""
+    assert int(R.lowbias32(0)) == 0 and int(R.lowbias32(1)) == 1753845952 and int(R.lowbias32(0xFFFFFFFF)) == 1734902346
+    key = R.make_key(123456789012345, R.STREAM_DROP_FC1)
+    vals = R.rand_u32(key, np.arange(3), np.arange(3))
+    assert vals.dtype == np.uint32 and len(set(vals.tolist())) == 3
+    m = R.dropout_mask(7, R.STREAM_DROP_PFF, 0.4, 2000, 16)
+    assert set(np.unique(m).tolist()) == {0.0, np.float32(1.0) / (np.float32(1.0) - np.float32(0.4))}
+    assert abs(float((m == 0).mean()) - 0.4) < 0.02

@@ -1,0 +1,197 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against plain torch-CPU restatements / the oracle.
+GPU only (-m gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import _lib
+from oracle import rng as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gemm(op, A, B, M, N, K, epi=None, colsum=None, gather=None, C_init=None):
+    lib = _lib.load()
+    out = torch.zeros(M, N, device=DEV) if C_init is None else C_init.clone()
+    ws = None
+    wsn = 0
+    if op == _lib.GEMM_TN:
+        wsn = lib.matcha_gemm_tn_workspace_bytes(M, N, K)
+        ws = torch.empty(wsn, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.matcha_gemm(op, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), M, N, K, None if epi is None else C.byref(epi),
+                               _lib.ptr(colsum), _lib.ptr(gather), _lib.ptr(ws), wsn, _stream()), "matcha_gemm")
+    torch.cuda.synchronize()
+    return out
+
+
+SHAPES = [(128, 64, 64), (1000, 64, 64), (37, 16, 16), (515, 512, 64), (515, 64, 512), (300, 128, 128), (70, 24, 20), (130, 96, 250)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nt_nn(M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.2
+    ref = (A.double() @ W.double().t()).float()
+    out = _gemm(_lib.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K).cpu()
+    assert (out - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
+    Wkn = W.t().contiguous()                       # [K,N]
+    out2 = _gemm(_lib.GEMM_NN, A.to(DEV), Wkn.to(DEV), M, N, K).cpu()
+    assert (out2 - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
+
+
+def test_gemm_unaligned_rows():
+    """K not a multiple of 4 (adj feature rows of n_i floats): the scalar-load path."""
+    M, N, K = 200, 64, 137
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    ref = (A.double() @ W.double().t()).float()
+    out = _gemm(_lib.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K).cpu()
+    assert (out - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("R_,M,N", [(1000, 64, 64), (5000, 512, 64), (777, 64, 512), (333, 16, 16), (4096, 64, 24), (50, 128, 128)])
+def test_gemm_tn(R_, M, N):
+    g = torch.Generator().manual_seed(R_ + M + N)
+    dY, X = torch.randn(R_, M, generator=g), torch.randn(R_, N, generator=g)
+    ref = (dY.double().t() @ X.double()).float()
+    refc = dY.double().sum(0).float()
+    col = torch.zeros(M, device=DEV)
+    out = _gemm(_lib.GEMM_TN, dY.to(DEV), X.to(DEV), M, N, R_, colsum=col).cpu()
+    tol = 3e-5 * max(1.0, ref.abs().max()) * max(1.0, (R_ / 1000) ** 0.5)
+    assert (out - ref).abs().max() <= tol
+    assert (col.cpu() - refc).abs().max() <= tol
+    # accumulate flag + determinism
+    epi = _lib.GemmEpilogue()
+    epi.flags = _lib.EPI_ACCUM
+    base = torch.ones(M, N, device=DEV)
+    out2 = _gemm(_lib.GEMM_TN, dY.to(DEV), X.to(DEV), M, N, R_, epi=epi, C_init=base).cpu()
+    assert (out2 - 1.0 - ref).abs().max() <= tol
+    out3 = _gemm(_lib.GEMM_TN, dY.to(DEV), X.to(DEV), M, N, R_).cpu()
+    assert torch.equal(out, out3)
+
+
+def test_gemm_tn_gather():
+    R_, M, N, NT = 3000, 64, 24, 500
+    g = torch.Generator().manual_seed(9)
+    dY, tab = torch.randn(R_, M, generator=g), torch.randn(NT, N, generator=g)
+    idx = torch.randint(0, NT, (R_,), generator=g)
+    ref = (dY.double().t() @ tab[idx].double()).float()
+    out = _gemm(_lib.GEMM_TN, dY.to(DEV), tab.to(DEV), M, N, R_, gather=idx.to(DEV)).cpu()
+    assert (out - ref).abs().max() <= 5e-5 * max(1.0, ref.abs().max())
+
+
+def test_gemm_epilogues():
+    M, N, K = 300, 64, 64
+    g = torch.Generator().manual_seed(3)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    aux = torch.tanh(torch.randn(M, N, generator=g))
+    ids = torch.randint(0, 3, (M,), generator=g)
+    seed = torch.tensor([123456789012345], dtype=torch.int64)
+    p = 0.3
+    lin = (A.double() @ W.double().t()).float() + bias
+    mask = torch.from_numpy(R.dropout_mask(int(seed[0]), R.STREAM_DROP_FC1, p, M, N))
+    # forward-style: bias, tanh, residual, dropout, rowmask
+    ref = (torch.tanh(lin) + res) * mask * (ids != 0).float()[:, None]
+    epi = _lib.GemmEpilogue()
+    epi.flags = _lib.EPI_BIAS | _lib.EPI_TANH | _lib.EPI_RESIDUAL | _lib.EPI_DROPOUT | _lib.EPI_ROWMASK
+    keep = [bias.to(DEV), res.to(DEV), ids.to(DEV), seed.to(DEV), aux.to(DEV)]
+    epi.bias, epi.residual, epi.row_ids, epi.seed = (t.data_ptr() for t in keep[:4])
+    epi.stream_id, epi.p_drop, epi.aux_scale = R.STREAM_DROP_FC1, p, 1.0
+    out = _gemm(_lib.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K, epi=epi).cpu()
+    assert (out - ref).abs().max() <= 2e-5
+    # the mask itself must be bit-identical to the oracle's: zeros in the same places
+    assert torch.equal((out == 0) | (ids == 0)[:, None], (mask == 0) | (ids == 0)[:, None])
+    # backward-style: dropout (same counter), dtanh with aux_scale
+    epi2 = _lib.GemmEpilogue()
+    epi2.flags = _lib.EPI_DROPOUT | _lib.EPI_DTANH
+    epi2.seed, epi2.aux = keep[3].data_ptr(), keep[4].data_ptr()
+    epi2.stream_id, epi2.p_drop, epi2.aux_scale = R.STREAM_DROP_FC1, p, 0.7
+    ref2 = (A.double() @ W.double().t()).float() * mask * (1 - (aux * 0.7) ** 2)
+    out2 = _gemm(_lib.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K, epi=epi2).cpu()
+    assert (out2 - ref2).abs().max() <= 2e-5 * max(1.0, ref2.abs().max())
+
+
+def _attn_ref(Q, K, V, B, L, d):
+    H = _lib.N_HEAD
+    q = Q.view(B, L, H, d).permute(0, 2, 1, 3)
+    k = K.view(B, L, H, d).permute(0, 2, 1, 3)
+    v = V.view(B, L, H, d).permute(0, 2, 1, 3)
+    s = q @ k.transpose(-1, -2) / np.sqrt(d)
+    s = s.masked_fill(torch.eye(L, dtype=torch.bool), -1e32)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * L, H * d)
+    return o, p
+
+
+@pytest.mark.parametrize("d", [16, 64, 128])
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 7, 8])
+def test_attention_fwd_bwd(d, L):
+    lib = _lib.load()
+    B, H = 37, _lib.N_HEAD
+    g = torch.Generator().manual_seed(d * 10 + L)
+    Q, K, V = (torch.randn(B * L, H * d, generator=g).requires_grad_(True) for _ in range(3))
+    o_ref, p_ref = _attn_ref(Q, K, V, B, L, d)
+    dO = torch.randn(B * L, H * d, generator=g)
+    o_ref.backward(dO)
+    Qd, Kd, Vd, dOd = (t.detach().to(DEV) for t in (Q, K, V, dO))
+    O = torch.empty_like(Qd)
+    P = torch.empty(B, H, L, L, device=DEV)
+    _lib.check(lib.matcha_attn_fwd(_lib.ptr(Qd), _lib.ptr(Kd), _lib.ptr(Vd), B, L, d, _lib.ptr(O), _lib.ptr(P), _stream()))
+    dQ, dK, dV = (torch.empty_like(Qd) for _ in range(3))
+    _lib.check(lib.matcha_attn_bwd(_lib.ptr(Qd), _lib.ptr(Kd), _lib.ptr(Vd), _lib.ptr(P), _lib.ptr(dOd), B, L, d, _lib.ptr(dQ),
+                                   _lib.ptr(dK), _lib.ptr(dV), _stream()))
+    torch.cuda.synchronize()
+    assert (O.cpu() - o_ref.detach()).abs().max() <= 2e-5 * max(1.0, o_ref.abs().max())
+    assert (P.cpu() - p_ref.detach()).abs().max() <= 1e-5
+    for got, ref in ((dQ, Q.grad), (dK, K.grad), (dV, V.grad)):
+        assert (got.cpu() - ref).abs().max() <= 3e-5 * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("d", [16, 64, 128, 256])
+def test_embed_and_ln3(d):
+    lib = _lib.load()
+    T, N, n_attr = 1000, 300, 24
+    g = torch.Generator().manual_seed(d)
+    table = torch.randn(N + 1, d, generator=g)
+    table[0] = 0
+    attr = torch.randn(N + 1, n_attr, generator=g)
+    attr[0] = 0
+    Wa, ba = torch.randn(d, n_attr, generator=g) * 0.2, torch.randn(d, generator=g)
+    x = torch.randint(0, N + 1, (T,), generator=g)
+    ref = table[x] + attr[x] @ Wa.t() + ba
+    dev = [t.to(DEV) for t in (x, table, attr, Wa, ba)]
+    x0 = torch.empty(T, d, device=DEV)
+    _lib.check(lib.matcha_embed_fwd(_lib.ptr(dev[0]), T, d, _lib.ptr(dev[1]), None, _lib.ptr(dev[2]), n_attr, _lib.ptr(dev[3]),
+                                    _lib.ptr(dev[4]), _lib.ptr(x0), _stream()))
+    torch.cuda.synchronize()
+    assert (x0.cpu() - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max())
+    # scatter-add backward (padding row untouched)
+    dx0 = torch.randn(T, d, generator=g)
+    dtab = torch.zeros(N + 1, d, device=DEV)
+    _lib.check(lib.matcha_embed_scatter_bwd(_lib.ptr(dev[0]), T, d, _lib.ptr(dx0.to(DEV)), _lib.ptr(dtab), _stream()))
+    torch.cuda.synchronize()
+    refg = torch.zeros(N + 1, d).index_add_(0, x, dx0)
+    refg[0] = 0
+    assert (dtab.cpu() - refg).abs().max() <= 1e-4
+    assert float(dtab[0].abs().max()) == 0.0
+    # LayerNorm x3
+    X = torch.randn(T, d, generator=g)
+    gb = [torch.randn(d, generator=g) for _ in range(6)]
+    outs = [torch.empty(T, d, device=DEV) for _ in range(3)]
+    stats = torch.empty(T, 2, device=DEV)
+    gbd = [t.to(DEV) for t in gb]
+    _lib.check(lib.matcha_ln3_fwd(_lib.ptr(X.to(DEV)), T, d, *[_lib.ptr(t) for t in gbd], *[_lib.ptr(t) for t in outs],
+                                  _lib.ptr(stats), _stream()))
+    torch.cuda.synchronize()
+    for i in range(3):
+        ref = torch.nn.functional.layer_norm(X, (d,), gb[2 * i], gb[2 * i + 1], 1e-5)
+        assert (outs[i].cpu() - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())

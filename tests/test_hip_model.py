@@ -1,0 +1,257 @@
+"""Model-level parity of the HIP path: Modules.Classifier (C ABI underneath) against the golden fixtures of the
+real reference and against the oracle on the same seeded inputs.  GPU only (-m gpu)."""
+import ctypes as C
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import synth, _lib
+from oracle import hypersagnn as O
+from oracle import rng as R
+from tests.helpers import GOLD, gold, oracle_state, rel_err, front_end
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4     # north_star: <= 1e-4 rel fp32
+GAUGE = "encode1.mul_head_attn.layer_norm2.bias"    # see tests/test_oracle_golden.py
+
+
+def hip_model(num, d, mode, seed):
+    """Our Modules.Classifier on cuda:0 with the deterministic synthetic weights."""
+    import Modules as M
+    attr = O.attribute_table(num)
+    sd = synth.make_state_dict(np.random.default_rng(seed), num, d, mode, attr)
+    N = int(np.sum(num))
+    if mode == "table":
+        ne = M.Wrap_Embedding(N + 1, d, padding_idx=0)
+    else:
+        intra, inter = synth.make_adjacency(np.random.default_rng(seed + 1000), num)
+        feats = O.corrcoef_features(intra, synth.chrom_range(num))
+        ne = M.MultipleEmbedding(feats, d, False, torch.as_tensor(np.cumsum(num)), synth.chrom_range(num), inter.copy())
+    clf = M.Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True, bottle_neck=d, attribute_dict=attr)
+    res = clf.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return clf.to("cuda"), sd
+
+
+def test_state_dict_keys_match_reference():
+    """Every key (and shape) of the reference's Classifier.state_dict(), G1."""
+    for mode in ("adj", "table"):
+        ref = gold(f"g1_tiny_{mode}_refinit.npz")
+        clf, _ = hip_model(synth.LAYOUTS["tiny"], 16, mode, 1)
+        mine = clf.state_dict()
+        assert list(mine.keys()) == list(ref.files)
+        for k in ref.files:
+            assert tuple(mine[k].shape) == ref[k].shape, k
+
+
+TABLE_CASES = [("tiny_table", "tiny", 16, 22), ("hg38_table_d64", "hg38_1mb", 64, 24)]
+
+
+@pytest.mark.parametrize("name,layout,d,seed", TABLE_CASES)
+def test_g2_eval_logits_table(name, layout, d, seed):
+    g = gold(f"g2_{name}.npz")
+    clf, _ = hip_model(synth.LAYOUTS[layout], d, "table", seed)
+    clf.eval()
+    with torch.no_grad():
+        for k in (2, 3, 4, 5):
+            x = torch.from_numpy(g[f"x_k{k}"])
+            lg = clf(x).cpu().numpy()
+            assert lg.shape == (len(x), 1)
+            assert rel_err(lg, g[f"logits_k{k}"]) < TOL, k
+            lg5 = clf(torch.nn.functional.pad(x, (0, 5 - k))).cpu().numpy()
+            assert rel_err(lg5, g[f"logits_k{k}_L5"]) < TOL, k     # pad slots are attended (fact 7)
+        lg, rc = clf(torch.from_numpy(g["x_mixed"]), return_recon=True)
+        assert rel_err(lg.cpu().numpy(), g["logits_mixed"]) < TOL
+        assert float(rc.cpu()[0]) == 0.0
+
+
+def test_reference_pickle_loads_and_runs_table():
+    """torch.load of a model2load written by the REFERENCE (main.py:322) -> our classes -> HIP forward."""
+    import Modules  # noqa: F401  (the pickle's GLOBALs are Modules.*)
+    out = gold("g1_tiny_table_refinit_out.npz")
+    clf = torch.load(os.path.join(GOLD, "ref_model2load_tiny_table"), map_location="cuda", weights_only=False)
+    assert type(clf).__module__ == "Modules" and type(clf).__name__ == "Classifier"
+    clf.eval()
+    with torch.no_grad():
+        lg = clf(torch.from_numpy(out["x"]))
+    assert rel_err(lg.cpu().numpy(), out["logits"]) < TOL
+    assert clf.layer_norm1.weight.device.type == "cuda"       # denoise_contact.py:101 reads this
+    # round trip through our own torch.save / torch.load
+    buf = io.BytesIO()
+    torch.save(clf, buf)
+    buf.seek(0)
+    clf2 = torch.load(buf, map_location="cuda", weights_only=False)
+    with torch.no_grad():
+        lg2 = clf2(torch.from_numpy(out["x"]))
+    assert torch.equal(lg.cpu(), lg2.cpu())
+    # checkpoint file of the reference (main.py:316-321) loads by key
+    ck = torch.load(os.path.join(GOLD, "ref_model_chkpt_tiny_table"), map_location="cpu", weights_only=False)
+    clf2.load_state_dict(ck["model_link"])
+
+
+def _train_g3(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused):
+    g = gold(f"g3_{name}_{tag}.npz")
+    num = synth.LAYOUTS[layout]
+    clf, sd = hip_model(num, d, "table", seed)
+    for m in clf.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    clf.eval()
+    N = int(np.sum(num))
+    with torch.no_grad():
+        emb0 = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
+    np.testing.assert_allclose(emb0 if full else emb0[::16], g["emb_before"], rtol=0, atol=1e-6)
+    clf.train()
+    if use_fused:
+        from matcha_amd.engine import Trainer
+        tr = Trainer(clf, lr=1e-3)
+    else:
+        opt = torch.optim.AdamW(list(clf.parameters()), lr=1e-3, amsgrad=False)     # exactly main.py:630
+    none_ref = set(g["grad_none"].tolist()) - {"attribute_dict_embedding.weight"}
+    for step in range(n_steps):
+        x, y, w = (torch.from_numpy(g[f"{n}{step}"]).cuda() for n in "xyw")
+        if use_fused:
+            bce, recon, logits = tr.step(x, y, w, alpha=alpha, beta=beta)
+            logits = logits.view(-1, 1)
+        else:
+            logits, recon = clf(x, return_recon=True)
+            bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, y, weight=w)
+            loss = bce * alpha + recon * beta
+            opt.zero_grad()
+            loss.backward()
+            if step == 0:
+                grads = {n: p.grad for n, p in clf.named_parameters()}
+                assert {n for n, v in grads.items() if v is None} - {"attribute_dict_embedding.weight"} == none_ref
+                for n, v in grads.items():
+                    if v is None or n == GAUGE:
+                        continue
+                    if full:
+                        ref = g["grad0/" + n]
+                        assert np.abs(v.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+                    else:
+                        gn = float(g["gradnorm0/" + n])
+                        assert abs(float(v.double().norm()) - gn) <= TOL * max(gn, 1e-3), n
+            opt.step()
+        assert rel_err(logits.detach().cpu().numpy(), g[f"logits{step}"]) < TOL, step
+        assert abs(float(bce) - float(g[f"bce{step}"])) < TOL * max(1.0, abs(float(g[f"bce{step}"])))
+        if step in (0, n_steps - 1):
+            params = dict(clf.named_parameters())
+            for key in g.files:
+                if key.startswith(f"param{step}/"):
+                    n = key.split("/", 1)[1]
+                    if n == GAUGE:
+                        continue
+                    ref = g[key]
+                    assert np.abs(params[n].detach().cpu().numpy() - ref).max() <= 2 * TOL * max(np.abs(ref).max(), 1e-3), (step, n)
+    clf.eval()
+    with torch.no_grad():
+        emb1 = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
+    ref = g["emb_after"]
+    mine = emb1 if full else emb1[::16]
+    assert np.abs(mine - ref).max() <= TOL * max(1.0, np.abs(ref).max())          # final embeddings (embeddings.npy)
+
+
+@pytest.mark.parametrize("use_fused", [False, True])
+@pytest.mark.parametrize("tag,alpha,beta", [("phase1", 0.0, 1.0), ("phase2", 1.0, 0.001)])
+def test_g3_training_tiny_table(tag, alpha, beta, use_fused):
+    _train_g3("tiny_table", "tiny", 16, 31, alpha, beta, tag, 10, True, use_fused)
+
+
+@pytest.mark.parametrize("use_fused", [False, True])
+def test_g3_training_hg38_table_d64(use_fused):
+    _train_g3("hg38_table_d64", "hg38_1mb", 64, 41, 1.0, 0.001, "phase2", 3, False, use_fused)
+
+
+@pytest.mark.parametrize("d,layout", [(32, "tiny"), (128, "c1")])
+def test_backward_matches_oracle_other_dims(d, layout):
+    """Gradients for embed dims the golden files do not cover (oracle autograd on the same inputs)."""
+    num = synth.LAYOUTS[layout]
+    clf, _ = hip_model(num, d, "table", 77)
+    P, fe, _ = oracle_state(num, d, "table", 77, requires_grad=True)
+    clf.eval()
+    x, y, w = synth.make_batch(np.random.default_rng(3), int(np.sum(num)), [2, 3, 5], 20)
+    xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
+    loss, bce, recon, logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, 1.0, 0.0)
+    lg = clf(xt)
+    l2 = torch.nn.functional.binary_cross_entropy_with_logits(lg, yt.cuda(), weight=wt.cuda())
+    l2.backward()
+    assert rel_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
+    for n, p in clf.named_parameters():
+        if grads.get(n) is None or n == GAUGE:
+            assert p.grad is None or n == GAUGE or not p.requires_grad
+            continue
+        ref = grads[n].numpy()
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+
+
+def test_training_dropout_masks_match_oracle_rng():
+    """Train-mode forward: the kernels' dropout masks are the counter-RNG of oracle/rng.py, bit for bit, so the
+    oracle with the same (injected) masks reproduces the logits."""
+    num = synth.LAYOUTS["tiny"]
+    d = 16
+    clf, _ = hip_model(num, d, "table", 5)
+    P, fe, _ = oracle_state(num, d, "table", 5)
+    clf.train()
+    x, _, _ = synth.make_batch(np.random.default_rng(4), int(np.sum(num)), [2, 4, 5], 16)
+    xt = torch.from_numpy(x)
+    rt = clf._runtime()
+    with torch.no_grad():
+        lg = clf(xt).cpu().numpy()
+    seed = (int(torch.initial_seed()) * 1000003 + rt.seed_counter) & 0x7FFFFFFFFFFFFFFF
+    T = x.size
+    masks = {"fc1": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_FC1, O.P_DROP_FC1, T, d)),
+             "pff": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_PFF, O.P_DROP_PFF, T, d))}
+    with torch.no_grad():
+        ref, _ = O.classifier_forward(P, fe, xt, masks=masks)
+    assert rel_err(lg, ref.numpy()) < TOL
+    # and the masks have the right rate
+    assert abs(float((masks["fc1"] == 0).float().mean()) - 0.3) < 0.05
+    assert abs(float((masks["pff"] == 0).float().mean()) - 0.4) < 0.05
+
+
+def test_adamw_fused_vs_torch():
+    """matcha_adamw_step against torch.optim.AdamW (what main.py:630 builds), with a segment that is skipped on
+    some steps (grad None -> no decay, no step increment)."""
+    lib = _lib.load()
+    sizes = [64, 7, 1000, 13, 4096]
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + (s + 3) // 4 * 4)
+    n = offs[-1]
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    params = [p0[offs[i]:offs[i] + sizes[i]].clone().requires_grad_(True) for i in range(len(sizes))]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    flat = p0.clone().cuda()
+    grad = torch.zeros(n, device="cuda")
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    seg_off = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    seg_group = torch.tensor([0, 0, 1, 0, 2], dtype=torch.int32, device="cuda")
+    seg_step = torch.zeros(len(sizes), dtype=torch.int32, device="cuda")
+    coef = torch.zeros(3 * len(sizes), device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in range(25):
+        touched = [1, 1 if step % 3 != 1 else 0, 1 if step % 2 == 0 else 0]
+        tt = torch.tensor(touched, dtype=torch.int32, device="cuda")
+        grad.zero_()
+        for i, p in enumerate(params):
+            if touched[int(seg_group[i])]:
+                gi = torch.randn(sizes[i], generator=g) * (10.0 ** (i - 2))
+                p.grad = gi.clone()
+                grad[offs[i]:offs[i] + sizes[i]] = gi.cuda()
+            else:
+                p.grad = None
+        opt.step()
+        _lib.check(lib.matcha_adamw_step(_lib.ptr(flat), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), n, _lib.ptr(seg_off), len(sizes),
+                                         _lib.ptr(seg_group), _lib.ptr(tt), _lib.ptr(seg_step), _lib.ptr(coef), 1e-3, 0.9, 0.999, 1e-8,
+                                         1e-2, 1.0, st))
+        torch.cuda.synchronize()
+        assert float(grad.abs().max()) == 0.0          # zero_grad fused
+    got = flat.cpu()
+    for i, p in enumerate(params):
+        ref = p.detach()
+        assert (got[offs[i]:offs[i] + sizes[i]] - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())), i
