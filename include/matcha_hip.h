@@ -43,6 +43,29 @@ const char* matcha_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box; never fails) */
 int matcha_device_count(void);
 
+/* Optional live timing of ONE kernel class with HIP events recorded on the launch stream (used by bench.py
+ * for the roofline of the dominant kernel, inside the timed region).  select(0) switches it off.  read()
+ * synchronises on the recorded events and returns the summed duration [ms], the number of launches and the
+ * summed algorithmic work (FLOP for the GEMM classes, bytes otherwise), then clears the accumulators.
+ * Process-global, single-threaded use; do not use while a stream capture is active. */
+#define MATCHA_PROF_GEMM_NT 1
+#define MATCHA_PROF_GEMM_NN 2
+#define MATCHA_PROF_GEMM_TN 3
+#define MATCHA_PROF_ATTN_FWD 4
+#define MATCHA_PROF_ATTN_BWD 5
+#define MATCHA_PROF_EMBED_FWD 6
+#define MATCHA_PROF_EMBED_SCATTER 7
+#define MATCHA_PROF_LN3_FWD 8
+#define MATCHA_PROF_LN3_BWD 9
+#define MATCHA_PROF_HEAD_FWD 10
+#define MATCHA_PROF_HEAD_BWD 11
+#define MATCHA_PROF_ADAMW 12
+#define MATCHA_PROF_NEG_SAMPLE 13
+#define MATCHA_PROF_ADJ_ENCODE 14
+#define MATCHA_PROF_GATHER_ROWS 15
+int matcha_profile_select(int32_t kernel_class);
+int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
+
 /* ------------------------------------------------------------------------------------------
  * Model description: shapes + one pointer per LIVE tensor of the reference's
  * Classifier.state_dict() (Modules.py:204-249).  The same struct type carries parameters

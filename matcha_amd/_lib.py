@@ -17,6 +17,9 @@ N_HEAD = 8
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_TANH, EPI_DROPOUT, EPI_ROWMASK, EPI_RESIDUAL, EPI_DTANH, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
+PROF = dict(gemm_nt=1, gemm_nn=2, gemm_tn=3, attn_fwd=4, attn_bwd=5, embed_fwd=6, embed_scatter=7, ln3_fwd=8, ln3_bwd=9,
+            head_fwd=10, head_bwd=11, adamw=12, neg_sample=13, adj_encode=14, gather_rows=15)
+
 _fp = C.c_void_p  # device pointers travel as void*
 
 
@@ -57,6 +60,8 @@ SIGNATURES = {
     "matcha_abi_version": (C.c_int, []),
     "matcha_last_error": (C.c_char_p, []),
     "matcha_device_count": (C.c_int, []),
+    "matcha_profile_select": (C.c_int, [_I32]),
+    "matcha_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "matcha_workspace_bytes": (_SZ, [C.POINTER(Shape), _I64, _I32]),
     "matcha_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,
                                  _I32, _fp, _fp, _fp, _fp, _fp, _SZ, _fp]),

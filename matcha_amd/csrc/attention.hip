@@ -8,10 +8,9 @@
 // Parity notes (SURVEY.md headline fact 7): only the DIAGONAL is masked (-1e32, Modules.py:443-445 with the
 // cached eye-complement :540-556); the key-pad mask never reaches the softmax (call bug :612 vs :513), so pad
 // slots are ordinary keys and values.  The kernel therefore needs no node ids at all.
-#include "common.hpp"
+#include "kernels.hpp"
 
 namespace matcha {
-
 
 template <int CH>
 struct Chunk {
@@ -266,6 +265,8 @@ int launch_attn_fwd(const float* Q, const float* K, const float* V, int64_t B, i
   if (B <= 0) return MATCHA_OK;
   const float inv_temp = 1.0f / sqrtf((float)d);
   dim3 grid((unsigned)cdiv(B, 4));
+  // algorithmic bytes: read Q,K,V, write O (+P)
+  ProfScope ps(MATCHA_PROF_ATTN_FWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 4.0 + (double)B * MATCHA_N_HEAD * L * L), st);
   ATTN_DISPATCH(attn_fwd_kernel, Q, K, V, B, L, d, inv_temp, O, P);
   MATCHA_CHECK_LAUNCH("attn_fwd_kernel");
   return MATCHA_OK;
@@ -276,6 +277,8 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
   if (B <= 0) return MATCHA_OK;
   const float inv_temp = 1.0f / sqrtf((float)d);
   dim3 grid((unsigned)cdiv(B, 4));
+  // algorithmic bytes: read Q,K,V,dO (+P), write dQ,dK,dV
+  ProfScope ps(MATCHA_PROF_ATTN_BWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 7.0 + (double)B * MATCHA_N_HEAD * L * L), st);
   ATTN_DISPATCH(attn_bwd_kernel, Q, K, V, P, dO, B, L, d, inv_temp, dQ, dK, dV);
   MATCHA_CHECK_LAUNCH("attn_bwd_kernel");
   return MATCHA_OK;

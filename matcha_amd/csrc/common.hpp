@@ -36,6 +36,17 @@ void set_error(const char* fmt, ...);
     if (rc__ != MATCHA_OK) return rc__; \
   } while (0)
 
+// Optional per-kernel-class timing with HIP events on the launch stream (matcha_profile_select/_read):
+// bench.py uses it to time the dominant kernel live, inside the timed region.  Off by default (one branch).
+extern int g_prof_class;
+void prof_record(bool start, double work, hipStream_t st);
+struct ProfScope {
+  bool on;
+  hipStream_t st;
+  ProfScope(int cls, double work, hipStream_t s) : on(cls == g_prof_class), st(s) { if (on) prof_record(true, work, st); }
+  ~ProfScope() { if (on) prof_record(false, 0.0, st); }
+};
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -265,6 +265,7 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
     for (int z = 0; z < g.batch; ++z) vec = vec && (((uintptr_t)g.B[z]) % 16 == 0);
   }
   dim3 grid((unsigned)cdiv(g.N, 64), (unsigned)cdiv(g.M, 128), (unsigned)g.batch);
+  ProfScope ps(b_kn ? MATCHA_PROF_GEMM_NN : MATCHA_PROF_GEMM_NT, 2.0 * (double)g.M * (double)g.N * (double)g.K * g.batch, st);
   if (b_kn) {
     if (vec) hipLaunchKernelGGL((gemm_rm_kernel<true, true>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_rm_kernel<true, false>), grid, dim3(256), 0, st, g);
@@ -296,7 +297,10 @@ int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int6
   g.slab = (float*)ws;
   g.colslab = colsum ? (float*)ws + (size_t)P * M * N : nullptr;
   g.M = M; g.N = N; g.R = R; g.lda = lda; g.ldb = ldb; g.rows_per_block = rpb; g.tiles_n = tn;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tm * tn, P), dim3(256), 0, st, g);
+  {
+    ProfScope ps(MATCHA_PROF_GEMM_TN, 2.0 * (double)M * (double)N * (double)R, st);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tm * tn, P), dim3(256), 0, st, g);
+  }
   MATCHA_CHECK_LAUNCH("gemm_tn_kernel");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(M * N, 256)), dim3(256), 0, st, g.slab, C, M * N, P, accumulate ? 1 : 0);
   MATCHA_CHECK_LAUNCH("slab_reduce_kernel");

@@ -15,6 +15,30 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- per-kernel-class event timing -------------------------------------------------------------------
+int g_prof_class = 0;
+static hipEvent_t* g_prof_ev = nullptr;     // pairs (start, stop)
+static int g_prof_cap = 0, g_prof_used = 0;
+static double g_prof_work = 0.0;
+void prof_record(bool start, double work, hipStream_t st) {
+  if (start) {
+    if (g_prof_used + 2 > g_prof_cap) {
+      const int ncap = g_prof_cap ? 2 * g_prof_cap : 1024;
+      hipEvent_t* ne = (hipEvent_t*)realloc(g_prof_ev, sizeof(hipEvent_t) * ncap);
+      if (!ne) return;
+      g_prof_ev = ne;
+      for (int i = g_prof_cap; i < ncap; ++i)
+        if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) { g_prof_cap = i & ~1; return; }
+      g_prof_cap = ncap;
+    }
+    g_prof_work += work;
+    (void)hipEventRecord(g_prof_ev[g_prof_used], st);
+  } else if (g_prof_used + 1 < g_prof_cap) {
+    (void)hipEventRecord(g_prof_ev[g_prof_used + 1], st);
+    g_prof_used += 2;
+  }
+}
+
 // adj_frontend.hip
 int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
                 const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st);
@@ -101,6 +125,29 @@ extern "C" int matcha_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
+}
+
+extern "C" int matcha_profile_select(int32_t kernel_class) {
+  g_prof_class = kernel_class;
+  g_prof_used = 0;
+  g_prof_work = 0.0;
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_profile_read(double* total_ms, int64_t* launches, double* work) {
+  double ms = 0.0;
+  for (int i = 0; i + 1 < g_prof_used; i += 2) {
+    if (hipEventSynchronize(g_prof_ev[i + 1]) != hipSuccess) { set_error("matcha_profile_read: event sync failed"); return MATCHA_EHIP; }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof_ev[i], g_prof_ev[i + 1]) != hipSuccess) { set_error("matcha_profile_read: elapsed failed"); return MATCHA_EHIP; }
+    ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = g_prof_used / 2;
+  if (work) *work = g_prof_work;
+  g_prof_used = 0;
+  g_prof_work = 0.0;
+  return MATCHA_OK;
 }
 
 extern "C" size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L) {

@@ -188,6 +188,7 @@ extern "C" int matcha_neg_sample(const void* set, const int64_t* set_edges, int6
   MATCHA_CHECK_ARG(n_set_edges == 0 || (set && set_edges), "matcha_neg_sample: non-empty set without buffers");
   MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L && neg_num >= 1, "matcha_neg_sample: L=%d neg_num=%d", L, neg_num);
   if (P <= 0) return MATCHA_OK;
+  ProfScope ps(MATCHA_PROF_NEG_SAMPLE, (double)P * L * 8.0 * (1.0 + neg_num), (hipStream_t)stream);
   hipLaunchKernelGGL(neg_sample_kernel, dim3((unsigned)cdiv(P * neg_num, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const int32_t*)set, set_edges, n_set_edges, L_set > 0 ? L_set : L, pos, P, L, neg_num, min_dis, node2chrom,
                      chrom_range, seed, neg);

@@ -487,6 +487,8 @@ int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, con
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st) {
   if (T <= 0) return MATCHA_OK;
   dim3 grid((unsigned)cdiv(T, 16));
+  // algorithmic bytes per token: index 8 + embedding row 4d + attribute row 4*n_attr read, x0 row 4d written
+  ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)T * (8.0 + 4.0 * d + 4.0 * n_attr + 4.0 * d), st);
   DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, T, d, table, dense, attr_table, n_attr, Wa, ba, x0));
   MATCHA_CHECK_LAUNCH("embed_fwd_kernel");
   return MATCHA_OK;
@@ -495,6 +497,8 @@ int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, con
 int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, float* rows, hipStream_t st) {
   if (T <= 0) return MATCHA_OK;
   dim3 grid((unsigned)cdiv(T, 16));
+  // gather read bytes = 4d + 8 per row (+ 4d written because the rows are materialised here)
+  ProfScope ps(MATCHA_PROF_GATHER_ROWS, (double)T * (8.0 + 8.0 * d), st);
   DISPATCH_NCH(d, hipLaunchKernelGGL((gather_rows_kernel<NCH>), grid, dim3(256), 0, st, ids, T, d, table, rows));
   MATCHA_CHECK_LAUNCH("gather_rows_kernel");
   return MATCHA_OK;
@@ -509,6 +513,7 @@ int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
 
 int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st) {
   if (T <= 0) return MATCHA_OK;
+  ProfScope ps(MATCHA_PROF_EMBED_SCATTER, (double)T * (8.0 + 8.0 * d), st);   // read dx0 row + index, add 4d bytes
   hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, x, T, d, dx0, dtable);
   MATCHA_CHECK_LAUNCH("embed_scatter_kernel");
   return MATCHA_OK;
@@ -518,6 +523,7 @@ int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const floa
                    const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st) {
   if (T <= 0) return MATCHA_OK;
   dim3 grid((unsigned)cdiv(T, 16));
+  ProfScope ps(MATCHA_PROF_LN3_FWD, (double)T * 16.0 * d, st);      // read X, write qin/kin/vin
   DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_fwd_kernel<NCH>), grid, dim3(256), 0, st, X, T, d, gq, bq, gk, bk, gv, bv, qin, kin, vin, stats));
   MATCHA_CHECK_LAUNCH("ln3_fwd_kernel");
   return MATCHA_OK;
@@ -540,6 +546,7 @@ int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const f
   if (T <= 0) return MATCHA_OK;
   int per;
   const int nblk = colsum_blocks(T, &per);
+  ProfScope ps(MATCHA_PROF_LN3_BWD, (double)T * 24.0 * d, st);      // read X, dqin, dkin, dvin, dXs; write dZ0
   DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, X, dqin, dkin, dvin, dXs, T, d, gq, gk, gv, dZ0, slab, per));
   MATCHA_CHECK_LAUNCH("ln3_bwd_kernel");
   ColsumDst dst = {{dgq, dbq, dgk, dbk, dgv, dbv, nullptr, nullptr}};
@@ -552,6 +559,7 @@ int launch_head_fwd(const int64_t* x, const float* H2, const float* X, int64_t B
                     const float* y, const float* w, float* logits, float* row_loss, float* bce_out, hipStream_t st) {
   if (B <= 0) return MATCHA_OK;
   float* rl = (y && w) ? row_loss : nullptr;
+  ProfScope ps(MATCHA_PROF_HEAD_FWD, (double)B * L * (8.0 * d + 8.0), st);   // read H2, X rows + ids
   DISPATCH_NCH(d, hipLaunchKernelGGL((head_fwd_kernel<NCH>), dim3((unsigned)cdiv(B, 16)), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, rl));
   MATCHA_CHECK_LAUNCH("head_fwd_kernel");
   if (rl && bce_out) {
@@ -568,6 +576,7 @@ int launch_head_bwd(const int64_t* x, const float* H2, const float* X, int64_t B
   int per;
   const int nblk = colsum_blocks(B, &per);
   float* slab_bc = slab + (size_t)nblk * 7 * d;
+  ProfScope ps(MATCHA_PROF_HEAD_BWD, (double)B * L * (16.0 * d + 8.0), st);  // read H2, X; write dH2, dXs
   DISPATCH_NCH(d, hipLaunchKernelGGL((head_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, dlogits, alpha, dH2, dXs, slab, slab_bc, per));
   MATCHA_CHECK_LAUNCH("head_bwd_kernel");
   ColsumDst dst = {{(float*)ghp.gp, (float*)ghp.bp, (float*)ghp.g1, (float*)ghp.b1, (float*)ghp.g2, (float*)ghp.b2, (float*)ghp.wc, nullptr}};

@@ -1,0 +1,100 @@
+"""Negative sampler (matcha_neg_sample / hash set) on the GPU: bit-exact against the oracle restatement that shares
+its counter RNG, the invariants of the reference's generate_negative (main.py:383-428), and the
+differing-node distribution against statistics captured from the REFERENCE's own sampler (golden)."""
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import synth
+from matcha_amd.sampler import HyperedgeSet, NegativeSampler
+from oracle import sampler as OS
+from tests.helpers import gold
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(layout, ks, m, seed):
+    num = synth.LAYOUTS[layout]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(seed)
+    L = max(ks)
+    pool = np.concatenate([np.pad(synth.make_edges_fast(rng, N, k, m), ((0, 0), (0, L - k))) for k in ks])
+    return num, N, L, pool
+
+
+def test_hashset_membership_exact():
+    num, N, L, pool = _setup("hg38_1mb", [2, 3, 5], 5000, 0)
+    hs = HyperedgeSet(torch.from_numpy(pool).cuda())
+    assert bool(hs.contains(torch.from_numpy(pool)).all())
+    known = {tuple(int(v) for v in r if v) for r in pool}
+    rng = np.random.default_rng(1)
+    q = np.sort(rng.integers(1, N + 1, size=(20000, 3)), axis=1)
+    q = q[(np.diff(q, axis=1) > 0).all(1)]
+    qp = np.pad(q, ((0, 0), (0, L - 3)))
+    got = hs.contains(torch.from_numpy(qp)).cpu().numpy()
+    ref = np.array([tuple(r.tolist()) in known for r in q])
+    assert np.array_equal(got, ref)
+    # a k=2 prefix of a k=3 edge is a different hyperedge; narrower query rows work too
+    pre = pool[pool[:, 2] != 0][:100].copy()
+    pre[:, 2:] = 0
+    refp = np.array([tuple(int(v) for v in r if v) in known for r in pre])
+    assert np.array_equal(hs.contains(torch.from_numpy(pre)).cpu().numpy(), refp)
+    assert np.array_equal(hs.contains(torch.from_numpy(pre[:, :2].copy())).cpu().numpy(), refp)
+    # duplicates in the input are fine
+    hs2 = HyperedgeSet(torch.from_numpy(np.concatenate([pool[:50], pool[:50]])).cuda())
+    assert bool(hs2.contains(torch.from_numpy(pool[:50])).all())
+
+
+@pytest.mark.parametrize("layout,ks,min_dis", [("tiny", [2, 3], 0), ("c1", [2, 3, 4, 5], 0), ("c1", [3], 2)])
+def test_sampler_bit_exact_vs_oracle(layout, ks, min_dis):
+    num, N, L, pool = _setup(layout, ks, 150 if layout == "tiny" else 400, 3)
+    known = {tuple(int(v) for v in r if v) for r in pool}
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    hs = HyperedgeSet(torch.from_numpy(pool).cuda())
+    smp = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=min_dis, seed=41)
+    pos = pool[np.random.default_rng(2).permutation(len(pool))[:200]]
+    neg = smp.sample(torch.from_numpy(pos).cuda()).cpu().numpy()
+    ref = OS.sample_negatives(pos, known, n2c, cr, 3, min_dis, seed=42)      # sampler advanced its seed 41 -> 42
+    assert np.array_equal(neg, ref)
+    # second draw uses the next seed
+    neg2 = smp.sample(torch.from_numpy(pos).cuda()).cpu().numpy()
+    assert np.array_equal(neg2, OS.sample_negatives(pos, known, n2c, cr, 3, min_dis, seed=43))
+    assert not np.array_equal(neg, neg2)
+
+
+def test_sampler_invariants_and_distribution():
+    g = gold("sampler_stats.npz")
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    for k in (2, 3, 5):
+        pos_all = synth.make_edges_fast(np.random.default_rng(3 + k), N, k, 3000)
+        hs = HyperedgeSet(torch.from_numpy(pos_all).cuda())
+        smp = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=0, seed=5)
+        batch = pos_all[:1500]
+        neg = smp.sample(torch.from_numpy(batch).cuda()).cpu().numpy()
+        assert neg.shape == (4500, k)
+        known = {tuple(r) for r in pos_all.tolist()}
+        hist = np.zeros(k + 1, dtype=np.int64)
+        for j, r in enumerate(neg):
+            p = batch[j // 3]
+            assert (np.diff(r) > 0).all()                                  # ascending, duplicate-free
+            assert tuple(r.tolist()) not in known                          # not a known hyperedge
+            assert sorted(n2c[r].tolist()) == sorted(n2c[p].tolist())      # replaced nodes stay in their chromosome
+            hist[len(set(r.tolist()) - set(p.tolist()))] += 1
+        assert hist[0] == 0
+        # number of changed nodes ~ Binomial(k,1/2) | != 0, minus redraws that land on the original node:
+        # compare with what the REFERENCE's generate_negative produced on the same kind of data (golden)
+        ref = g[f"diff_hist_k{k}"].astype(np.float64)
+        chi2 = (((hist - ref) ** 2) / np.maximum(ref, 1.0))[1:].sum()
+        assert chi2 < 40.0, (k, hist, ref)
+
+
+def test_sampler_phase1_quirk_empty_set():
+    """Empty 'dict' (main.py:589) -> the while loop never runs -> negatives are copies of the positives."""
+    num = synth.LAYOUTS["c1"]
+    pos = np.pad(synth.make_edges(np.random.default_rng(0), 512, 3, 64), ((0, 0), (0, 2)))
+    hs = HyperedgeSet.empty("cuda", 5)
+    smp = NegativeSampler(hs, synth.node2chrom(num), synth.chrom_range(num), neg_num=3, seed=1)
+    neg = smp.sample(torch.from_numpy(pos).cuda()).cpu().numpy()
+    assert np.array_equal(neg, np.repeat(pos, 3, axis=0))
