@@ -134,14 +134,16 @@ struct GemmTnArgs {
   const float* A;   // [R, M]  (dY)
   const float* B;   // [R, N]  (activations), optionally row-gathered
   const int64_t* b_gather;
-  float* slab;      // [P, M*N]
-  float* colslab;   // [P, M] or null
+  float* slab;      // partition p at slab + p*slab_stride: [M*N]
+  float* colslab;   // partition p at colslab + p*slab_stride: [M]; or null
+  int64_t slab_stride;
   int64_t M, N, R, lda, ldb;
   int64_t rows_per_block;
   int tiles_n;
 };
 
 // block = 256 threads; one 64x64 output tile x one R-partition; the 4 waves split the partition's rows.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   __shared__ float red[64 * 64];
   __shared__ float redc[64];
@@ -169,32 +171,54 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
   float cs[2] = {0.f, 0.f};
 
-  // wave w takes 8-row groups w, w+4, w+8, ... of the partition
-  for (int64_t r0 = rbeg + 8 * wave; r0 < rend; r0 += 32) {
-    float a[2][4], b[2][4];
+  // Wave w takes 8-row groups w, w+4, w+8, ... of the partition.  Loads are UNCONDITIONAL (row/column indices
+  // clamped into range, out-of-range operands zeroed by a multiplicative 0/1 mask): a predicated load makes hipcc
+  // branch around every load and wait vmcnt(0) each time, serialising 16 round trips per group.  The next
+  // group's 16 loads are issued before the current group's 16 MFMAs (register double buffer).
+  const float amf[2] = {amv[0] ? 1.f : 0.f, amv[1] ? 1.f : 0.f};
+  const float bnf[2] = {bnv[0] ? 1.f : 0.f, bnv[1] ? 1.f : 0.f};
+  const int64_t last = rend - 1;
+  auto load_group = [&](int64_t r0, float (&a)[2][4], float (&b)[2][4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int64_t row = r0 + 4 * h + c;
-      const bool ok = row < rend;
-      const int64_t rr = ok ? row : (rend - 1);
-      const int64_t brow = g.b_gather ? g.b_gather[rr] : rr;
+      int64_t rr = r0 + 4 * h + c;
+      rr = rr < last ? rr : last;
+      const int64_t brow = GATHER ? g.b_gather[rr] : rr;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float av = g.A[rr * g.lda + am[t]];
-        const float bv = g.B[brow * g.ldb + bn[t]];
-        a[t][c] = (ok && amv[t]) ? av : 0.f;
-        b[t][c] = (ok && bnv[t]) ? bv : 0.f;
+        a[t][c] = g.A[rr * g.lda + am[t]];
+        b[t][c] = g.B[brow * g.ldb + bn[t]];
       }
     }
+  };
+  auto mma_group = [&](int64_t r0, float (&a)[2][4], float (&b)[2][4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][c], b[j][c], acc[i][j], 0, 0, 0);
-      cs[0] += a[0][c];
-      cs[1] += a[1][c];
+      const float rowf = (r0 + 4 * h + c) < rend ? 1.f : 0.f;
+      const float a0 = a[0][c] * (amf[0] * rowf), a1 = a[1][c] * (amf[1] * rowf);
+      const float b0 = b[0][c] * bnf[0], b1 = b[1][c] * bnf[1];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      cs[0] += a0;
+      cs[1] += a1;
+    }
+  };
+  {
+    int64_t r0 = rbeg + 8 * wave;
+    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+    if (r0 < rend) load_group(r0, a0, b0);
+    while (r0 < rend) {
+      const int64_t rn = r0 + 32;
+      if (rn < rend) load_group(rn, a1, b1);
+      mma_group(r0, a0, b0);
+      r0 = rn;
+      if (r0 >= rend) break;
+      const int64_t rn2 = r0 + 32;
+      if (rn2 < rend) load_group(rn2, a0, b0);
+      mma_group(r0, a1, b1);
+      r0 = rn2;
     }
   }
 
@@ -222,32 +246,57 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     }
     __syncthreads();
   }
-  float* slab = g.slab + p * (g.M * g.N);
+  float* slab = g.slab + p * g.slab_stride;
   for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
     const int64_t row = mo0 + idx / 64, col = no0 + idx % 64;
     if (row < g.M && col < g.N) slab[row * g.N + col] = red[idx];
   }
   if (do_col && threadIdx.x < 64) {
     const int64_t row = mo0 + threadIdx.x;
-    if (row < g.M) g.colslab[p * g.M + row] = redc[threadIdx.x];
+    if (row < g.M) g.colslab[p * g.slab_stride + row] = redc[threadIdx.x];
   }
 }
 
-// out[i] (+)= sum_p slab[p][i], p ascending
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int P, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += slab[(int64_t)p * n + i];
-  out[i] = accumulate ? out[i] + s : s;
+// out[i] (+)= sum_p slab[p][i] in a FIXED order: block = 64 outputs x 16 partition lanes; lane q sums slabs
+// q, q+16, ... (ascending), then the 16 partial sums are added q = 0..15.  Coalesced 256-B reads per slab row.
+// Element i < n1 goes to out1[i], element n1 <= i < stride to out2[i - n1] (the column sums behind a TN slab).
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out1, int64_t n1,
+                                                           float* __restrict__ out2, int64_t stride, int P, int accumulate) {
+  __shared__ float part[16][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
+  const int64_t n = out2 ? stride : n1;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int p = q;
+    for (; p + 16 < P; p += 32) { s0 += slab[(int64_t)p * stride + i]; s1 += slab[(int64_t)(p + 16) * stride + i]; }
+    if (p < P) s0 += slab[(int64_t)p * stride + i];
+  }
+  part[q][o] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += part[t][o];
+    float* dst = i < n1 ? out1 + i : out2 + (i - n1);
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st) {
+  const int64_t n = out2 ? stride : n1;
+  if (n <= 0) return MATCHA_OK;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, slab, out1, n1, out2, stride, P, accumulate ? 1 : 0);
+  MATCHA_CHECK_LAUNCH("slab_reduce_kernel");
+  return MATCHA_OK;
 }
 
 static void tn_partition(int64_t M, int64_t N, int64_t R, int* tiles_m, int* tiles_n, int* P, int64_t* rows_per_block) {
   *tiles_m = (int)cdiv(M, 64);
   *tiles_n = (int)cdiv(N, 64);
   const int64_t tiles = (int64_t)(*tiles_m) * (*tiles_n);
-  int64_t want = cdiv(2048, tiles);                 // ~8 blocks per CU in total
-  int64_t maxp = cdiv(R, 256);                      // at least 256 rows per block
+  int64_t want = cdiv(1024, tiles);                 // ~4 blocks (16 waves) per CU in total
+  int64_t maxp = cdiv(R, 1024);                     // at least 1024 rows (32 eight-row groups per wave) per block
   int64_t p = want < maxp ? want : maxp;
   if (p < 1) p = 1;
   int64_t rpb = cdiv(cdiv(R, p), 32) * 32;          // multiple of 32 rows so the waves' 8-row groups tile it
@@ -256,7 +305,9 @@ static void tn_partition(int64_t M, int64_t N, int64_t R, int* tiles_m, int* til
   if (*P < 1) *P = 1;
 }
 
-int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
+// direct-from-global variant: only for operands that cannot be loaded as aligned 16-B vectors (gemm_lds.hip has the
+// LDS-staged kernel every aligned shape uses)
+int launch_gemm_rm_direct(bool b_kn, const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return MATCHA_OK;
   bool vec = (g.K % 4 == 0) && (g.lda % 4 == 0);
   for (int z = 0; z < g.batch; ++z) vec = vec && (((uintptr_t)g.A[z]) % 16 == 0);
@@ -294,21 +345,18 @@ int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int6
   if (ws_bytes < need) { set_error("gemm TN workspace too small: %zu < %zu", ws_bytes, need); return MATCHA_ENOMEM; }
   GemmTnArgs g;
   g.A = A; g.B = B; g.b_gather = b_gather;
+  // one slab row per partition: [M*N outputs | M column sums]
   g.slab = (float*)ws;
-  g.colslab = colsum ? (float*)ws + (size_t)P * M * N : nullptr;
+  g.slab_stride = M * N + (colsum ? M : 0);
+  g.colslab = colsum ? (float*)ws + M * N : nullptr;
   g.M = M; g.N = N; g.R = R; g.lda = lda; g.ldb = ldb; g.rows_per_block = rpb; g.tiles_n = tn;
   {
     ProfScope ps(MATCHA_PROF_GEMM_TN, 2.0 * (double)M * (double)N * (double)R, st);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tm * tn, P), dim3(256), 0, st, g);
+    if (b_gather) hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(tm * tn, P), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(tm * tn, P), dim3(256), 0, st, g);
   }
   MATCHA_CHECK_LAUNCH("gemm_tn_kernel");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(M * N, 256)), dim3(256), 0, st, g.slab, C, M * N, P, accumulate ? 1 : 0);
-  MATCHA_CHECK_LAUNCH("slab_reduce_kernel");
-  if (colsum) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, g.colslab, colsum, M, P, accumulate ? 1 : 0);
-    MATCHA_CHECK_LAUNCH("slab_reduce_kernel(colsum)");
-  }
-  return MATCHA_OK;
+  return launch_slab_reduce(g.slab, C, M * N, colsum, g.slab_stride, P, accumulate, st);
 }
 
 }  // namespace matcha

@@ -165,33 +165,50 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ table, const float* __restrict__ dense,
                                                         const float* __restrict__ attr_table, int n_attr,
                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
-                                                        float* __restrict__ x0) {
-  const int s = threadIdx.x & 15;
-  const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (t >= T) return;
-  const int64_t id = x[t];
-  Row e;
-  if (table) load_row<NCH>(table + id * d, s, d, e);
-  else if (dense) load_row<NCH>(dense + t * d, s, d, e);
-  else zero_row<NCH>(e);
-  Row out;
-  load_row<NCH>(ba, s, d, out);
-  const float* arow = attr_table + id * n_attr;
-  for (int c0 = 0; c0 < n_attr; ++c0) {
-    const float a = arow[c0];
+                                                        float* __restrict__ x0, int tok_per_blk) {
+  // attribute_nn.weight [d, n_attr] is staged TRANSPOSED in LDS ([n_attr][d]) once per workgroup, so that the 16
+  // lanes of a token read consecutive float4s (conflict-free; the 16 token groups broadcast) instead of each
+  // lane walking a strided column of the weight in global memory.
+  extern __shared__ __attribute__((aligned(16))) float wt[];
+  for (int idx = threadIdx.x; idx < n_attr * d; idx += 256) {
+    const int j = idx / n_attr, c0 = idx - j * n_attr;
+    wt[c0 * d + j] = Wa[idx];
+  }
+  __syncthreads();
+  const int s = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int grp = (threadIdx.x & 63) & ~15;            // first lane of this token's 16-lane group inside the wave
+  Row bias;
+  load_row<NCH>(ba, s, d, bias);
+  const int64_t t0 = (int64_t)blockIdx.x * tok_per_blk;
+  for (int i = slot; i < tok_per_blk; i += 16) {
+    const int64_t t = t0 + i;
+    if (t >= T) break;
+    const int64_t id = x[t];
+    Row e;
+    if (table) load_row<NCH>(table + id * d, s, d, e);           // <- the embedding-row gather (K1)
+    else if (dense) load_row<NCH>(dense + t * d, s, d, e);
+    else zero_row<NCH>(e);
+    Row out = bias;
+    const float* arow = attr_table + id * n_attr;
+    for (int base = 0; base < n_attr; base += 16) {
+      const float av = (base + s < n_attr) ? arow[base + s] : 0.f;   // 16 attribute values per coalesced load
+      const int nc = n_attr - base < 16 ? n_attr - base : 16;
+      for (int c0 = 0; c0 < nc; ++c0) {
+        const float a = __shfl(av, grp + c0, kWave);
+        const float* wrow = wt + (base + c0) * d;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int j = 4 * s + 64 * c;
-      if (j < d) {
-        out.v[c].x += a * Wa[(j + 0) * n_attr + c0];
-        out.v[c].y += a * Wa[(j + 1) * n_attr + c0];
-        out.v[c].z += a * Wa[(j + 2) * n_attr + c0];
-        out.v[c].w += a * Wa[(j + 3) * n_attr + c0];
+        for (int c = 0; c < NCH; ++c) {
+          const int j = 4 * s + 64 * c;
+          if (j < d) {
+            const float4 wv = *reinterpret_cast<const float4*>(wrow + j);
+            out.v[c].x += a * wv.x; out.v[c].y += a * wv.y; out.v[c].z += a * wv.z; out.v[c].w += a * wv.w;
+          }
+        }
       }
     }
+    acc_row<NCH>(out, e);
+    store_row<NCH>(x0 + t * d, s, d, out);
   }
-  acc_row<NCH>(out, e);
-  store_row<NCH>(x0 + t * d, s, d, out);
 }
 
 // K1 alone: rows[t] = table[ids[t]]   (Wrap_Embedding.forward, Modules.py:33-34; save_embeddings main.py:471)
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int64_t* __restrict
                                                        const float* __restrict__ y, const float* __restrict__ w,
                                                        const float* __restrict__ logits, const float* __restrict__ dlogits,
                                                        float alpha, float* __restrict__ dH2, float* __restrict__ dXs,
-                                                       float* __restrict__ slab, float* __restrict__ slab_bc, int rows_per_blk) {
+                                                       float* __restrict__ slab, int rows_per_blk) {
   __shared__ float lds[16 * 256];
   __shared__ float lds_bc[16];
   const int s = threadIdx.x & 15, slot = threadIdx.x >> 4;
@@ -429,24 +446,26 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int64_t* __restrict
       store_row<NCH>(dXs + t * d, s, d, dxs);
     }
   }
-  block_colsum_store<NCH, 7>(part, d, slab + (int64_t)blockIdx.x * 7 * d, lds);
+  block_colsum_store<NCH, 7>(part, d, slab + (int64_t)blockIdx.x * (7 * d + 1), lds);
   if (s == 0) lds_bc[slot] = part_bc;
   __syncthreads();
   if (threadIdx.x == 0) {
     float a = 0.f;
     for (int t = 0; t < 16; ++t) a += lds_bc[t];
-    slab_bc[blockIdx.x] = a;
+    slab[(int64_t)blockIdx.x * (7 * d + 1) + 7 * d] = a;
   }
 }
 
 // sum of row losses / B in a fixed order (one block): losses[0] = bce
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out) {
-  __shared__ float red[256];
-  float a = 0.f;
-  for (int64_t i = threadIdx.x; i < B; i += 256) a += row_loss[i];
-  red[threadIdx.x] = a;
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int64_t i = threadIdx.x;
+  for (; i + 3072 < B; i += 4096) { a0 += row_loss[i]; a1 += row_loss[i + 1024]; a2 += row_loss[i + 2048]; a3 += row_loss[i + 3072]; }
+  for (; i < B; i += 1024) a0 += row_loss[i];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -457,19 +476,27 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 struct ColsumDst {
   float* p[8];
 };
-__global__ void colsum_reduce_kernel(const float* __restrict__ slab, int nblk, int nv, int d, ColsumDst dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nv * d) return;
-  float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += slab[(int64_t)b * nv * d + i];
-  const int v = i / d, j = i - v * d;
-  if (dst.p[v]) dst.p[v][j] += a;
-}
-__global__ void scalar_reduce_kernel(const float* __restrict__ slab, int n, float* dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float a = 0.f;
-    for (int i = 0; i < n; ++i) a += slab[i];
-    dst[0] += a;
+// Fixed-order parallel reduction (64 outputs x 16 block-lanes per workgroup, like slab_reduce_kernel); an optional
+// scalar (the classifier bias gradient) lives behind the nv*d column sums of every block: stride = nv*d + has_scalar.
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ slab, int nblk, int nv, int d, int stride,
+                                                             ColsumDst dst) {
+  __shared__ float part[16][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < stride) {
+    int b = q;
+    for (; b + 16 < nblk; b += 32) { s0 += slab[(int64_t)b * stride + i]; s1 += slab[(int64_t)(b + 16) * stride + i]; }
+    if (b < nblk) s0 += slab[(int64_t)b * stride + i];
+  }
+  part[q][o] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && i < stride) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += part[t][o];
+    const int v = i / d, j = i - v * d;           // i == nv*d  ->  v == nv, j == 0: the scalar slot
+    if (dst.p[v]) dst.p[v][j] += s;
   }
 }
 
@@ -486,10 +513,12 @@ static inline int nch_of(int d) { return d <= 64 ? 1 : (d <= 128 ? 2 : 4); }
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st) {
   if (T <= 0) return MATCHA_OK;
-  dim3 grid((unsigned)cdiv(T, 16));
+  const int tok_per_blk = T >= 256 * 1024 ? 256 : (T >= 16 * 1024 ? 64 : 16);
+  dim3 grid((unsigned)cdiv(T, tok_per_blk));
+  const size_t lds = (size_t)n_attr * d * sizeof(float);
   // algorithmic bytes per token: index 8 + embedding row 4d + attribute row 4*n_attr read, x0 row 4d written
   ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)T * (8.0 + 4.0 * d + 4.0 * n_attr + 4.0 * d), st);
-  DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, T, d, table, dense, attr_table, n_attr, Wa, ba, x0));
+  DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), lds, st, x, T, d, table, dense, attr_table, n_attr, Wa, ba, x0, tok_per_blk));
   MATCHA_CHECK_LAUNCH("embed_fwd_kernel");
   return MATCHA_OK;
 }
@@ -532,7 +561,7 @@ int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const floa
 // number of blocks used by the column-sum kernels for n items (tokens / rows)
 int colsum_blocks(int64_t n, int* per_blk) {
   int64_t blocks = cdiv(n, 64);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;                   // 2 workgroups per CU; fewer slabs to reduce
   if (blocks < 1) blocks = 1;
   int64_t per = cdiv(cdiv(n, blocks), 16) * 16;
   if (per < 16) per = 16;
@@ -550,7 +579,7 @@ int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const f
   DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, X, dqin, dkin, dvin, dXs, T, d, gq, gk, gv, dZ0, slab, per));
   MATCHA_CHECK_LAUNCH("ln3_bwd_kernel");
   ColsumDst dst = {{dgq, dbq, dgk, dbk, dgv, dbv, nullptr, nullptr}};
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(6 * d, 256)), dim3(256), 0, st, slab, nblk, 6, d, dst);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(6 * d, 64)), dim3(1024), 0, st, slab, nblk, 6, d, 6 * d, dst);
   MATCHA_CHECK_LAUNCH("colsum_reduce_kernel");
   return MATCHA_OK;
 }
@@ -563,7 +592,7 @@ int launch_head_fwd(const int64_t* x, const float* H2, const float* X, int64_t B
   DISPATCH_NCH(d, hipLaunchKernelGGL((head_fwd_kernel<NCH>), dim3((unsigned)cdiv(B, 16)), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, rl));
   MATCHA_CHECK_LAUNCH("head_fwd_kernel");
   if (rl && bce_out) {
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, rl, B, bce_out);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rl, B, bce_out);
     MATCHA_CHECK_LAUNCH("loss_reduce_kernel");
   }
   return MATCHA_OK;
@@ -575,15 +604,14 @@ int launch_head_bwd(const int64_t* x, const float* H2, const float* X, int64_t B
   if (B <= 0) return MATCHA_OK;
   int per;
   const int nblk = colsum_blocks(B, &per);
-  float* slab_bc = slab + (size_t)nblk * 7 * d;
-  ProfScope ps(MATCHA_PROF_HEAD_BWD, (double)B * L * (16.0 * d + 8.0), st);  // read H2, X; write dH2, dXs
-  DISPATCH_NCH(d, hipLaunchKernelGGL((head_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, dlogits, alpha, dH2, dXs, slab, slab_bc, per));
+  {
+    ProfScope ps(MATCHA_PROF_HEAD_BWD, (double)B * L * (16.0 * d + 8.0), st);  // read H2, X; write dH2, dXs
+    DISPATCH_NCH(d, hipLaunchKernelGGL((head_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, dlogits, alpha, dH2, dXs, slab, per));
+  }
   MATCHA_CHECK_LAUNCH("head_bwd_kernel");
-  ColsumDst dst = {{(float*)ghp.gp, (float*)ghp.bp, (float*)ghp.g1, (float*)ghp.b1, (float*)ghp.g2, (float*)ghp.b2, (float*)ghp.wc, nullptr}};
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(7 * d, 256)), dim3(256), 0, st, slab, nblk, 7, d, dst);
+  ColsumDst dst = {{(float*)ghp.gp, (float*)ghp.bp, (float*)ghp.g1, (float*)ghp.b1, (float*)ghp.g2, (float*)ghp.b2, (float*)ghp.wc, (float*)ghp.bc}};
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(7 * d + 1, 64)), dim3(1024), 0, st, slab, nblk, 7, d, 7 * d + 1, dst);
   MATCHA_CHECK_LAUNCH("colsum_reduce_kernel");
-  hipLaunchKernelGGL(scalar_reduce_kernel, dim3(1), dim3(64), 0, st, slab_bc, nblk, (float*)ghp.bc);
-  MATCHA_CHECK_LAUNCH("scalar_reduce_kernel");
   return MATCHA_OK;
 }
 
