@@ -215,6 +215,16 @@ def main():
                 roof = dict(bound="hbm", kernel=prof_cls, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches_per_step=n.value / args.steps,
                             avg_launch_ms=round(per_launch_ms, 5), work_per_launch=wk.value / n.value)
+    if roof is not None:
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE; profiles/): separate
+        # rocprofv3 --pmc runs of this same command, see profiles/r01_pmc_traffic.json
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)["classes"].get(prof_cls)
+            if pmc and args.rows == 65536 and args.front_end == "table":
+                roof["traffic"] = round(pmc["hbm_bytes_per_launch"], 1)
+        except (OSError, ValueError, KeyError):
+            pass
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -252,7 +262,9 @@ def cpu_baseline(args, num, ks, L, pool, wts, neg_num):
     negatives, main.py:527-528) and at a large batch, bounded to ~args.cpu_seconds in total."""
     from oracle import hypersagnn as O
     from oracle import sampler as OS
-    cores = os.cpu_count() or 1
+    # A 256-thread intra-op pool on [384, 64]-sized operands is slower than a handful of threads (oversubscription),
+    # so the port runs with the thread count the reference's own survey timing used (8) unless the host has fewer.
+    cores = min(8, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     attr = attribute_table(num)
     sd = synth.make_state_dict(np.random.default_rng(0), num, args.dim, "table" if args.front_end == "table" else "adj", attr)

@@ -21,6 +21,7 @@ import torch
 
 from . import _lib
 from .Modules import Classifier, _Runtime
+from .parallel import allreduce_gradients, broadcast_parameters
 
 
 class Trainer:
@@ -49,6 +50,7 @@ class Trainer:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            broadcast_parameters(rt.flat, 0, process_group)      # every rank starts from rank 0's weights
 
     # ---- buffers ------------------------------------------------------------------------------------
     def _buffers(self, B: int, L: int):
@@ -88,8 +90,7 @@ class Trainer:
 
     def all_reduce(self):
         if self.world > 1:
-            torch.distributed.all_reduce(self.gflat, group=self.pg)
-            torch.distributed.all_reduce(self.touched, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            allreduce_gradients(self.gflat, self.touched, self.pg)
 
     def optimizer_step(self):
         rt = self.rt

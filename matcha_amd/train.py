@@ -1,0 +1,287 @@
+"""Training driver: the flow of the reference's ``Code/main.py`` on the MI355X-native step.
+
+Same inputs (``./config.JSON`` keys; ``temp_dir/{chrom_range.npy, node2chrom.npy, all_<k>_counter.npy,
+all_<k>_freq_counter.npy, intra_adj.npy, inter_adj.npy}``, main.py:538-571), same two phases (main.py:637-643 and
+:671-679), same outputs (``temp_dir/model.chkpt`` = {'model_link': state_dict, 'epoch'}, ``temp_dir/model2load`` =
+the pickled module, ``../embeddings.npy`` float32 [N,d]; main.py:316-322, :476, :685).  What differs: batches stay on
+the GPU, negatives are drawn by the device sampler, and one step is forward+backward+AdamW through the C ABI
+(matcha_amd.engine.Trainer) with no per-step host synchronisation.
+
+    cd <dir with config.JSON> && python -m matcha_amd.train [--front-end adj|table] [--epochs1 3 --epochs2 30]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import time
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import utils as U
+from .Modules import Classifier, DataGenerator, MultipleEmbedding, Wrap_Embedding
+from .engine import Trainer
+from .sampler import HyperedgeSet, NegativeSampler
+
+NEG_NUM = 3          # main.py:527
+BATCH_SIZE = 96      # main.py:528 (positives per step)
+MODEL_NAME = "model.chkpt"   # main.py:530
+
+
+def get_attributes(num: List[int]) -> np.ndarray:
+    """[N+1, C+1] attribute table: one-hot chromosome || (bin index)/num[0]; row 0 (padding) zeros (main.py:497-512)."""
+    C = len(num)
+    blocks = [np.zeros((1, C + 1), dtype=np.float32)]
+    for i, n in enumerate(num):
+        a = np.zeros((n, C + 1), dtype=np.float32)
+        a[:, i] = 1.0
+        a[:, C] = np.arange(n, dtype=np.float32) / np.float32(num[0])
+        blocks.append(a)
+    return np.concatenate(blocks, axis=0)
+
+
+def load_kmers(temp_dir: str, size_list: List[int], cutoff: float) -> Tuple[np.ndarray, np.ndarray]:
+    """all_<k>_counter.npy / all_<k>_freq_counter.npy -> (edges int64 [M, max_k] zero-padded, weights float32 [M]) keeping
+    rows whose quantile-transformed frequency exceeds ``cutoff`` (main.py:551-566, :649-660)."""
+    from sklearn.preprocessing import QuantileTransformer
+    L = max(size_list)
+    edges, weights = [], []
+    for k in size_list:
+        data = np.load(os.path.join(temp_dir, "all_%d_counter.npy" % k)).astype(np.int64)
+        freq = np.load(os.path.join(temp_dir, "all_%d_freq_counter.npy" % k)).astype("float32")
+        q = QuantileTransformer(n_quantiles=1000, output_distribution="uniform").fit_transform(freq.reshape(-1, 1)).reshape(-1)
+        keep = q > cutoff
+        edges.append(np.pad(data[keep], ((0, 0), (0, L - k))))
+        weights.append(q[keep].astype(np.float32))
+    return np.concatenate(edges, axis=0), np.concatenate(weights, axis=0)
+
+
+def build_features(temp_dir: str, chrom_range: np.ndarray):
+    """Per-chromosome np.corrcoef of the intra-chromosomal contact block, NaN -> 0 (main.py:569-577) + raw inter matrix."""
+    inter = np.load(os.path.join(temp_dir, "inter_adj.npy")).astype("float32")
+    adj = np.load(os.path.join(temp_dir, "intra_adj.npy")).astype("float32")
+    feats = []
+    for lo, hi in chrom_range:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c = np.corrcoef(adj[lo - 1:hi - 1, lo - 1:hi - 1]).astype("float32")
+        c[np.isnan(c)] = 0.0
+        feats.append(c)
+    return feats, inter
+
+
+@torch.no_grad()
+def save_embeddings(model: Classifier, n_nodes: int, path: Optional[str] = "../embeddings.npy", batch_size: int = 4096) -> np.ndarray:
+    """Eval-mode get_node_embeddings for ids 1..N -> float32 [N,d], row i = node id i+1 (main.py:462-479)."""
+    was = model.training
+    model.eval()
+    dev = model.layer_norm1.weight.device
+    ids = torch.arange(1, n_nodes + 1, dtype=torch.long, device=dev).view(-1, 1)
+    out = [model.get_node_embeddings(ids[j:j + batch_size])[:, 0, :].cpu().numpy() for j in range(0, n_nodes, batch_size)]
+    emb = np.concatenate(out, axis=0)
+    if path is not None:
+        np.save(path, emb)
+    model.train(was)
+    return emb
+
+
+@torch.no_grad()
+def predict(model: Classifier, rows, batch_size: int = 100000) -> np.ndarray:
+    """Logits [n,1] for a list / array of hyperedges, zero-padded per chunk like pad_sequence (main.py:482-494)."""
+    model.eval()
+    dev = model.layer_norm1.weight.device
+    outs = []
+    for j in range(0, len(rows), batch_size):
+        x = U.pad_rows(rows[j:j + batch_size]).to(dev)
+        outs.append(model(x).cpu().numpy())
+    return np.concatenate(outs, axis=0)
+
+
+class Session:
+    """Everything one training run needs on the device: model, fused trainer, positive set, negative sampler."""
+
+    def __init__(self, model: Classifier, node2chrom: np.ndarray, chrom_range: np.ndarray, min_size: int, max_size: int, min_dis: int,
+                 seed: int = 0):
+        self.model = model
+        self.dev = model.layer_norm1.weight.device
+        self.min_size, self.max_size, self.min_dis = min_size, max_size, min_dis
+        self.node2chrom, self.chrom_range = node2chrom, chrom_range
+        self.n_chrom = len(chrom_range)
+        self.trainer = Trainer(model, lr=1e-3, base_seed=seed)                    # AdamW(lr=1e-3), main.py:630
+        self.set_known(None)
+        self.rng = np.random.default_rng(seed)
+
+    def new_optimizer(self):
+        """main.py:671 builds a fresh AdamW (moments and step counts reset) for phase 2."""
+        self.trainer = Trainer(self.model, lr=1e-3, base_seed=int(self.rng.integers(1 << 30)))
+
+    def set_known(self, edges: Optional[np.ndarray]):
+        """The 'dict' negatives are checked against (main.py:589 empty sets in phase 1; build_hash at :664)."""
+        if edges is None or len(edges) == 0:
+            hs = HyperedgeSet.empty(self.dev, self.max_size)
+        else:
+            hs = HyperedgeSet(torch.from_numpy(np.ascontiguousarray(edges)).to(self.dev))
+        self.sampler = NegativeSampler(hs, self.node2chrom, self.chrom_range, neg_num=NEG_NUM, min_dis=self.min_dis,
+                                       seed=int(np.random.randint(1 << 30)))
+
+    def make_batch(self, pos: torch.Tensor, pos_w: torch.Tensor):
+        """generate_negative's output (main.py:443-448): x = [pos; neg], y = [1..; 0..], w = [pos_w..; 1..]."""
+        P = pos.shape[0]
+        neg = self.sampler.sample(pos)
+        x = torch.cat([pos, neg], dim=0)
+        y = torch.cat([torch.ones(P, device=self.dev), torch.zeros(neg.shape[0], device=self.dev)])
+        w = torch.cat([pos_w.to(torch.float32), torch.ones(neg.shape[0], device=self.dev)])
+        sizes = (x != 0).sum(dim=1)
+        return x, y, w, sizes
+
+    def random_chrom(self) -> int:
+        return int(np.random.choice(np.arange(self.n_chrom), 1)[0]) if self.n_chrom else 0   # Modules.py:192
+
+
+def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: float, beta: float, batch_size: int = BATCH_SIZE):
+    """main.py:119-197: shuffle, floor(len/batch) steps of (negatives, forward, backward, AdamW), epoch metrics."""
+    dev = sess.dev
+    model = sess.model
+    model.train()
+    e = torch.from_numpy(edges).to(dev)
+    w = torch.from_numpy(weights.astype(np.float32)).to(dev)
+    perm = torch.randperm(len(e), device=dev)                                   # sync_shuffle, utils.py:142-149
+    e, w = e[perm], w[perm]
+    n_batch = len(e) // batch_size
+    bce_sum = torch.zeros((), device=dev)
+    rec_sum = torch.zeros((), device=dev)
+    preds, labels, sizes = [], [], []
+    for i in range(n_batch):
+        pos, pw = e[i * batch_size:(i + 1) * batch_size], w[i * batch_size:(i + 1) * batch_size]
+        x, y, ww, s = sess.make_batch(pos, pw)
+        bce, recon, logits = sess.trainer.step(x, y, ww, alpha=alpha, beta=beta, random_chrom=sess.random_chrom())
+        bce_sum += bce
+        rec_sum += recon[0]
+        preds.append(torch.sigmoid(logits).clone())                             # main.py:58
+        labels.append(y)
+        sizes.append(s)
+    pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()
+    auc, aupr = U.roc_auc_cuda(label, pred, size, sess.max_size)
+    acc = U.accuracy(pred, label, size, sess.max_size)
+    return float(bce_sum) / max(n_batch, 1), float(rec_sum) / max(n_batch, 1), acc, auc, aupr
+
+
+@torch.no_grad()
+def eval_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, batch_size: int = BATCH_SIZE, max_rows: int = 10000):
+    """main.py:200-258: <= 10000 shuffled validation positives, fresh negatives, forward + loss only."""
+    dev = sess.dev
+    model = sess.model
+    model.eval()
+    import ctypes as C
+    from . import _lib
+    e = torch.from_numpy(edges).to(dev)
+    w = torch.from_numpy(weights.astype(np.float32)).to(dev)
+    perm = torch.randperm(len(e), device=dev)[:max_rows]
+    e, w = e[perm], w[perm]
+    n_batch = len(e) // batch_size
+    bce_sum, rec_sum = 0.0, 0.0
+    preds, labels, sizes = [], [], []
+    for i in range(n_batch):
+        pos, pw = e[i * batch_size:(i + 1) * batch_size], w[i * batch_size:(i + 1) * batch_size]
+        x, y, ww, s = sess.make_batch(pos, pw)
+        logits, recon = model(x, return_recon=True)
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y, weight=ww)
+        bce_sum += float(bce)
+        rec_sum += float(recon[0])
+        preds.append(torch.sigmoid(logits.view(-1)))
+        labels.append(y)
+        sizes.append(s)
+    pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()
+    auc, aupr = U.roc_auc_cuda(label, pred, size, sess.max_size)
+    acc = U.accuracy(pred, label, size, sess.max_size)
+    return bce_sum / max(n_batch, 1), rec_sum / max(n_batch, 1), acc, auc, aupr
+
+
+def train(sess: Session, training_data, validation_data, epochs: int, alpha: float, beta: float, temp_dir: str, n_nodes: int,
+          batch_size: int = BATCH_SIZE, batches_per_epoch: int = 1000, emb_path: Optional[str] = "../embeddings.npy", log=print):
+    """main.py:261-342: per epoch save embeddings, draw batches_per_epoch*batch rows per size, train, validate, checkpoint.
+    (The reference's 'best' checkpoint is in fact the last one -- it compares the parsed size label, main.py:313-322 --
+    so every epoch is saved.)"""
+    edges, weights = training_data
+    rows = [r[r != 0] for r in edges]
+    gen = DataGenerator(rows, weights, int(batch_size), batches_per_epoch, min_size=sess.min_size, max_size=sess.max_size)
+    for epoch in range(epochs):
+        save_embeddings(sess.model, n_nodes, emb_path)
+        t0 = time.time()
+        e_part, w_part = gen.next_iter()
+        bce, rec, acc, auc, aupr = train_epoch(sess, e_part, w_part, alpha, beta, batch_size)
+        log(f"[ Epoch {epoch} of {epochs} ]  - (Training)   bce: {bce:7.4f}, recon: {rec:7.4f} acc: {acc}, auc: {auc}, aupr: {aupr}, "
+            f"elapse: {time.time() - t0:3.3f} s")
+        t0 = time.time()
+        vb, vr, vacc, vauc, vaupr = eval_epoch(sess, validation_data[0], validation_data[1], batch_size)
+        log(f"  - (Validation-hyper) bce: {vb:7.4f}, recon: {vr:7.4f},  acc: {vacc}, auc: {vauc}, aupr: {vaupr}, elapse: {time.time() - t0:3.3f} s")
+        torch.save({"model_link": sess.model.state_dict(), "epoch": epoch}, os.path.join(temp_dir, MODEL_NAME))   # main.py:316-321
+        torch.save(sess.model, os.path.join(temp_dir, "model2load"))                                               # main.py:322
+    ck = torch.load(os.path.join(temp_dir, MODEL_NAME), map_location=sess.dev, weights_only=False)              # main.py:326-327
+    sess.model.load_state_dict(ck["model_link"])
+
+
+def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 30, batches_per_epoch: int = 1000, device: str = "cuda",
+        emb_path: Optional[str] = "../embeddings.npy", log=print) -> Classifier:
+    """The script body of main.py:516-685."""
+    d = int(config["embed_dim"])
+    size_list = [int(v) for v in config["k-mer_size"]]
+    min_size, max_size = min(size_list), max(size_list)
+    temp_dir = config["temp_dir"]
+    min_dis = int(config["min_distance"])
+    chrom_range = np.load(os.path.join(temp_dir, "chrom_range.npy")).astype(np.int64)
+    n2c_dict = np.load(os.path.join(temp_dir, "node2chrom.npy"), allow_pickle=True).item()
+    num = [int(v[1] - v[0]) for v in chrom_range]
+    N = int(np.sum(num))
+    node2chrom = np.full(N + 1, -1, dtype=np.int32)
+    for k, v in n2c_dict.items():
+        if 0 < int(k) <= N:
+            node2chrom[int(k)] = int(v)
+
+    data, weight = load_kmers(temp_dir, size_list, float(config["quantile_cutoff_for_positive"]))
+    weight = weight / np.mean(weight) * NEG_NUM                                  # main.py:594-595
+    idx = np.arange(len(data))
+    np.random.shuffle(idx)                                                        # main.py:598
+    split = int(0.8 * len(idx))
+    train_data, test_data = data[idx[:split]], data[idx[split:]]
+    train_w, test_w = weight[idx[:split]], weight[idx[split:]]
+
+    attr = get_attributes(num)
+    if front_end == "adj":
+        feats, inter = build_features(temp_dir, chrom_range)
+        ne = MultipleEmbedding(feats, d, False, torch.as_tensor(np.cumsum(num)), chrom_range, inter)   # main.py:609-613
+    else:
+        ne = Wrap_Embedding(N + 1, d, padding_idx=0)
+    model = Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True, bottle_neck=d, attribute_dict=attr).to(device)
+    save_embeddings(model, N, emb_path)                                           # main.py:625
+
+    sess = Session(model, node2chrom, chrom_range.astype(np.int32), min_size, max_size, min_dis)
+    # phase 1: alpha 0, beta 1, empty dict (negatives == positives)             main.py:637-643
+    train(sess, (train_data, train_w), (test_data, test_w), epochs1, 0.0, 1.0, temp_dir, N, batches_per_epoch=batches_per_epoch,
+          emb_path=emb_path, log=log)
+    # phase 2: dict of all k-mers above the unlabel cutoff, fresh AdamW, alpha 1, beta 1e-3   main.py:646-679
+    dict_data, _ = load_kmers(temp_dir, size_list, float(config["quantile_cutoff_for_unlabel"]))
+    sess.set_known(dict_data)
+    sess.new_optimizer()
+    train(sess, (train_data, train_w), (test_data, test_w), epochs2, 1.0, 0.001, temp_dir, N, batches_per_epoch=batches_per_epoch,
+          emb_path=emb_path, log=log)
+    save_embeddings(model, N, emb_path)                                           # main.py:684
+    torch.save(model, os.path.join(temp_dir, "model2load"))                      # main.py:685
+    return model
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--config", default="./config.JSON")
+    ap.add_argument("--front-end", choices=["adj", "table"], default="adj")
+    ap.add_argument("--epochs1", type=int, default=3)
+    ap.add_argument("--epochs2", type=int, default=30)
+    ap.add_argument("--batches-per-epoch", type=int, default=1000)
+    a = ap.parse_args(argv)
+    run(U.get_config(a.config), a.front_end, a.epochs1, a.epochs2, a.batches_per_epoch)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""Training driver (matcha_amd/train.py == the flow of the reference's main.py): host logic on CPU, a short end-to-end
+run on the GPU writing the reference's output files."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import synth, utils as U
+from tests.helpers import gold
+
+
+def _write_temp_dir(tmp, layout="tiny", ks=(2, 3), m=400, d=16, seed=0):
+    num = synth.LAYOUTS[layout]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(seed)
+    temp = os.path.join(tmp, "Temp")
+    os.makedirs(temp)
+    cr = synth.chrom_range(num)
+    np.save(os.path.join(temp, "chrom_range.npy"), cr)
+    n2c = synth.node2chrom(num)
+    np.save(os.path.join(temp, "node2chrom.npy"), {int(i): int(n2c[i]) for i in range(1, N + 1)}, allow_pickle=True)
+    for k in ks:
+        np.save(os.path.join(temp, "all_%d_counter.npy" % k), synth.make_edges(rng, N, k, m))
+        np.save(os.path.join(temp, "all_%d_freq_counter.npy" % k), synth.make_freq(rng, m))
+    intra, inter = synth.make_adjacency(rng, num)
+    np.save(os.path.join(temp, "intra_adj.npy"), intra)
+    np.save(os.path.join(temp, "inter_adj.npy"), inter)
+    cfg = {"cluster_path": "x", "mcool_path": "x", "resolution": 1000000, "chrom_list": ["chr%d" % (i + 1) for i in range(len(num))],
+           "chrom_size": "x", "temp_dir": temp, "max_cluster_size": 25, "min_distance": 0, "k-mer_size": list(ks), "min_freq_cutoff": 2,
+           "quantile_cutoff_for_positive": 0.6, "quantile_cutoff_for_unlabel": 0.4, "embed_dim": d}
+    with open(os.path.join(tmp, "config.JSON"), "w") as f:
+        json.dump(cfg, f)
+    return cfg, num
+
+
+def test_host_helpers(tmp_path):
+    from matcha_amd import train as T
+    g = gold("g5_tiny_preproc.npz")
+    assert np.array_equal(T.get_attributes(synth.LAYOUTS["tiny"]), g["attr"])           # main.py:497-512 via the reference
+    cfg, num = _write_temp_dir(str(tmp_path))
+    assert U.get_config(os.path.join(tmp_path, "config.JSON"))["embed_dim"] == 16
+    e, w = T.load_kmers(cfg["temp_dir"], [2, 3], 0.6)
+    assert e.shape[1] == 3 and len(e) == len(w) and (w > 0.6).all()
+    assert 0.3 * 800 < len(e) < 0.5 * 800                                                # ~40 % of rows pass the 0.6 quantile
+    assert ((e != 0).sum(1) >= 2).all() and (np.diff(np.where(e == 0, 10 ** 9, e), axis=1) > 0).all()
+    feats, inter = T.build_features(cfg["temp_dir"], synth.chrom_range(num))
+    assert [f.shape for f in feats] == [(n, n) for n in num] and not np.isnan(np.concatenate([f.ravel() for f in feats])).any()
+    # utils surface
+    assert isinstance(U.np2tensor_hyper([[1, 2], [3, 4]]), torch.Tensor)
+    ragged = U.np2tensor_hyper([[1, 2], [3, 4, 5]])
+    assert isinstance(ragged, list) and U.pad_rows([[1, 2], [3, 4, 5]]).tolist() == [[1, 2, 0], [3, 4, 5]]
+    a, b = U.sync_shuffle([torch.arange(10), torch.arange(10) * 2], 4)
+    assert len(a) == 4 and torch.equal(a * 2, b)
+    y = torch.tensor([1., 0., 1., 0.])
+    p = torch.tensor([.9, .2, .6, .4])
+    s = torch.tensor([2, 2, 3, 3])
+    assert U.accuracy(p, y, s) == "2 1.000 3 1.000 "
+    auc, aupr = U.roc_auc_cuda(y, p, s, 3)
+    assert auc.startswith("all 1.000") and aupr.split(" ")[-2] == "3"                    # the label main.py:313 parses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front_end", ["table"])
+def test_end_to_end_run_writes_reference_outputs(tmp_path, front_end):
+    from matcha_amd import train as T
+    import Modules  # noqa: F401
+    cfg, num = _write_temp_dir(str(tmp_path), m=600)
+    N = int(np.sum(num))
+    np.random.seed(0)
+    torch.manual_seed(0)
+    emb_path = os.path.join(tmp_path, "embeddings.npy")
+    logs = []
+    model = T.run(cfg, front_end=front_end, epochs1=1, epochs2=2, batches_per_epoch=4, emb_path=emb_path, log=logs.append)
+    temp = cfg["temp_dir"]
+    emb = np.load(emb_path)
+    assert emb.shape == (N, 16) and emb.dtype == np.float32 and np.isfinite(emb).all()
+    ck = torch.load(os.path.join(temp, "model.chkpt"), map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"model_link", "epoch"} and ck["epoch"] == 1
+    loaded = torch.load(os.path.join(temp, "model2load"), map_location="cuda", weights_only=False)
+    x = torch.tensor([[1, 5, 9], [2, 20, 0]])
+    with torch.no_grad():
+        model.eval()
+        loaded.eval()
+        assert torch.allclose(model(x), loaded(x), atol=1e-6)
+    assert any("Training" in l for l in logs) and any("Validation" in l for l in logs)
+    # phase 2 learns something on separable synthetic data: bce of the last epoch is finite and below chance-level log(2)*E[w]
+    last = [l for l in logs if "Training" in l][-1]
+    bce = float(last.split("bce:")[1].split(",")[0])
+    assert np.isfinite(bce)
+    # predict surface (main.py:482-494) with ragged input
+    out = T.predict(model, [[1, 5], [2, 20, 40]])
+    assert out.shape == (2, 1)
