@@ -120,7 +120,7 @@ typedef struct matcha_frozen {
   const float* attr_table;   /* [N+1, n_attr] attribute_dict_embedding.weight, row 0 zeros (main.py:508) */
   const int32_t* bounds;     /* [C+1] Modules.py:138 num_list = [0, n_0, n_0+n_1, ...] (adj; device)     */
   const float* feats;        /* adj: sum_i [n_i, n_i] feature matrices (main.py:571-577), chrom i at feat_off[i] */
-  const int64_t* feat_off;   /* [C+1] element offsets into feats (HOST pointer)                           */
+  const int64_t* feat_off;   /* [C+1] element offsets into feats (device)                                 */
   const float* inter;        /* adj: [N, N] z-scored inter-chromosome matrix (Modules.py:146-154)         */
   const int32_t* bounds_host;/* [C+1] same as bounds, HOST pointer                                         */
 } matcha_frozen;

@@ -357,10 +357,11 @@ class _Runtime:
             self.bounds_host = np.asarray(self.bounds_list, dtype=np.int32)
             self.frozen.bounds = self.bounds_dev.data_ptr()
             self.frozen.feats = self.feat_pack.data_ptr()
-            self.frozen.feat_off = self.feat_off_host.ctypes.data
+            self.feat_off_dev = torch.from_numpy(offs).to(dev)
+            self.frozen.feat_off = self.feat_off_dev.data_ptr()
             self.frozen.inter = self.inter.data_ptr()
             self.frozen.bounds_host = self.bounds_host.ctypes.data
-            self._keep += [self.feat_pack, self.inter, self.bounds_dev]
+            self._keep += [self.feat_pack, self.inter, self.bounds_dev, self.feat_off_dev]
         self.shape = _lib.Shape(d, self.n_attr, self.n_nodes, self.n_chrom, self.mode, self.max_bins)
         self.params = self.tensors_for(self.flat)
         self.seed = torch.zeros(1, dtype=torch.int64, device=dev)

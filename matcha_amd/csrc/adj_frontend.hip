@@ -1,21 +1,585 @@
-// adj-mode front end (MultipleEmbedding, Modules.py:125-201): placeholder until the grouped gather-GEMM lands.
+// adj-mode front end: MultipleEmbedding.forward (Modules.py:176-201) and its backward on the GPU.
+//
+//   per chromosome i:  rows = feats_i[x - lo_i]  (SparseEmbedding :67, the gather)  -> dropout(0.2) (:186)
+//                      -> W0_i (d x n_i, no bias) -> tanh -> W1_i (d x d)  (TiedAutoEncoder :104-113) -> final[sel] (:188)
+//   recon branch:      for tokens outside chromosome r (r drawn by the caller, :192) and not padding:
+//                      100 * mean( (inter[x-1, cols of r] - Linear_r(tanh(final)))^2 )   (:194-199)
+//
+// GPU formulation: token slots are bucket-sorted by chromosome once per step (stable counting sort -> `order`,
+// `seg`), so each chromosome owns a contiguous run of sorted rows and the per-chromosome Python loop becomes
+//   * one gather-GEMM launch (feature rows gathered by node id straight into LDS tiles, dropout applied while
+//     staging, f32 MFMA against W0_i, tanh)            -> Hs [sorted rows, d]
+//   * one grouped launch of the generic LDS GEMM (per-group weight W1_i, C rows scattered back to token slots).
+// A workgroup whose 128-row tile straddles a chromosome boundary simply processes both sub-ranges.
+// Weight gradients of the per-chromosome tensors are accumulated with float atomics (row-contiguous 128-B
+// segments); they are the only non-bitwise-reproducible sums of the adj path.
+#include <string.h>
+
 #include "kernels.hpp"
 
 namespace matcha {
 
-size_t adj_workspace_bytes(const matcha_shape& s, int64_t T) { (void)s; (void)T; return 0; }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
-                const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st) {
-  set_error("adj mode is not built into this library yet");
-  return MATCHA_EINVAL;
+constexpr int kSortTok = 1024;   // tokens per workgroup in the counting sort
+constexpr int kMaxChrom = 63;     // buckets = chromosomes + 1 (padding)
+constexpr int kLdA = 68;
+
+struct AdjWs {
+  int32_t *order, *other_map, *seg, *counts /* [0]=m (other tokens), [1]=non-pad tokens */, *hist, *base;
+  float *Hs, *TH, *rec, *dTH, *dZ, *lossslab;
+  int nblk;
+  int64_t nr_pad;
+  size_t total;
+};
+
+static size_t adj_carve(const matcha_shape& s, int64_t T, char* base, AdjWs& w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  const int C = s.n_chrom;
+  w.nblk = (int)cdiv(T, kSortTok);
+  w.nr_pad = align_up((size_t)(s.max_bins > 0 ? s.max_bins : 1), 4);
+  w.order = (int32_t*)take(T * 4);
+  w.other_map = (int32_t*)take(T * 4);
+  w.seg = (int32_t*)take((C + 2) * 4);
+  w.counts = (int32_t*)take(16);
+  w.hist = (int32_t*)take((size_t)w.nblk * (C + 1) * 4);
+  w.base = (int32_t*)take((size_t)w.nblk * (C + 1) * 4);
+  w.Hs = (float*)take((size_t)T * s.d * 4);
+  w.TH = (float*)take((size_t)T * s.d * 4);
+  w.rec = (float*)take((size_t)T * w.nr_pad * 4);
+  w.dTH = (float*)take((size_t)T * s.d * 4);
+  w.dZ = (float*)take((size_t)T * s.d * 4);
+  w.lossslab = (float*)take((size_t)(cdiv(T, 64) + 8) * 4);
+  w.total = off;
+  return off;
 }
 
-int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
-                 const int64_t* x, int64_t T, const float* dnode, const float* drecon, matcha_tensors& g, int32_t* touched,
-                 void* ws, size_t ws_bytes, hipStream_t st) {
-  set_error("adj mode is not built into this library yet");
-  return MATCHA_EINVAL;
+size_t adj_workspace_bytes(const matcha_shape& s, int64_t T) {
+  AdjWs w;
+  return adj_carve(s, T, nullptr, w);
+}
+
+__device__ __forceinline__ int chrom_of(int64_t id, const int32_t* __restrict__ bounds, int C) {
+  if (id == 0) return C;                          // padding bucket
+  int c = 0;
+  while (c + 1 < C && id > bounds[c + 1]) ++c;   // ids of chromosome c: bounds[c]+1 .. bounds[c+1]
+  return c;
+}
+
+// ---- stable counting sort of token slots by chromosome -------------------------------------------------------
+__global__ __launch_bounds__(256) void adj_hist_kernel(const int64_t* __restrict__ x, int64_t T, const int32_t* __restrict__ bounds, int C,
+                                                       int32_t* __restrict__ hist) {
+  __shared__ int cnt[kMaxChrom + 1];
+  if (threadIdx.x <= C) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t t0 = (int64_t)blockIdx.x * kSortTok + threadIdx.x * 4;
+  for (int i = 0; i < 4; ++i)
+    if (t0 + i < T) atomicAdd(&cnt[chrom_of(x[t0 + i], bounds, C)], 1);
+  __syncthreads();
+  if (threadIdx.x <= C) hist[(int64_t)blockIdx.x * (C + 1) + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// one workgroup: seg[] (segment starts), base[blk][c] (first sorted position of block blk's tokens of bucket c),
+// counts[0] = number of "other" tokens (non-pad, not in chromosome r), counts[1] = non-pad tokens; touched flags
+__global__ void adj_scan_kernel(const int32_t* __restrict__ hist, int nblk, int C, int r_chrom, int32_t* __restrict__ base,
+                                int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched) {
+  __shared__ int tot[kMaxChrom + 2];
+  const int c = threadIdx.x;
+  if (c <= C) {
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) {
+      base[(int64_t)b * (C + 1) + c] = run;
+      run += hist[(int64_t)b * (C + 1) + c];
+    }
+    tot[c] = run;
+  }
+  __syncthreads();
+  if (c == 0) {
+    int run = 0;
+    for (int k = 0; k <= C; ++k) { seg[k] = run; run += tot[k]; }
+    seg[C + 1] = run;
+    const int nonpad = seg[C];
+    const int in_r = (r_chrom >= 0 && r_chrom < C) ? tot[r_chrom] : 0;
+    counts[0] = (r_chrom >= 0) ? nonpad - in_r : 0;
+    counts[1] = nonpad;
+    if (touched) {
+      touched[0] = 1;
+      touched[1] = 0;
+      for (int k = 0; k < C; ++k) {
+        touched[2 + k] = tot[k] > 0 ? 1 : 0;                                  // wstack[k] ran (Modules.py:182-183)
+        touched[2 + C + k] = (k == r_chrom && nonpad - in_r > 0) ? 1 : 0;     // recon[r] ran (:195)
+      }
+    }
+  }
+  __syncthreads();
+  if (c <= C) {
+    const int s0 = seg[c];
+    for (int b = 0; b < nblk; ++b) base[(int64_t)b * (C + 1) + c] += s0;
+  }
+}
+
+__global__ __launch_bounds__(256) void adj_scatter_kernel(const int64_t* __restrict__ x, int64_t T, const int32_t* __restrict__ bounds, int C,
+                                                          int r_chrom, const int32_t* __restrict__ base, const int32_t* __restrict__ seg,
+                                                          int32_t* __restrict__ order, int32_t* __restrict__ other_map) {
+  extern __shared__ int tc[];                 // [C+1][256] per-thread counts -> exclusive prefix
+  const int tid = threadIdx.x;
+  for (int k = 0; k <= C; ++k) tc[k * 256 + tid] = 0;
+  const int64_t t0 = (int64_t)blockIdx.x * kSortTok + tid * 4;
+  int ch[4];
+  for (int i = 0; i < 4; ++i) {
+    ch[i] = (t0 + i < T) ? chrom_of(x[t0 + i], bounds, C) : -1;
+    if (ch[i] >= 0) tc[ch[i] * 256 + tid] += 1;
+  }
+  __syncthreads();
+  if (tid <= C) {
+    int run = 0;
+    for (int k = 0; k < 256; ++k) { const int v = tc[tid * 256 + k]; tc[tid * 256 + k] = run; run += v; }
+  }
+  __syncthreads();
+  const int r0 = (r_chrom >= 0 && r_chrom < C) ? seg[r_chrom] : 0, r1 = (r_chrom >= 0 && r_chrom < C) ? seg[r_chrom + 1] : 0;
+  const int nonpad = seg[C];
+  for (int i = 0; i < 4; ++i) {
+    if (ch[i] < 0) continue;
+    const int pos = base[(int64_t)blockIdx.x * (C + 1) + ch[i]] + tc[ch[i] * 256 + tid];
+    tc[ch[i] * 256 + tid] += 1;
+    order[pos] = (int32_t)(t0 + i);
+    if (r_chrom >= 0 && pos < nonpad && !(pos >= r0 && pos < r1)) other_map[pos < r0 ? pos : pos - (r1 - r0)] = (int32_t)(t0 + i);
+  }
+}
+
+// ---- gather-GEMM: Hs[p] = tanh( (feats_c[x - lo_c] * dropmask) . W0_c^T ) for sorted rows p ---------------------
+struct AdjEncArgs {
+  const int64_t* x;
+  const int32_t *order, *seg, *bounds;
+  const int64_t* feat_off;
+  const float *feats, *w0;
+  float* Hs;
+  int64_t T;
+  int C, d;
+  const uint64_t* seed;
+  float p_drop;
+};
+
+template <int NT>   // NT = ceil(d / 32) column tiles per wave
+__global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                              // [128][68]
+  float* Bs = lds + 128 * kLdA;                 // [32*NT][68]
+  __shared__ int64_t rowoff[128];               // element offset of the gathered feature row inside feats
+  __shared__ int rowslot[128];                  // token slot (dropout counter), -1 = row not in this sub-range
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;
+  const int64_t nonpad = g.seg[g.C];
+  if (m0 >= nonpad) return;
+  const int64_t m_end = m0 + 128 < nonpad ? m0 + 128 : nonpad;
+  const bool drop = g.p_drop > 0.f;
+  uint32_t key = 0, thr = 0;
+  float keep_scale = 1.f;
+  if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
+  int c_lo = 0;
+  while (c_lo < g.C && g.seg[c_lo + 1] <= m0) ++c_lo;
+  for (int c = c_lo; c < g.C && g.seg[c] < m_end; ++c) {
+    const int64_t row_lo = g.seg[c] > m0 ? g.seg[c] : m0;
+    const int64_t row_hi = g.seg[c + 1] < m_end ? g.seg[c + 1] : m_end;
+    if (row_lo >= row_hi) continue;
+    const int lo = g.bounds[c], n_c = g.bounds[c + 1] - g.bounds[c];
+    const float* W0 = g.w0 + (int64_t)g.d * lo;                 // [d, n_c] row-major
+    __syncthreads();
+    if (tid < 128) {
+      const int64_t p = m0 + tid;
+      const bool in = p >= row_lo && p < row_hi;
+      const int64_t pc = in ? p : row_lo;                         // out-of-range rows alias a valid row (never stored)
+      const int slot = g.order[pc];
+      rowoff[tid] = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
+      rowslot[tid] = in ? slot : -1;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+    for (int kc = 0; kc < n_c; kc += 64) {
+      __syncthreads();
+      // stage A: wave w gathers rows w, w+4, ...; a wave-instruction reads 64 consecutive floats of one feature row
+      const int kk = kc + lane;
+      const int kcl = kk < n_c ? kk : n_c - 1;
+      const float kmask = kk < n_c ? 1.f : 0.f;
+      for (int rr = wave; rr < 128; rr += 4) {
+        float v = g.feats[rowoff[rr] + kcl] * kmask;
+        if (drop) {
+          const int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
+          v = (rng_u32(key, (uint32_t)slot, (uint32_t)kk) >= thr) ? v * keep_scale : 0.f;   // counter = (token slot, column)
+        }
+        As[rr * kLdA + lane] = v;
+      }
+      for (int j = wave; j < 32 * NT; j += 4) {
+        const int jc = j < g.d ? j : g.d - 1;
+        Bs[j * kLdA + lane] = (j < g.d) ? W0[(int64_t)jc * n_c + kcl] * kmask : 0.f;
+      }
+      __syncthreads();
+      const float* arow = &As[(32 * wave + r) * kLdA + 4 * h];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * cc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * t + r) * kLdA + 8 * cc + 4 * h]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    const int64_t mrow0 = m0 + 32 * wave + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 32 * t + r;
+      if (col >= g.d) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int64_t p = mrow0 + (reg & 3) + 8 * (reg >> 2);
+        if (p < row_lo || p >= row_hi) continue;
+        g.Hs[p * g.d + col] = tanhf(acc[t][reg]);
+      }
+    }
+  }
+}
+
+// ---- grouped weight gradients with atomics -----------------------------------------------------------------------
+//   MODE 0: dW1_c[j][k] += sum_p dnode[order[p]][j] * Hs[p][k]
+//   MODE 1: dW0_c[j][col] += sum_p dZ[p][j] * feats_c[x_p - lo_c][col] * dropmask(slot_p, col)
+struct AdjTnArgs {
+  const float* A;            // MODE 0: dnode [T,d] (token-slot order);  MODE 1: dZ [T,d] (sorted order)
+  const float* Bd;           // MODE 0: Hs [T,d]
+  const int64_t* x;
+  const int32_t *order, *seg, *bounds;
+  const int64_t* feat_off;
+  const float* feats;
+  float* out;                // MODE 0: adj_w1 grads [C,d,d];  MODE 1: adj_w0 grads (chromosome c at d*bounds[c], row stride n_c)
+  int C, d, rows_per_block;
+  const uint64_t* seed;
+  float p_drop;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void adj_tn_kernel(AdjTnArgs g) {
+  __shared__ float red[64 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int mo0 = blockIdx.x * 64;             // output row tile (j)
+  const int no0 = blockIdx.y * 64;             // output column tile (k or feature column)
+  const int64_t nonpad = g.seg[g.C];
+  const int64_t rb = (int64_t)blockIdx.z * g.rows_per_block;
+  if (rb >= nonpad) return;
+  const int64_t re = rb + g.rows_per_block < nonpad ? rb + g.rows_per_block : nonpad;
+  const bool drop = MODE == 1 && g.p_drop > 0.f;
+  uint32_t key = 0, thr = 0;
+  float keep_scale = 1.f;
+  if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
+  int am[2]; float amf[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { am[t] = mo0 + 32 * t + r; amf[t] = am[t] < g.d ? 1.f : 0.f; if (am[t] >= g.d) am[t] = g.d - 1; }
+  int c = 0;
+  while (c < g.C && g.seg[c + 1] <= rb) ++c;
+  for (; c < g.C && g.seg[c] < re; ++c) {
+    const int64_t p_lo = g.seg[c] > rb ? g.seg[c] : rb;
+    const int64_t p_hi = g.seg[c + 1] < re ? g.seg[c + 1] : re;
+    if (p_lo >= p_hi) continue;
+    const int lo = g.bounds[c], n_c = g.bounds[c + 1] - g.bounds[c];
+    const int ncols = MODE == 0 ? g.d : n_c;
+    if (no0 >= ncols) continue;
+    int bn[2]; float bnf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { bn[t] = no0 + 32 * t + r; bnf[t] = bn[t] < ncols ? 1.f : 0.f; if (bn[t] >= ncols) bn[t] = ncols - 1; }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    for (int64_t r0 = p_lo + 8 * wave; r0 < p_hi; r0 += 32) {
+      float a[2][4], b[2][4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        int64_t p = r0 + 4 * h + cc;
+        const float rowf = p < p_hi ? 1.f : 0.f;
+        p = p < p_hi ? p : p_hi - 1;
+        const int slot = g.order[p];
+        const int64_t arow = MODE == 0 ? (int64_t)slot : p;
+        int64_t brow = 0;
+        if (MODE == 1) brow = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[t][cc] = g.A[arow * g.d + am[t]] * (amf[t] * rowf);
+          float bv = MODE == 0 ? g.Bd[p * g.d + bn[t]] : g.feats[brow + bn[t]];
+          if (drop) bv = (rng_u32(key, (uint32_t)slot, (uint32_t)bn[t]) >= thr) ? bv * keep_scale : 0.f;
+          b[t][cc] = bv * bnf[t];
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][cc], b[0][cc], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][cc], b[1][cc], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][cc], b[0][cc], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][cc], b[1][cc], acc[1][1], 0, 0, 0);
+      }
+    }
+    // combine the four waves (fixed order) and add the tile to the chromosome's gradient
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int idx = (32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + 32 * j + r;
+              red[idx] = (w == 0) ? acc[i][j][reg] : red[idx] + acc[i][j][reg];
+            }
+      }
+      __syncthreads();
+    }
+    float* out = MODE == 0 ? g.out + (int64_t)c * g.d * g.d : g.out + (int64_t)g.d * lo;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+      const int row = mo0 + idx / 64, col = no0 + idx % 64;
+      if (row < g.d && col < ncols) atomicAdd(out + (int64_t)row * ncols + col, red[idx]);
+    }
+  }
+}
+
+// ---- recon branch ------------------------------------------------------------------------------------------------
+// TH[j] = tanh(node[other_map[j]]) for j < m
+__global__ __launch_bounds__(256) void adj_tanh_gather_kernel(const float* __restrict__ node, const int32_t* __restrict__ other_map,
+                                                              const int32_t* __restrict__ counts, int d, float* __restrict__ TH) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = i / d;
+  if (j >= counts[0]) return;
+  const int col = (int)(i - j * d);
+  TH[i] = tanhf(node[(int64_t)other_map[j] * d + col]);
+}
+
+// D[j][col] = rec[j][col] - inter[x_j - 1][bounds[r] + col]  (in place; pad columns zeroed); per-block sums of D^2
+__global__ __launch_bounds__(256) void adj_recon_loss_kernel(float* __restrict__ rec, int64_t nr_pad, int n_r, int col0, const float* __restrict__ inter,
+                                                             int64_t n_nodes, const int64_t* __restrict__ x, const int32_t* __restrict__ other_map,
+                                                             const int32_t* __restrict__ counts, float* __restrict__ slab) {
+  __shared__ float red[256];
+  const int m = counts[0];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float s = 0.f;
+  // one wave per row, 64 rows per workgroup
+  for (int rr = wave; rr < 64; rr += 4) {
+    const int64_t j = (int64_t)blockIdx.x * 64 + rr;
+    if (j >= m) break;
+    const int64_t node = x[other_map[j]];
+    const float* trow = inter + (node - 1) * n_nodes + col0;
+    float* rrow = rec + j * nr_pad;
+    for (int col = lane; col < nr_pad; col += 64) {
+      float dv = 0.f;
+      if (col < n_r) { dv = rrow[col] - trow[col]; s += dv * dv; }
+      rrow[col] = dv;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) slab[blockIdx.x] = red[0];
+}
+
+// recon_loss = 100 * sum / (m * n_r)  (mean over columns, mean over rows, * 100; Modules.py:199), 0 when m == 0 (:195)
+__global__ __launch_bounds__(256) void adj_recon_final_kernel(const float* __restrict__ slab, int nslab, const int32_t* __restrict__ counts, int n_r,
+                                                              float* __restrict__ out) {
+  __shared__ float red[256];
+  const int m = counts[0];
+  const int used = (m + 63) / 64;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < used && i < nslab; i += 256) s += slab[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = m > 0 ? 100.f * red[0] / ((float)m * (float)n_r) : 0.f;
+}
+
+// D *= g * 200 / (m * n_r)   with g = *drecon (autograd) or beta
+__global__ __launch_bounds__(256) void adj_scale_kernel(float* __restrict__ D, int64_t nr_pad, int n_r, const int32_t* __restrict__ counts,
+                                                        const float* __restrict__ drecon, float beta) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int m = counts[0];
+  if (i >= (int64_t)m * nr_pad) return;
+  const float gscale = (drecon ? drecon[0] : beta) * 200.f / ((float)m * (float)n_r);
+  D[i] *= gscale;
+}
+
+// dnode[other_map[j]] += dTH[j] * (1 - TH[j]^2)
+__global__ __launch_bounds__(256) void adj_recon_dnode_kernel(const float* __restrict__ dTH, const float* __restrict__ TH,
+                                                              const int32_t* __restrict__ other_map, const int32_t* __restrict__ counts, int d,
+                                                              float* __restrict__ dnode) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = i / d;
+  if (j >= counts[0]) return;
+  const int col = (int)(i - j * d);
+  const float t = TH[i];
+  dnode[(int64_t)other_map[j] * d + col] += dTH[i] * (1.f - t * t);
+}
+
+// ---- host orchestration ----------------------------------------------------------------------------------------------
+static int check_adj(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f) {
+  MATCHA_CHECK_ARG(s.n_chrom >= 1 && s.n_chrom <= kMaxChrom, "adj mode: n_chrom=%d outside 1..%d", s.n_chrom, kMaxChrom);
+  MATCHA_CHECK_ARG(s.max_bins >= 1, "adj mode: max_bins must be set");
+  MATCHA_CHECK_ARG(p.adj_w0 && p.adj_w1 && f.bounds && f.feats && f.feat_off, "adj mode: null tensor (adj_w0/adj_w1/bounds/feats/feat_off)");
+  return MATCHA_OK;
+}
+
+static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int64_t* x, int64_t T, int r_chrom, AdjWs& w, int32_t* touched,
+                       hipStream_t st) {
+  const int C = s.n_chrom;
+  hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist);
+  MATCHA_CHECK_LAUNCH("adj_hist_kernel");
+  hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(64), 0, st, w.hist, w.nblk, C, r_chrom, w.base, w.seg, w.counts, touched);
+  MATCHA_CHECK_LAUNCH("adj_scan_kernel");
+  hipLaunchKernelGGL(adj_scatter_kernel, dim3(w.nblk), dim3(256), (size_t)(C + 1) * 256 * sizeof(int), st, x, T, f.bounds, C, r_chrom, w.base,
+                     w.seg, w.order, w.other_map);
+  MATCHA_CHECK_LAUNCH("adj_scatter_kernel");
+  return MATCHA_OK;
+}
+
+int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* x, int64_t T,
+                float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  MATCHA_TRY(check_adj(s, p, f));
+  MATCHA_CHECK_ARG(ws && ((uintptr_t)ws) % 256 == 0, "adj_forward: workspace missing or misaligned");
+  AdjWs w;
+  const size_t need = adj_carve(s, T, (char*)ws, w);
+  if (ws_bytes < need) { set_error("adj_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
+  const int C = s.n_chrom, d = s.d;
+  const int r = (recon_out && o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
+  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, st));
+  const bool train = o.training != 0 && o.p_drop_adj > 0.f;
+  MATCHA_CHECK_ARG(!train || o.seed, "adj_forward: dropout needs a seed");
+  // layer 1: gather-GEMM + tanh -> Hs (sorted rows)
+  {
+    AdjEncArgs a;
+    a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats; a.w0 = p.adj_w0;
+    a.Hs = w.Hs; a.T = T; a.C = C; a.d = d; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f;
+    const int nt = (int)cdiv(d, 32);
+    dim3 grid((unsigned)cdiv(T, 128));
+    ProfScope ps(MATCHA_PROF_ADJ_ENCODE, 0.0, st);
+    if (nt <= 1) hipLaunchKernelGGL((adj_encode_fwd_kernel<1>), grid, dim3(256), (size_t)(128 + 32) * kLdA * 4, st, a);
+    else if (nt == 2) hipLaunchKernelGGL((adj_encode_fwd_kernel<2>), grid, dim3(256), (size_t)(128 + 64) * kLdA * 4, st, a);
+    else if (nt <= 4) hipLaunchKernelGGL((adj_encode_fwd_kernel<4>), grid, dim3(256), (size_t)(128 + 128) * kLdA * 4, st, a);
+    else hipLaunchKernelGGL((adj_encode_fwd_kernel<8>), grid, dim3(256), (size_t)(128 + 256) * kLdA * 4, st, a);
+    MATCHA_CHECK_LAUNCH("adj_encode_fwd_kernel");
+  }
+  // layer 2: node[order[p]] = Hs[p] . W1_c^T ; padding slots stay 0 (Modules.py:178)
+  if (hipMemsetAsync(node_out, 0, (size_t)T * d * sizeof(float), st) != hipSuccess) { set_error("memset(node) failed"); return MATCHA_EHIP; }
+  {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = w.Hs; g.B[0] = p.adj_w1; g.C[0] = node_out; g.batch = 1;
+    g.M = T; g.N = d; g.K = d; g.lda = d; g.ldb = d; g.ldc = d; g.aux_scale = 1.f;
+    g.c_row_map = w.order; g.seg = w.seg; g.n_groups = C; g.b_group_stride = (int64_t)d * d;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  if (!recon_out) return MATCHA_OK;
+  if (r < 0) {
+    if (hipMemsetAsync(recon_out, 0, sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    return MATCHA_OK;
+  }
+  // recon branch (Modules.py:192-199)
+  MATCHA_CHECK_ARG(p.recon_w && p.recon_b && f.inter && f.bounds_host, "adj_forward: recon tensors / bounds_host missing");
+  const int lo_r = f.bounds_host[r], n_r = f.bounds_host[r + 1] - f.bounds_host[r];
+  hipLaunchKernelGGL(adj_tanh_gather_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, node_out, w.other_map, w.counts, d, w.TH);
+  MATCHA_CHECK_LAUNCH("adj_tanh_gather_kernel");
+  {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = w.TH; g.B[0] = p.recon_w + (int64_t)d * lo_r; g.C[0] = w.rec; g.batch = 1;
+    g.M = T; g.N = n_r; g.K = d; g.lda = d; g.ldb = d; g.ldc = w.nr_pad; g.aux_scale = 1.f;
+    g.flags = MATCHA_EPI_BIAS; g.bias[0] = p.recon_b + lo_r; g.m_dev = w.counts;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  const int nslab = (int)cdiv(T, 64);
+  hipLaunchKernelGGL(adj_recon_loss_kernel, dim3(nslab), dim3(256), 0, st, w.rec, w.nr_pad, n_r, lo_r, f.inter, (int64_t)s.n_nodes, x, w.other_map,
+                     w.counts, w.lossslab);
+  MATCHA_CHECK_LAUNCH("adj_recon_loss_kernel");
+  hipLaunchKernelGGL(adj_recon_final_kernel, dim3(1), dim3(256), 0, st, w.lossslab, nslab, w.counts, n_r, recon_out);
+  MATCHA_CHECK_LAUNCH("adj_recon_final_kernel");
+  return MATCHA_OK;
+}
+
+int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* x, int64_t T,
+                 float* dnode, const float* drecon, matcha_tensors& g_, int32_t* touched, void* ws, size_t ws_bytes, void* gemm_ws,
+                 size_t gemm_ws_bytes, hipStream_t st) {
+  MATCHA_TRY(check_adj(s, p, f));
+  AdjWs w;
+  const size_t need = adj_carve(s, T, (char*)ws, w);
+  if (ws_bytes < need) { set_error("adj_backward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
+  MATCHA_CHECK_ARG(g_.adj_w0 && g_.adj_w1, "adj_backward: gradient buffers missing");
+  const int C = s.n_chrom, d = s.d;
+  const int r = (o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
+  const bool train = o.training != 0 && o.p_drop_adj > 0.f;
+  if (touched) {     // order/seg/other_map of the forward are still in the workspace; only the flags are (re)written
+    hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(64), 0, st, w.hist, w.nblk, C, r, w.base, w.seg, w.counts, touched);
+    MATCHA_CHECK_LAUNCH("adj_scan_kernel(flags)");
+  }
+  // ---- recon branch: d loss / d rec = g * 200/(m n_r) * (rec - target) ----
+  if (r >= 0 && (drecon || o.beta != 0.f)) {
+    MATCHA_CHECK_ARG(g_.recon_w && g_.recon_b && f.bounds_host, "adj_backward: recon gradient buffers missing");
+    const int lo_r = f.bounds_host[r], n_r = f.bounds_host[r + 1] - f.bounds_host[r];
+    hipLaunchKernelGGL(adj_scale_kernel, dim3((unsigned)cdiv(T * w.nr_pad, 256)), dim3(256), 0, st, w.rec, w.nr_pad, n_r, w.counts, drecon, o.beta);
+    MATCHA_CHECK_LAUNCH("adj_scale_kernel");
+    // dWr[n_r, d] += D^T TH ; dbr += colsum(D)
+    MATCHA_TRY(launch_gemm_tn(w.rec, w.TH, g_.recon_w + (int64_t)d * lo_r, g_.recon_b + lo_r, n_r, d, T, w.nr_pad, d, nullptr, true, gemm_ws,
+                              gemm_ws_bytes, st, w.counts));
+    // dTH = D . Wr   (K = n_r)
+    {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A[0] = w.rec; g.B[0] = p.recon_w + (int64_t)d * lo_r; g.C[0] = w.dTH; g.batch = 1;
+      g.M = T; g.N = d; g.K = n_r; g.lda = w.nr_pad; g.ldb = d; g.ldc = d; g.aux_scale = 1.f; g.m_dev = w.counts;
+      MATCHA_TRY(launch_gemm_rm(true, g, st));
+    }
+    hipLaunchKernelGGL(adj_recon_dnode_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, w.dTH, w.TH, w.other_map, w.counts, d, dnode);
+    MATCHA_CHECK_LAUNCH("adj_recon_dnode_kernel");
+  }
+  // ---- encoder ----
+  const int rpb = 1024;
+  const unsigned zblocks = (unsigned)cdiv(T, rpb);
+  {
+    AdjTnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = dnode; a.Bd = w.Hs; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
+    a.out = g_.adj_w1; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = 0.f;
+    hipLaunchKernelGGL((adj_tn_kernel<0>), dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(d, 64), zblocks), dim3(256), 0, st, a);
+    MATCHA_CHECK_LAUNCH("adj_tn_kernel<0>");
+  }
+  {   // dZ[p] = (dnode[order[p]] . W1_c) * (1 - Hs[p]^2)
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = dnode; g.B[0] = p.adj_w1; g.C[0] = w.dZ; g.batch = 1;
+    g.M = T; g.N = d; g.K = d; g.lda = d; g.ldb = d; g.ldc = d; g.aux_scale = 1.f;
+    g.flags = MATCHA_EPI_DTANH; g.aux = w.Hs;
+    g.a_row_map = w.order; g.seg = w.seg; g.n_groups = C; g.b_group_stride = (int64_t)d * d;
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  {
+    AdjTnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = w.dZ; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
+    a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f;
+    hipLaunchKernelGGL((adj_tn_kernel<1>), dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(s.max_bins, 64), zblocks), dim3(256), 0, st, a);
+    MATCHA_CHECK_LAUNCH("adj_tn_kernel<1>");
+  }
+  return MATCHA_OK;
 }
 
 }  // namespace matcha

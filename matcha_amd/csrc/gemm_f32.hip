@@ -137,6 +137,7 @@ struct GemmTnArgs {
   float* slab;      // partition p at slab + p*slab_stride: [M*N]
   float* colslab;   // partition p at colslab + p*slab_stride: [M]; or null
   int64_t slab_stride;
+  const int32_t* r_dev;
   int64_t M, N, R, lda, ldb;
   int64_t rows_per_block;
   int tiles_n;
@@ -153,8 +154,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   const int64_t mo0 = (int64_t)(tile / g.tiles_n) * 64;
   const int64_t no0 = (int64_t)(tile % g.tiles_n) * 64;
   const int64_t p = blockIdx.y;
+  const int64_t R = g.r_dev ? (int64_t)(*g.r_dev) : g.R;      // row count may live on the device (adj front end)
   const int64_t rbeg = p * g.rows_per_block;
-  int64_t rend = rbeg + g.rows_per_block; if (rend > g.R) rend = g.R;
+  int64_t rend = rbeg + g.rows_per_block; if (rend > R) rend = R;
+  if (rend < rbeg) rend = rbeg;                               // empty partition: writes a zero slab
   const bool do_col = (g.colslab != nullptr) && (no0 == 0);
 
   int64_t am[2], bn[2];
@@ -296,7 +299,7 @@ static void tn_partition(int64_t M, int64_t N, int64_t R, int* tiles_m, int* til
   *tiles_n = (int)cdiv(N, 64);
   const int64_t tiles = (int64_t)(*tiles_m) * (*tiles_n);
   int64_t want = cdiv(1024, tiles);                 // ~4 blocks (16 waves) per CU in total
-  int64_t maxp = cdiv(R, 1024);                     // at least 1024 rows (32 eight-row groups per wave) per block
+  int64_t maxp = cdiv(R, 64);                       // at least 64 rows (two 8-row groups per wave) per block
   int64_t p = want < maxp ? want : maxp;
   if (p < 1) p = 1;
   int64_t rpb = cdiv(cdiv(R, p), 32) * 32;          // multiple of 32 rows so the waves' 8-row groups tile it
@@ -337,14 +340,14 @@ size_t gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t R) {
 // C[M,N] (+)= A[R,M]^T . B[R,N];  colsum[M] (+)= sum_r A[r,:]
 int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int64_t M, int64_t N, int64_t R,
                    int64_t lda, int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
+                   hipStream_t st, const int32_t* r_dev) {
   if (M <= 0 || N <= 0) return MATCHA_OK;
   int tm, tn, P; int64_t rpb;
   tn_partition(M, N, R > 0 ? R : 1, &tm, &tn, &P, &rpb);
   const size_t need = (size_t)P * (size_t)(M * N + M) * sizeof(float);
   if (ws_bytes < need) { set_error("gemm TN workspace too small: %zu < %zu", ws_bytes, need); return MATCHA_ENOMEM; }
   GemmTnArgs g;
-  g.A = A; g.B = B; g.b_gather = b_gather;
+  g.A = A; g.B = B; g.b_gather = b_gather; g.r_dev = r_dev;
   // one slab row per partition: [M*N outputs | M column sums]
   g.slab = (float*)ws;
   g.slab_stride = M * N + (colsum ? M : 0);

@@ -10,6 +10,11 @@
 //   workgroup = 256 threads = 4 waves; tile = 128 rows x 64 columns x 64 deep; wave = 32 rows x 64 columns
 //   LDS: A tile [128][68] + B tile [64][68] floats = 52 KiB -> 3 workgroups per CU
 //   epilogue flags are COMPILE-TIME (a runtime-flag epilogue costs ~700 basic blocks in the unrolled store loop)
+//
+// Optional indirections for the adj front end (MultipleEmbedding, Modules.py:176-201), all resolved per workgroup:
+//   m_dev      row count read from device memory (segment sizes are only known on the device)
+//   a_row_map  gather of A rows, c_row_map scatter of C rows (tokens sorted by chromosome <-> token slots)
+//   seg        grouped mode: rows sorted by group, group c uses weight B + c*b_group_stride (per-chromosome W1)
 #include "kernels.hpp"
 
 namespace matcha {
@@ -34,10 +39,12 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
   const int r = lane & 31, h = lane >> 5;
   const int z = blockIdx.z;
   const float* __restrict__ A = g.A[z];
-  const float* __restrict__ B = g.B[z];
   float* __restrict__ C = g.C[z];
+  const int64_t M = g.m_dev ? (int64_t)(*g.m_dev) : g.M;
+  const int64_t N = g.N, K = g.K;
   const int64_t m0 = (int64_t)blockIdx.y * kBM;
-  const int64_t M = g.M, N = g.N, K = g.K;
+  if (m0 >= M) return;
+  const int64_t m_end = (m0 + kBM < M) ? m0 + kBM : M;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;      // staging: thread -> (row within 16-row slab, float4 column)
 
   uint32_t key = 0, thr = 0;
@@ -49,103 +56,136 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
   }
   const float* bias = g.bias[z];
 
-  for (int nt_i = 0; nt_i < n_tiles_per_block; ++nt_i) {
-    const int64_t n0 = ((int64_t)blockIdx.x * n_tiles_per_block + nt_i) * kBN;
-    if (n0 >= N) break;
-    f32x16 acc0 = {0}, acc1 = {0};
-    for (int64_t kc = 0; kc < K; kc += kBK) {
-      const bool stage_a = (nt_i == 0) || (K > kBK);       // K <= 64: the A tile stays resident across column tiles
-      if (kc > 0 || nt_i > 0) __syncthreads();             // previous tile's LDS reads are done
-      const bool full_k = kc + kBK <= K;
-      if (stage_a) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int row = srow + 16 * i;
-          int64_t gm = m0 + row; gm = gm < M ? gm : M - 1;
-          const float* src = A + gm * g.lda + kc + sc4;
-          float4 v;
-          if (full_k) v = *reinterpret_cast<const float4*>(src);
-          else v = (kc + sc4 + 3 < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(&As[row * kLd + sc4]) = v;
-        }
-      }
-      if (!B_KN) {                                         // B[n][k]: 64 rows x 16 float4
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = srow + 16 * i;
-          int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
-          const float* src = B + gn * g.ldb + kc + sc4;
-          float4 v;
-          if (full_k) v = *reinterpret_cast<const float4*>(src);
-          else v = (kc + sc4 + 3 < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(&Bs[row * kLd + sc4]) = v;
-        }
-      } else {                                             // B[k][n]: 64 k-rows x 16 float4 along n
-        const bool full_n = n0 + kBN <= N;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = srow + 16 * i;                   // k within the chunk
-          const int64_t gk = kc + row;
-          const int64_t gkc = gk < K ? gk : K - 1;
-          float4 v;
-          if (full_n) v = *reinterpret_cast<const float4*>(B + gkc * g.ldb + n0 + sc4);
-          else {
-            const float* src = B + gkc * g.ldb;
-            v.x = (n0 + sc4 + 0 < N) ? src[n0 + sc4 + 0] : 0.f;
-            v.y = (n0 + sc4 + 1 < N) ? src[n0 + sc4 + 1] : 0.f;
-            v.z = (n0 + sc4 + 2 < N) ? src[n0 + sc4 + 2] : 0.f;
-            v.w = (n0 + sc4 + 3 < N) ? src[n0 + sc4 + 3] : 0.f;
-          }
-          if (gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(&Bs[row * kLd + sc4]) = v;
-        }
-      }
-      __syncthreads();
-      // ---- 32 rows x 64 columns x 64 deep per wave: 64 MFMAs ----
-      const float* arow = &As[(32 * wave + r) * kLd + 4 * h];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
-        float4 b0, b1;
-        if (!B_KN) {
-          b0 = *reinterpret_cast<const float4*>(&Bs[r * kLd + 8 * c + 4 * h]);
-          b1 = *reinterpret_cast<const float4*>(&Bs[(32 + r) * kLd + 8 * c + 4 * h]);
-        } else {
-          const float* bp = &Bs[(8 * c + 4 * h) * kLd + r];
-          b0 = make_float4(bp[0], bp[kLd], bp[2 * kLd], bp[3 * kLd]);
-          b1 = make_float4(bp[32], bp[kLd + 32], bp[2 * kLd + 32], bp[3 * kLd + 32]);
-        }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-      }
+  // groups intersecting this row tile (1 pass when not grouped)
+  int c_lo = 0, c_hi = 0;
+  if (g.seg) {
+    while (c_lo < g.n_groups && g.seg[c_lo + 1] <= m0) ++c_lo;
+    c_hi = c_lo;
+    while (c_hi < g.n_groups && g.seg[c_hi + 1] < m_end) ++c_hi;
+  }
+  bool a_resident = false, lds_dirty = false;
+  for (int grp = c_lo; grp <= c_hi; ++grp) {
+    int64_t row_lo = m0, row_hi = m_end;
+    const float* __restrict__ B = g.B[z];
+    if (g.seg) {
+      if (grp >= g.n_groups) break;                        // trailing segment (padding slots): no weights, skipped
+      const int64_t s0 = g.seg[grp], s1 = g.seg[grp + 1];
+      row_lo = s0 > m0 ? s0 : m0;
+      row_hi = s1 < m_end ? s1 : m_end;
+      if (row_lo >= row_hi) continue;
+      B += (int64_t)grp * g.b_group_stride;
     }
-    // ---- epilogue: bias -> tanh -> +residual -> dropout -> row mask -> *(1 - (aux*aux_scale)^2) -> (+=) ----
-    const int64_t mrow0 = m0 + 32 * wave + 4 * h;
+    for (int nt_i = 0; nt_i < n_tiles_per_block; ++nt_i) {
+      const int64_t n0 = ((int64_t)blockIdx.x * n_tiles_per_block + nt_i) * kBN;
+      if (n0 >= N) break;
+      f32x16 acc0 = {0}, acc1 = {0};
+      for (int64_t kc = 0; kc < K; kc += kBK) {
+        const bool stage_a = !a_resident || (K > kBK);     // K <= 64: the A tile stays resident across column tiles
+        if (lds_dirty) __syncthreads();                    // previous tile's LDS reads are done
+        lds_dirty = true;
+        const bool full_k = kc + kBK <= K;
+        if (stage_a) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int64_t col = n0 + nt * 32 + r;
-      if (col >= N) continue;
-      const float bv = Epilogue<FLAGS>::has(g, MATCHA_EPI_BIAS) ? bias[col] : 0.f;
-      const f32x16 acc = nt == 0 ? acc0 : acc1;
+          for (int i = 0; i < 8; ++i) {
+            const int row = srow + 16 * i;
+            int64_t gm = m0 + row; gm = gm < M ? gm : M - 1;
+            if (g.a_row_map) gm = g.a_row_map[gm];
+            const float* src = A + gm * g.lda + kc + sc4;
+            float4 v;
+            if (full_k) v = *reinterpret_cast<const float4*>(src);
+            else {
+              // lda is a multiple of 4 and >= K, so a 16-B load that STARTS below K stays inside the row
+              const int64_t k = kc + sc4;
+              v = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+              v.y = (k + 1 < K) ? v.y : 0.f; v.z = (k + 2 < K) ? v.z : 0.f; v.w = (k + 3 < K) ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(&As[row * kLd + sc4]) = v;
+          }
+          a_resident = true;
+        }
+        if (!B_KN) {                                         // B[n][k]: 64 rows x 16 float4
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int64_t row = mrow0 + (reg & 3) + 8 * (reg >> 2);
-        if (row >= M) continue;
-        float v = acc[reg] + bv;
-        const int64_t off = row * g.ldc + col;
-        if (Epilogue<FLAGS>::has(g, MATCHA_EPI_TANH)) v = tanhf(v);
-        if (Epilogue<FLAGS>::has(g, MATCHA_EPI_RESIDUAL)) v += g.residual[off];
-        if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DROPOUT)) v = (rng_u32(key, (uint32_t)row, (uint32_t)col) >= thr) ? v * keep_scale : 0.f;
-        if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ROWMASK)) v = (g.row_ids[row] != 0) ? v : 0.f;
-        if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DTANH)) { const float a = g.aux[off] * g.aux_scale; v *= (1.f - a * a); }
-        if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ACCUM)) v += C[off];
-        C[off] = v;
+          for (int i = 0; i < 4; ++i) {
+            const int row = srow + 16 * i;
+            int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
+            const float* src = B + gn * g.ldb + kc + sc4;
+            float4 v;
+            if (full_k) v = *reinterpret_cast<const float4*>(src);
+            else {
+              const int64_t k = kc + sc4;
+              v = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+              v.y = (k + 1 < K) ? v.y : 0.f; v.z = (k + 2 < K) ? v.z : 0.f; v.w = (k + 3 < K) ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(&Bs[row * kLd + sc4]) = v;
+          }
+        } else {                                             // B[k][n]: 64 k-rows x 16 float4 along n
+          const bool full_n = n0 + kBN <= N;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = srow + 16 * i;                   // k within the chunk
+            const int64_t gk = kc + row;
+            const int64_t gkc = gk < K ? gk : K - 1;
+            float4 v;
+            if (full_n) v = *reinterpret_cast<const float4*>(B + gkc * g.ldb + n0 + sc4);
+            else {
+              const float* src = B + gkc * g.ldb;
+              v.x = (n0 + sc4 + 0 < N) ? src[n0 + sc4 + 0] : 0.f;
+              v.y = (n0 + sc4 + 1 < N) ? src[n0 + sc4 + 1] : 0.f;
+              v.z = (n0 + sc4 + 2 < N) ? src[n0 + sc4 + 2] : 0.f;
+              v.w = (n0 + sc4 + 3 < N) ? src[n0 + sc4 + 3] : 0.f;
+            }
+            if (gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Bs[row * kLd + sc4]) = v;
+          }
+        }
+        __syncthreads();
+        // ---- 32 rows x 64 columns x 64 deep per wave: 64 MFMAs ----
+        const float* arow = &As[(32 * wave + r) * kLd + 4 * h];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
+          float4 b0, b1;
+          if (!B_KN) {
+            b0 = *reinterpret_cast<const float4*>(&Bs[r * kLd + 8 * c + 4 * h]);
+            b1 = *reinterpret_cast<const float4*>(&Bs[(32 + r) * kLd + 8 * c + 4 * h]);
+          } else {
+            const float* bp = &Bs[(8 * c + 4 * h) * kLd + r];
+            b0 = make_float4(bp[0], bp[kLd], bp[2 * kLd], bp[3 * kLd]);
+            b1 = make_float4(bp[32], bp[kLd + 32], bp[2 * kLd + 32], bp[3 * kLd + 32]);
+          }
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+      }
+      // ---- epilogue: bias -> tanh -> +residual -> dropout -> row mask -> *(1 - (aux*aux_scale)^2) -> (+=) ----
+      const int64_t mrow0 = m0 + 32 * wave + 4 * h;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int64_t col = n0 + nt * 32 + r;
+        if (col >= N) continue;
+        const float bv = Epilogue<FLAGS>::has(g, MATCHA_EPI_BIAS) ? bias[col] : 0.f;
+        const f32x16 acc = nt == 0 ? acc0 : acc1;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int64_t lrow = mrow0 + (reg & 3) + 8 * (reg >> 2);
+          if (lrow < row_lo || lrow >= row_hi) continue;
+          const int64_t row = g.c_row_map ? (int64_t)g.c_row_map[lrow] : lrow;
+          float v = acc[reg] + bv;
+          const int64_t off = row * g.ldc + col;
+          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_TANH)) v = tanhf(v);
+          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_RESIDUAL)) v += g.residual[off];
+          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DROPOUT)) v = (rng_u32(key, (uint32_t)row, (uint32_t)col) >= thr) ? v * keep_scale : 0.f;
+          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ROWMASK)) v = (g.row_ids[row] != 0) ? v : 0.f;
+          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DTANH)) { const float a = g.aux[off] * g.aux_scale; v *= (1.f - a * a); }
+          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ACCUM)) v += C[off];
+          C[off] = v;
+        }
       }
     }
   }
@@ -158,10 +198,15 @@ static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, hipStream_t st) {
 
 int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return MATCHA_OK;
-  bool vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);
+  bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.lda >= g.K || b_kn);
   for (int z = 0; z < g.batch; ++z) vec = vec && (((uintptr_t)g.A[z]) % 16 == 0) && (((uintptr_t)g.B[z]) % 16 == 0);
+  if (!b_kn) vec = vec && (g.ldb >= g.K);
   if (b_kn) vec = vec && (g.N % 4 == 0);
-  if (!vec) return launch_gemm_rm_direct(b_kn, g, st);
+  const bool indirect = g.m_dev || g.a_row_map || g.c_row_map || g.seg;
+  if (!vec) {
+    if (indirect) { set_error("gemm: row maps / grouped mode need 16-byte aligned operands"); return MATCHA_EINVAL; }
+    return launch_gemm_rm_direct(b_kn, g, st);
+  }
   const int tiles_n = (int)cdiv(g.N, kBN);
   // K <= 64: one workgroup keeps its activation tile in LDS and walks up to 8 column tiles
   int ntpb = 1;
@@ -174,6 +219,7 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
   if (!b_kn) {
     switch (F) {
       case 0: launch_one<false, 0>(g, grid, ntpb, st); break;
+      case B_: launch_one<false, B_>(g, grid, ntpb, st); break;
       case B_ | T_: launch_one<false, B_ | T_>(g, grid, ntpb, st); break;
       case B_ | T_ | D_: launch_one<false, B_ | T_ | D_>(g, grid, ntpb, st); break;
       case B_ | M_: launch_one<false, B_ | M_>(g, grid, ntpb, st); break;

@@ -21,6 +21,13 @@ struct GemmArgs {
   uint32_t stream_id;
   float p_drop;
   float aux_scale;
+  // optional indirections (adj front end; all device pointers, null = off)
+  const int32_t* m_dev;       // number of rows lives on the device (rows >= *m_dev are neither read nor written)
+  const int32_t* a_row_map;   // A row of logical row m is a_row_map[m]
+  const int32_t* c_row_map;   // C (and residual/aux/row-mask) row of logical row m is c_row_map[m]
+  const int32_t* seg;         // grouped mode: logical rows are sorted by group; group c owns rows [seg[c], seg[c+1])
+  int n_groups;               //   and uses B + c*b_group_stride; rows of groups >= n_groups are skipped
+  int64_t b_group_stride;
 };
 
 struct HeadParams {
@@ -31,7 +38,9 @@ struct HeadParams {
 int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st);
 size_t gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t R);
 int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int64_t M, int64_t N, int64_t R, int64_t lda,
-                   int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                   int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                   const int32_t* r_dev = nullptr);
+int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st);
 
 // token_kernels.hip
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,

@@ -43,8 +43,8 @@ void prof_record(bool start, double work, hipStream_t st) {
 int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
                 const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st);
 int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
-                 const int64_t* x, int64_t T, const float* dnode, const float* drecon, matcha_tensors& g, int32_t* touched,
-                 void* ws, size_t ws_bytes, hipStream_t st);
+                 const int64_t* x, int64_t T, float* dnode, const float* drecon, matcha_tensors& g, int32_t* touched,
+                 void* ws, size_t ws_bytes, void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st);
 size_t adj_workspace_bytes(const matcha_shape& s, int64_t T);
 
 struct Workspace {
@@ -87,6 +87,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   size_t g2 = gemm_tn_ws_bytes(d, hd, T); if (g2 > gb) gb = g2; // dfc1
   g2 = gemm_tn_ws_bytes(d, d, T); if (g2 > gb) gb = g2;
   g2 = gemm_tn_ws_bytes(d, s.n_attr, T); if (g2 > gb) gb = g2;
+  if (s.mode == 1) { g2 = gemm_tn_ws_bytes(s.max_bins, d, T); if (g2 > gb) gb = g2; }   // recon head gradient
   w.gemm_ws_bytes = gb; w.gemm_ws = take(gb / sizeof(float));
   w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, T) : 0;
   w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
@@ -310,7 +311,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     MATCHA_TRY(launch_embed_scatter(x, T, d, w.dX0, g_.table, st));
     if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
   } else {
-    MATCHA_TRY(adj_backward(s, p, *frozen, *opts, x, T, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, st));
+    MATCHA_TRY(adj_backward(s, p, *frozen, *opts, x, T, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st));
   }
   return MATCHA_OK;
 }

@@ -1,0 +1,190 @@
+"""adj front end (MultipleEmbedding, what the reference's main.py actually runs) on the HIP path vs the golden
+fixtures of the real reference and vs the oracle.  GPU only (-m gpu)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import synth
+from oracle import hypersagnn as O
+from oracle import rng as R
+from tests.helpers import GOLD, gold, oracle_state, rel_err
+from tests.test_hip_model import GAUGE, TOL, hip_model
+
+pytestmark = pytest.mark.gpu
+
+ADJ_CASES = [("tiny_adj", "tiny", 16, 21), ("c1_adj", "c1", 16, 23), ("hg38_adj_d64", "hg38_1mb", 64, 25)]
+
+
+@pytest.mark.parametrize("name,layout,d,seed", ADJ_CASES)
+def test_g2_eval_logits_adj(name, layout, d, seed):
+    g = gold(f"g2_{name}.npz")
+    clf, _ = hip_model(synth.LAYOUTS[layout], d, "adj", seed)
+    clf.eval()
+    with torch.no_grad():
+        for k in (2, 3, 4, 5):
+            x = torch.from_numpy(g[f"x_k{k}"])
+            np.random.seed(7)                           # the generator seeded numpy with 7 before each forward (Modules.py:192)
+            lg, rc = clf(x, return_recon=True)
+            assert rel_err(lg.cpu().numpy(), g[f"logits_k{k}"]) < TOL, k
+            assert rel_err(rc.cpu().numpy(), g[f"recon_k{k}"]) < TOL, k
+            np.random.seed(7)
+            lg5, rc5 = clf(torch.nn.functional.pad(x, (0, 5 - k)), return_recon=True)
+            assert rel_err(lg5.cpu().numpy(), g[f"logits_k{k}_L5"]) < TOL, k
+            assert rel_err(rc5.cpu().numpy(), g[f"recon_k{k}_L5"]) < TOL, k
+        np.random.seed(7)
+        lg, rc = clf(torch.from_numpy(g["x_mixed"]), return_recon=True)
+        assert rel_err(lg.cpu().numpy(), g["logits_mixed"]) < TOL
+        assert rel_err(rc.cpu().numpy(), g["recon_mixed"]) < TOL
+
+
+def test_reference_pickle_loads_and_runs_adj():
+    import Modules  # noqa: F401
+    out = gold("g1_tiny_adj_refinit_out.npz")
+    clf = torch.load(os.path.join(GOLD, "ref_model2load_tiny_adj"), map_location="cuda", weights_only=False)
+    clf.eval()
+    np.random.seed(7)
+    with torch.no_grad():
+        lg, rc = clf(torch.from_numpy(out["x"]), return_recon=True)
+    assert rel_err(lg.cpu().numpy(), out["logits"]) < TOL
+    assert rel_err(rc.cpu().numpy(), out["recon"]) < TOL
+    buf = io.BytesIO()
+    torch.save(clf, buf)
+    buf.seek(0)
+    clf2 = torch.load(buf, map_location="cuda", weights_only=False)
+    np.random.seed(7)
+    with torch.no_grad():
+        lg2 = clf2(torch.from_numpy(out["x"]))
+    assert torch.allclose(lg.cpu(), lg2.cpu(), atol=1e-6)
+
+
+def _train_g3_adj(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused):
+    g = gold(f"g3_{name}_{tag}.npz")
+    num = synth.LAYOUTS[layout]
+    clf, sd = hip_model(num, d, "adj", seed)
+    for m in clf.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    N = int(np.sum(num))
+    clf.eval()
+    with torch.no_grad():
+        emb0 = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
+    np.testing.assert_allclose(emb0 if full else emb0[::16], g["emb_before"], rtol=0, atol=2e-6)
+    clf.train()
+    if use_fused:
+        from matcha_amd.engine import Trainer
+        tr = Trainer(clf, lr=1e-3)
+    else:
+        opt = torch.optim.AdamW(list(clf.parameters()), lr=1e-3, amsgrad=False)
+    none_ref = set(g["grad_none"].tolist()) - {"attribute_dict_embedding.weight"}
+    np.random.seed(1234)                                  # autograd path draws random_chrom like the reference
+    for step in range(n_steps):
+        x, y, w = (torch.from_numpy(g[f"{n}{step}"]).cuda() for n in "xyw")
+        if use_fused:
+            bce, recon, logits = tr.step(x, y, w, alpha=alpha, beta=beta, random_chrom=int(g["chroms"][step]))
+            logits = logits.view(-1, 1)
+        else:
+            logits, recon = clf(x, return_recon=True)
+            bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, y, weight=w)
+            loss = bce * alpha + recon * beta
+            opt.zero_grad()
+            loss.backward()
+            if step == 0:
+                grads = {n: p.grad for n, p in clf.named_parameters()}
+                assert {n for n, v in grads.items() if v is None} - {"attribute_dict_embedding.weight"} == none_ref
+                for n, v in grads.items():
+                    if v is None or n == GAUGE:
+                        continue
+                    if full:
+                        ref = g["grad0/" + n]
+                        assert np.abs(v.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+                    else:
+                        gn = float(g["gradnorm0/" + n])
+                        assert abs(float(v.double().norm()) - gn) <= TOL * max(gn, 1e-3), n
+            opt.step()
+        assert rel_err(logits.detach().cpu().numpy(), g[f"logits{step}"]) < TOL, step
+        assert abs(float(bce) - float(g[f"bce{step}"])) < TOL * max(1.0, abs(float(g[f"bce{step}"])))
+        assert abs(float(recon.reshape(-1)[0]) - float(g[f"recon{step}"][0])) < TOL * max(1.0, abs(float(g[f"recon{step}"][0]))), step
+        if step in (0, n_steps - 1):
+            params = dict(clf.named_parameters())
+            for key in g.files:
+                if key.startswith(f"param{step}/"):
+                    n = key.split("/", 1)[1]
+                    if n == GAUGE:
+                        continue
+                    ref = g[key]
+                    assert np.abs(params[n].detach().cpu().numpy() - ref).max() <= 2 * TOL * max(np.abs(ref).max(), 1e-3), (step, n)
+    clf.eval()
+    with torch.no_grad():
+        emb1 = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
+    ref = g["emb_after"]
+    mine = emb1 if full else emb1[::16]
+    assert np.abs(mine - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("use_fused", [False, True])
+@pytest.mark.parametrize("tag,alpha,beta", [("phase1", 0.0, 1.0), ("phase2", 1.0, 0.001)])
+def test_g3_training_tiny_adj(tag, alpha, beta, use_fused):
+    _train_g3_adj("tiny_adj", "tiny", 16, 31, alpha, beta, tag, 10, True, use_fused)
+
+
+@pytest.mark.parametrize("use_fused", [False, True])
+def test_g3_training_hg38_adj_d64(use_fused):
+    _train_g3_adj("hg38_adj_d64", "hg38_1mb", 64, 42, 1.0, 0.001, "phase2", 3, False, use_fused)
+
+
+def test_adj_training_dropout_masks_match_oracle_rng():
+    """Train mode incl. the dropout(0.2) on the gathered feature rows: kernel masks == oracle/rng.py masks."""
+    num, d = synth.LAYOUTS["tiny"], 16
+    clf, _ = hip_model(num, d, "adj", 5)
+    P, fe, _ = oracle_state(num, d, "adj", 5)
+    clf.train()
+    x, _, _ = synth.make_batch(np.random.default_rng(4), int(np.sum(num)), [2, 4, 5], 16)
+    xt = torch.from_numpy(x)
+    rt = clf._runtime()
+    np.random.seed(3)
+    chrom = int(np.random.choice(np.arange(len(num)), 1)[0])
+    np.random.seed(3)
+    with torch.no_grad():
+        lg, rc = clf(xt, return_recon=True)
+    seed = (int(torch.initial_seed()) * 1000003 + rt.seed_counter) & 0x7FFFFFFFFFFFFFFF
+    T = x.size
+    masks = {"adj": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_ADJ, O.P_DROP_ADJ, T, max(num))),
+             "fc1": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_FC1, O.P_DROP_FC1, T, d)),
+             "pff": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_PFF, O.P_DROP_PFF, T, d))}
+    with torch.no_grad():
+        ref, rref = O.classifier_forward(P, fe, xt, masks=masks, random_chrom=chrom)
+    assert rel_err(lg.cpu().numpy(), ref.numpy()) < TOL
+    assert rel_err(rc.cpu().numpy(), rref.numpy()) < TOL
+
+
+def test_adj_backward_with_dropout_matches_oracle():
+    """Gradients in train mode (all three dropouts on) against oracle autograd with the same injected masks."""
+    num, d = synth.LAYOUTS["tiny"], 16
+    clf, _ = hip_model(num, d, "adj", 8)
+    P, fe, _ = oracle_state(num, d, "adj", 8, requires_grad=True)
+    clf.train()
+    x, y, w = synth.make_batch(np.random.default_rng(6), int(np.sum(num)), [2, 3, 5], 24)
+    xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
+    rt = clf._runtime()
+    np.random.seed(11)
+    chrom = int(np.random.choice(np.arange(len(num)), 1)[0])
+    np.random.seed(11)
+    lg, rc = clf(xt, return_recon=True)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, yt.cuda(), weight=wt.cuda()) + 0.01 * rc
+    loss.backward()
+    seed = (int(torch.initial_seed()) * 1000003 + rt.seed_counter) & 0x7FFFFFFFFFFFFFFF
+    T = x.size
+    masks = {"adj": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_ADJ, O.P_DROP_ADJ, T, max(num))),
+             "fc1": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_FC1, O.P_DROP_FC1, T, d)),
+             "pff": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_PFF, O.P_DROP_PFF, T, d))}
+    _, _, _, logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, 1.0, 0.01, random_chrom=chrom, masks=masks)
+    assert rel_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
+    for n, p in clf.named_parameters():
+        if grads.get(n) is None or n == GAUGE:
+            continue
+        ref = grads[n].numpy()
+        assert p.grad is not None, n
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n

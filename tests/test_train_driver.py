@@ -62,7 +62,7 @@ def test_host_helpers(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("front_end", ["table"])
+@pytest.mark.parametrize("front_end", ["table", "adj"])
 def test_end_to_end_run_writes_reference_outputs(tmp_path, front_end):
     from matcha_amd import train as T
     import Modules  # noqa: F401
