@@ -97,7 +97,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # torch.distributed.run / torchrun
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=device)
 
@@ -131,6 +132,7 @@ def main():
     clf = make_model(args, num, device)
     clf.train()                                                           # dropout ON, as in the reference's training step
     trainer = Trainer(clf, lr=1e-3, base_seed=99 + rank)
+    trainer.force_collectives = launched and world == 1        # 1-rank torchrun: still go through RCCL
 
     x = torch.zeros((B, L), dtype=torch.long, device=device)
     y = torch.cat([torch.ones(P, device=device), torch.zeros(B - P, device=device)])      # main.py:444-445
@@ -163,7 +165,7 @@ def main():
         runner = graph.replay
 
     def barrier():
-        if world > 1:
+        if world > 1 or launched:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
@@ -252,7 +254,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, num, ks, L, pool, wts, neg_num)
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False))
-    if world > 1:
+    if world > 1 or launched:
         torch.distributed.destroy_process_group()
 
 

@@ -86,20 +86,33 @@ __global__ __launch_bounds__(256) void adj_hist_kernel(const int64_t* __restrict
 
 // one workgroup: seg[] (segment starts), base[blk][c] (first sorted position of block blk's tokens of bucket c),
 // counts[0] = number of "other" tokens (non-pad, not in chromosome r), counts[1] = non-pad tokens; touched flags
-__global__ void adj_scan_kernel(const int32_t* __restrict__ hist, int nblk, int C, int r_chrom, int32_t* __restrict__ base,
-                                int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched) {
+// 1024 threads: 16 lanes per bucket, each lane owns a contiguous chunk of sort blocks (local sums -> 16-lane scan)
+__global__ __launch_bounds__(1024) void adj_scan_kernel(const int32_t* __restrict__ hist, int nblk, int C, int r_chrom, int32_t* __restrict__ base,
+                                                        int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched) {
   __shared__ int tot[kMaxChrom + 2];
-  const int c = threadIdx.x;
+  const int c = threadIdx.x >> 4, sl = threadIdx.x & 15;
+  const int chunk = (nblk + 15) / 16;
+  const int b0 = sl * chunk, b1 = (b0 + chunk < nblk) ? b0 + chunk : nblk;
+  int local = 0;
+  if (c <= C)
+    for (int b = b0; b < b1; ++b) local += hist[(int64_t)b * (C + 1) + c];
+  int incl = local;                                  // inclusive scan over the 16 lanes of the bucket
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    const int v = __shfl_up(incl, o, 16);
+    if (sl >= o) incl += v;
+  }
+  int my_start = incl - local;
   if (c <= C) {
-    int run = 0;
-    for (int b = 0; b < nblk; ++b) {
+    int run = my_start;
+    for (int b = b0; b < b1; ++b) {
       base[(int64_t)b * (C + 1) + c] = run;
       run += hist[(int64_t)b * (C + 1) + c];
     }
-    tot[c] = run;
+    if (sl == 15) tot[c] = incl;
   }
   __syncthreads();
-  if (c == 0) {
+  if (threadIdx.x == 0) {
     int run = 0;
     for (int k = 0; k <= C; ++k) { seg[k] = run; run += tot[k]; }
     seg[C + 1] = run;
@@ -119,7 +132,17 @@ __global__ void adj_scan_kernel(const int32_t* __restrict__ hist, int nblk, int 
   __syncthreads();
   if (c <= C) {
     const int s0 = seg[c];
-    for (int b = 0; b < nblk; ++b) base[(int64_t)b * (C + 1) + c] += s0;
+    for (int b = b0; b < b1; ++b) base[(int64_t)b * (C + 1) + c] += s0;
+  }
+}
+
+// touched flags only (backward): which per-chromosome tensors received a gradient this step
+__global__ void adj_flags_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ counts, int C, int r_chrom, int32_t* __restrict__ touched) {
+  const int k = threadIdx.x;
+  if (k == 0) { touched[0] = 1; touched[1] = 0; }
+  if (k < C) {
+    touched[2 + k] = seg[k + 1] > seg[k] ? 1 : 0;
+    touched[2 + C + k] = (k == r_chrom && counts[0] > 0) ? 1 : 0;
   }
 }
 
@@ -445,7 +468,7 @@ static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int6
   const int C = s.n_chrom;
   hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist);
   MATCHA_CHECK_LAUNCH("adj_hist_kernel");
-  hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(64), 0, st, w.hist, w.nblk, C, r_chrom, w.base, w.seg, w.counts, touched);
+  hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(1024), 0, st, w.hist, w.nblk, C, r_chrom, w.base, w.seg, w.counts, touched);
   MATCHA_CHECK_LAUNCH("adj_scan_kernel");
   hipLaunchKernelGGL(adj_scatter_kernel, dim3(w.nblk), dim3(256), (size_t)(C + 1) * 256 * sizeof(int), st, x, T, f.bounds, C, r_chrom, w.base,
                      w.seg, w.order, w.other_map);
@@ -528,8 +551,8 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
   const int r = (o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
   const bool train = o.training != 0 && o.p_drop_adj > 0.f;
   if (touched) {     // order/seg/other_map of the forward are still in the workspace; only the flags are (re)written
-    hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(64), 0, st, w.hist, w.nblk, C, r, w.base, w.seg, w.counts, touched);
-    MATCHA_CHECK_LAUNCH("adj_scan_kernel(flags)");
+    hipLaunchKernelGGL(adj_flags_kernel, dim3(1), dim3(64), 0, st, w.seg, w.counts, C, r, touched);
+    MATCHA_CHECK_LAUNCH("adj_flags_kernel");
   }
   // ---- recon branch: d loss / d rec = g * 200/(m n_r) * (rec - target) ----
   if (r >= 0 && (drecon || o.beta != 0.f)) {

@@ -87,7 +87,13 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   size_t g2 = gemm_tn_ws_bytes(d, hd, T); if (g2 > gb) gb = g2; // dfc1
   g2 = gemm_tn_ws_bytes(d, d, T); if (g2 > gb) gb = g2;
   g2 = gemm_tn_ws_bytes(d, s.n_attr, T); if (g2 > gb) gb = g2;
-  if (s.mode == 1) { g2 = gemm_tn_ws_bytes(s.max_bins, d, T); if (g2 > gb) gb = g2; }   // recon head gradient
+  if (s.mode == 1) {   // recon head gradient [n_r, d] for any chromosome r: the slab count depends on ceil(n_r/64)
+    for (int64_t m = 64;; m += 64) {
+      const int64_t mm = m < s.max_bins ? m : s.max_bins;
+      g2 = gemm_tn_ws_bytes(mm, d, T); if (g2 > gb) gb = g2;
+      if (mm >= s.max_bins) break;
+    }
+  }
   w.gemm_ws_bytes = gb; w.gemm_ws = take(gb / sizeof(float));
   w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, T) : 0;
   w.adj_ws = take(w.adj_ws_bytes / sizeof(float));

@@ -48,6 +48,7 @@ class Trainer:
         self._logits = {}
         self.pg = process_group
         self.world = 1
+        self.force_collectives = False      # bench.py sets it under a 1-rank torchrun launch to exercise the RCCL path
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
             broadcast_parameters(rt.flat, 0, process_group)      # every rank starts from rank 0's weights
@@ -89,8 +90,9 @@ class Trainer:
         return logits
 
     def all_reduce(self):
-        if self.world > 1:
-            allreduce_gradients(self.gflat, self.touched, self.pg)
+        if self.world > 1 or self.force_collectives:
+            torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            torch.distributed.all_reduce(self.touched, op=torch.distributed.ReduceOp.MAX, group=self.pg)
 
     def optimizer_step(self):
         rt = self.rt
