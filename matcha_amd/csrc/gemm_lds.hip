@@ -1,4 +1,4 @@
-// LDS-staged fp32 MFMA GEMM for the token-major layers (NT: Y = X.W^T; NN: dX = dY.W).
+// LDS-staged, software-pipelined fp32 MFMA GEMM for the token-major layers (NT: Y = X.W^T; NN: dX = dY.W).
 //
 // Why LDS here: the MFMA fragment of a row-major operand is "one 16-B piece per lane, consecutive lanes 256 B
 // apart", which the texture path serves as 64 separate requests per wave-instruction (measured: the direct-from-
@@ -8,7 +8,9 @@
 // output columns, so X is read from HBM exactly once per layer.
 //
 //   workgroup = 256 threads = 4 waves; tile = 128 rows x 64 columns x 64 deep; wave = 32 rows x 64 columns
-//   LDS: A tile [128][68] + B tile [64][68] floats = 52 KiB -> 3 workgroups per CU
+//   a "step" = one (column tile, k chunk): its operands are loaded global->registers WHILE the previous step's
+//   64 MFMAs per wave run, written to the other LDS buffer afterwards, one barrier per step
+//   LDS: K <= 64: A [128][68] + 2 x B [64][68] = 68 KiB (2 workgroups/CU); K > 64: 2 x A + 2 x B = 102 KiB (1/CU)
 //   epilogue flags are COMPILE-TIME (a runtime-flag epilogue costs ~700 basic blocks in the unrolled store loop)
 //
 // Optional indirections for the adj front end (MultipleEmbedding, Modules.py:176-201), all resolved per workgroup:
@@ -31,10 +33,14 @@ struct Epilogue {
   __device__ __forceinline__ static bool has(const GemmArgs& g, int f) { return FLAGS >= 0 ? (FLAGS & f) != 0 : (g.flags & f) != 0; }
 };
 
+struct StageRegs {
+  float4 a[8];
+  float4 b[4];
+};
+
 template <bool B_KN, int FLAGS>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_per_block) {
-  __shared__ __attribute__((aligned(16))) float As[kBM * kLd];
-  __shared__ __attribute__((aligned(16))) float Bs[kBN * kLd];   // NT: [n][k]   NN: [k][n]
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int z = blockIdx.z;
@@ -46,6 +52,11 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
   if (m0 >= M) return;
   const int64_t m_end = (m0 + kBM < M) ? m0 + kBM : M;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;      // staging: thread -> (row within 16-row slab, float4 column)
+  const bool kmulti = K > kBK;
+  float* const As0 = lds;
+  float* const As1 = kmulti ? lds + kBM * kLd : lds;
+  float* const Bs0 = lds + (kmulti ? 2 : 1) * kBM * kLd;
+  float* const Bs1 = Bs0 + kBN * kLd;
 
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
@@ -55,6 +66,20 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
     keep_scale = 1.f / (1.f - g.p_drop);
   }
   const float* bias = g.bias[z];
+  const int nkc = (int)((K + kBK - 1) / kBK);
+  const int64_t tiles_n = (N + kBN - 1) / kBN;
+  int n_nt = n_tiles_per_block;
+  if ((int64_t)blockIdx.x * n_tiles_per_block + n_nt > tiles_n) n_nt = (int)(tiles_n - (int64_t)blockIdx.x * n_tiles_per_block);
+  const int nsteps = n_nt * nkc;
+
+  // A row pointers of this thread's 8 staging rows (constant over steps)
+  const float* arow_ptr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int64_t gm = m0 + srow + 16 * i; gm = gm < M ? gm : M - 1;
+    if (g.a_row_map) gm = g.a_row_map[gm];
+    arow_ptr[i] = A + gm * g.lda + sc4;
+  }
 
   // groups intersecting this row tile (1 pass when not grouped)
   int c_lo = 0, c_hi = 0;
@@ -63,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
     c_hi = c_lo;
     while (c_hi < g.n_groups && g.seg[c_hi + 1] < m_end) ++c_hi;
   }
-  bool a_resident = false, lds_dirty = false;
+  bool a_resident = false;
   for (int grp = c_lo; grp <= c_hi; ++grp) {
     int64_t row_lo = m0, row_hi = m_end;
     const float* __restrict__ B = g.B[z];
@@ -75,125 +100,156 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
       if (row_lo >= row_hi) continue;
       B += (int64_t)grp * g.b_group_stride;
     }
-    for (int nt_i = 0; nt_i < n_tiles_per_block; ++nt_i) {
+
+    // ---- global -> registers for step s -------------------------------------------------------------------
+    auto gload = [&](int s, StageRegs& rg, bool with_a) {
+      const int nt_i = s / nkc;
+      const int64_t kc = (int64_t)(s - nt_i * nkc) * kBK;
       const int64_t n0 = ((int64_t)blockIdx.x * n_tiles_per_block + nt_i) * kBN;
-      if (n0 >= N) break;
-      f32x16 acc0 = {0}, acc1 = {0};
-      for (int64_t kc = 0; kc < K; kc += kBK) {
-        const bool stage_a = !a_resident || (K > kBK);     // K <= 64: the A tile stays resident across column tiles
-        if (lds_dirty) __syncthreads();                    // previous tile's LDS reads are done
-        lds_dirty = true;
-        const bool full_k = kc + kBK <= K;
-        if (stage_a) {
+      const bool full_k = kc + kBK <= K;
+      if (with_a) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int row = srow + 16 * i;
-            int64_t gm = m0 + row; gm = gm < M ? gm : M - 1;
-            if (g.a_row_map) gm = g.a_row_map[gm];
-            const float* src = A + gm * g.lda + kc + sc4;
-            float4 v;
-            if (full_k) v = *reinterpret_cast<const float4*>(src);
-            else {
-              // lda is a multiple of 4 and >= K, so a 16-B load that STARTS below K stays inside the row
-              const int64_t k = kc + sc4;
-              v = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-              v.y = (k + 1 < K) ? v.y : 0.f; v.z = (k + 2 < K) ? v.z : 0.f; v.w = (k + 3 < K) ? v.w : 0.f;
-            }
-            *reinterpret_cast<float4*>(&As[row * kLd + sc4]) = v;
+        for (int i = 0; i < 8; ++i) {
+          const float* src = arow_ptr[i] + kc;
+          float4 v;
+          if (full_k) v = *reinterpret_cast<const float4*>(src);
+          else {
+            // lda is a multiple of 4 and >= K, so a 16-B load that STARTS below K stays inside the row
+            const int64_t k = kc + sc4;
+            v = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.y = (k + 1 < K) ? v.y : 0.f; v.z = (k + 2 < K) ? v.z : 0.f; v.w = (k + 3 < K) ? v.w : 0.f;
           }
-          a_resident = true;
-        }
-        if (!B_KN) {                                         // B[n][k]: 64 rows x 16 float4
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = srow + 16 * i;
-            int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
-            const float* src = B + gn * g.ldb + kc + sc4;
-            float4 v;
-            if (full_k) v = *reinterpret_cast<const float4*>(src);
-            else {
-              const int64_t k = kc + sc4;
-              v = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-              v.y = (k + 1 < K) ? v.y : 0.f; v.z = (k + 2 < K) ? v.z : 0.f; v.w = (k + 3 < K) ? v.w : 0.f;
-            }
-            *reinterpret_cast<float4*>(&Bs[row * kLd + sc4]) = v;
-          }
-        } else {                                             // B[k][n]: 64 k-rows x 16 float4 along n
-          const bool full_n = n0 + kBN <= N;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = srow + 16 * i;                   // k within the chunk
-            const int64_t gk = kc + row;
-            const int64_t gkc = gk < K ? gk : K - 1;
-            float4 v;
-            if (full_n) v = *reinterpret_cast<const float4*>(B + gkc * g.ldb + n0 + sc4);
-            else {
-              const float* src = B + gkc * g.ldb;
-              v.x = (n0 + sc4 + 0 < N) ? src[n0 + sc4 + 0] : 0.f;
-              v.y = (n0 + sc4 + 1 < N) ? src[n0 + sc4 + 1] : 0.f;
-              v.z = (n0 + sc4 + 2 < N) ? src[n0 + sc4 + 2] : 0.f;
-              v.w = (n0 + sc4 + 3 < N) ? src[n0 + sc4 + 3] : 0.f;
-            }
-            if (gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&Bs[row * kLd + sc4]) = v;
-          }
-        }
-        __syncthreads();
-        // ---- 32 rows x 64 columns x 64 deep per wave: 64 MFMAs ----
-        const float* arow = &As[(32 * wave + r) * kLd + 4 * h];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
-          float4 b0, b1;
-          if (!B_KN) {
-            b0 = *reinterpret_cast<const float4*>(&Bs[r * kLd + 8 * c + 4 * h]);
-            b1 = *reinterpret_cast<const float4*>(&Bs[(32 + r) * kLd + 8 * c + 4 * h]);
-          } else {
-            const float* bp = &Bs[(8 * c + 4 * h) * kLd + r];
-            b0 = make_float4(bp[0], bp[kLd], bp[2 * kLd], bp[3 * kLd]);
-            b1 = make_float4(bp[32], bp[kLd + 32], bp[2 * kLd + 32], bp[3 * kLd + 32]);
-          }
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+          rg.a[i] = v;
         }
       }
-      // ---- epilogue: bias -> tanh -> +residual -> dropout -> row mask -> *(1 - (aux*aux_scale)^2) -> (+=) ----
-      const int64_t mrow0 = m0 + 32 * wave + 4 * h;
+      if (!B_KN) {                                         // B[n][k]: 64 rows x 16 float4
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int64_t col = n0 + nt * 32 + r;
-        if (col >= N) continue;
-        const float bv = Epilogue<FLAGS>::has(g, MATCHA_EPI_BIAS) ? bias[col] : 0.f;
-        const f32x16 acc = nt == 0 ? acc0 : acc1;
+        for (int i = 0; i < 4; ++i) {
+          int64_t gn = n0 + srow + 16 * i; gn = gn < N ? gn : N - 1;
+          const float* src = B + gn * g.ldb + kc + sc4;
+          float4 v;
+          if (full_k) v = *reinterpret_cast<const float4*>(src);
+          else {
+            const int64_t k = kc + sc4;
+            v = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.y = (k + 1 < K) ? v.y : 0.f; v.z = (k + 2 < K) ? v.z : 0.f; v.w = (k + 3 < K) ? v.w : 0.f;
+          }
+          rg.b[i] = v;
+        }
+      } else {                                             // B[k][n]: 64 k-rows x 16 float4 along n
+        const bool full_n = n0 + kBN <= N;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int64_t lrow = mrow0 + (reg & 3) + 8 * (reg >> 2);
-          if (lrow < row_lo || lrow >= row_hi) continue;
-          const int64_t row = g.c_row_map ? (int64_t)g.c_row_map[lrow] : lrow;
-          float v = acc[reg] + bv;
-          const int64_t off = row * g.ldc + col;
-          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_TANH)) v = tanhf(v);
-          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_RESIDUAL)) v += g.residual[off];
-          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DROPOUT)) v = (rng_u32(key, (uint32_t)row, (uint32_t)col) >= thr) ? v * keep_scale : 0.f;
-          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ROWMASK)) v = (g.row_ids[row] != 0) ? v : 0.f;
-          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DTANH)) { const float a = g.aux[off] * g.aux_scale; v *= (1.f - a * a); }
-          if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ACCUM)) v += C[off];
-          C[off] = v;
+        for (int i = 0; i < 4; ++i) {
+          const int64_t gk = kc + srow + 16 * i;
+          const int64_t gkc = gk < K ? gk : K - 1;
+          float4 v;
+          if (full_n) v = *reinterpret_cast<const float4*>(B + gkc * g.ldb + n0 + sc4);
+          else {
+            const float* src = B + gkc * g.ldb;
+            v.x = (n0 + sc4 + 0 < N) ? src[n0 + sc4 + 0] : 0.f;
+            v.y = (n0 + sc4 + 1 < N) ? src[n0 + sc4 + 1] : 0.f;
+            v.z = (n0 + sc4 + 2 < N) ? src[n0 + sc4 + 2] : 0.f;
+            v.w = (n0 + sc4 + 3 < N) ? src[n0 + sc4 + 3] : 0.f;
+          }
+          if (gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          rg.b[i] = v;
         }
       }
+    };
+    auto lstore = [&](const StageRegs& rg, float* As, float* Bs, bool with_a) {
+      if (with_a) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&As[(srow + 16 * i) * kLd + sc4]) = rg.a[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[(srow + 16 * i) * kLd + sc4]) = rg.b[i];
+    };
+
+    StageRegs rg;
+    {
+      const bool wa = kmulti || !a_resident;
+      gload(0, rg, wa);
+      lstore(rg, As0, Bs0, wa);
+      a_resident = true;
+    }
+    __syncthreads();
+    f32x16 acc0 = {0}, acc1 = {0};
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      const bool more = s + 1 < nsteps;
+      if (more) gload(s + 1, rg, kmulti);                  // in flight during this step's MFMAs
+      const int nt_i = s / nkc;
+      const int kci = s - nt_i * nkc;
+      if (kci == 0) { acc0 = (f32x16){0}; acc1 = (f32x16){0}; }
+      const float* As = (kmulti && buf) ? As1 : As0;
+      const float* Bs = buf ? Bs1 : Bs0;
+      // ---- 32 rows x 64 columns x 64 deep per wave: 64 MFMAs ----
+      const float* arow = &As[(32 * wave + r) * kLd + 4 * h];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
+        float4 b0, b1;
+        if (!B_KN) {
+          b0 = *reinterpret_cast<const float4*>(&Bs[r * kLd + 8 * c + 4 * h]);
+          b1 = *reinterpret_cast<const float4*>(&Bs[(32 + r) * kLd + 8 * c + 4 * h]);
+        } else {
+          const float* bp = &Bs[(8 * c + 4 * h) * kLd + r];
+          b0 = make_float4(bp[0], bp[kLd], bp[2 * kLd], bp[3 * kLd]);
+          b1 = make_float4(bp[32], bp[kLd + 32], bp[2 * kLd + 32], bp[3 * kLd + 32]);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      }
+      if (kci == nkc - 1) {
+        // ---- epilogue: bias -> tanh -> +residual -> dropout -> row mask -> *(1 - (aux*aux_scale)^2) -> (+=) ----
+        const int64_t n0 = ((int64_t)blockIdx.x * n_tiles_per_block + nt_i) * kBN;
+        const int64_t mrow0 = m0 + 32 * wave + 4 * h;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int64_t col = n0 + nt * 32 + r;
+          if (col >= N) continue;
+          const float bv = Epilogue<FLAGS>::has(g, MATCHA_EPI_BIAS) ? bias[col] : 0.f;
+          const f32x16 acc = nt == 0 ? acc0 : acc1;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int64_t lrow = mrow0 + (reg & 3) + 8 * (reg >> 2);
+            if (lrow < row_lo || lrow >= row_hi) continue;
+            const int64_t row = g.c_row_map ? (int64_t)g.c_row_map[lrow] : lrow;
+            float v = acc[reg] + bv;
+            const int64_t off = row * g.ldc + col;
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_TANH)) v = tanhf(v);
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_RESIDUAL)) v += g.residual[off];
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DROPOUT)) v = (rng_u32(key, (uint32_t)row, (uint32_t)col) >= thr) ? v * keep_scale : 0.f;
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ROWMASK)) v = (g.row_ids[row] != 0) ? v : 0.f;
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DTANH)) { const float a = g.aux[off] * g.aux_scale; v *= (1.f - a * a); }
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ACCUM)) v += C[off];
+            C[off] = v;
+          }
+        }
+      }
+      if (more) lstore(rg, (kmulti && !buf) ? As1 : As0, buf ? Bs0 : Bs1, kmulti);
+      __syncthreads();
     }
   }
 }
 
 template <bool B_KN, int FLAGS>
-static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_lds_kernel<B_KN, FLAGS>), grid, dim3(256), 0, st, g, ntpb);
+static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, size_t lds_bytes, hipStream_t st) {
+  auto kfn = gemm_lds_kernel<B_KN, FLAGS>;
+  if (lds_bytes > 64 * 1024) {
+    static bool configured = false;      // per instantiation
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      configured = true;
+    }
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds_bytes, st, g, ntpb);
 }
 
 int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
@@ -211,6 +267,7 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
   // K <= 64: one workgroup keeps its activation tile in LDS and walks up to 8 column tiles
   int ntpb = 1;
   if (g.K <= kBK) { ntpb = tiles_n < 8 ? tiles_n : 8; }
+  const size_t lds_bytes = (size_t)((g.K > kBK ? 2 : 1) * kBM + 2 * kBN) * kLd * sizeof(float);
   dim3 grid((unsigned)cdiv(tiles_n, ntpb), (unsigned)cdiv(g.M, kBM), (unsigned)g.batch);
   ProfScope ps(b_kn ? MATCHA_PROF_GEMM_NN : MATCHA_PROF_GEMM_NT, 2.0 * (double)g.M * (double)g.N * (double)g.K * g.batch, st);
   const int F = g.flags;
@@ -218,23 +275,23 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
                 G_ = MATCHA_EPI_DTANH;
   if (!b_kn) {
     switch (F) {
-      case 0: launch_one<false, 0>(g, grid, ntpb, st); break;
-      case B_: launch_one<false, B_>(g, grid, ntpb, st); break;
-      case B_ | T_: launch_one<false, B_ | T_>(g, grid, ntpb, st); break;
-      case B_ | T_ | D_: launch_one<false, B_ | T_ | D_>(g, grid, ntpb, st); break;
-      case B_ | M_: launch_one<false, B_ | M_>(g, grid, ntpb, st); break;
-      case B_ | M_ | D_: launch_one<false, B_ | M_ | D_>(g, grid, ntpb, st); break;
-      case B_ | R_: launch_one<false, B_ | R_>(g, grid, ntpb, st); break;
-      default: launch_one<false, -1>(g, grid, ntpb, st); break;
+      case 0: launch_one<false, 0>(g, grid, ntpb, lds_bytes, st); break;
+      case B_: launch_one<false, B_>(g, grid, ntpb, lds_bytes, st); break;
+      case B_ | T_: launch_one<false, B_ | T_>(g, grid, ntpb, lds_bytes, st); break;
+      case B_ | T_ | D_: launch_one<false, B_ | T_ | D_>(g, grid, ntpb, lds_bytes, st); break;
+      case B_ | M_: launch_one<false, B_ | M_>(g, grid, ntpb, lds_bytes, st); break;
+      case B_ | M_ | D_: launch_one<false, B_ | M_ | D_>(g, grid, ntpb, lds_bytes, st); break;
+      case B_ | R_: launch_one<false, B_ | R_>(g, grid, ntpb, lds_bytes, st); break;
+      default: launch_one<false, -1>(g, grid, ntpb, lds_bytes, st); break;
     }
   } else {
     switch (F) {
-      case 0: launch_one<true, 0>(g, grid, ntpb, st); break;
-      case G_: launch_one<true, G_>(g, grid, ntpb, st); break;
-      case G_ | D_: launch_one<true, G_ | D_>(g, grid, ntpb, st); break;
-      case R_ | M_: launch_one<true, R_ | M_>(g, grid, ntpb, st); break;
-      case R_ | M_ | D_: launch_one<true, R_ | M_ | D_>(g, grid, ntpb, st); break;
-      default: launch_one<true, -1>(g, grid, ntpb, st); break;
+      case 0: launch_one<true, 0>(g, grid, ntpb, lds_bytes, st); break;
+      case G_: launch_one<true, G_>(g, grid, ntpb, lds_bytes, st); break;
+      case G_ | D_: launch_one<true, G_ | D_>(g, grid, ntpb, lds_bytes, st); break;
+      case R_ | M_: launch_one<true, R_ | M_>(g, grid, ntpb, lds_bytes, st); break;
+      case R_ | M_ | D_: launch_one<true, R_ | M_ | D_>(g, grid, ntpb, lds_bytes, st); break;
+      default: launch_one<true, -1>(g, grid, ntpb, lds_bytes, st); break;
     }
   }
   MATCHA_CHECK_LAUNCH("gemm_lds_kernel");

@@ -1,0 +1,121 @@
+"""Wider shapes and size-independent properties of the HIP path (GPU only):
+other embed dims / widths than the golden files cover (BASELINE.json configs[3], [4]: d = 128, 256, k up to 8), and
+at the bench's full batch size properties the domain offers: row-permutation equivariance, node-order invariance
+inside a hyperedge (SURVEY.md headline fact 7, last sentence), batch-width dependence, run-to-run determinism."""
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import synth
+from oracle import hypersagnn as O
+from tests.helpers import oracle_state, rel_err
+from tests.test_hip_model import GAUGE, TOL, hip_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode,d,layout,ks", [("table", 256, "tiny", [2, 5, 8]), ("table", 64, "c1", [3, 6, 7, 8]),
+                                              ("adj", 128, "c1", [2, 3, 5]), ("adj", 32, "tiny", [2, 4])])
+def test_forward_backward_vs_oracle_wide(mode, d, layout, ks):
+    num = synth.LAYOUTS[layout]
+    clf, _ = hip_model(num, d, mode, 91)
+    P, fe, _ = oracle_state(num, d, mode, 91, requires_grad=True)
+    clf.eval()
+    x, y, w = synth.make_batch(np.random.default_rng(5), int(np.sum(num)), ks, 12)
+    xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
+    np.random.seed(21)
+    chrom = int(np.random.choice(np.arange(len(num)), 1)[0])
+    np.random.seed(21)
+    lg, rc = clf(xt, return_recon=True)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, yt.cuda(), weight=wt.cuda()) + 0.01 * rc
+    loss.backward()
+    _, _, recon, logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, 1.0, 0.01, random_chrom=chrom)
+    assert rel_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
+    assert abs(float(rc.detach().cpu()[0]) - float(recon[0])) <= TOL * max(1.0, abs(float(recon[0])))
+    for n, p in clf.named_parameters():
+        if grads.get(n) is None or n == GAUGE:
+            continue
+        ref = grads[n].numpy()
+        assert p.grad is not None, n
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+
+
+def _big_batch(N, B, rng):
+    ks = [2, 3, 4, 5]
+    xs = [np.pad(synth.make_edges_fast(rng, N, k, B // 4), ((0, 0), (0, 5 - k))) for k in ks]
+    x = np.concatenate(xs)
+    return x[rng.permutation(len(x))]
+
+
+def test_full_size_properties_table():
+    """65 536 rows (the bench batch): properties that need no oracle run."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, 64, "table", 3)
+    clf.eval()
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(_big_batch(N, 65536, rng)).cuda()
+    with torch.no_grad():
+        base = clf(x)
+        assert base.shape == (65536, 1) and bool(torch.isfinite(base).all())
+        # (1) determinism of the inference path: bitwise equal on a second run
+        assert torch.equal(base, clf(x))
+        # (2) rows are independent: permuting the batch permutes the logits (same batch width L)
+        perm = torch.randperm(len(x), device="cuda")
+        assert torch.allclose(clf(x[perm]), base[perm], rtol=0, atol=1e-6)
+        # (3) a subset evaluated alone at the same width gives the same logits
+        assert torch.allclose(clf(x[:1000]), base[:1000], rtol=0, atol=1e-6)
+        # (4) node order inside a hyperedge does not matter (real nodes permuted, pads kept last)
+        xs = x[:4096].clone()
+        k = (xs != 0).sum(1)
+        for r_ in range(0, 4096, 7):
+            kk = int(k[r_])
+            xs[r_, :kk] = xs[r_, :kk].flip(0)
+        assert torch.allclose(clf(xs), base[:4096], rtol=0, atol=2e-5)
+        # (5) the batch width matters for rows with k < L (pads are attended): k=2 rows alone at L=2 differ from L=5
+        two = x[(x != 0).sum(1) == 2][:512]
+        assert float((clf(two[:, :2].contiguous()) - clf(two)).abs().max()) > 1e-3
+    # (6) sigmoid(logits) are probabilities and gradients at full size are finite
+    clf.train()
+    y = (torch.rand(len(x), 1, device="cuda") < 0.25).float()
+    lg = clf(x)
+    torch.nn.functional.binary_cross_entropy_with_logits(lg, y).backward()
+    for n, p in clf.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()), n
+    # table rows that never occur in x got no gradient; the padding row never does
+    g = clf.node_embedding.weight.grad
+    assert float(g[0].abs().max()) == 0.0
+    seen = torch.zeros(N + 1, dtype=torch.bool, device="cuda")
+    seen[x[:64].reshape(-1)] = True
+    clf.zero_grad()
+    torch.nn.functional.binary_cross_entropy_with_logits(clf(x[:64]), y[:64]).backward()
+    g = clf.node_embedding.weight.grad
+    assert float(g[~seen].abs().max()) == 0.0 and float(g[seen][1:].abs().max()) > 0.0
+
+
+def test_full_size_train_step_is_reproducible():
+    """Two Trainers from identical weights fed the same batch produce the same loss and (up to the embedding
+    scatter's atomic ordering) the same parameters; everything except the table is bitwise equal."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(_big_batch(N, 16384, rng)).cuda()
+    y = (torch.rand(len(x), device="cuda") < 0.25).float()
+    w = torch.ones(len(x), device="cuda")
+    outs = []
+    for _ in range(2):
+        clf, _ = hip_model(num, 64, "table", 3)
+        clf.train()
+        tr = Trainer(clf, base_seed=5)
+        bce, _, _ = tr.step(x, y, w)
+        torch.cuda.synchronize()
+        outs.append((float(bce), {n: p.detach().clone() for n, p in clf.named_parameters()}))
+    assert outs[0][0] == outs[1][0]
+    for n in outs[0][1]:
+        a, b = outs[0][1][n], outs[1][1][n]
+        if n == "node_embedding.weight":
+            assert torch.allclose(a, b, rtol=0, atol=1e-6)
+        else:
+            assert torch.equal(a, b), n
