@@ -205,6 +205,11 @@ def main():
         ms, n, wk = C.c_double(), C.c_int64(), C.c_double()
         _lib.check(lib.matcha_profile_read(C.byref(ms), C.byref(n), C.byref(wk)))
         lib.matcha_profile_select(0)
+        # The library sizes launches for the upper bound B*L + 1 token rows and counts work for that bound; the ragged
+        # path only computes the real tokens (+ 1 shared padding token), so scale to the ALGORITHMIC work actually done.
+        if prof_cls not in ("adamw", "neg_sample"):
+            fill = (float((x != 0).sum().item()) + 1.0) / (B * L + 1.0)
+            wk = C.c_double(wk.value * fill)
         if n.value and ms.value > 0:
             per_launch_ms = ms.value / n.value
             if prof_cls in GEMM_CLASSES:

@@ -253,11 +253,18 @@ int matcha_ln3_fwd(const float* X, int64_t T, int32_t d, const float* gq, const 
                    float* stats /* [T,2] mean,rstd */, matcha_stream_t stream);
 
 /* K9: per (hyperedge, head) attention with the diagonal masked and pad slots attended (Modules.py:449-458;
- * SURVEY.md headline fact 7).  Q,K,V,O: [B*L, 8d]; P: [B, 8, L, L]. */
-int matcha_attn_fwd(const float* Q, const float* K, const float* V, int64_t B, int32_t L, int32_t d,
-                    float* O, float* P, matcha_stream_t stream);
+ * SURVEY.md headline fact 7), on the ragged token layout: hyperedge b owns the compact token rows
+ * [row_off[b], row_off[b+1]) (k_b = their number <= L real nodes), row row_off[B] is the ONE shared padding token
+ * whose K/V stand for each of the L - k_b padding slots of the batch-wide [B, L] layout.
+ * Q,K,V,O,dQ,dK,dV: [row_off[B] + 1, 8d]; P: [B, 8, L, L] (row i: real columns j < k_b, then the per-slot
+ * padding probability in column k_b).  row_off: device int32 [B+1].  bwd also writes dK/dV (and dQ = 0) of the
+ * padding token row; `ws` needs matcha_attn_bwd_workspace_bytes(B, d) bytes. */
+size_t matcha_attn_bwd_workspace_bytes(int64_t B, int32_t d);
+int matcha_attn_fwd(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int32_t L,
+                    int32_t d, float* O, float* P, matcha_stream_t stream);
 int matcha_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO,
-                    int64_t B, int32_t L, int32_t d, float* dQ, float* dK, float* dV, matcha_stream_t stream);
+                    const int32_t* row_off, int64_t B, int32_t L, int32_t d, float* dQ, float* dK, float* dV,
+                    void* ws, size_t ws_bytes, matcha_stream_t stream);
 
 #ifdef __cplusplus
 }

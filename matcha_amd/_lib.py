@@ -78,8 +78,9 @@ SIGNATURES = {
     "matcha_embed_fwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _I32, _fp, _fp, _fp, _fp]),
     "matcha_embed_scatter_bwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp]),
     "matcha_ln3_fwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "matcha_attn_fwd": (C.c_int, [_fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp]),
-    "matcha_attn_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp, _fp]),
+    "matcha_attn_bwd_workspace_bytes": (_SZ, [_I64, _I32]),
+    "matcha_attn_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp]),
+    "matcha_attn_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp, _fp, _SZ, _fp]),
 }
 
 _lib = None

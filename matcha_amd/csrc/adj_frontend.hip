@@ -73,8 +73,9 @@ __device__ __forceinline__ int chrom_of(int64_t id, const int32_t* __restrict__ 
 
 // ---- stable counting sort of token slots by chromosome -------------------------------------------------------
 __global__ __launch_bounds__(256) void adj_hist_kernel(const int64_t* __restrict__ x, int64_t T, const int32_t* __restrict__ bounds, int C,
-                                                       int32_t* __restrict__ hist) {
+                                                       int32_t* __restrict__ hist, const int32_t* __restrict__ t_dev) {
   __shared__ int cnt[kMaxChrom + 1];
+  if (t_dev) T = *t_dev;                 // ragged layout: token count on the device; slots beyond it are ignored
   if (threadIdx.x <= C) cnt[threadIdx.x] = 0;
   __syncthreads();
   const int64_t t0 = (int64_t)blockIdx.x * kSortTok + threadIdx.x * 4;
@@ -148,8 +149,10 @@ __global__ void adj_flags_kernel(const int32_t* __restrict__ seg, const int32_t*
 
 __global__ __launch_bounds__(256) void adj_scatter_kernel(const int64_t* __restrict__ x, int64_t T, const int32_t* __restrict__ bounds, int C,
                                                           int r_chrom, const int32_t* __restrict__ base, const int32_t* __restrict__ seg,
-                                                          int32_t* __restrict__ order, int32_t* __restrict__ other_map) {
-  extern __shared__ int tc[];                 // [C+1][256] per-thread counts -> exclusive prefix
+                                                          int32_t* __restrict__ order, int32_t* __restrict__ other_map,
+                                                          const int32_t* __restrict__ t_dev) {
+  extern __shared__ int tc[];
+  if (t_dev) T = *t_dev;                 // [C+1][256] per-thread counts -> exclusive prefix
   const int tid = threadIdx.x;
   for (int k = 0; k <= C; ++k) tc[k * 256 + tid] = 0;
   const int64_t t0 = (int64_t)blockIdx.x * kSortTok + tid * 4;
@@ -186,6 +189,7 @@ struct AdjEncArgs {
   int C, d;
   const uint64_t* seed;
   float p_drop;
+  const int32_t* slot_map;     // token index -> original slot (dropout counter); null = identity
 };
 
 template <int NT>   // NT = ceil(d / 32) column tiles per wave
@@ -234,7 +238,8 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
       for (int rr = wave; rr < 128; rr += 4) {
         float v = g.feats[rowoff[rr] + kcl] * kmask;
         if (drop) {
-          const int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
+          int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
+          if (g.slot_map) slot = g.slot_map[slot];
           v = (rng_u32(key, (uint32_t)slot, (uint32_t)kk) >= thr) ? v * keep_scale : 0.f;   // counter = (token slot, column)
         }
         As[rr * kLdA + lane] = v;
@@ -287,6 +292,7 @@ struct AdjTnArgs {
   int C, d, rows_per_block;
   const uint64_t* seed;
   float p_drop;
+  const int32_t* slot_map;
 };
 
 template <int MODE>
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void adj_tn_kernel(AdjTnArgs g) {
         for (int t = 0; t < 2; ++t) {
           a[t][cc] = g.A[arow * g.d + am[t]] * (amf[t] * rowf);
           float bv = MODE == 0 ? g.Bd[p * g.d + bn[t]] : g.feats[brow + bn[t]];
-          if (drop) bv = (rng_u32(key, (uint32_t)slot, (uint32_t)bn[t]) >= thr) ? bv * keep_scale : 0.f;
+          if (drop) bv = (rng_u32(key, (uint32_t)(g.slot_map ? g.slot_map[slot] : slot), (uint32_t)bn[t]) >= thr) ? bv * keep_scale : 0.f;
           b[t][cc] = bv * bnf[t];
         }
       }
@@ -464,20 +470,20 @@ static int check_adj(const matcha_shape& s, const matcha_tensors& p, const match
 }
 
 static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int64_t* x, int64_t T, int r_chrom, AdjWs& w, int32_t* touched,
-                       hipStream_t st) {
+                       const int32_t* t_dev, hipStream_t st) {
   const int C = s.n_chrom;
-  hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist);
+  hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist, t_dev);
   MATCHA_CHECK_LAUNCH("adj_hist_kernel");
   hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(1024), 0, st, w.hist, w.nblk, C, r_chrom, w.base, w.seg, w.counts, touched);
   MATCHA_CHECK_LAUNCH("adj_scan_kernel");
   hipLaunchKernelGGL(adj_scatter_kernel, dim3(w.nblk), dim3(256), (size_t)(C + 1) * 256 * sizeof(int), st, x, T, f.bounds, C, r_chrom, w.base,
-                     w.seg, w.order, w.other_map);
+                     w.seg, w.order, w.other_map, t_dev);
   MATCHA_CHECK_LAUNCH("adj_scatter_kernel");
   return MATCHA_OK;
 }
 
 int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* x, int64_t T,
-                float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st) {
+                float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* t_dev, const int32_t* slot_map) {
   MATCHA_TRY(check_adj(s, p, f));
   MATCHA_CHECK_ARG(ws && ((uintptr_t)ws) % 256 == 0, "adj_forward: workspace missing or misaligned");
   AdjWs w;
@@ -485,14 +491,14 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
   if (ws_bytes < need) { set_error("adj_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
   const int C = s.n_chrom, d = s.d;
   const int r = (recon_out && o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
-  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, st));
+  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, t_dev, st));
   const bool train = o.training != 0 && o.p_drop_adj > 0.f;
   MATCHA_CHECK_ARG(!train || o.seed, "adj_forward: dropout needs a seed");
   // layer 1: gather-GEMM + tanh -> Hs (sorted rows)
   {
     AdjEncArgs a;
     a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats; a.w0 = p.adj_w0;
-    a.Hs = w.Hs; a.T = T; a.C = C; a.d = d; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f;
+    a.Hs = w.Hs; a.T = T; a.C = C; a.d = d; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
     const int nt = (int)cdiv(d, 32);
     dim3 grid((unsigned)cdiv(T, 128));
     ProfScope ps(MATCHA_PROF_ADJ_ENCODE, 0.0, st);
@@ -510,6 +516,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
     g.A[0] = w.Hs; g.B[0] = p.adj_w1; g.C[0] = node_out; g.batch = 1;
     g.M = T; g.N = d; g.K = d; g.lda = d; g.ldb = d; g.ldc = d; g.aux_scale = 1.f;
     g.c_row_map = w.order; g.seg = w.seg; g.n_groups = C; g.b_group_stride = (int64_t)d * d;
+    g.m_dev = w.seg + C;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
   if (!recon_out) return MATCHA_OK;
@@ -541,7 +548,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
 
 int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* x, int64_t T,
                  float* dnode, const float* drecon, matcha_tensors& g_, int32_t* touched, void* ws, size_t ws_bytes, void* gemm_ws,
-                 size_t gemm_ws_bytes, hipStream_t st) {
+                 size_t gemm_ws_bytes, hipStream_t st, const int32_t* slot_map) {
   MATCHA_TRY(check_adj(s, p, f));
   AdjWs w;
   const size_t need = adj_carve(s, T, (char*)ws, w);
@@ -592,13 +599,14 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     g.M = T; g.N = d; g.K = d; g.lda = d; g.ldb = d; g.ldc = d; g.aux_scale = 1.f;
     g.flags = MATCHA_EPI_DTANH; g.aux = w.Hs;
     g.a_row_map = w.order; g.seg = w.seg; g.n_groups = C; g.b_group_stride = (int64_t)d * d;
+    g.m_dev = w.seg + C;     // sorted rows beyond the non-padding tokens do not exist (order[] is only filled up to the token count)
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
   {
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));
     a.A = w.dZ; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
-    a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f;
+    a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
     hipLaunchKernelGGL((adj_tn_kernel<1>), dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(s.max_bins, 64), zblocks), dim3(256), 0, st, a);
     MATCHA_CHECK_LAUNCH("adj_tn_kernel<1>");
   }

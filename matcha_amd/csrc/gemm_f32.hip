@@ -154,9 +154,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   const int64_t mo0 = (int64_t)(tile / g.tiles_n) * 64;
   const int64_t no0 = (int64_t)(tile % g.tiles_n) * 64;
   const int64_t p = blockIdx.y;
-  const int64_t R = g.r_dev ? (int64_t)(*g.r_dev) : g.R;      // row count may live on the device (adj front end)
-  const int64_t rbeg = p * g.rows_per_block;
-  int64_t rend = rbeg + g.rows_per_block; if (rend > R) rend = R;
+  const int64_t R = g.r_dev ? (int64_t)(*g.r_dev) : g.R;      // row count may live on the device (ragged layout)
+  int64_t rpb = g.rows_per_block;
+  if (g.r_dev) {                                               // split the ACTUAL rows evenly over the launched partitions
+    rpb = (R + gridDim.y - 1) / gridDim.y;
+    rpb = (rpb + 31) / 32 * 32;
+    if (rpb < 32) rpb = 32;
+  }
+  const int64_t rbeg = p * rpb;
+  int64_t rend = rbeg + rpb; if (rend > R) rend = R;
   if (rend < rbeg) rend = rbeg;                               // empty partition: writes a zero slab
   const bool do_col = (g.colslab != nullptr) && (no0 == 0);
 

@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
             const int64_t off = row * g.ldc + col;
             if (Epilogue<FLAGS>::has(g, MATCHA_EPI_TANH)) v = tanhf(v);
             if (Epilogue<FLAGS>::has(g, MATCHA_EPI_RESIDUAL)) v += g.residual[off];
-            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DROPOUT)) v = (rng_u32(key, (uint32_t)row, (uint32_t)col) >= thr) ? v * keep_scale : 0.f;
+            if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DROPOUT)) {
+              const uint32_t crow = g.rng_row_map ? (uint32_t)g.rng_row_map[row] : (uint32_t)row;
+              v = (rng_u32(key, crow, (uint32_t)col) >= thr) ? v * keep_scale : 0.f;
+            }
             if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ROWMASK)) v = (g.row_ids[row] != 0) ? v : 0.f;
             if (Epilogue<FLAGS>::has(g, MATCHA_EPI_DTANH)) { const float a = g.aux[off] * g.aux_scale; v *= (1.f - a * a); }
             if (Epilogue<FLAGS>::has(g, MATCHA_EPI_ACCUM)) v += C[off];

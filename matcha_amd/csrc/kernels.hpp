@@ -28,7 +28,21 @@ struct GemmArgs {
   const int32_t* seg;         // grouped mode: logical rows are sorted by group; group c owns rows [seg[c], seg[c+1])
   int n_groups;               //   and uses B + c*b_group_stride; rows of groups >= n_groups are skipped
   int64_t b_group_stride;
+  const int32_t* rng_row_map; // dropout counter row of C row m is rng_row_map[m] (compact token -> original slot)
 };
+
+// ragged.hip: CSR plan of the real tokens of x [B, L] (+ one shared padding token at index Tr)
+struct Ragged {
+  int32_t* row_off;    // [B+1]
+  int32_t* tok_slot;   // [T+1]
+  int64_t* tok_id;     // [T+1]
+  int32_t* count;      // {Tr + 1, Tr}
+  int32_t* blk_sum;
+  int nblk;
+};
+size_t ragged_bytes(int64_t B, int L);
+void ragged_carve(int64_t B, int L, char* base, Ragged& r);
+int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st);
 
 struct HeadParams {
   const float *gp, *bp, *g1, *b1, *g2, *b2, *wc, *bc;
@@ -44,25 +58,28 @@ int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, 
 
 // token_kernels.hip
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
-                     int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st);
-int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st);
+                     int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev = nullptr);
+int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st, const int32_t* t_dev = nullptr);
 int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, float* rows, hipStream_t st);
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
 int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const float* bq, const float* gk, const float* bk,
-                   const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st);
+                   const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st,
+                   const int32_t* t_dev = nullptr);
 int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const float* dvin, const float* dXs, int64_t T, int d,
                    const float* gq, const float* gk, const float* gv, float* dZ0, float* slab, float* dgq, float* dbq,
-                   float* dgk, float* dbk, float* dgv, float* dbv, hipStream_t st);
-int launch_head_fwd(const int64_t* x, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
+                   float* dgk, float* dbk, float* dgv, float* dbv, hipStream_t st, const int32_t* t_dev = nullptr);
+int launch_head_fwd(const int32_t* row_off, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
                     const float* y, const float* w, float* logits, float* row_loss, float* bce_out, hipStream_t st);
-int launch_head_bwd(const int64_t* x, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
+int launch_head_bwd(const int32_t* row_off, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
                     const float* y, const float* w, const float* logits, const float* dlogits, float alpha, float* dH2,
                     float* dXs, float* slab, const HeadParams& ghp, hipStream_t st);
 size_t colsum_slab_bytes(int64_t n, int nv, int d);
 
 // attention.hip
-int launch_attn_fwd(const float* Q, const float* K, const float* V, int64_t B, int L, int d, float* O, float* P, hipStream_t st);
-int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, int64_t B, int L, int d,
-                    float* dQ, float* dK, float* dV, hipStream_t st);
+int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float* O, float* P,
+                    hipStream_t st);
+int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
+                    int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st);
+size_t attn_bwd_slab_bytes(int64_t B, int d);
 
 }  // namespace matcha

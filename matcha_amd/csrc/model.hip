@@ -1,6 +1,10 @@
 // Orchestration of one classifier step behind the C ABI: Classifier.forward (Modules.py:278-318) and its
 // backward as a fixed sequence of kernel launches on the caller's stream -- no allocation, no host
 // synchronisation, so the whole step is hipGraph-capturable.
+//
+// Token layout: ragged (ragged.hip).  The token-level layers run on Tn = Tr + 1 rows -- the Tr real tokens of the
+// batch plus ONE shared padding token -- instead of B*L slots; Tr is only known on the device, so every launch is
+// sized for the upper bound B*L + 1 and reads the true count from `count` (m_dev / r_dev / t_dev).
 #include <string.h>
 
 #include "kernels.hpp"
@@ -41,61 +45,70 @@ void prof_record(bool start, double work, hipStream_t st) {
 
 // adj_frontend.hip
 int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
-                const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st);
+                const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st,
+                const int32_t* t_dev, const int32_t* slot_map);
 int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
                  const int64_t* x, int64_t T, float* dnode, const float* drecon, matcha_tensors& g, int32_t* touched,
-                 void* ws, size_t ws_bytes, void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st);
+                 void* ws, size_t ws_bytes, void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st, const int32_t* slot_map);
 size_t adj_workspace_bytes(const matcha_shape& s, int64_t T);
 
 struct Workspace {
+  Ragged rg;
   // saved by forward
   float *x0, *X, *qin, *kin, *vin, *stats, *Q, *K, *V, *P, *O, *Y, *H1, *H2, *row_loss, *logits, *node;
   // backward temporaries
   float *dH2, *dXs, *dZ1, *ddyn0, *dO, *dQ, *dK, *dV, *dqin, *dkin, *dvin, *dZ0, *dX0;
-  float* slab;      size_t slab_bytes;    // column-sum slabs (LayerNorm / tail parameter gradients)
+  float* slab;      size_t slab_bytes;    // column-sum slabs (LayerNorm / tail parameter gradients, attention pad-token grads)
   float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
   void* adj_ws;     size_t adj_ws_bytes;
   size_t total;
 };
 
 static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
-  const int64_t T = B * L, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
+  const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
   size_t off = 0;
   auto take = [&](size_t n_floats) {
     float* p = base ? (float*)(base + off) : nullptr;
     off += align_up(n_floats * sizeof(float), 256);
     return p;
   };
-  w.x0 = take(T * d); w.X = take(T * d);
-  w.qin = take(T * d); w.kin = take(T * d); w.vin = take(T * d);
-  w.stats = take(T * 2);
-  w.Q = take(T * hd); w.K = take(T * hd); w.V = take(T * hd);
+  {
+    const size_t rb = ragged_bytes(B, L);
+    if (base) ragged_carve(B, L, base + off, w.rg);
+    off += align_up(rb, 256);
+  }
+  w.x0 = take(Tn * d); w.X = take(Tn * d);
+  w.qin = take(Tn * d); w.kin = take(Tn * d); w.vin = take(Tn * d);
+  w.stats = take(Tn * 2);
+  w.Q = take(Tn * hd); w.K = take(Tn * hd); w.V = take(Tn * hd);
   w.P = take(B * MATCHA_N_HEAD * L * L);
-  w.O = take(T * hd);
-  w.Y = take(T * d); w.H1 = take(T * d); w.H2 = take(T * d);
+  w.O = take(Tn * hd);
+  w.Y = take(Tn * d); w.H1 = take(Tn * d); w.H2 = take(Tn * d);
   w.row_loss = take(B); w.logits = take(B);
-  w.node = take(s.mode == 1 ? T * d : 0);
-  w.dH2 = take(T * d); w.dXs = take(T * d); w.dZ1 = take(T * d); w.ddyn0 = take(T * d);
-  w.dO = take(T * hd); w.dQ = take(T * hd); w.dK = take(T * hd); w.dV = take(T * hd);
-  w.dqin = take(T * d); w.dkin = take(T * d); w.dvin = take(T * d);
-  w.dZ0 = take(T * d); w.dX0 = take(T * d);
-  size_t sb = colsum_slab_bytes(T, 6, (int)d);
-  const size_t sb2 = colsum_slab_bytes(B, 7, (int)d);
+  w.node = take(s.mode == 1 ? Tn * d : 0);
+  w.dH2 = take(Tn * d); w.dXs = take(Tn * d); w.dZ1 = take(Tn * d); w.ddyn0 = take(Tn * d);
+  w.dO = take(Tn * hd); w.dQ = take(Tn * hd); w.dK = take(Tn * hd); w.dV = take(Tn * hd);
+  w.dqin = take(Tn * d); w.dkin = take(Tn * d); w.dvin = take(Tn * d);
+  w.dZ0 = take(Tn * d); w.dX0 = take(Tn * d);
+  size_t sb = colsum_slab_bytes(Tn, 6, (int)d);
+  size_t sb2 = colsum_slab_bytes(B, 7, (int)d);
+  if (sb2 > sb) sb = sb2;
+  sb2 = attn_bwd_slab_bytes(B, (int)d);
   if (sb2 > sb) sb = sb2;
   w.slab_bytes = sb; w.slab = take(sb / sizeof(float));
-  size_t gb = gemm_tn_ws_bytes(hd, d, T);                       // dWq/dWk/dWv
-  size_t g2 = gemm_tn_ws_bytes(d, hd, T); if (g2 > gb) gb = g2; // dfc1
-  g2 = gemm_tn_ws_bytes(d, d, T); if (g2 > gb) gb = g2;
-  g2 = gemm_tn_ws_bytes(d, s.n_attr, T); if (g2 > gb) gb = g2;
+  size_t gb = gemm_tn_ws_bytes(hd, d, Tn);                       // dWq/dWk/dWv
+  size_t g2 = gemm_tn_ws_bytes(d, hd, Tn); if (g2 > gb) gb = g2; // dfc1
+  g2 = gemm_tn_ws_bytes(d, d, Tn); if (g2 > gb) gb = g2;
+  g2 = gemm_tn_ws_bytes(d, s.n_attr, Tn); if (g2 > gb) gb = g2;
   if (s.mode == 1) {   // recon head gradient [n_r, d] for any chromosome r: the slab count depends on ceil(n_r/64)
     for (int64_t m = 64;; m += 64) {
       const int64_t mm = m < s.max_bins ? m : s.max_bins;
-      g2 = gemm_tn_ws_bytes(mm, d, T); if (g2 > gb) gb = g2;
+      g2 = gemm_tn_ws_bytes(mm, d, Tn); if (g2 > gb) gb = g2;
       if (mm >= s.max_bins) break;
     }
   }
   w.gemm_ws_bytes = gb; w.gemm_ws = take(gb / sizeof(float));
-  w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, T) : 0;
+  w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, Tn) : 0;
   w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
   w.total = off;
   return off;
@@ -107,18 +120,20 @@ static int check_shape(const matcha_shape* s, int64_t B, int32_t L) {
                    "embed_dim d=%d unsupported (multiples of 8 up to 64, then 128, 192, 256)", s->d);
   MATCHA_CHECK_ARG(s->d % 4 == 0, "d must be a multiple of 4");
   MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L, "L=%d outside 1..%d", L, MATCHA_MAX_L);
-  MATCHA_CHECK_ARG(B >= 1, "B=%lld must be >= 1", (long long)B);
+  MATCHA_CHECK_ARG(B >= 1 && B * (int64_t)L < (1ll << 31) - 2, "B=%lld must be >= 1 and B*L < 2^31", (long long)B);
   MATCHA_CHECK_ARG(s->mode == 0 || s->mode == 1, "mode=%d must be 0 (table) or 1 (adj)", s->mode);
-  MATCHA_CHECK_ARG(s->n_attr >= 1, "n_attr=%d", s->n_attr);
+  MATCHA_CHECK_ARG(s->n_attr >= 1 && (size_t)s->n_attr * s->d * 4 <= 160 * 1024, "n_attr=%d does not fit the LDS staging", s->n_attr);
   return MATCHA_OK;
 }
 
-static GemmArgs gemm1(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, bool b_kn) {
+static GemmArgs gemm1(const Workspace& w, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, bool b_kn) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A[0] = A; g.B[0] = B; g.C[0] = C; g.batch = 1;
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = b_kn ? N : K; g.ldc = N;
   g.aux_scale = 1.f;
+  g.m_dev = w.rg.count;            // true token count (Tr + 1) lives on the device
+  g.rng_row_map = w.rg.tok_slot;   // dropout counters follow the original [B, L] slots
   return g;
 }
 
@@ -176,7 +191,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   Workspace w;
   const size_t need = carve(s, B, L, (char*)ws, w);
   if (ws_bytes < need) { set_error("matcha_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
-  const int64_t T = B * L;
+  const int64_t Tn = B * L + 1;                 // upper bound; the true count is *w.rg.count
   const int d = s.d;
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
   const bool train = opts->training != 0;
@@ -186,55 +201,59 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
                        p.fc1_b && p.pff0_w && p.pff0_b && p.pff1_w && p.pff1_b && p.pff_ln_g && p.pff_ln_b && p.ln1_g && p.ln1_b &&
                        p.ln2_g && p.ln2_b && p.cls_w && p.cls_b && p.ln_q_g && p.ln_q_b && p.ln_k_g && p.ln_k_b && p.ln_v_g && p.ln_v_b,
                    "matcha_forward: a parameter pointer is null");
+  const int32_t* cnt = w.rg.count;
+  const int64_t* ids = w.rg.tok_id;
 
+  // CSR plan: real tokens + one shared padding token
+  MATCHA_TRY(launch_ragged_plan(x, B, L, w.rg, st));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
-    MATCHA_TRY(launch_embed_fwd(x, T, d, p.table, nullptr, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st));
+    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, p.table, nullptr, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st, cnt));
     if (recon_out && hipMemsetAsync(recon_out, 0, sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
   } else {
-    MATCHA_TRY(adj_forward(s, p, *frozen, *opts, x, T, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st));
-    MATCHA_TRY(launch_embed_fwd(x, T, d, nullptr, w.node, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st));
+    MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot));
+    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, nullptr, w.node, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st, cnt));
   }
   // X = tanh(next_w(x0))   (Modules.py:270)
   {
-    GemmArgs g = gemm1(w.x0, p.next_w, w.X, T, d, d, false);
+    GemmArgs g = gemm1(w, w.x0, p.next_w, w.X, Tn, d, d, false);
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
   // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
-  MATCHA_TRY(launch_ln3_fwd(w.X, T, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st));
+  MATCHA_TRY(launch_ln3_fwd(w.X, Tn, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st, cnt));
   {
-    GemmArgs g = gemm1(w.qin, p.w_q, w.Q, T, hd, d, false);
+    GemmArgs g = gemm1(w, w.qin, p.w_q, w.Q, Tn, hd, d, false);
     g.A[1] = w.kin; g.B[1] = p.w_k; g.C[1] = w.K;
     g.A[2] = w.vin; g.B[2] = p.w_v; g.C[2] = w.V;
     g.batch = 3;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
-  MATCHA_TRY(launch_attn_fwd(w.Q, w.K, w.V, B, L, d, w.O, w.P, st));
-  // Y = (dropout(fc1(O))) * non_pad_mask    (Modules.py:572, :614)
+  MATCHA_TRY(launch_attn_fwd(w.Q, w.K, w.V, w.rg.row_off, B, L, d, w.O, w.P, st));
+  // Y = (dropout(fc1(O))) * non_pad_mask    (Modules.py:572, :614); the mask only zeroes the shared padding token's row
   {
-    GemmArgs g = gemm1(w.O, p.fc1_w, w.Y, T, d, hd, false);
-    g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_ROWMASK; g.bias[0] = p.fc1_b; g.row_ids = x;
+    GemmArgs g = gemm1(w, w.O, p.fc1_w, w.Y, Tn, d, hd, false);
+    g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_ROWMASK; g.bias[0] = p.fc1_b; g.row_ids = ids;
     if (train && opts->p_drop_fc1 > 0.f) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
   // pff_n1: H1 = dropout(tanh(conv0(Y)));  H2 = conv1(H1) + Y      (Modules.py:353-371)
   {
-    GemmArgs g = gemm1(w.Y, p.pff0_w, w.H1, T, d, d, false);
+    GemmArgs g = gemm1(w, w.Y, p.pff0_w, w.H1, Tn, d, d, false);
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.pff0_b;
     if (train && opts->p_drop_pff > 0.f) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropPff; g.p_drop = opts->p_drop_pff; }
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
   {
-    GemmArgs g = gemm1(w.H1, p.pff1_w, w.H2, T, d, d, false);
+    GemmArgs g = gemm1(w, w.H1, p.pff1_w, w.H2, Tn, d, d, false);
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_RESIDUAL; g.bias[0] = p.pff1_b; g.residual = w.Y;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
   // LayerNorms, (dynamic-static)^2, Conv1d(d->1), masked mean, weighted BCE   (Modules.py:373-374, :290-311; main.py:56)
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
-  MATCHA_TRY(launch_head_fwd(x, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, w.row_loss, losses, st));
+  MATCHA_TRY(launch_head_fwd(w.rg.row_off, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, w.row_loss, losses, st));
   if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
     set_error("logits copy failed"); return MATCHA_EHIP;
   }
@@ -255,69 +274,72 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   Workspace w;
   const size_t need = carve(s, B, L, (char*)ws, w);
   if (ws_bytes < need) { set_error("matcha_backward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
-  const int64_t T = B * L;
+  const int64_t Tn = B * L + 1;
   const int d = s.d;
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
   const bool train = opts->training != 0;
   const bool drop_fc1 = train && opts->p_drop_fc1 > 0.f, drop_pff = train && opts->p_drop_pff > 0.f;
+  const int32_t* cnt = w.rg.count;             // the plan (row_off, tok_id, tok_slot, count) is still in the workspace
+  const int64_t* ids = w.rg.tok_id;
 
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   HeadParams ghp = {g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.cls_b};
-  MATCHA_TRY(launch_head_bwd(x, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, dlogits, opts->alpha, w.dH2, w.dXs, w.slab, ghp, st));
+  MATCHA_TRY(launch_head_bwd(w.rg.row_off, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, dlogits, opts->alpha, w.dH2, w.dXs, w.slab, ghp, st));
   // pff_n1 conv1: dW1 += dH2^T H1 ; db1 += colsum(dH2) ; dZ1 = (dH2 W1) * dropmask * (1 - tanh^2)
-  MATCHA_TRY(launch_gemm_tn(w.dH2, w.H1, g_.pff1_w, g_.pff1_b, d, d, T, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.dH2, w.H1, g_.pff1_w, g_.pff1_b, d, d, Tn, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
-    GemmArgs g = gemm1(w.dH2, p.pff1_w, w.dZ1, T, d, d, true);
+    GemmArgs g = gemm1(w, w.dH2, p.pff1_w, w.dZ1, Tn, d, d, true);
     g.flags = MATCHA_EPI_DTANH; g.aux = w.H1;
     if (drop_pff) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropPff; g.p_drop = opts->p_drop_pff; g.aux_scale = 1.f - opts->p_drop_pff; }
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
   // pff_n1 conv0: dW0 += dZ1^T Y ; ddyn0 = (dZ1 W0 + dH2[residual]) * dropmask_fc1 * non_pad
-  MATCHA_TRY(launch_gemm_tn(w.dZ1, w.Y, g_.pff0_w, g_.pff0_b, d, d, T, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.dZ1, w.Y, g_.pff0_w, g_.pff0_b, d, d, Tn, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
-    GemmArgs g = gemm1(w.dZ1, p.pff0_w, w.ddyn0, T, d, d, true);
-    g.flags = MATCHA_EPI_RESIDUAL | MATCHA_EPI_ROWMASK; g.residual = w.dH2; g.row_ids = x;
+    GemmArgs g = gemm1(w, w.dZ1, p.pff0_w, w.ddyn0, Tn, d, d, true);
+    g.flags = MATCHA_EPI_RESIDUAL | MATCHA_EPI_ROWMASK; g.residual = w.dH2; g.row_ids = ids;
     if (drop_fc1) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
   // fc1: dW += ddyn0^T O ; db += colsum ; dO = ddyn0 Wfc1
-  MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, g_.fc1_w, g_.fc1_b, d, hd, T, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, g_.fc1_w, g_.fc1_b, d, hd, Tn, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
-    GemmArgs g = gemm1(w.ddyn0, p.fc1_w, w.dO, T, hd, d, true);
+    GemmArgs g = gemm1(w, w.ddyn0, p.fc1_w, w.dO, Tn, hd, d, true);
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
-  MATCHA_TRY(launch_attn_bwd(w.Q, w.K, w.V, w.P, w.dO, B, L, d, w.dQ, w.dK, w.dV, st));
+  MATCHA_TRY(launch_attn_bwd(w.Q, w.K, w.V, w.P, w.dO, w.rg.row_off, B, L, d, w.dQ, w.dK, w.dV, w.slab, st));
   // Q/K/V projections: dW += dQ^T qin ; dqin = dQ Wq  (batched x3)
-  MATCHA_TRY(launch_gemm_tn(w.dQ, w.qin, g_.w_q, nullptr, hd, d, T, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
-  MATCHA_TRY(launch_gemm_tn(w.dK, w.kin, g_.w_k, nullptr, hd, d, T, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
-  MATCHA_TRY(launch_gemm_tn(w.dV, w.vin, g_.w_v, nullptr, hd, d, T, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.dQ, w.qin, g_.w_q, nullptr, hd, d, Tn, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
+  MATCHA_TRY(launch_gemm_tn(w.dK, w.kin, g_.w_k, nullptr, hd, d, Tn, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
+  MATCHA_TRY(launch_gemm_tn(w.dV, w.vin, g_.w_v, nullptr, hd, d, Tn, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
-    GemmArgs g = gemm1(w.dQ, p.w_q, w.dqin, T, d, hd, true);
+    GemmArgs g = gemm1(w, w.dQ, p.w_q, w.dqin, Tn, d, hd, true);
     g.A[1] = w.dK; g.B[1] = p.w_k; g.C[1] = w.dkin;
     g.A[2] = w.dV; g.B[2] = p.w_v; g.C[2] = w.dvin;
     g.batch = 3;
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
   // LayerNorm x3 backward + static-branch gradient + tanh'
-  MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, T, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
-                            g_.ln_q_b, g_.ln_k_g, g_.ln_k_b, g_.ln_v_g, g_.ln_v_b, st));
+  MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, Tn, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
+                            g_.ln_q_b, g_.ln_k_g, g_.ln_k_b, g_.ln_v_g, g_.ln_v_b, st, cnt));
   // next_w: dW += dZ0^T x0 ; db += colsum ; dX0 = dZ0 Wn
-  MATCHA_TRY(launch_gemm_tn(w.dZ0, w.x0, g_.next_w, g_.next_b, d, d, T, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  MATCHA_TRY(launch_gemm_tn(w.dZ0, w.x0, g_.next_w, g_.next_b, d, d, Tn, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
-    GemmArgs g = gemm1(w.dZ0, p.next_w, w.dX0, T, d, d, true);
+    GemmArgs g = gemm1(w, w.dZ0, p.next_w, w.dX0, Tn, d, d, true);
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
-  // attribute_nn: dWa += dX0^T attr_table[x] ; dba += colsum(dX0)
-  MATCHA_TRY(launch_gemm_tn(w.dX0, frozen->attr_table, g_.attr_w, g_.attr_b, d, s.n_attr, T, d, s.n_attr, x, true, w.gemm_ws,
-                            w.gemm_ws_bytes, st));
+  // attribute_nn: dWa += dX0^T attr_table[id] ; dba += colsum(dX0)
+  MATCHA_TRY(launch_gemm_tn(w.dX0, frozen->attr_table, g_.attr_w, g_.attr_b, d, s.n_attr, Tn, d, s.n_attr, ids, true, w.gemm_ws,
+                            w.gemm_ws_bytes, st, cnt));
   // node embedding
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
-    MATCHA_TRY(launch_embed_scatter(x, T, d, w.dX0, g_.table, st));
+    MATCHA_TRY(launch_embed_scatter(ids, Tn, d, w.dX0, g_.table, st, cnt));
     if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
   } else {
-    MATCHA_TRY(adj_backward(s, p, *frozen, *opts, x, T, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st));
+    MATCHA_TRY(adj_backward(s, p, *frozen, *opts, ids, Tn, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st,
+                            w.rg.tok_slot));
   }
   return MATCHA_OK;
 }
@@ -328,12 +350,13 @@ extern "C" int matcha_node_embeddings(const matcha_shape* shp, const matcha_tens
   MATCHA_CHECK_ARG(shp && params && frozen && ids && rows, "matcha_node_embeddings: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (shp->mode == 0) {
-    // Wrap_Embedding: plain row gather (Modules.py:33-34); implemented as embed_fwd with a zero attribute path
+    // Wrap_Embedding: plain row gather (Modules.py:33-34)
     MATCHA_CHECK_ARG(params->table, "matcha_node_embeddings: null table");
     return launch_gather_rows(ids, T, shp->d, params->table, rows, st);
   }
   matcha_step_opts o;
   memset(&o, 0, sizeof(o));
   o.random_chrom = -1;   // no reconstruction branch
-  return adj_forward(*shp, *params, *frozen, o, ids, T, rows, nullptr, ws, ws_bytes, st);
+  MATCHA_CHECK_ARG(ws && ws_bytes >= adj_workspace_bytes(*shp, T), "matcha_node_embeddings: adj mode needs a workspace of matcha_workspace_bytes()");
+  return adj_forward(*shp, *params, *frozen, o, ids, T, rows, nullptr, ws, ws_bytes, st, nullptr, nullptr);
 }

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ table, const float* __restrict__ dense,
                                                         const float* __restrict__ attr_table, int n_attr,
                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
-                                                        float* __restrict__ x0, int tok_per_blk) {
+                                                        float* __restrict__ x0, int tok_per_blk, const int32_t* __restrict__ t_dev) {
+  if (t_dev) T = *t_dev;                                // ragged layout: the token count lives on the device
   // attribute_nn.weight [d, n_attr] is staged TRANSPOSED in LDS ([n_attr][d]) once per workgroup, so that the 16
   // lanes of a token read consecutive float4s (conflict-free; the 16 token groups broadcast) instead of each
   // lane walking a strided column of the weight in global memory.
@@ -230,7 +231,9 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
 
 // dtable[x[t]] += dx0[t]  (row 0 = padding_idx never receives a gradient)
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ x, int64_t T, int d,
-                                                            const float* __restrict__ dx0, float* __restrict__ dtable) {
+                                                            const float* __restrict__ dx0, float* __restrict__ dtable,
+                                                            const int32_t* __restrict__ t_dev) {
+  if (t_dev) T = *t_dev;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= T * d) return;
   const int64_t t = i / d;
@@ -247,7 +250,9 @@ template <int NCH>
 __global__ __launch_bounds__(256) void ln3_fwd_kernel(const float* __restrict__ X, int64_t T, int d,
                                                       const float* gq, const float* bq, const float* gk, const float* bk,
                                                       const float* gv, const float* bv, float* __restrict__ qin,
-                                                      float* __restrict__ kin, float* __restrict__ vin, float* __restrict__ stats) {
+                                                      float* __restrict__ kin, float* __restrict__ vin, float* __restrict__ stats,
+                                                      const int32_t* __restrict__ t_dev) {
+  if (t_dev) T = *t_dev;
   const int s = threadIdx.x & 15;
   const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (t >= T) return;
@@ -271,8 +276,14 @@ __global__ __launch_bounds__(256) void ln3_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ dkin, const float* __restrict__ dvin,
                                                       const float* __restrict__ dXs, int64_t T, int d,
                                                       const float* gq, const float* gk, const float* gv,
-                                                      float* __restrict__ dZ0, float* __restrict__ slab, int tok_per_blk) {
+                                                      float* __restrict__ dZ0, float* __restrict__ slab, int tok_per_blk,
+                                                      const int32_t* __restrict__ t_dev) {
   __shared__ float lds[16 * 256];
+  if (t_dev) {                                          // split the ACTUAL tokens evenly over the launched workgroups
+    T = *t_dev;
+    tok_per_blk = (int)((T + gridDim.x - 1) / gridDim.x);
+    tok_per_blk = (tok_per_blk + 15) / 16 * 16;
+  }
   const int s = threadIdx.x & 15, slot = threadIdx.x >> 4;
   Row Gq, Gk, Gv;
   load_row<NCH>(gq, s, d, Gq); load_row<NCH>(gk, s, d, Gk); load_row<NCH>(gv, s, d, Gv);
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void ln3_bwd_kernel(const float* __restrict__ 
 //   logit = sum_t out_t / (k + 1e-15)              (:309-311)
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ H2,
+__global__ __launch_bounds__(256) void head_fwd_kernel(const int32_t* __restrict__ row_off, const float* __restrict__ H2,
                                                        const float* __restrict__ X, int64_t B, int L, int d, HeadParams hp,
                                                        const float* __restrict__ y, const float* __restrict__ w,
                                                        float* __restrict__ logits, float* __restrict__ row_loss) {
@@ -335,9 +346,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const int64_t* __restrict
   load_row<NCH>(hp.wc, s, d, Wc);
   const float bc = hp.bc[0];
   float total = 0.f, cnt = 0.f;
-  for (int l = 0; l < L; ++l) {
-    const int64_t t = b * L + l;
-    if (x[t] == 0) continue;                          // uniform within the 16-lane group
+  const int t_lo = row_off[b], t_hi = row_off[b + 1];   // the hyperedge's real tokens (ragged layout: pads are not stored)
+  for (int64_t t = t_lo; t < t_hi; ++t) {
     Row h, hh, u, uh, dn, xr, xh, sn;
     float m, r;
     load_row<NCH>(H2 + t * d, s, d, h);
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const int64_t* __restrict
 // the static branch); parameter gradients as per-block column sums slab[blk][7][d] + slab_bc[blk]:
 //   {dgp, dbp, dg1, db1, dg2, db2, dwc}, dbc.
 template <int NCH>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ H2,
+__global__ __launch_bounds__(256) void head_bwd_kernel(const int32_t* __restrict__ row_off, const float* __restrict__ H2,
                                                        const float* __restrict__ X, int64_t B, int L, int d, HeadParams hp,
                                                        const float* __restrict__ y, const float* __restrict__ w,
                                                        const float* __restrict__ logits, const float* __restrict__ dlogits,
@@ -394,8 +404,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int64_t* __restrict
   for (int i = slot; i < rows_per_blk; i += 16) {
     const int64_t b = b0 + i;
     if (b >= B) break;
-    float cnt = 0.f;
-    for (int l = 0; l < L; ++l) cnt += (x[b * L + l] != 0) ? 1.f : 0.f;
+    const int t_lo = row_off[b], t_hi = row_off[b + 1];
+    const float cnt = (float)(t_hi - t_lo);
     float dz;
     if (dlogits) dz = dlogits[b];
     else {
@@ -404,15 +414,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int64_t* __restrict
       dz = alpha * w[b] * (sg - y[b]) / (float)B;
     }
     const float dout = dz / (cnt + 1e-15f);
-    for (int l = 0; l < L; ++l) {
-      const int64_t t = b * L + l;
-      Row zr;
-      zero_row<NCH>(zr);
-      if (x[t] == 0) {                               // pads: masked out of the mean -> zero gradient
-        store_row<NCH>(dH2 + t * d, s, d, zr);
-        store_row<NCH>(dXs + t * d, s, d, zr);
-        continue;
-      }
+    for (int64_t t = t_lo; t < t_hi; ++t) {
       Row h, hh, u, uh, dn, xr, xh, sn;
       float m, rh, ru, rx;
       load_row<NCH>(H2 + t * d, s, d, h);
@@ -445,6 +447,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int64_t* __restrict
       ln_bwd_row<NCH>(tmp, xh, rx, s, d, dxs);
       store_row<NCH>(dXs + t * d, s, d, dxs);
     }
+  }
+  if (blockIdx.x == 0 && slot == 0) {        // the shared padding token is masked out of every mean: zero gradient rows
+    Row zr;
+    zero_row<NCH>(zr);
+    const int64_t tp = row_off[B];
+    store_row<NCH>(dH2 + tp * d, s, d, zr);
+    store_row<NCH>(dXs + tp * d, s, d, zr);
   }
   block_colsum_store<NCH, 7>(part, d, slab + (int64_t)blockIdx.x * (7 * d + 1), lds);
   if (s == 0) lds_bc[slot] = part_bc;
@@ -511,14 +520,14 @@ static inline int nch_of(int d) { return d <= 64 ? 1 : (d <= 128 ? 2 : 4); }
   }
 
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
-                     int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st) {
+                     int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev) {
   if (T <= 0) return MATCHA_OK;
   const int tok_per_blk = T >= 256 * 1024 ? 256 : (T >= 16 * 1024 ? 64 : 16);
   dim3 grid((unsigned)cdiv(T, tok_per_blk));
   const size_t lds = (size_t)n_attr * d * sizeof(float);
   // algorithmic bytes per token: index 8 + embedding row 4d + attribute row 4*n_attr read, x0 row 4d written
   ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)T * (8.0 + 4.0 * d + 4.0 * n_attr + 4.0 * d), st);
-  DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), lds, st, x, T, d, table, dense, attr_table, n_attr, Wa, ba, x0, tok_per_blk));
+  DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), lds, st, x, T, d, table, dense, attr_table, n_attr, Wa, ba, x0, tok_per_blk, t_dev));
   MATCHA_CHECK_LAUNCH("embed_fwd_kernel");
   return MATCHA_OK;
 }
@@ -540,20 +549,20 @@ int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
   return MATCHA_OK;
 }
 
-int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st) {
+int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st, const int32_t* t_dev) {
   if (T <= 0) return MATCHA_OK;
   ProfScope ps(MATCHA_PROF_EMBED_SCATTER, (double)T * (8.0 + 8.0 * d), st);   // read dx0 row + index, add 4d bytes
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, x, T, d, dx0, dtable);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, x, T, d, dx0, dtable, t_dev);
   MATCHA_CHECK_LAUNCH("embed_scatter_kernel");
   return MATCHA_OK;
 }
 
 int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const float* bq, const float* gk, const float* bk,
-                   const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st) {
+                   const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st, const int32_t* t_dev) {
   if (T <= 0) return MATCHA_OK;
   dim3 grid((unsigned)cdiv(T, 16));
   ProfScope ps(MATCHA_PROF_LN3_FWD, (double)T * 16.0 * d, st);      // read X, write qin/kin/vin
-  DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_fwd_kernel<NCH>), grid, dim3(256), 0, st, X, T, d, gq, bq, gk, bk, gv, bv, qin, kin, vin, stats));
+  DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_fwd_kernel<NCH>), grid, dim3(256), 0, st, X, T, d, gq, bq, gk, bk, gv, bv, qin, kin, vin, stats, t_dev));
   MATCHA_CHECK_LAUNCH("ln3_fwd_kernel");
   return MATCHA_OK;
 }
@@ -571,12 +580,12 @@ int colsum_blocks(int64_t n, int* per_blk) {
 
 int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const float* dvin, const float* dXs, int64_t T, int d,
                    const float* gq, const float* gk, const float* gv, float* dZ0, float* slab, float* dgq, float* dbq,
-                   float* dgk, float* dbk, float* dgv, float* dbv, hipStream_t st) {
+                   float* dgk, float* dbk, float* dgv, float* dbv, hipStream_t st, const int32_t* t_dev) {
   if (T <= 0) return MATCHA_OK;
   int per;
   const int nblk = colsum_blocks(T, &per);
   ProfScope ps(MATCHA_PROF_LN3_BWD, (double)T * 24.0 * d, st);      // read X, dqin, dkin, dvin, dXs; write dZ0
-  DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, X, dqin, dkin, dvin, dXs, T, d, gq, gk, gv, dZ0, slab, per));
+  DISPATCH_NCH(d, hipLaunchKernelGGL((ln3_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, X, dqin, dkin, dvin, dXs, T, d, gq, gk, gv, dZ0, slab, per, t_dev));
   MATCHA_CHECK_LAUNCH("ln3_bwd_kernel");
   ColsumDst dst = {{dgq, dbq, dgk, dbk, dgv, dbv, nullptr, nullptr}};
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(6 * d, 64)), dim3(1024), 0, st, slab, nblk, 6, d, 6 * d, dst);
@@ -584,12 +593,12 @@ int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const f
   return MATCHA_OK;
 }
 
-int launch_head_fwd(const int64_t* x, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
+int launch_head_fwd(const int32_t* row_off, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
                     const float* y, const float* w, float* logits, float* row_loss, float* bce_out, hipStream_t st) {
   if (B <= 0) return MATCHA_OK;
   float* rl = (y && w) ? row_loss : nullptr;
   ProfScope ps(MATCHA_PROF_HEAD_FWD, (double)B * L * (8.0 * d + 8.0), st);   // read H2, X rows + ids
-  DISPATCH_NCH(d, hipLaunchKernelGGL((head_fwd_kernel<NCH>), dim3((unsigned)cdiv(B, 16)), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, rl));
+  DISPATCH_NCH(d, hipLaunchKernelGGL((head_fwd_kernel<NCH>), dim3((unsigned)cdiv(B, 16)), dim3(256), 0, st, row_off, H2, X, B, L, d, hp, y, w, logits, rl));
   MATCHA_CHECK_LAUNCH("head_fwd_kernel");
   if (rl && bce_out) {
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rl, B, bce_out);
@@ -598,7 +607,7 @@ int launch_head_fwd(const int64_t* x, const float* H2, const float* X, int64_t B
   return MATCHA_OK;
 }
 
-int launch_head_bwd(const int64_t* x, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
+int launch_head_bwd(const int32_t* row_off, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
                     const float* y, const float* w, const float* logits, const float* dlogits, float alpha, float* dH2,
                     float* dXs, float* slab, const HeadParams& ghp, hipStream_t st) {
   if (B <= 0) return MATCHA_OK;
@@ -606,7 +615,7 @@ int launch_head_bwd(const int64_t* x, const float* H2, const float* X, int64_t B
   const int nblk = colsum_blocks(B, &per);
   {
     ProfScope ps(MATCHA_PROF_HEAD_BWD, (double)B * L * (16.0 * d + 8.0), st);  // read H2, X; write dH2, dXs
-    DISPATCH_NCH(d, hipLaunchKernelGGL((head_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, x, H2, X, B, L, d, hp, y, w, logits, dlogits, alpha, dH2, dXs, slab, per));
+    DISPATCH_NCH(d, hipLaunchKernelGGL((head_bwd_kernel<NCH>), dim3(nblk), dim3(256), 0, st, row_off, H2, X, B, L, d, hp, y, w, logits, dlogits, alpha, dH2, dXs, slab, per));
   }
   MATCHA_CHECK_LAUNCH("head_bwd_kernel");
   ColsumDst dst = {{(float*)ghp.gp, (float*)ghp.bp, (float*)ghp.g1, (float*)ghp.b1, (float*)ghp.g2, (float*)ghp.b2, (float*)ghp.wc, (float*)ghp.bc}};
@@ -630,13 +639,13 @@ extern "C" int matcha_embed_fwd(const int64_t* x, int64_t T, int32_t d, const fl
                                 float* x0, matcha_stream_t stream) {
   MATCHA_CHECK_ARG(x && attr_table && attr_w && attr_b && x0, "matcha_embed_fwd: null pointer");
   MATCHA_CHECK_ARG(d % 4 == 0 && d > 0 && d <= 256, "matcha_embed_fwd: d=%d must be a multiple of 4, <= 256", d);
-  return launch_embed_fwd(x, T, d, table, dense, attr_table, n_attr, attr_w, attr_b, x0, (hipStream_t)stream);
+  return launch_embed_fwd(x, T, d, table, dense, attr_table, n_attr, attr_w, attr_b, x0, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int matcha_embed_scatter_bwd(const int64_t* x, int64_t T, int32_t d, const float* dx0, float* dtable,
                                         matcha_stream_t stream) {
   MATCHA_CHECK_ARG(x && dx0 && dtable, "matcha_embed_scatter_bwd: null pointer");
-  return launch_embed_scatter(x, T, d, dx0, dtable, (hipStream_t)stream);
+  return launch_embed_scatter(x, T, d, dx0, dtable, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int matcha_ln3_fwd(const float* X, int64_t T, int32_t d, const float* gq, const float* bq, const float* gk,
@@ -644,5 +653,5 @@ extern "C" int matcha_ln3_fwd(const float* X, int64_t T, int32_t d, const float*
                               float* stats, matcha_stream_t stream) {
   MATCHA_CHECK_ARG(X && gq && bq && gk && bk && gv && bv && qin && kin && vin, "matcha_ln3_fwd: null pointer");
   MATCHA_CHECK_ARG(d % 4 == 0 && d > 0 && d <= 256, "matcha_ln3_fwd: d=%d must be a multiple of 4, <= 256", d);
-  return launch_ln3_fwd(X, T, d, gq, bq, gk, bk, gv, bv, qin, kin, vin, stats, (hipStream_t)stream);
+  return launch_ln3_fwd(X, T, d, gq, bq, gk, bk, gv, bv, qin, kin, vin, stats, (hipStream_t)stream, nullptr);
 }

@@ -134,26 +134,56 @@ def _attn_ref(Q, K, V, B, L, d):
 
 @pytest.mark.parametrize("d", [16, 64, 128])
 @pytest.mark.parametrize("L", [1, 2, 3, 5, 7, 8])
-def test_attention_fwd_bwd(d, L):
+@pytest.mark.parametrize("ragged", [False, True])
+def test_attention_fwd_bwd(d, L, ragged):
+    """Ragged attention kernel vs the padded dense computation the reference performs: hyperedge b has k_b real tokens,
+    its L - k_b padding slots all carry the ONE shared padding token's K/V (and are attended, fact 7)."""
     lib = _lib.load()
     B, H = 37, _lib.N_HEAD
-    g = torch.Generator().manual_seed(d * 10 + L)
-    Q, K, V = (torch.randn(B * L, H * d, generator=g).requires_grad_(True) for _ in range(3))
+    g = torch.Generator().manual_seed(d * 10 + L + (1000 if ragged else 0))
+    ks = torch.randint(1, L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
+    row_off = torch.zeros(B + 1, dtype=torch.int32)
+    row_off[1:] = torch.cumsum(ks, 0).to(torch.int32)
+    Tr = int(row_off[B])
+    # compact tensors: Tr real rows + the padding token's row
+    Qc, Kc, Vc = (torch.randn(Tr + 1, H * d, generator=g).requires_grad_(True) for _ in range(3))
+    # dense [B*L] view built by gathering compact rows (pads -> row Tr)
+    idx = torch.full((B, L), Tr, dtype=torch.long)
+    for b in range(B):
+        idx[b, :ks[b]] = torch.arange(int(row_off[b]), int(row_off[b + 1]))
+    real = (idx != Tr).reshape(-1)
+    Q, K, V = Qc[idx.reshape(-1)], Kc[idx.reshape(-1)], Vc[idx.reshape(-1)]
     o_ref, p_ref = _attn_ref(Q, K, V, B, L, d)
-    dO = torch.randn(B * L, H * d, generator=g)
-    o_ref.backward(dO)
-    Qd, Kd, Vd, dOd = (t.detach().to(DEV) for t in (Q, K, V, dO))
-    O = torch.empty_like(Qd)
-    P = torch.empty(B, H, L, L, device=DEV)
-    _lib.check(lib.matcha_attn_fwd(_lib.ptr(Qd), _lib.ptr(Kd), _lib.ptr(Vd), B, L, d, _lib.ptr(O), _lib.ptr(P), _stream()))
-    dQ, dK, dV = (torch.empty_like(Qd) for _ in range(3))
-    _lib.check(lib.matcha_attn_bwd(_lib.ptr(Qd), _lib.ptr(Kd), _lib.ptr(Vd), _lib.ptr(P), _lib.ptr(dOd), B, L, d, _lib.ptr(dQ),
-                                   _lib.ptr(dK), _lib.ptr(dV), _stream()))
+    dO_dense = torch.randn(B * L, H * d, generator=g) * real[:, None].float()     # pad queries' outputs are masked downstream
+    o_ref.backward(dO_dense)
+    dOc = torch.zeros(Tr + 1, H * d)
+    dOc[idx.reshape(-1)[real]] = dO_dense[real]
+    Qd, Kd, Vd, dOd, ro = (t.detach().to(DEV) for t in (Qc, Kc, Vc, dOc, row_off))
+    O = torch.zeros_like(Qd)
+    P = torch.zeros(B, H, L, L, device=DEV)
+    _lib.check(lib.matcha_attn_fwd(_lib.ptr(Qd), _lib.ptr(Kd), _lib.ptr(Vd), _lib.ptr(ro), B, L, d, _lib.ptr(O), _lib.ptr(P), _stream()))
+    dQ, dK, dV = (torch.zeros_like(Qd) for _ in range(3))
+    wsn = lib.matcha_attn_bwd_workspace_bytes(B, d)
+    ws = torch.empty(wsn, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.matcha_attn_bwd(_lib.ptr(Qd), _lib.ptr(Kd), _lib.ptr(Vd), _lib.ptr(P), _lib.ptr(dOd), _lib.ptr(ro), B, L, d, _lib.ptr(dQ),
+                                   _lib.ptr(dK), _lib.ptr(dV), _lib.ptr(ws), wsn, _stream()))
     torch.cuda.synchronize()
-    assert (O.cpu() - o_ref.detach()).abs().max() <= 2e-5 * max(1.0, o_ref.abs().max())
-    assert (P.cpu() - p_ref.detach()).abs().max() <= 1e-5
-    for got, ref in ((dQ, Q.grad), (dK, K.grad), (dV, V.grad)):
-        assert (got.cpu() - ref).abs().max() <= 3e-5 * max(1.0, ref.abs().max())
+    o_dense = o_ref.detach()[real]
+    assert (O.cpu()[:Tr] - o_dense).abs().max() <= 2e-5 * max(1.0, o_dense.abs().max())
+    # probabilities of the real columns
+    Pc = P.cpu()
+    for b in range(0, B, 5):
+        k = int(ks[b])
+        assert (Pc[b, :, :k, :k] - p_ref.detach()[b, :, :k, :k]).abs().max() <= 1e-5
+        if k < L:
+            assert (Pc[b, :, :k, k] - p_ref.detach()[b, :, :k, k]).abs().max() <= 1e-5
+    # gradients: Q of real tokens; K/V of real tokens and of the shared padding token (sum over all its slots)
+    for got, leaf in ((dQ, Qc), (dK, Kc), (dV, Vc)):
+        ref = leaf.grad
+        if leaf is Qc:
+            ref = ref.clone()
+            ref[Tr] = 0         # pad queries never influence anything downstream
+        assert (got.cpu() - ref).abs().max() <= 5e-5 * max(1.0, ref.abs().max())
 
 
 @pytest.mark.parametrize("d", [16, 64, 128, 256])
