@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs collected by tools/collect_profiles.sh into the committed summaries under profiles/.
+Usage: python tools/summarize_profiles.py <tag> <round-prefix e.g. r01>"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+src = glob.glob(f"gpurun_out/{tag}_stats/*/*_kernel_stats.csv")[0]
+shutil.copy(src, f"profiles/{rnd}_kernel_stats.csv")
+rows = list(csv.DictReader(open(src)))
+with open(f"profiles/{rnd}_kernel_stats.md", "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats ({rnd})\n\n")
+    f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 "
+            "--prof none --no-cpu-baseline`\n(7 steps of 65536 rows; hg38-1Mb, table front end, d=64, L=5; raw CSV next to this file)\n\n")
+    f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
+    for r in rows[:26]:
+        f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
+
+
+def load(d, name):
+    f = glob.glob(f"gpurun_out/{tag}_{d}/*/*_counter_collection.csv")[0]
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            out[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
+    return out
+
+
+def cls(n):
+    if "gemm_tn_kernel" in n:
+        return "gemm_tn"
+    if "gemm_lds_kernel<false" in n:
+        return "gemm_nt"
+    if "gemm_lds_kernel<true" in n:
+        return "gemm_nn"
+    for k in ("attn_fwd", "attn_bwd", "embed_fwd", "embed_scatter", "ln3_fwd", "ln3_bwd", "head_fwd", "head_bwd", "adamw_kernel", "neg_sample", "adj_encode"):
+        if k in n:
+            return k.replace("_kernel", "")
+    return None
+
+
+fe, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
+ids = sorted(fe)
+start = max(i for i in ids if "neg_sample" in fe[i][0])     # the last full step
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for i in ids:
+    if i < start:
+        continue
+    c = cls(fe[i][0])
+    if c:
+        a = agg[c]
+        a[0] += 1
+        a[1] += fe[i][1] * 1024 * 2          # KB -> B; x2: gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md §HBM)
+        a[2] += wr.get(i, (None, 0))[1] * 1024
+out = {c: {"launches_per_step": v[0], "hbm_read_bytes_per_launch": v[1] / v[0], "hbm_write_bytes_per_launch": v[2] / v[0],
+           "hbm_bytes_per_launch": (v[1] + v[2]) / v[0]} for c, v in agg.items()}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of bench.py --steps 2 --warmup 1, 65536 rows/step); "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; bytes per launch averaged over the launches of the class in one step",
+           "classes": out}, open(f"profiles/{rnd}_pmc_traffic.json", "w"), indent=1)
+for c, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"]):
+    print(f"{c:14s} x{v['launches_per_step']:2d}  {v['hbm_bytes_per_launch']/1e6:9.1f} MB/launch")
