@@ -63,6 +63,8 @@ int matcha_device_count(void);
 #define MATCHA_PROF_NEG_SAMPLE 13
 #define MATCHA_PROF_ADJ_ENCODE 14
 #define MATCHA_PROF_GATHER_ROWS 15
+#define MATCHA_PROF_FUSED_FWD 16
+#define MATCHA_PROF_FUSED_BWD 17
 int matcha_profile_select(int32_t kernel_class);
 int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
 
@@ -135,6 +137,8 @@ typedef struct matcha_step_opts {
   float alpha;               /* main.py:166 loss = bce*alpha + recon*beta */
   float beta;
   const uint64_t* seed;      /* DEVICE pointer to the 64-bit dropout seed of this step (graph-replay safe) */
+  int32_t forward_only;      /* 1: matcha_backward will NOT be called on this workspace (inference / no_grad): the
+                                forward may keep every intermediate on chip (fused kernel) and save nothing          */
 } matcha_step_opts;
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */

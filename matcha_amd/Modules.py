@@ -481,6 +481,8 @@ class Classifier(nn.Module):
         o.p_drop_adj, o.p_drop_fc1, o.p_drop_pff = self._dropout_p()
         o.alpha, o.beta = 1.0, 1.0
         o.random_chrom = 0
+        # no autograd graph will be built -> the library may run its fully fused forward and keep nothing for backward
+        o.forward_only = 0 if (torch.is_grad_enabled() and any(p.requires_grad for p in rt.live)) else 1
         if rt.mode == 1:
             # the reference draws this from numpy's global generator on EVERY forward, train and eval (Modules.py:192)
             o.random_chrom = int(np.random.choice(np.arange(rt.n_chrom), 1)[0])

@@ -1,0 +1,440 @@
+// Fused forward of the whole encoder + classifier tail for embed_dim 64 (the metric's dim):
+//   X  ->  x_hat  ->  per head { Q,K,V = x_hat.W'^T + c  ->  attention (diag masked, pads attended)  ->  dyn += O.Wfc1_h^T }
+//      ->  Y = mask*dropout(dyn + b)  ->  H1 = dropout(tanh(conv0 Y))  ->  H2 = conv1 H1 + Y
+//      ->  LN_pff, LN1, LN2(X), (dn - sn)^2 . wc + bc  ->  per-hyperedge mean  ->  logit (+ weighted BCE term)
+// (Modules.py:519-572, :353-376, :290-311; main.py:56).  Everything between X and the logits stays in LDS/registers:
+// per token the kernel reads 256 B (X) and, in training, writes 768 B (Y, H1, H2 for the backward pass) instead of the
+// ~20 KB of Q/K/V/O/... round trips of the layer-by-layer path.
+//
+// Work decomposition: one 256-thread workgroup per TILE of whole hyperedges, <= 63 real tokens + the shared padding token
+// as the last row (its K/V rows come out of the same projection GEMMs).  Tile i owns the hyperedges whose first token
+// index lies in [59 i, 59 (i+1)), so tiles need no precomputed plan (two binary searches in row_off).
+// A 64x64x64 GEMM is split into four 32x32 quadrants, one per wave (32 f32 MFMAs each).
+// The three LayerNorm affines in front of Q/K/V are folded into the projection weights once per step
+// (W' = W * g, c = W . b), so one x_hat fragment set, held in registers for the whole tile, feeds all 24 projections.
+#include "kernels.hpp"
+
+namespace matcha {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTM = 64;          // tile rows (tokens)
+constexpr int kLdT = 68;         // LDS row stride (floats)
+constexpr int kTileF = kTM * kLdT;
+constexpr float kEps = 1e-5f;
+
+// W'[n][k] = W[n][k] * g[k];  c[n] = sum_k W[n][k] * b[k]      (grid: (H*d rows, 3 matrices), 64 threads)
+struct FoldArgs {
+  const float* W[3]; const float* g[3]; const float* b[3];
+  float* Wp[3]; float* c[3];
+};
+__global__ __launch_bounds__(64) void fold_ln_kernel(FoldArgs a) {
+  const int z = blockIdx.y, n = blockIdx.x, k = threadIdx.x;
+  const float w = a.W[z][n * 64 + k];
+  a.Wp[z][n * 64 + k] = w * a.g[z][k];
+  const float s = group_sum<64>(w * a.b[z][k]);
+  if (k == 0) a.c[z][n] = s;
+}
+
+struct FusedFwdArgs {
+  const float* X;                 // [Tn, 64]
+  const int32_t* row_off;         // [B+1]
+  const int32_t* tok_slot;        // [Tn]
+  const int32_t* count;           // {Tr+1, Tr}
+  int64_t B;
+  int L;
+  const float* wq; const float* wk; const float* wv;     // folded, [512, 64]
+  const float* cq; const float* ck; const float* cv;     // [512]
+  const float* fc1_w; const float* fc1_b;                // [64, 512], [64]
+  const float* p0w; const float* p0b; const float* p1w; const float* p1b;
+  HeadParams hp;
+  const float* y; const float* w;
+  float* Y; float* H1; float* H2;                        // saved for backward (null: not saved)
+  float* logits; float* row_loss;
+  const uint64_t* seed;
+  float p_fc1, p_pff;
+};
+
+__device__ __forceinline__ int lower_bound_rows(const int32_t* __restrict__ row_off, int64_t B, int target) {
+  // first b in [0, B] with row_off[b] >= target
+  int64_t lo = 0, hi = B;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (row_off[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  return (int)lo;
+}
+
+// stage a [64 x 64] fp32 block (row stride src_ld) into an LDS tile [64][68]
+__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, int64_t src_ld) {
+  const int srow = threadIdx.x >> 4, sc4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = srow + 16 * i;
+    *reinterpret_cast<float4*>(&dst[row * kLdT + sc4]) = *reinterpret_cast<const float4*>(src + row * src_ld + sc4);
+  }
+}
+
+// acc(32x32 quadrant) += A[rows 32*wr.., :] . B^T,  A fragments in registers, B tile in LDS as [n][k]
+__device__ __forceinline__ f32x16 quad_gemm_regA(f32x16 acc, const float4 (&afr)[8], const float* __restrict__ Bs, int wc, int r, int h) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLdT + 8 * c + 4 * h]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[c].x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[c].y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[c].z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[c].w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// same with the A tile in LDS ([row][k])
+__device__ __forceinline__ f32x16 quad_gemm_ldsA(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int r, int h) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLdT + 8 * c + 4 * h]);
+    const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLdT + 8 * c + 4 * h]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// write a quadrant (+ per-column bias) to an LDS tile
+__device__ __forceinline__ void quad_store(float* __restrict__ Ts, const f32x16& acc, const float* __restrict__ bias, int wr, int wc, int r, int h) {
+  const int col = 32 * wc + r;
+  const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    Ts[row * kLdT + col] = acc[reg] + bv;
+  }
+}
+
+// attention of one hyperedge for one head from LDS tiles; 8 lanes, lane `sub` owns features [8 sub, 8 sub + 8)
+template <int ML>
+__device__ __forceinline__ void attn_group_fwd(float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs, int li0, int k,
+                                               int n_pad, int pad_row, int sub, float inv_temp) {
+  float q[ML][8], kk[ML][8], kp[8];
+#pragma unroll
+  for (int i = 0; i < ML; ++i)
+    if (i < k) {
+      const float4 a = *reinterpret_cast<const float4*>(&Qs[(li0 + i) * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Qs[(li0 + i) * kLdT + 8 * sub + 4]);
+      q[i][0] = a.x; q[i][1] = a.y; q[i][2] = a.z; q[i][3] = a.w; q[i][4] = b.x; q[i][5] = b.y; q[i][6] = b.z; q[i][7] = b.w;
+      const float4 c = *reinterpret_cast<const float4*>(&Ks[(li0 + i) * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[(li0 + i) * kLdT + 8 * sub + 4]);
+      kk[i][0] = c.x; kk[i][1] = c.y; kk[i][2] = c.z; kk[i][3] = c.w; kk[i][4] = e.x; kk[i][5] = e.y; kk[i][6] = e.z; kk[i][7] = e.w;
+    }
+  if (n_pad > 0) {
+    const float4 c = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub + 4]);
+    kp[0] = c.x; kp[1] = c.y; kp[2] = c.z; kp[3] = c.w; kp[4] = e.x; kp[5] = e.y; kp[6] = e.z; kp[7] = e.w;
+  }
+  float S[ML][ML], Sp[ML];
+  const float padf = (float)n_pad;
+#pragma unroll
+  for (int i = 0; i < ML; ++i)
+    if (i < k) {
+      float mx = -3.4e38f;
+#pragma unroll
+      for (int j = 0; j < ML; ++j)
+        if (j < k) {
+          float a = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a += q[i][e] * kk[j][e];
+          float v = group_sum<8>(a) * inv_temp;
+          if (i == j) v = -1e32f;
+          S[i][j] = v;
+          mx = fmaxf(mx, v);
+        }
+      Sp[i] = 0.f;
+      if (n_pad > 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += q[i][e] * kp[e];
+        Sp[i] = group_sum<8>(a) * inv_temp;
+        mx = fmaxf(mx, Sp[i]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j < ML; ++j)
+        if (j < k) { S[i][j] = expf(S[i][j] - mx); den += S[i][j]; }
+      if (n_pad > 0) { Sp[i] = expf(Sp[i] - mx); den += padf * Sp[i]; }
+      const float inv = 1.f / den;
+#pragma unroll
+      for (int j = 0; j < ML; ++j)
+        if (j < k) S[i][j] *= inv;
+      Sp[i] = n_pad > 0 ? Sp[i] * inv : 0.f;
+    }
+  // O_i = sum_j P_ij V_j + n_pad Pp_i V_pad   -> overwrites this hyperedge's own Q rows
+  float v[ML][8], vp[8];
+#pragma unroll
+  for (int j = 0; j < ML; ++j)
+    if (j < k) {
+      const float4 a = *reinterpret_cast<const float4*>(&Vs[(li0 + j) * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[(li0 + j) * kLdT + 8 * sub + 4]);
+      v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w; v[j][4] = b.x; v[j][5] = b.y; v[j][6] = b.z; v[j][7] = b.w;
+    }
+  if (n_pad > 0) {
+    const float4 a = *reinterpret_cast<const float4*>(&Vs[pad_row * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[pad_row * kLdT + 8 * sub + 4]);
+    vp[0] = a.x; vp[1] = a.y; vp[2] = a.z; vp[3] = a.w; vp[4] = b.x; vp[5] = b.y; vp[6] = b.z; vp[7] = b.w;
+  }
+#pragma unroll
+  for (int i = 0; i < ML; ++i)
+    if (i < k) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (n_pad > 0) ? padf * Sp[i] * vp[e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < ML; ++j)
+        if (j < k) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += S[i][j] * v[j][e];
+        }
+      *reinterpret_cast<float4*>(&Qs[(li0 + i) * kLdT + 8 * sub]) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(&Qs[(li0 + i) * kLdT + 8 * sub + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// LayerNorm statistics of a 64-float row held as one float4 per lane over 16 lanes
+__device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rstd) {
+  const float s = group_sum<16>((v.x + v.y) + (v.z + v.w));
+  mean = s * (1.f / 64.f);
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+  const float q = group_sum<16>((a * a + b * b) + (c * c + e * e));
+  rstd = 1.0f / sqrtf(q * (1.f / 64.f) + kEps);
+}
+__device__ __forceinline__ float4 ln_apply(const float4& v, float mean, float rstd, const float4& g, const float4& b) {
+  return make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y, (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w);
+}
+
+template <int ML>
+__global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xs = lds;                    // raw X rows (static branch)                 -> out_t scratch at the end
+  float* Xh = lds + 1 * kTileF;       // x_hat, then Y
+  float* Bs0 = lds + 2 * kTileF;      // weight tiles (double buffer)
+  float* Bs1 = lds + 3 * kTileF;
+  float* Qs = lds + 4 * kTileF;       // Q, then O (per head); later H1
+  float* Ks = lds + 5 * kTileF;       // K; later H2
+  float* Vs = lds + 6 * kTileF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wc = wave >> 1;          // quadrant of this wave
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+
+  // ---- tile -> hyperedges [b0, b1), tokens [t0, t1) (+ the padding token as local row n_real) ----
+  // window of first-token indices: a hyperedge starting at <= 63 - L ends at <= 63, so the tile holds <= 63 real tokens
+  const int win = kTM - g.L;
+  const int ws = blockIdx.x * win;
+  const int b0 = lower_bound_rows(g.row_off, g.B, ws);
+  const int b1 = lower_bound_rows(g.row_off, g.B, ws + win);
+  if (b0 >= b1) return;                              // no hyperedge starts in this window
+  const int t0 = g.row_off[b0];
+  const int t1 = g.row_off[b1];
+  const int n_real = t1 - t0;                        // <= 63
+  const int tok_pad = g.count[1];                    // Tr: index of the shared padding token
+  const int n_h = b1 - b0;
+  const float inv_temp = 0.125f;                     // 1/sqrt(64)
+
+  // ---- stage X rows, LayerNorm statistics -> x_hat ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = srow + 16 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row <= n_real) {
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      v = *reinterpret_cast<const float4*>(g.X + tok * 64 + sc4);
+    }
+    *reinterpret_cast<float4*>(&Xs[row * kLdT + sc4]) = v;
+    float mean, rstd;
+    ln_row16(v, mean, rstd);
+    *reinterpret_cast<float4*>(&Xh[row * kLdT + sc4]) = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+  }
+  __syncthreads();
+  float4 afr[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) afr[c] = *reinterpret_cast<const float4*>(&Xh[(32 * wr + r) * kLdT + 8 * c + 4 * h]);
+
+  f32x16 dyn = {0};
+  for (int hd = 0; hd < MATCHA_N_HEAD; ++hd) {
+    // ---- projections of this head: Q, K, V quadrants -> LDS ----
+    __syncthreads();                                   // previous head's fc1 GEMM is done with Qs / Bs1
+    stage_tile(Bs0, g.wq + (int64_t)hd * 64 * 64, 64);
+    stage_tile(Bs1, g.wk + (int64_t)hd * 64 * 64, 64);
+    __syncthreads();
+    {
+      f32x16 acc = {0};
+      acc = quad_gemm_regA(acc, afr, Bs0, wc, r, h);
+      quad_store(Qs, acc, g.cq + hd * 64, wr, wc, r, h);
+      f32x16 acc2 = {0};
+      acc2 = quad_gemm_regA(acc2, afr, Bs1, wc, r, h);
+      quad_store(Ks, acc2, g.ck + hd * 64, wr, wc, r, h);
+    }
+    __syncthreads();
+    stage_tile(Bs0, g.wv + (int64_t)hd * 64 * 64, 64);
+    stage_tile(Bs1, g.fc1_w + (int64_t)hd * 64, 512);  // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
+    __syncthreads();
+    {
+      f32x16 acc = {0};
+      acc = quad_gemm_regA(acc, afr, Bs0, wc, r, h);
+      quad_store(Vs, acc, g.cv + hd * 64, wr, wc, r, h);
+    }
+    __syncthreads();
+    // ---- attention: 8 lanes per hyperedge, 8 hyperedges per wave per pass ----
+    for (int e0 = 0; e0 < n_h; e0 += 32) {
+      const int e = e0 + wave * 8 + (lane >> 3);
+      if (e < n_h) {
+        const int li0 = g.row_off[b0 + e] - t0;
+        const int k = g.row_off[b0 + e + 1] - g.row_off[b0 + e];
+        if (k > 0) attn_group_fwd<ML>(Qs, Ks, Vs, li0, k, g.L - k, n_real, lane & 7, inv_temp);
+      }
+    }
+    __syncthreads();
+    // ---- dyn += O_h . Wfc1[:, head block]^T ----
+    dyn = quad_gemm_ldsA(dyn, Qs, Bs1, wr, wc, r, h);
+  }
+  __syncthreads();
+
+  // ---- Y = mask * dropout(dyn + b) ; saved + kept in LDS (Xh is free now: its fragments live in afr) ----
+  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
+  uint32_t key1 = 0, thr1 = 0, key2 = 0, thr2 = 0;
+  float ks1 = 1.f, ks2 = 1.f;
+  if (drop1) { key1 = rng_key(*g.seed, kStreamDropFc1); thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
+  if (drop2) { key2 = rng_key(*g.seed, kStreamDropPff); thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
+  float* Ys = Xh;
+  {
+    const int col = 32 * wc + r;
+    const float bv = g.fc1_b[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      float v = 0.f;
+      if (row < n_real) {                              // the padding token's row (and unused rows) are masked to 0
+        v = dyn[reg] + bv;
+        if (drop1) v = (rng_u32(key1, (uint32_t)g.tok_slot[t0 + row], (uint32_t)col) >= thr1) ? v * ks1 : 0.f;
+        if (g.Y) g.Y[(int64_t)(t0 + row) * 64 + col] = v;
+      } else if (row == n_real && g.Y) {
+        g.Y[(int64_t)tok_pad * 64 + col] = 0.f;        // every tile writes the same zeros: benign
+      }
+      Ys[row * kLdT + col] = v;
+    }
+  }
+  stage_tile(Bs0, g.p0w, 64);
+  stage_tile(Bs1, g.p1w, 64);
+  __syncthreads();
+  // ---- H1 = dropout(tanh(Y W0^T + b0)) -> Qs ; H2 = H1 W1^T + b1 + Y -> Ks ----
+  float* H1s = Qs;
+  float* H2s = Ks;
+  {
+    f32x16 acc = {0};
+    acc = quad_gemm_ldsA(acc, Ys, Bs0, wr, wc, r, h);
+    const int col = 32 * wc + r;
+    const float bv = g.p0b[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      float v = tanhf(acc[reg] + bv);
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      if (drop2 && row <= n_real) v = (rng_u32(key2, (uint32_t)g.tok_slot[tok], (uint32_t)col) >= thr2) ? v * ks2 : 0.f;
+      if (g.H1 && row <= n_real) g.H1[tok * 64 + col] = v;
+      H1s[row * kLdT + col] = v;
+    }
+  }
+  __syncthreads();
+  {
+    f32x16 acc = {0};
+    acc = quad_gemm_ldsA(acc, H1s, Bs1, wr, wc, r, h);
+    const int col = 32 * wc + r;
+    const float bv = g.p1b[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const float v = acc[reg] + bv + Ys[row * kLdT + col];
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      if (g.H2 && row <= n_real) g.H2[tok * 64 + col] = v;
+      H2s[row * kLdT + col] = v;
+    }
+  }
+  __syncthreads();
+  // ---- tail per token (16 lanes per row): out_t = sum_j (LN1(LN_pff(H2)) - LN2(X))_j^2 wc_j + bc ----
+  float* outs = Vs;                                     // [64] scratch
+  {
+    const float4 Gp = *reinterpret_cast<const float4*>(g.hp.gp + sc4), Bp = *reinterpret_cast<const float4*>(g.hp.bp + sc4);
+    const float4 G1 = *reinterpret_cast<const float4*>(g.hp.g1 + sc4), B1 = *reinterpret_cast<const float4*>(g.hp.b1 + sc4);
+    const float4 G2 = *reinterpret_cast<const float4*>(g.hp.g2 + sc4), B2 = *reinterpret_cast<const float4*>(g.hp.b2 + sc4);
+    const float4 Wc = *reinterpret_cast<const float4*>(g.hp.wc + sc4);
+    const float bc = g.hp.bc[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      const float4 hv = *reinterpret_cast<const float4*>(&H2s[row * kLdT + sc4]);
+      float m, rs;
+      ln_row16(hv, m, rs);
+      const float4 u = ln_apply(hv, m, rs, Gp, Bp);
+      ln_row16(u, m, rs);
+      const float4 dn = ln_apply(u, m, rs, G1, B1);
+      const float4 xv = *reinterpret_cast<const float4*>(&Xs[row * kLdT + sc4]);
+      ln_row16(xv, m, rs);
+      const float4 sn = ln_apply(xv, m, rs, G2, B2);
+      const float a = dn.x - sn.x, b = dn.y - sn.y, c = dn.z - sn.z, e = dn.w - sn.w;
+      const float o = group_sum<16>((a * a * Wc.x + b * b * Wc.y) + (c * c * Wc.z + e * e * Wc.w)) + bc;
+      if ((tid & 15) == 0) outs[row] = o;
+    }
+  }
+  __syncthreads();
+  // ---- per-hyperedge masked mean -> logit (+ BCE term) ----
+  for (int e = tid; e < n_h; e += 256) {
+    const int64_t b = b0 + e;
+    const int li0 = g.row_off[b] - t0, k = g.row_off[b + 1] - g.row_off[b];
+    float tot = 0.f;
+    for (int i = 0; i < k; ++i) tot += outs[li0 + i];
+    const float z = tot / ((float)k + 1e-15f);
+    g.logits[b] = z;
+    if (g.row_loss) g.row_loss[b] = g.w[b] * (fmaxf(z, 0.f) - z * g.y[b] + log1pf(expf(-fabsf(z))));
+  }
+}
+
+size_t fused_fold_floats() { return (size_t)3 * (MATCHA_N_HEAD * 64 * 64 + MATCHA_N_HEAD * 64); }
+
+int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
+  FoldArgs a;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
+  a.W[0] = p.w_q; a.W[1] = p.w_k; a.W[2] = p.w_v;
+  a.g[0] = p.ln_q_g; a.g[1] = p.ln_k_g; a.g[2] = p.ln_v_g;
+  a.b[0] = p.ln_q_b; a.b[1] = p.ln_k_b; a.b[2] = p.ln_v_b;
+  for (int z = 0; z < 3; ++z) { a.Wp[z] = ws + z * wsz; a.c[z] = ws + 3 * wsz + z * csz; }
+  hipLaunchKernelGGL(fold_ln_kernel, dim3(MATCHA_N_HEAD * 64, 3), dim3(64), 0, st, a);
+  MATCHA_CHECK_LAUNCH("fold_ln_kernel");
+  return MATCHA_OK;
+}
+
+int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
+                     float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
+                     hipStream_t st) {
+  FusedFwdArgs g;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
+  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.B = B; g.L = L;
+  g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
+  g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
+  g.fc1_w = p.fc1_w; g.fc1_b = p.fc1_b; g.p0w = p.pff0_w; g.p0b = p.pff0_b; g.p1w = p.pff1_w; g.p1b = p.pff1_b;
+  g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
+  g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;
+  g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
+  const int ntiles = (int)cdiv(B * L + 1, kTM - L);
+  const size_t lds = (size_t)7 * kTileF * sizeof(float);
+  auto launch = [&](auto kfn) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);
+  };
+  ProfScope ps(MATCHA_PROF_FUSED_FWD, 0.0, st);
+  switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+    case 2: launch(fused_fwd_kernel<2>); break;
+    case 3: launch(fused_fwd_kernel<3>); break;
+    case 4: launch(fused_fwd_kernel<4>); break;
+    case 5: launch(fused_fwd_kernel<5>); break;
+    case 6: launch(fused_fwd_kernel<6>); break;
+    default: launch(fused_fwd_kernel<8>); break;
+  }
+  MATCHA_CHECK_LAUNCH("fused_fwd_kernel");
+  return MATCHA_OK;
+}
+
+}  // namespace matcha

@@ -74,6 +74,14 @@ int launch_head_bwd(const int32_t* row_off, const float* H2, const float* X, int
                     const float* y, const float* w, const float* logits, const float* dlogits, float alpha, float* dH2,
                     float* dXs, float* slab, const HeadParams& ghp, hipStream_t st);
 size_t colsum_slab_bytes(int64_t n, int nv, int d);
+int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st);
+
+// fused_fwd.hip (embed_dim 64)
+size_t fused_fold_floats();
+int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st);
+int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
+                     float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
+                     hipStream_t st);
 
 // attention.hip
 int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float* O, float* P,

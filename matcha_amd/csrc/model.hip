@@ -5,6 +5,7 @@
 // Token layout: ragged (ragged.hip).  The token-level layers run on Tn = Tr + 1 rows -- the Tr real tokens of the
 // batch plus ONE shared padding token -- instead of B*L slots; Tr is only known on the device, so every launch is
 // sized for the upper bound B*L + 1 and reads the true count from `count` (m_dev / r_dev / t_dev).
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.hpp"
@@ -61,8 +62,14 @@ struct Workspace {
   float* slab;      size_t slab_bytes;    // column-sum slabs (LayerNorm / tail parameter gradients, attention pad-token grads)
   float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
   void* adj_ws;     size_t adj_ws_bytes;
+  float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
   size_t total;
 };
+
+static bool fused_enabled(const matcha_shape& s) {
+  static const bool off = getenv("MATCHA_DISABLE_FUSED") != nullptr;     // A/B switch for tests and profiling
+  return s.d == 64 && !off;
+}
 
 static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
   const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
@@ -110,6 +117,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.gemm_ws_bytes = gb; w.gemm_ws = take(gb / sizeof(float));
   w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, Tn) : 0;
   w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
+  w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
   w.total = off;
   return off;
 }
@@ -221,6 +229,17 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     GemmArgs g = gemm1(w, w.x0, p.next_w, w.X, Tn, d, d, false);
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
+  if (fused_enabled(s) && opts->forward_only) {
+    // inference: everything from X to the logits in one kernel, nothing saved
+    MATCHA_TRY(launch_fold_ln(p, w.folded, st));
+    MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, nullptr, nullptr, nullptr, w.logits, w.row_loss, opts->seed,
+                                train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st));
+    if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
+    if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      set_error("logits copy failed"); return MATCHA_EHIP;
+    }
+    return MATCHA_OK;
   }
   // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
   MATCHA_TRY(launch_ln3_fwd(w.X, Tn, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st, cnt));

@@ -593,6 +593,12 @@ int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const f
   return MATCHA_OK;
 }
 
+int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, row_loss, B, bce_out);
+  MATCHA_CHECK_LAUNCH("loss_reduce_kernel");
+  return MATCHA_OK;
+}
+
 int launch_head_fwd(const int32_t* row_off, const float* H2, const float* X, int64_t B, int L, int d, const HeadParams& hp,
                     const float* y, const float* w, float* logits, float* row_loss, float* bce_out, hipStream_t st) {
   if (B <= 0) return MATCHA_OK;

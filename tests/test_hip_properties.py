@@ -119,3 +119,27 @@ def test_full_size_train_step_is_reproducible():
             assert torch.allclose(a, b, rtol=0, atol=1e-6)
         else:
             assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_forward_matches_layerwise(mode, train):
+    """d = 64: the fused no-grad forward kernel against the layer-by-layer kernels (same weights, same dropout seed)."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, 64, mode, 17)
+    clf.train(train)
+    rng = np.random.default_rng(2)
+    for ks in ([2, 3, 4, 5], [5], [2], [3, 8]):
+        xs = [np.pad(synth.make_edges_fast(rng, N, k, 600), ((0, 0), (0, max(ks) - k))) for k in ks]
+        x = torch.from_numpy(np.concatenate(xs)[rng.permutation(600 * len(ks))]).cuda()
+        rt = clf._runtime()
+        np.random.seed(4)
+        c0 = rt.seed_counter
+        lg_layer, rc_layer = clf(x, return_recon=True)                 # grad enabled -> layer-wise kernels (saves activations)
+        rt.seed_counter = c0                                          # same dropout seed for the second run
+        np.random.seed(4)
+        with torch.no_grad():
+            lg_fused, rc_fused = clf(x, return_recon=True)             # no grad -> fused kernel
+        assert torch.allclose(lg_fused, lg_layer.detach(), rtol=1e-5, atol=2e-5), (mode, train, ks)
+        assert torch.allclose(rc_fused, rc_layer.detach(), rtol=1e-5, atol=1e-5)
