@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < kMaxL; ++j)
           if (j < k) {
-            float v = group_sum<8>(S[i][j]) * inv_temp;
+            float v = group_sum8_dpp(S[i][j]) * inv_temp;
             if (i == j) v = -1e32f;
             S[i][j] = v;
             mx = fmaxf(mx, v);
           }
-        if (n_pad > 0) { Sp[i] = group_sum<8>(Sp[i]) * inv_temp; mx = fmaxf(mx, Sp[i]); }
+        if (n_pad > 0) { Sp[i] = group_sum8_dpp(Sp[i]) * inv_temp; mx = fmaxf(mx, Sp[i]); }
         float den = 0.f;
 #pragma unroll
         for (int j = 0; j < kMaxL; ++j)
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         float sig = 0.f;
 #pragma unroll
         for (int j = 0; j < kMaxL; ++j)
-          if (j < k) { dP[i][j] = group_sum<8>(dP[i][j]); sig += Pm[i][j] * dP[i][j]; }
-        if (n_pad > 0) { dPp[i] = group_sum<8>(dPp[i]); sig += padf * Pp[i] * dPp[i]; }
+          if (j < k) { dP[i][j] = group_sum8_dpp(dP[i][j]); sig += Pm[i][j] * dP[i][j]; }
+        if (n_pad > 0) { dPp[i] = group_sum8_dpp(dPp[i]); sig += padf * Pp[i] * dPp[i]; }
 #pragma unroll
         for (int j = 0; j < kMaxL; ++j)
           if (j < k) dP[i][j] = Pm[i][j] * (dP[i][j] - sig) * inv_temp;

@@ -12,6 +12,8 @@
 // A 64x64x64 GEMM is split into four 32x32 quadrants, one per wave (32 f32 MFMAs each).
 // The three LayerNorm affines in front of Q/K/V are folded into the projection weights once per step
 // (W' = W * g, c = W . b), so one x_hat fragment set, held in registers for the whole tile, feeds all 24 projections.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace matcha {
@@ -41,6 +43,7 @@ struct FusedFwdArgs {
   const int32_t* row_off;         // [B+1]
   const int32_t* tok_slot;        // [Tn]
   const int32_t* count;           // {Tr+1, Tr}
+  const int32_t* tile_b0;         // [ntiles+1]
   int64_t B;
   int L;
   const float* wq; const float* wk; const float* wv;     // folded, [512, 64]
@@ -53,6 +56,7 @@ struct FusedFwdArgs {
   float* logits; float* row_loss;
   const uint64_t* seed;
   float p_fc1, p_pff;
+  int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 = skip attention, 2 = skip projection GEMMs
 };
 
 __device__ __forceinline__ int lower_bound_rows(const int32_t* __restrict__ row_off, int64_t B, int target) {
@@ -140,7 +144,7 @@ __device__ __forceinline__ void attn_group_fwd(float* __restrict__ Qs, const flo
           float a = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) a += q[i][e] * kk[j][e];
-          float v = group_sum<8>(a) * inv_temp;
+          float v = group_sum8_dpp(a) * inv_temp;
           if (i == j) v = -1e32f;
           S[i][j] = v;
           mx = fmaxf(mx, v);
@@ -150,7 +154,7 @@ __device__ __forceinline__ void attn_group_fwd(float* __restrict__ Qs, const flo
         float a = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) a += q[i][e] * kp[e];
-        Sp[i] = group_sum<8>(a) * inv_temp;
+        Sp[i] = group_sum8_dpp(a) * inv_temp;
         mx = fmaxf(mx, Sp[i]);
       }
       float den = 0.f;
@@ -205,16 +209,34 @@ __device__ __forceinline__ float4 ln_apply(const float4& v, float mean, float rs
   return make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y, (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w);
 }
 
+// 64 x 64 weight block: global -> registers (issued early), registers -> LDS tile (after the barrier that frees it).
+// Named float4 registers + macros on purpose: with a struct passed by reference hipcc kept the prefetch registers in
+// scratch memory and waited vmcnt(0) right after every load, i.e. no prefetch at all.
+#define TILE_GLOAD(R, SRC, LD)                                                                           \
+  do {                                                                                                   \
+    const float* src__ = (SRC);                                                                          \
+    R##0 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow) * (LD) + sc4);                       \
+    R##1 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 16) * (LD) + sc4);                  \
+    R##2 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 32) * (LD) + sc4);                  \
+    R##3 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 48) * (LD) + sc4);                  \
+  } while (0)
+#define TILE_LSTORE(DST, R)                                                                              \
+  do {                                                                                                   \
+    *reinterpret_cast<float4*>(&(DST)[(srow) * kLdT + sc4]) = R##0;                                      \
+    *reinterpret_cast<float4*>(&(DST)[(srow + 16) * kLdT + sc4]) = R##1;                                 \
+    *reinterpret_cast<float4*>(&(DST)[(srow + 32) * kLdT + sc4]) = R##2;                                 \
+    *reinterpret_cast<float4*>(&(DST)[(srow + 48) * kLdT + sc4]) = R##3;                                 \
+  } while (0)
+
+// LDS: one weight tile + Q/K/V tiles = 4 x 17 KiB -> two workgroups per CU; the next weight tile is always in flight
+// in registers while the current GEMM / attention phase runs.
 template <int ML>
-__global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
+__global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Xs = lds;                    // raw X rows (static branch)                 -> out_t scratch at the end
-  float* Xh = lds + 1 * kTileF;       // x_hat, then Y
-  float* Bs0 = lds + 2 * kTileF;      // weight tiles (double buffer)
-  float* Bs1 = lds + 3 * kTileF;
-  float* Qs = lds + 4 * kTileF;       // Q, then O (per head); later H1
-  float* Ks = lds + 5 * kTileF;       // K; later H2
-  float* Vs = lds + 6 * kTileF;
+  float* Bs = lds;                    // current weight tile
+  float* Qs = lds + 1 * kTileF;       // Q, then O (per head); later H1
+  float* Ks = lds + 2 * kTileF;       // K; later H2
+  float* Vs = lds + 3 * kTileF;       // V; later Y
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave & 1, wc = wave >> 1;          // quadrant of this wave
@@ -222,10 +244,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
 
   // ---- tile -> hyperedges [b0, b1), tokens [t0, t1) (+ the padding token as local row n_real) ----
   // window of first-token indices: a hyperedge starting at <= 63 - L ends at <= 63, so the tile holds <= 63 real tokens
-  const int win = kTM - g.L;
-  const int ws = blockIdx.x * win;
-  const int b0 = lower_bound_rows(g.row_off, g.B, ws);
-  const int b1 = lower_bound_rows(g.row_off, g.B, ws + win);
+  const int b0 = g.tile_b0[blockIdx.x], b1 = g.tile_b0[blockIdx.x + 1];      // planned by ragged.hip (no search here)
   if (b0 >= b1) return;                              // no hyperedge starts in this window
   const int t0 = g.row_off[b0];
   const int t1 = g.row_off[b1];
@@ -234,72 +253,107 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
   const int n_h = b1 - b0;
   const float inv_temp = 0.125f;                     // 1/sqrt(64)
 
-  // ---- stage X rows, LayerNorm statistics -> x_hat ----
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = srow + 16 * i;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row <= n_real) {
-      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
-      v = *reinterpret_cast<const float4*>(g.X + tok * 64 + sc4);
-    }
-    *reinterpret_cast<float4*>(&Xs[row * kLdT + sc4]) = v;
-    float mean, rstd;
-    ln_row16(v, mean, rstd);
-    *reinterpret_cast<float4*>(&Xh[row * kLdT + sc4]) = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-  }
-  __syncthreads();
+  // weight tiles are fetched TWO phases ahead into two alternating register sets (A: Wq / Wv, B: Wk / Wfc1)
+  float4 wA0, wA1, wA2, wA3, wB0, wB1, wB2, wB3;
+  TILE_GLOAD(wA, g.wq, 64);
+  TILE_GLOAD(wB, g.wk, 64);
+  // per-tile metadata in LDS: local row offsets of the tile's hyperedges and the folded projection biases of all heads
+  // (small dependent global loads inside the head loop each cost a full L2 round trip at one or two waves per SIMD)
+  int* roff = reinterpret_cast<int*>(lds + 4 * kTileF);          // [n_h + 1] (<= 64 hyperedges + 1)
+  float* cbias = lds + 4 * kTileF + 80;                           // [3][512]
+  for (int i = tid; i <= n_h; i += 256) roff[i] = g.row_off[b0 + i] - t0;
+  for (int i = tid; i < 3 * 512; i += 256) cbias[i] = (i < 512) ? g.cq[i] : (i < 1024 ? g.ck[i - 512] : g.cv[i - 1024]);
+
+  // ---- x_hat fragments straight from global memory: lane (r, h) holds k = 8c + 4h .. +3 of row 32 wr + r; the other
+  //      half of the row lives in lane r + 32, so the LayerNorm statistics need one cross-half shuffle ----
   float4 afr[8];
+  {
+    const int row = 32 * wr + r;
+    const bool valid = row <= n_real;
+    const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+    float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) afr[c] = *reinterpret_cast<const float4*>(&Xh[(32 * wr + r) * kLdT + 8 * c + 4 * h]);
+    for (int c = 0; c < 8; ++c) {
+      afr[c] = valid ? *reinterpret_cast<const float4*>(g.X + tok * 64 + 8 * c + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (afr[c].x + afr[c].y) + (afr[c].z + afr[c].w);
+    }
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float a = afr[c].x - mean, b = afr[c].y - mean, e = afr[c].z - mean, f = afr[c].w - mean;
+      q += (a * a + b * b) + (e * e + f * f);
+    }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.f / 64.f) + kEps);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      afr[c] = make_float4((afr[c].x - mean) * rstd, (afr[c].y - mean) * rstd, (afr[c].z - mean) * rstd, (afr[c].w - mean) * rstd);
+  }
 
   f32x16 dyn = {0};
   for (int hd = 0; hd < MATCHA_N_HEAD; ++hd) {
-    // ---- projections of this head: Q, K, V quadrants -> LDS ----
-    __syncthreads();                                   // previous head's fc1 GEMM is done with Qs / Bs1
-    stage_tile(Bs0, g.wq + (int64_t)hd * 64 * 64, 64);
-    stage_tile(Bs1, g.wk + (int64_t)hd * 64 * 64, 64);
+    const int64_t wofs = (int64_t)hd * 64 * 64;
+    const bool last = hd + 1 == MATCHA_N_HEAD;
+    // ---- Q ----
+    __syncthreads();                                   // everyone is done with Bs (previous fc1 GEMM) and with Qs
+    TILE_LSTORE(Bs, wA);
+    TILE_GLOAD(wA, g.wv + wofs, 64);
     __syncthreads();
     {
       f32x16 acc = {0};
-      acc = quad_gemm_regA(acc, afr, Bs0, wc, r, h);
-      quad_store(Qs, acc, g.cq + hd * 64, wr, wc, r, h);
-      f32x16 acc2 = {0};
-      acc2 = quad_gemm_regA(acc2, afr, Bs1, wc, r, h);
-      quad_store(Ks, acc2, g.ck + hd * 64, wr, wc, r, h);
+      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
+      quad_store(Qs, acc, cbias + hd * 64, wr, wc, r, h);
     }
+    // ---- K ----
     __syncthreads();
-    stage_tile(Bs0, g.wv + (int64_t)hd * 64 * 64, 64);
-    stage_tile(Bs1, g.fc1_w + (int64_t)hd * 64, 512);  // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
+    TILE_LSTORE(Bs, wB);
+    TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
     __syncthreads();
     {
       f32x16 acc = {0};
-      acc = quad_gemm_regA(acc, afr, Bs0, wc, r, h);
-      quad_store(Vs, acc, g.cv + hd * 64, wr, wc, r, h);
+      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
+      quad_store(Ks, acc, cbias + 512 + hd * 64, wr, wc, r, h);
     }
+    // ---- V ----
     __syncthreads();
+    TILE_LSTORE(Bs, wA);
+    TILE_GLOAD(wA, last ? g.p0w : g.wq + wofs + 64 * 64, 64);
+    __syncthreads();
+    {
+      f32x16 acc = {0};
+      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
+      quad_store(Vs, acc, cbias + 1024 + hd * 64, wr, wc, r, h);
+    }
+    __syncthreads();                                   // Q, K, V tiles complete; Bs free
+    TILE_LSTORE(Bs, wB);                               // fc1 block (read after the next barrier)
+    TILE_GLOAD(wB, last ? g.p1w : g.wk + wofs + 64 * 64, 64);
     // ---- attention: 8 lanes per hyperedge, 8 hyperedges per wave per pass ----
-    for (int e0 = 0; e0 < n_h; e0 += 32) {
+    for (int e0 = 0; e0 < n_h && !(g.dbg & 1); e0 += 32) {
       const int e = e0 + wave * 8 + (lane >> 3);
       if (e < n_h) {
-        const int li0 = g.row_off[b0 + e] - t0;
-        const int k = g.row_off[b0 + e + 1] - g.row_off[b0 + e];
+        const int li0 = roff[e];
+        const int k = roff[e + 1] - li0;
         if (k > 0) attn_group_fwd<ML>(Qs, Ks, Vs, li0, k, g.L - k, n_real, lane & 7, inv_temp);
       }
     }
     __syncthreads();
     // ---- dyn += O_h . Wfc1[:, head block]^T ----
-    dyn = quad_gemm_ldsA(dyn, Qs, Bs1, wr, wc, r, h);
+    if (!(g.dbg & 2)) dyn = quad_gemm_ldsA(dyn, Qs, Bs, wr, wc, r, h);
   }
-  __syncthreads();
+  __syncthreads();                                     // last fc1 GEMM done: Bs, Qs, Ks, Vs free
 
-  // ---- Y = mask * dropout(dyn + b) ; saved + kept in LDS (Xh is free now: its fragments live in afr) ----
+  // ---- Y = mask * dropout(dyn + b) -> Vs (+ global) ----
   const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
   uint32_t key1 = 0, thr1 = 0, key2 = 0, thr2 = 0;
   float ks1 = 1.f, ks2 = 1.f;
   if (drop1) { key1 = rng_key(*g.seed, kStreamDropFc1); thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
   if (drop2) { key2 = rng_key(*g.seed, kStreamDropPff); thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
-  float* Ys = Xh;
+  float* Ys = Vs;
+  float* H1s = Qs;
+  float* H2s = Ks;
+  TILE_LSTORE(Bs, wA);                                 // conv0 weight (fetched during the last head)
   {
     const int col = 32 * wc + r;
     const float bv = g.fc1_b[col];
@@ -317,15 +371,11 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
       Ys[row * kLdT + col] = v;
     }
   }
-  stage_tile(Bs0, g.p0w, 64);
-  stage_tile(Bs1, g.p1w, 64);
   __syncthreads();
-  // ---- H1 = dropout(tanh(Y W0^T + b0)) -> Qs ; H2 = H1 W1^T + b1 + Y -> Ks ----
-  float* H1s = Qs;
-  float* H2s = Ks;
+  // ---- H1 = dropout(tanh(Y W0^T + b0)) -> Qs ----
   {
     f32x16 acc = {0};
-    acc = quad_gemm_ldsA(acc, Ys, Bs0, wr, wc, r, h);
+    acc = quad_gemm_ldsA(acc, Ys, Bs, wr, wc, r, h);
     const int col = 32 * wc + r;
     const float bv = g.p0b[col];
 #pragma unroll
@@ -339,9 +389,12 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
+  TILE_LSTORE(Bs, wB);                                 // conv1 weight
+  __syncthreads();
+  // ---- H2 = H1 W1^T + b1 + Y -> Ks ----
   {
     f32x16 acc = {0};
-    acc = quad_gemm_ldsA(acc, H1s, Bs1, wr, wc, r, h);
+    acc = quad_gemm_ldsA(acc, H1s, Bs, wr, wc, r, h);
     const int col = 32 * wc + r;
     const float bv = g.p1b[col];
 #pragma unroll
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
   }
   __syncthreads();
   // ---- tail per token (16 lanes per row): out_t = sum_j (LN1(LN_pff(H2)) - LN2(X))_j^2 wc_j + bc ----
-  float* outs = Vs;                                     // [64] scratch
+  float* outs = Bs;                                     // [64] scratch (the weight tile is no longer needed)
   {
     const float4 Gp = *reinterpret_cast<const float4*>(g.hp.gp + sc4), Bp = *reinterpret_cast<const float4*>(g.hp.bp + sc4);
     const float4 G1 = *reinterpret_cast<const float4*>(g.hp.g1 + sc4), B1 = *reinterpret_cast<const float4*>(g.hp.b1 + sc4);
@@ -371,7 +424,8 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
       const float4 u = ln_apply(hv, m, rs, Gp, Bp);
       ln_row16(u, m, rs);
       const float4 dn = ln_apply(u, m, rs, G1, B1);
-      const float4 xv = *reinterpret_cast<const float4*>(&Xs[row * kLdT + sc4]);
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      const float4 xv = *reinterpret_cast<const float4*>(g.X + tok * 64 + sc4);     // static branch: LN2 of the raw X row
       ln_row16(xv, m, rs);
       const float4 sn = ln_apply(xv, m, rs, G2, B2);
       const float a = dn.x - sn.x, b = dn.y - sn.y, c = dn.z - sn.z, e = dn.w - sn.w;
@@ -383,7 +437,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedFwdArgs g) {
   // ---- per-hyperedge masked mean -> logit (+ BCE term) ----
   for (int e = tid; e < n_h; e += 256) {
     const int64_t b = b0 + e;
-    const int li0 = g.row_off[b] - t0, k = g.row_off[b + 1] - g.row_off[b];
+    const int li0 = roff[e], k = roff[e + 1] - roff[e];
     float tot = 0.f;
     for (int i = 0; i < k; ++i) tot += outs[li0 + i];
     const float z = tot / ((float)k + 1e-15f);
@@ -411,15 +465,16 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
                      hipStream_t st) {
   FusedFwdArgs g;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
-  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.B = B; g.L = L;
+  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.tile_b0 = rg.tile_b0; g.B = B; g.L = L;
   g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
   g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
   g.fc1_w = p.fc1_w; g.fc1_b = p.fc1_b; g.p0w = p.pff0_w; g.p0b = p.pff0_b; g.p1w = p.pff1_w; g.p1b = p.pff1_b;
   g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
-  const int ntiles = (int)cdiv(B * L + 1, kTM - L);
-  const size_t lds = (size_t)7 * kTileF * sizeof(float);
+  { static const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
+  const int ntiles = rg.ntiles;
+  const size_t lds = ((size_t)4 * kTileF + 80 + 3 * 512) * sizeof(float);
   auto launch = [&](auto kfn) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);

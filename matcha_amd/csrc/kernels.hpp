@@ -39,6 +39,8 @@ struct Ragged {
   int32_t* count;      // {Tr + 1, Tr}
   int32_t* blk_sum;
   int nblk;
+  int32_t* tile_b0;    // [ntiles+1] first hyperedge of each fused-kernel tile (window 64 - L first-token indices)
+  int ntiles;
 };
 size_t ragged_bytes(int64_t B, int L);
 void ragged_carve(int64_t B, int L, char* base, Ragged& r);

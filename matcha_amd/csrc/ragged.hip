@@ -95,6 +95,23 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
   }
 }
 
+// Tiles of the fused kernels: tile w owns the hyperedges whose first token index lies in [w*win, (w+1)*win), win = 64 - L
+// (<= 63 real tokens per tile).  tile_b0[w] = first hyperedge of tile w, tile_b0[ntiles] = B.  Consecutive hyperedges
+// start at most L < win tokens apart, so the window index grows by at most one per hyperedge.
+__global__ __launch_bounds__(256) void tile_plan_kernel(const int32_t* __restrict__ row_off, int64_t B, int win, int ntiles,
+                                                        int32_t* __restrict__ tile_b0) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b < B) {
+    const int w = row_off[b] / win;
+    const int wprev = b > 0 ? row_off[b - 1] / win : -1;
+    if (w != wprev && w <= ntiles) tile_b0[w] = (int32_t)b;
+  }
+  if (b == B - 1 || (B == 0 && b == 0)) {
+    const int wlast = B > 0 ? row_off[B - 1] / win : -1;
+    for (int w = wlast + 1; w <= ntiles; ++w) tile_b0[w] = (int32_t)B;
+  }
+}
+
 size_t ragged_bytes(int64_t B, int L) {
   const int64_t T = B * L;
   size_t n = 0;
@@ -103,6 +120,7 @@ size_t ragged_bytes(int64_t B, int L) {
   n += align_up((size_t)(T + 1) * 8, 256);        // tok_id
   n += 256;                                        // count
   n += align_up((size_t)cdiv(B, kRowsPerBlock) * 4, 256);
+  n += align_up((size_t)(cdiv(T + 1, 64 - L) + 2) * 4, 256);   // tile_b0
   return n;
 }
 
@@ -116,6 +134,8 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.count = (int32_t*)take(256);
   r.blk_sum = (int32_t*)take((size_t)cdiv(B, kRowsPerBlock) * 4);
   r.nblk = (int)cdiv(B, kRowsPerBlock);
+  r.ntiles = (int)cdiv(T + 1, 64 - L);
+  r.tile_b0 = (int32_t*)take((size_t)(r.ntiles + 2) * 4);
 }
 
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st) {
@@ -125,6 +145,8 @@ int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipS
   MATCHA_CHECK_LAUNCH("row_scan_kernel");
   hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
+  hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, r.row_off, B, 64 - L, r.ntiles, r.tile_b0);
+  MATCHA_CHECK_LAUNCH("tile_plan_kernel");
   return MATCHA_OK;
 }
 
