@@ -1,0 +1,694 @@
+// Fused backward of the multi-head attention block for embed_dim 64 (training path of the metric's configuration).
+//
+// Given X (the encoder input, [Tn, 64]) and dDyn = dL/d(fc1 output before bias) ([Tn, 64], produced by the pff / tail
+// backward kernels), one kernel recomputes Q, K, V and the attention probabilities of ONE head, and produces for that head
+//   dWfc1[:, head block], dW'q, dW'k, dW'v (LayerNorm-folded projections, fused_fwd.hip), their bias gradients,
+//   the padding token's dK / dV, and the head's contribution to d x_hat,
+// without ever materialising Q/K/V/O/P or their gradients in HBM (Modules.py:519-572 backward).
+//
+// Work decomposition ("head-major"): workgroup (head, chunk) walks the 64-token tiles of its chunk of hyperedges.  The
+// head's four 64x64 weight blocks stay resident (three in LDS, the fc1 block in registers) and its four 64x64 weight
+// gradients accumulate in MFMA accumulators for the whole walk; they are written once per workgroup into a slab and
+// reduced in a fixed order by fb_unfold_kernel, which also un-folds the LayerNorm affines:
+//   W' = W * g, c = W . b   =>   dW = dW' * g + dc (x) b,   dg = sum_n dW' * W,   db = W^T dc.
+// Per token the kernel reads X and dDyn once per head (L2 hits: the 8 heads of a chunk run on the same XCD) and writes
+// one 256 B partial of d x_hat per head; lnhat_bwd_kernel sums the 8 partials and applies the LayerNorm backward.
+//
+// LDS: 9 tiles of 64 x 68 floats (W'q W'k W'v | x_hat dDyn | Q K V | F) = 153 KiB -> one workgroup per CU, 256 CUs =
+// 8 heads x 32 chunks.  F holds the fc1 block, then dO, then O.  Q/K/V are overwritten in place by dQ/dK/dV.
+#include <stdlib.h>
+
+#include "kernels.hpp"
+
+namespace matcha {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kLd = 68;              // LDS row stride (floats)
+constexpr int kTile = 64 * kLd;
+constexpr float kEpsLn = 1e-5f;
+constexpr int kWgSlab = 4 * 4096 + 6 * 64;   // dW'q dW'k dW'v dWfc1 | dcq dck dcv dKpad dVpad dfc1_b
+constexpr int kVecOff = 4 * 4096;
+constexpr int kMaxChunks = 64;
+
+struct FusedBwdArgs {
+  const float* X;                 // [Tn, 64]
+  const float* dDyn;              // [Tn, 64]
+  const int32_t* row_off;         // [B+1]
+  const int32_t* count;           // {Tr+1, Tr}
+  const int32_t* tile_b0;         // [ntiles+1]
+  int L;
+  int ntiles;                     // upper bound
+  int nchunks;
+  const float* wq; const float* wk; const float* wv;     // folded [512, 64]
+  const float* cq; const float* ck; const float* cv;     // [512]
+  const float* fc1_w;                                    // [64, 512]
+  float* dxh;                     // [8][tcap][64]
+  int64_t tcap;
+  float* wslab;                   // [8][nchunks][kWgSlab]
+};
+
+#define FB_GLOAD(R, SRC, LD)                                                                             \
+  do {                                                                                                   \
+    const float* src__ = (SRC);                                                                          \
+    R##0 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow) * (LD) + sc4);                       \
+    R##1 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 16) * (LD) + sc4);                  \
+    R##2 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 32) * (LD) + sc4);                  \
+    R##3 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 48) * (LD) + sc4);                  \
+  } while (0)
+#define FB_LSTORE(DST, R)                                                                                \
+  do {                                                                                                   \
+    *reinterpret_cast<float4*>(&(DST)[(srow) * kLd + sc4]) = R##0;                                       \
+    *reinterpret_cast<float4*>(&(DST)[(srow + 16) * kLd + sc4]) = R##1;                                  \
+    *reinterpret_cast<float4*>(&(DST)[(srow + 32) * kLd + sc4]) = R##2;                                  \
+    *reinterpret_cast<float4*>(&(DST)[(srow + 48) * kLd + sc4]) = R##3;                                  \
+  } while (0)
+
+#define LD8(dst, p)                                                                                      \
+  do {                                                                                                   \
+    const float4 a__ = *reinterpret_cast<const float4*>(p), b__ = *reinterpret_cast<const float4*>((p) + 4); \
+    dst[0] = a__.x; dst[1] = a__.y; dst[2] = a__.z; dst[3] = a__.w;                                      \
+    dst[4] = b__.x; dst[5] = b__.y; dst[6] = b__.z; dst[7] = b__.w;                                      \
+  } while (0)
+#define ST8(p, src)                                                                                      \
+  do {                                                                                                   \
+    *reinterpret_cast<float4*>(p) = make_float4(src[0], src[1], src[2], src[3]);                         \
+    *reinterpret_cast<float4*>((p) + 4) = make_float4(src[4], src[5], src[6], src[7]);                   \
+  } while (0)
+
+// out[t][n] += A[t][k] . B[n][k]   (A rows and B rows in LDS)
+__device__ __forceinline__ f32x16 gemm_nt(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int r, int h) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLd + 8 * c + 4 * h]);
+    const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLd + 8 * c + 4 * h]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// out[t][k] += A[t][n] . W[n][k]   (A rows in LDS, W stored [n][k] in LDS: its fragment is a column walk)
+__device__ __forceinline__ f32x16 gemm_nn(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Ws, int wr, int wc, int r, int h) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLd + 8 * c + 4 * h]);
+    const float* wp = &Ws[(8 * c + 4 * h) * kLd + 32 * wc + r];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wp[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wp[kLd], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wp[2 * kLd], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * kLd], acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ void quad_store(float* __restrict__ Ts, const f32x16& acc, const float* __restrict__ bias, int wr, int wc, int r, int h) {
+  const int col = 32 * wc + r;
+  const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    Ts[row * kLd + col] = acc[reg] + bv;
+  }
+}
+
+__device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rstd) {
+  const float s = group_sum<16>((v.x + v.y) + (v.z + v.w));
+  mean = s * (1.f / 64.f);
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+  const float q = group_sum<16>((a * a + b * b) + (c * c + e * e));
+  rstd = 1.0f / sqrtf(q * (1.f / 64.f) + kEpsLn);
+}
+
+// Attention forward + backward of one hyperedge for one head on LDS tiles; 8 lanes, lane `sub` owns features
+// [8 sub, 8 sub + 8).  Formulas: attention.hip (attn_bwd_kernel).  In: Q, K, V rows, dO rows (Fs).  Out: O -> Fs rows,
+// dQ/dK/dV over the Q/K/V rows.  acc: this lane's running sums {dQ, dK, dV column sums, dK_pad, dV_pad} x 8 features.
+template <int ML>
+__device__ __forceinline__ void attn_group_fb(float* __restrict__ Qs, float* __restrict__ Ks, float* __restrict__ Vs, float* __restrict__ Fs,
+                                              const float* __restrict__ kpad, const float* __restrict__ vpad, int li0, int k, int n_pad,
+                                              int sub, float inv_temp, float (&acc)[40]) {
+  const float padf = (float)n_pad;
+  const bool hp = n_pad > 0;
+  float P[ML][ML], Pp[ML];
+  {
+    float q[ML][8], kk[ML][8], kp[8];
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        LD8(q[i], &Qs[(li0 + i) * kLd + 8 * sub]);
+        LD8(kk[i], &Ks[(li0 + i) * kLd + 8 * sub]);
+      }
+    LD8(kp, kpad + 8 * sub);
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += q[i][e] * kk[j][e];
+            float v = group_sum8_dpp(a) * inv_temp;
+            if (i == j) v = -1e32f;
+            P[i][j] = v;
+            mx = fmaxf(mx, v);
+          }
+        Pp[i] = 0.f;
+        if (hp) {
+          float a = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a += q[i][e] * kp[e];
+          Pp[i] = group_sum8_dpp(a) * inv_temp;
+          mx = fmaxf(mx, Pp[i]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) { P[i][j] = expf(P[i][j] - mx); den += P[i][j]; }
+        if (hp) { Pp[i] = expf(Pp[i] - mx); den += padf * Pp[i]; }
+        const float inv = 1.f / den;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) P[i][j] *= inv;
+        Pp[i] = hp ? Pp[i] * inv : 0.f;
+      }
+  }
+  float dS[ML][ML], dSp[ML];
+  {
+    float v[ML][8], go[ML][8], vp[8];
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        LD8(v[i], &Vs[(li0 + i) * kLd + 8 * sub]);
+        LD8(go[i], &Fs[(li0 + i) * kLd + 8 * sub]);
+      }
+    LD8(vp, vpad + 8 * sub);
+    // O_i (needed by the fc1 weight gradient) replaces dO_i in Fs
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = hp ? padf * Pp[i] * vp[e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += P[i][j] * v[j][e];
+          }
+        ST8(&Fs[(li0 + i) * kLd + 8 * sub], o);
+      }
+    // dP -> dS
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        float sig = 0.f;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += go[i][e] * v[j][e];
+            a = group_sum8_dpp(a);
+            dS[i][j] = a;
+            sig += P[i][j] * a;
+          }
+        dSp[i] = 0.f;
+        if (hp) {
+          float a = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a += go[i][e] * vp[e];
+          a = group_sum8_dpp(a);
+          dSp[i] = a;
+          sig += padf * Pp[i] * a;
+        }
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) dS[i][j] = P[i][j] * (dS[i][j] - sig) * inv_temp;
+        dSp[i] = hp ? Pp[i] * (dSp[i] - sig) * inv_temp : 0.f;
+      }
+    // dV_j = sum_i P_ij dO_i ;  dV_pad += n_pad sum_i Pp_i dO_i
+#pragma unroll
+    for (int j = 0; j < ML; ++j)
+      if (j < k) {
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < ML; ++i)
+          if (i < k) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] += P[i][j] * go[i][e];
+          }
+        ST8(&Vs[(li0 + j) * kLd + 8 * sub], gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[16 + e] += gv[e];
+        if (hp) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[32 + e] += padf * Pp[j] * go[j][e];
+        }
+      }
+  }
+  {
+    float q[ML][8], kk[ML][8], kp[8];
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        LD8(q[i], &Qs[(li0 + i) * kLd + 8 * sub]);
+        LD8(kk[i], &Ks[(li0 + i) * kLd + 8 * sub]);
+      }
+    LD8(kp, kpad + 8 * sub);
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+      if (i < k) {
+        float gq[8], gk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gq[e] = hp ? padf * dSp[i] * kp[e] : 0.f; gk[e] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j < k) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              gq[e] += dS[i][j] * kk[j][e];      // dQ_i += dS_ij K_j
+              gk[e] += dS[j][i] * q[j][e];       // dK_i += dS_ji Q_j
+            }
+          }
+        ST8(&Qs[(li0 + i) * kLd + 8 * sub], gq);
+        ST8(&Ks[(li0 + i) * kLd + 8 * sub], gk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += gq[e]; acc[8 + e] += gk[e]; }
+        if (hp) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[24 + e] += padf * dSp[i] * q[i][e];
+        }
+      }
+  }
+}
+
+template <int ML>
+__global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wq = lds;
+  float* Wk = lds + 1 * kTile;
+  float* Wv = lds + 2 * kTile;
+  float* Xs = lds + 3 * kTile;        // x_hat (rows >= n_real are zero)
+  float* Ds = lds + 4 * kTile;        // dDyn  (rows >= n_real are zero)
+  float* Qs = lds + 5 * kTile;        // Q -> dQ
+  float* Ks = lds + 6 * kTile;        // K -> dK
+  float* Vs = lds + 7 * kTile;        // V -> dV
+  float* Fs = lds + 8 * kTile;        // Wfc1 block -> dO -> O
+  float* sm = lds + 9 * kTile;
+  int* roff = reinterpret_cast<int*>(sm);   // [<= 65]
+  float* cb = sm + 72;                // [3][64] folded projection biases of this head
+  float* kpad = cb + 192;             // K / V rows of the shared padding token for this head
+  float* vpad = kpad + 64;
+  float* xpad = vpad + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+  const int sub = lane & 7;
+
+  // (head, chunk): the 8 heads of one chunk share an XCD (workgroups are dealt round-robin over the 8 XCDs), so X and
+  // dDyn are fetched from HBM once and served to the other seven heads from that XCD's L2.
+  int head, chunk;
+  if ((g.nchunks & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    head = j & 7;
+    chunk = (j >> 3) * 8 + xcd;
+  } else {
+    head = blockIdx.x & 7;
+    chunk = blockIdx.x >> 3;
+  }
+  const int win = 64 - g.L;
+  const int tr = g.count[1];
+  int ntr = (tr + win - 1) / win;
+  if (ntr > g.ntiles) ntr = g.ntiles;
+  const int per = (ntr + g.nchunks - 1) / g.nchunks;
+  const int tile_lo = chunk * per;
+  const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
+  const float inv_temp = 0.125f;
+
+  // ---- resident weights ----
+  const int64_t wofs = (int64_t)head * 64 * 64;
+  float4 fw0, fw1, fw2, fw3;
+  {
+    float4 t0, t1, t2, t3;
+    FB_GLOAD(t, g.wq + wofs, 64); FB_LSTORE(Wq, t);
+    FB_GLOAD(t, g.wk + wofs, 64); FB_LSTORE(Wk, t);
+    FB_GLOAD(t, g.wv + wofs, 64); FB_LSTORE(Wv, t);
+  }
+  FB_GLOAD(fw, g.fc1_w + (int64_t)head * 64, 512);        // fc1_w[n][head*64 + k] as an [n][k] tile
+  if (tid < 192) cb[tid] = (tid < 64 ? g.cq : (tid < 128 ? g.ck : g.cv))[head * 64 + (tid & 63)];
+  if (tid < 16) {
+    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
+    float m, rs;
+    ln_row16(xv, m, rs);
+    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int n = tid & 63;
+    const float* W = tid < 64 ? Wk : Wv;
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += xpad[k] * W[n * kLd + k];
+    (tid < 64 ? kpad : vpad)[n] = s + cb[64 + (tid >> 6) * 64 + n];
+  }
+
+  f32x16 aWq = {0}, aWk = {0}, aWv = {0}, aWf = {0};
+  float accp[40];
+#pragma unroll
+  for (int i = 0; i < 40; ++i) accp[i] = 0.f;
+  float4 fbs = make_float4(0.f, 0.f, 0.f, 0.f);      // fc1 bias gradient partial (head 0 only)
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b0 = g.tile_b0[tile], b1 = g.tile_b0[tile + 1];
+    if (b0 >= b1) continue;
+    const int t0 = g.row_off[b0];
+    const int n_real = g.row_off[b1] - t0;
+    if (n_real <= 0) continue;
+    const int n_h = b1 - b0;
+    const bool lroff = n_h <= 64;
+    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
+    // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the local row offsets ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      const int rc = row < n_real ? row : n_real - 1;
+      const float msk = row < n_real ? 1.f : 0.f;
+      const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)(t0 + rc) * 64 + sc4);
+      const float4 dv = *reinterpret_cast<const float4*>(g.dDyn + (int64_t)(t0 + rc) * 64 + sc4);
+      float m, rs;
+      ln_row16(xv, m, rs);
+      rs *= msk;
+      *reinterpret_cast<float4*>(&Xs[row * kLd + sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+      const float4 dm = make_float4(dv.x * msk, dv.y * msk, dv.z * msk, dv.w * msk);
+      *reinterpret_cast<float4*>(&Ds[row * kLd + sc4]) = dm;
+      fbs.x += dm.x; fbs.y += dm.y; fbs.z += dm.z; fbs.w += dm.w;
+    }
+    FB_LSTORE(Fs, fw);
+    if (lroff)
+      for (int i = tid; i <= n_h; i += 256) roff[i] = g.row_off[b0 + i] - t0;
+    __syncthreads();
+    // ---- recompute Q, K, V; dO = dDyn . Wfc1[:, head block] ----
+    {
+      f32x16 acc = {0};
+      acc = gemm_nt(acc, Xs, Wq, wr, wc, r, h);
+      quad_store(Qs, acc, cb, wr, wc, r, h);
+    }
+    {
+      f32x16 acc = {0};
+      acc = gemm_nt(acc, Xs, Wk, wr, wc, r, h);
+      quad_store(Ks, acc, cb + 64, wr, wc, r, h);
+    }
+    {
+      f32x16 acc = {0};
+      acc = gemm_nt(acc, Xs, Wv, wr, wc, r, h);
+      quad_store(Vs, acc, cb + 128, wr, wc, r, h);
+    }
+    {
+      f32x16 acc = {0};
+      acc = gemm_nn(acc, Ds, Fs, wr, wc, r, h);
+      __syncthreads();                                // every wave has read the fc1 block
+      quad_store(Fs, acc, nullptr, wr, wc, r, h);
+    }
+    __syncthreads();
+    // ---- attention forward + backward, 8 lanes per hyperedge ----
+    for (int e0 = 0; e0 < n_h; e0 += 32) {
+      const int e = e0 + wave * 8 + (lane >> 3);
+      if (e < n_h) {
+        const int li0 = lroff ? roff[e] : g.row_off[b0 + e] - t0;
+        const int k = (lroff ? roff[e + 1] : g.row_off[b0 + e + 1] - t0) - li0;
+        if (k > 0) attn_group_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, li0, k, g.L - k, sub, inv_temp, accp);
+      }
+    }
+    __syncthreads();
+    // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
+#pragma unroll 4
+    for (int m = 0; m < 32; ++m) {
+      const int t = 2 * m + h;
+      const float xk = Xs[t * kLd + 32 * wc + r];
+      const float ok = Fs[t * kLd + 32 * wc + r];
+      const float gq = Qs[t * kLd + 32 * wr + r];
+      const float gk = Ks[t * kLd + 32 * wr + r];
+      const float gv = Vs[t * kLd + 32 * wr + r];
+      const float gd = Ds[t * kLd + 32 * wr + r];
+      aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(gq, xk, aWq, 0, 0, 0);
+      aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(gk, xk, aWk, 0, 0, 0);
+      aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xk, aWv, 0, 0, 0);
+      aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(gd, ok, aWf, 0, 0, 0);
+    }
+    // ---- this head's share of d x_hat = dQ W'q + dK W'k + dV W'v ----
+    {
+      f32x16 dx = {0};
+      dx = gemm_nn(dx, Qs, Wq, wr, wc, r, h);
+      dx = gemm_nn(dx, Ks, Wk, wr, wc, r, h);
+      dx = gemm_nn(dx, Vs, Wv, wr, wc, r, h);
+      float* out = g.dxh + ((int64_t)head * g.tcap + t0) * 64 + 32 * wc + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (row < n_real) out[(int64_t)row * 64] = dx[reg];
+      }
+    }
+  }
+
+  // ---- workgroup slab ----
+  __syncthreads();
+  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
+  {
+    const int col = 32 * wc + r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      slab[0 * 4096 + row * 64 + col] = aWq[reg];
+      slab[1 * 4096 + row * 64 + col] = aWk[reg];
+      slab[2 * 4096 + row * 64 + col] = aWv[reg];
+      slab[3 * 4096 + row * 64 + col] = aWf[reg];
+    }
+  }
+  // per-lane attention sums: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
+  float* red = Xs;                      // [4][5][64]
+#pragma unroll
+  for (int i = 0; i < 40; ++i) {
+    float v = accp[i];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 8) red[(wave * 5 + (i >> 3)) * 64 + 8 * lane + (i & 7)] = v;
+  }
+  float* red2 = Ds;                     // [16][64] fc1 bias partials of the staging rows
+  *reinterpret_cast<float4*>(&red2[srow * 64 + sc4]) = fbs;
+  __syncthreads();
+  for (int i = tid; i < 320; i += 256) {
+    const int vec = i >> 6, f = i & 63;
+    slab[kVecOff + i] = ((red[(0 * 5 + vec) * 64 + f] + red[(1 * 5 + vec) * 64 + f]) + red[(2 * 5 + vec) * 64 + f]) + red[(3 * 5 + vec) * 64 + f];
+  }
+  if (tid < 64) {
+    float s = 0.f;
+    if (head == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red2[q * 64 + tid];
+    }
+    slab[kVecOff + 320 + tid] = s;
+  }
+}
+
+// ---- slab reduction + un-folding of the LayerNorm affines -------------------------------------------------------
+struct UnfoldArgs {
+  const float* wslab; int nchunks;
+  const float* X; const int32_t* count;
+  const float* W[3]; const float* g[3]; const float* b[3];     // original projection weights [512, 64] and LN affines
+  float* gW[3]; float* gfc1;                                    // accumulated into
+  float* part;                                                  // [32][3][3][64]: {dg, db, dx_hat_pad} partials
+};
+// grid (4 row slices, 4 matrices {q, k, v, fc1}, 8 heads), 256 threads = 16 rows x 16 lanes (float4)
+__global__ __launch_bounds__(256) void fb_unfold_kernel(UnfoldArgs a) {
+  __shared__ float red[16][3][64];
+  const int slice = blockIdx.x, mat = blockIdx.y, head = blockIdx.z;
+  const int tid = threadIdx.x, rl = tid >> 4, c4 = (tid & 15) * 4;
+  const int row = slice * 16 + rl;
+  const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlab;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < a.nchunks; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * kWgSlab + mat * 4096 + row * 64 + c4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (mat == 3) {       // dfc1[n][head*64 + k]
+    float4* o = reinterpret_cast<float4*>(a.gfc1 + (int64_t)row * 512 + head * 64 + c4);
+    float4 v = *o;
+    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+    *o = v;
+    return;
+  }
+  float dc = 0.f, dpad = 0.f;
+  for (int c = 0; c < a.nchunks; ++c) {
+    const float* vb = base + (int64_t)c * kWgSlab + kVecOff;
+    dc += vb[mat * 64 + row];
+    if (mat > 0) dpad += vb[192 + (mat - 1) * 64 + row];
+  }
+  // the padding token's K / V rows are x_hat_pad . W'^T + c: its dK / dV enter dW' and dc like one more token
+  const float4 xv = *reinterpret_cast<const float4*>(a.X + (int64_t)a.count[1] * 64 + c4);
+  float m, rs;
+  ln_row16(xv, m, rs);
+  s.x += dpad * (xv.x - m) * rs; s.y += dpad * (xv.y - m) * rs; s.z += dpad * (xv.z - m) * rs; s.w += dpad * (xv.w - m) * rs;
+  dc += dpad;
+  const int64_t wi = ((int64_t)head * 64 + row) * 64 + c4;
+  const float4 W = *reinterpret_cast<const float4*>(a.W[mat] + wi);
+  const float4 G = *reinterpret_cast<const float4*>(a.g[mat] + c4), Bv = *reinterpret_cast<const float4*>(a.b[mat] + c4);
+  {
+    float4* o = reinterpret_cast<float4*>(a.gW[mat] + wi);
+    float4 v = *o;
+    v.x += s.x * G.x + dc * Bv.x; v.y += s.y * G.y + dc * Bv.y; v.z += s.z * G.z + dc * Bv.z; v.w += s.w * G.w + dc * Bv.w;
+    *o = v;
+  }
+  *reinterpret_cast<float4*>(&red[rl][0][c4]) = make_float4(s.x * W.x, s.y * W.y, s.z * W.z, s.w * W.w);                              // dg
+  *reinterpret_cast<float4*>(&red[rl][1][c4]) = make_float4(dc * W.x, dc * W.y, dc * W.z, dc * W.w);                                  // db
+  *reinterpret_cast<float4*>(&red[rl][2][c4]) = make_float4(dpad * W.x * G.x, dpad * W.y * G.y, dpad * W.z * G.z, dpad * W.w * G.w);  // dx_hat_pad
+  __syncthreads();
+  if (tid < 192) {
+    const int which = tid >> 6, k = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][which][k];
+    a.part[(((int64_t)(head * 4 + slice) * 3 + mat) * 3 + which) * 64 + k] = t;
+  }
+}
+
+struct Unfold2Args {
+  const float* part; const float* wslab; int nchunks;
+  float* dg[3]; float* db[3]; float* dfc1_b; float* dxpad;
+};
+// one block, 512 threads: vec 0..5 = {dg, db} x {q, k, v}; vec 6 = dx_hat of the padding token; vec 7 = fc1 bias gradient
+__global__ __launch_bounds__(512) void fb_unfold2_kernel(Unfold2Args a) {
+  const int vec = threadIdx.x >> 6, k = threadIdx.x & 63;
+  float s = 0.f;
+  if (vec < 6) {
+    const int mat = vec >> 1, which = vec & 1;
+    for (int p = 0; p < 32; ++p) s += a.part[(((int64_t)p * 3 + mat) * 3 + which) * 64 + k];
+    float* o = (which == 0 ? a.dg[mat] : a.db[mat]) + k;
+    *o += s;
+  } else if (vec == 6) {
+    for (int p = 0; p < 32; ++p) s += a.part[(((int64_t)p * 3 + 1) * 3 + 2) * 64 + k] + a.part[(((int64_t)p * 3 + 2) * 3 + 2) * 64 + k];
+    a.dxpad[k] = s;
+  } else {
+    for (int c = 0; c < a.nchunks; ++c) s += a.wslab[(int64_t)c * kWgSlab + kVecOff + 320 + k];     // head 0's slabs
+    a.dfc1_b[k] += s;
+  }
+}
+
+// dZ0 = ( LNbwd_noaffine( sum_h dxh[h] ) + dXs ) * (1 - X^2)     (Modules.py:519-521 backward, :270 tanh')
+__global__ __launch_bounds__(256) void lnhat_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dxh, int64_t tcap,
+                                                        const float* __restrict__ dxpad, const float* __restrict__ dXs,
+                                                        float* __restrict__ dZ0, const int32_t* __restrict__ count) {
+  const int T = count[0];
+  const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int c4 = (threadIdx.x & 15) * 4;
+  if (t >= T) return;
+  const float4 xv = *reinterpret_cast<const float4*>(X + t * 64 + c4);
+  float m, rs;
+  ln_row16(xv, m, rs);
+  const float4 xh = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+  float4 d;
+  if (t < T - 1) {
+    d = *reinterpret_cast<const float4*>(dxh + t * 64 + c4);
+#pragma unroll
+    for (int hd = 1; hd < MATCHA_N_HEAD; ++hd) {
+      const float4 v = *reinterpret_cast<const float4*>(dxh + ((int64_t)hd * tcap + t) * 64 + c4);
+      d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+    }
+  } else {
+    d = *reinterpret_cast<const float4*>(dxpad + c4);
+  }
+  const float a = group_sum<16>((d.x + d.y) + (d.z + d.w)) * (1.f / 64.f);
+  const float b = group_sum<16>((d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w)) * (1.f / 64.f);
+  const float4 s = *reinterpret_cast<const float4*>(dXs + t * 64 + c4);
+  float4 o;
+  o.x = (rs * (d.x - a - xh.x * b) + s.x) * (1.f - xv.x * xv.x);
+  o.y = (rs * (d.y - a - xh.y * b) + s.y) * (1.f - xv.y * xv.y);
+  o.z = (rs * (d.z - a - xh.z * b) + s.z) * (1.f - xv.z * xv.z);
+  o.w = (rs * (d.w - a - xh.w * b) + s.w) * (1.f - xv.w * xv.w);
+  *reinterpret_cast<float4*>(dZ0 + t * 64 + c4) = o;
+}
+
+int chunks_for(int ntiles) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    cus = n;
+  }
+  int c = cus / MATCHA_N_HEAD;
+  if (c > kMaxChunks) c = kMaxChunks;
+  if (c > ntiles) c = ntiles;
+  return c < 1 ? 1 : c;
+}
+
+}  // namespace
+
+size_t fused_bwd_ws_floats(int64_t B, int L) {
+  (void)B; (void)L;
+  return (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab + (size_t)32 * 3 * 3 * 64 + 64;
+}
+
+int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
+                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st) {
+  const int64_t tcap = B * L + 1;
+  const int nchunks = chunks_for(rg.ntiles);
+  float* wslab = ws;
+  float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
+  float* dxpad = part + 32 * 3 * 3 * 64;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
+  {
+    FusedBwdArgs g;
+    g.X = X; g.dDyn = dDyn; g.row_off = rg.row_off; g.count = rg.count; g.tile_b0 = rg.tile_b0; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
+    g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
+    g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
+    g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab;
+    const size_t lds = ((size_t)9 * kTile + 72 + 192 + 3 * 64) * sizeof(float);
+    auto launch = [&](auto kfn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
+    };
+    ProfScope ps(MATCHA_PROF_FUSED_BWD, 0.0, st);
+    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+      case 2: launch(fused_bwd_kernel<2>); break;
+      case 3: launch(fused_bwd_kernel<3>); break;
+      case 4: launch(fused_bwd_kernel<4>); break;
+      case 5: launch(fused_bwd_kernel<5>); break;
+      case 6: launch(fused_bwd_kernel<6>); break;
+      default: launch(fused_bwd_kernel<8>); break;
+    }
+    MATCHA_CHECK_LAUNCH("fused_bwd_kernel");
+  }
+  {
+    UnfoldArgs a;
+    a.wslab = wslab; a.nchunks = nchunks; a.X = X; a.count = rg.count;
+    a.W[0] = p.w_q; a.W[1] = p.w_k; a.W[2] = p.w_v;
+    a.g[0] = p.ln_q_g; a.g[1] = p.ln_k_g; a.g[2] = p.ln_v_g;
+    a.b[0] = p.ln_q_b; a.b[1] = p.ln_k_b; a.b[2] = p.ln_v_b;
+    a.gW[0] = grads.w_q; a.gW[1] = grads.w_k; a.gW[2] = grads.w_v; a.gfc1 = grads.fc1_w;
+    a.part = part;
+    hipLaunchKernelGGL(fb_unfold_kernel, dim3(4, 4, MATCHA_N_HEAD), dim3(256), 0, st, a);
+    MATCHA_CHECK_LAUNCH("fb_unfold_kernel");
+    Unfold2Args b;
+    b.part = part; b.wslab = wslab; b.nchunks = nchunks;
+    b.dg[0] = grads.ln_q_g; b.dg[1] = grads.ln_k_g; b.dg[2] = grads.ln_v_g;
+    b.db[0] = grads.ln_q_b; b.db[1] = grads.ln_k_b; b.db[2] = grads.ln_v_b;
+    b.dfc1_b = grads.fc1_b; b.dxpad = dxpad;
+    hipLaunchKernelGGL(fb_unfold2_kernel, dim3(1), dim3(512), 0, st, b);
+    MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
+  }
+  hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
+  MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
+  return MATCHA_OK;
+}
+
+}  // namespace matcha

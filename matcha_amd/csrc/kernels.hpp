@@ -85,6 +85,12 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
                      hipStream_t st);
 
+// fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
+// three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)
+size_t fused_bwd_ws_floats(int64_t B, int L);
+int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
+                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st);
+
 // attention.hip
 int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float* O, float* P,
                     hipStream_t st);

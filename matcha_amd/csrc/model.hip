@@ -63,13 +63,15 @@ struct Workspace {
   float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
   void* adj_ws;     size_t adj_ws_bytes;
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
+  float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   size_t total;
 };
 
-static bool fused_enabled(const matcha_shape& s) {
-  static const bool off = getenv("MATCHA_DISABLE_FUSED") != nullptr;     // A/B switch for tests and profiling
-  return s.d == 64 && !off;
-}
+// A/B switches for tests and profiling (read on every call so a test can flip them):
+//   MATCHA_DISABLE_FUSED        layer-by-layer kernels everywhere
+//   MATCHA_DISABLE_FUSED_TRAIN  fused kernel only for no-grad forwards; training runs layer by layer
+static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && getenv("MATCHA_DISABLE_FUSED") == nullptr; }
+static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && getenv("MATCHA_DISABLE_FUSED_TRAIN") == nullptr; }
 
 static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
   const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
@@ -118,6 +120,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, Tn) : 0;
   w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
   w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
+  w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.total = off;
   return off;
 }
@@ -230,11 +233,13 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
-  if (fused_enabled(s) && opts->forward_only) {
-    // inference: everything from X to the logits in one kernel, nothing saved
+  if (fused_enabled(s) && (opts->forward_only || fused_train_enabled(s))) {
+    // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
+    // token) and the backward pass recomputes the attention block from X (fused_bwd.hip)
+    const bool save = !opts->forward_only;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
-    MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, nullptr, nullptr, nullptr, w.logits, w.row_loss, opts->seed,
-                                train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st));
+    MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
+                                w.logits, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
     if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -321,6 +326,11 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     if (drop_fc1) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
+  if (fused_train_enabled(s)) {
+    // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
+    // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
+    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, w.dZ0, st));
+  } else {
   // fc1: dW += ddyn0^T O ; db += colsum ; dO = ddyn0 Wfc1
   MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, g_.fc1_w, g_.fc1_b, d, hd, Tn, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
@@ -342,6 +352,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   // LayerNorm x3 backward + static-branch gradient + tanh'
   MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, Tn, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
                             g_.ln_q_b, g_.ln_k_g, g_.ln_k_b, g_.ln_v_g, g_.ln_v_b, st, cnt));
+  }
   // next_w: dW += dZ0^T x0 ; db += colsum ; dX0 = dZ0 Wn
   MATCHA_TRY(launch_gemm_tn(w.dZ0, w.x0, g_.next_w, g_.next_b, d, d, Tn, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {

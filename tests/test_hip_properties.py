@@ -2,6 +2,8 @@
 other embed dims / widths than the golden files cover (BASELINE.json configs[3], [4]: d = 128, 256, k up to 8), and
 at the bench's full batch size properties the domain offers: row-permutation equivariance, node-order invariance
 inside a hyperedge (SURVEY.md headline fact 7, last sentence), batch-width dependence, run-to-run determinism."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -121,25 +123,111 @@ def test_full_size_train_step_is_reproducible():
             assert torch.equal(a, b), n
 
 
+class _env:
+    """Set an environment switch of libmatcha_hip for the duration of a with-block (the library re-reads it per call)."""
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        os.environ[self.name] = "1"
+
+    def __exit__(self, *a):
+        os.environ.pop(self.name, None)
+
+
+def _mixed_batch(N, ks, per, rng):
+    xs = [np.pad(synth.make_edges_fast(rng, N, k, per), ((0, 0), (0, max(ks) - k))) for k in ks]
+    return torch.from_numpy(np.concatenate(xs)[rng.permutation(per * len(ks))]).cuda()
+
+
 @pytest.mark.parametrize("mode", ["table", "adj"])
 @pytest.mark.parametrize("train", [False, True])
 def test_fused_forward_matches_layerwise(mode, train):
-    """d = 64: the fused no-grad forward kernel against the layer-by-layer kernels (same weights, same dropout seed)."""
+    """d = 64: the fused forward kernel against the layer-by-layer kernels (same weights, same dropout seed)."""
     num = synth.LAYOUTS["hg38_1mb"]
     N = int(np.sum(num))
     clf, _ = hip_model(num, 64, mode, 17)
     clf.train(train)
     rng = np.random.default_rng(2)
     for ks in ([2, 3, 4, 5], [5], [2], [3, 8]):
-        xs = [np.pad(synth.make_edges_fast(rng, N, k, 600), ((0, 0), (0, max(ks) - k))) for k in ks]
-        x = torch.from_numpy(np.concatenate(xs)[rng.permutation(600 * len(ks))]).cuda()
+        x = _mixed_batch(N, ks, 600, rng)
         rt = clf._runtime()
         np.random.seed(4)
         c0 = rt.seed_counter
-        lg_layer, rc_layer = clf(x, return_recon=True)                 # grad enabled -> layer-wise kernels (saves activations)
+        with _env("MATCHA_DISABLE_FUSED"), torch.no_grad():
+            lg_layer, rc_layer = clf(x, return_recon=True)             # layer-wise kernels
         rt.seed_counter = c0                                          # same dropout seed for the second run
         np.random.seed(4)
         with torch.no_grad():
-            lg_fused, rc_fused = clf(x, return_recon=True)             # no grad -> fused kernel
-        assert torch.allclose(lg_fused, lg_layer.detach(), rtol=1e-5, atol=2e-5), (mode, train, ks)
-        assert torch.allclose(rc_fused, rc_layer.detach(), rtol=1e-5, atol=1e-5)
+            lg_fused, rc_fused = clf(x, return_recon=True)             # fused kernel
+        assert torch.allclose(lg_fused, lg_layer, rtol=1e-5, atol=2e-5), (mode, train, ks)
+        assert torch.allclose(rc_fused, rc_layer, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+@pytest.mark.parametrize("ks", [[2, 3, 4, 5], [5], [2], [3, 8], [1, 4]])
+def test_fused_backward_matches_layerwise(mode, ks):
+    """d = 64 training step: fused forward (saving Y/H1/H2) + head-major fused backward against the layer-by-layer
+    kernels; same weights, same dropout seed, same batch.  Every parameter gradient must agree."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, 64, mode, 23)
+    clf.train(True)
+    rng = np.random.default_rng(3)
+    x = _mixed_batch(N, ks, 700, rng)
+    y = (torch.rand(len(x), 1, device="cuda") < 0.3).float()
+    rt = clf._runtime()
+    c0 = rt.seed_counter
+    res = []
+    for layerwise in (True, False):
+        rt.seed_counter = c0
+        np.random.seed(8)
+        clf.zero_grad()
+        if layerwise:
+            os.environ["MATCHA_DISABLE_FUSED"] = "1"
+        try:
+            lg, rc = clf(x, return_recon=True)
+            (torch.nn.functional.binary_cross_entropy_with_logits(lg, y) + 0.05 * rc.sum()).backward()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MATCHA_DISABLE_FUSED", None)
+        res.append((lg.detach().clone(), {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.grad is not None}))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
+    assert res[0][1].keys() == res[1][1].keys()
+    for n, a in res[0][1].items():
+        b = res[1][1][n]
+        scale = max(float(a.abs().max()), 1e-6)
+        if n == GAUGE:
+            continue
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+
+
+def test_fused_kernels_with_empty_rows():
+    """Rows that are all padding (k = 0) cluster in one tile of the fused kernels: more than 64 hyperedges per tile."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, 64, "table", 5)
+    clf.train(False)
+    rng = np.random.default_rng(6)
+    x = _mixed_batch(N, [2, 3, 5], 50, rng)
+    x = torch.cat([x[:40], torch.zeros(200, x.shape[1], dtype=x.dtype, device="cuda"), x[40:]])
+    y = (torch.rand(len(x), 1, device="cuda") < 0.3).float()
+    res = []
+    for layerwise in (True, False):
+        clf.zero_grad()
+        if layerwise:
+            os.environ["MATCHA_DISABLE_FUSED"] = "1"
+        try:
+            lg = clf(x)
+            torch.nn.functional.binary_cross_entropy_with_logits(lg, y).backward()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MATCHA_DISABLE_FUSED", None)
+        res.append((lg.detach().clone(), {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.grad is not None}))
+    assert float(res[1][0][40:240].abs().max()) == 0.0
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
+    for n, a in res[0][1].items():
+        if n == GAUGE:
+            continue
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - res[1][1][n]).abs().max()) <= 2e-5 * scale + 1e-9, n
