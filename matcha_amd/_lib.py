@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmatcha_hip.so")
+LIB_PATH = os.environ.get("MATCHA_HIP_LIB") or os.path.join(_HERE, "lib", "libmatcha_hip.so")   # override: A/B builds
 
 MAX_L = 8
 N_HEAD = 8

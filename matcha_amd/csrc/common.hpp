@@ -86,6 +86,12 @@ __device__ __forceinline__ float group_sum8_dpp(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
   return v;
 }
+// Sum over groups of 16 adjacent lanes (one DPP row): the 8-lane tree, then row_mirror (lane i <-> 15 - i).
+__device__ __forceinline__ float group_sum16_dpp(float v) {
+  v = group_sum8_dpp(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
 
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {

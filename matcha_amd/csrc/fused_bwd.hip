@@ -38,7 +38,8 @@ struct FusedBwdArgs {
   const float* dDyn;              // [Tn, 64]
   const int32_t* row_off;         // [B+1]
   const int32_t* count;           // {Tr+1, Tr}
-  const int32_t* tile_b0;         // [ntiles+1]
+  const int32_t* tile_meta;       // [ntiles+2][4]
+  const int32_t* tok_pos;         // [Tn]
   int L;
   int ntiles;                     // upper bound
   int nchunks;
@@ -48,6 +49,7 @@ struct FusedBwdArgs {
   float* dxh;                     // [8][tcap][64]
   int64_t tcap;
   float* wslab;                   // [8][nchunks][kWgSlab]
+  int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 attention, 2 recompute GEMMs, 4 weight-grad GEMMs, 8 dx_hat GEMMs
 };
 
 #define FB_GLOAD(R, SRC, LD)                                                                             \
@@ -122,175 +124,153 @@ __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rs
   rstd = 1.0f / sqrtf(q * (1.f / 64.f) + kEpsLn);
 }
 
-// Attention forward + backward of one hyperedge for one head on LDS tiles; 8 lanes, lane `sub` owns features
-// [8 sub, 8 sub + 8).  Formulas: attention.hip (attn_bwd_kernel).  In: Q, K, V rows, dO rows (Fs).  Out: O -> Fs rows,
-// dQ/dK/dV over the Q/K/V rows.  acc: this lane's running sums {dQ, dK, dV column sums, dK_pad, dV_pad} x 8 features.
+// Attention forward + backward on LDS tiles, token-parallel: one 8-lane group per QUERY token (lane `sub` owns features
+// [8 sub, 8 sub + 8)), so a tile's <= 63 tokens fill the 32 groups of the workgroup in two passes and the work per group
+// is O(k) instead of O(k^2).  Formulas: attention.hip (attn_bwd_kernel).
+//   row phase (token i):    P_i., Pp_i, O_i, dS_i., dSp_i, dQ_i  -- everything that needs only row i of the score matrix;
+//                           P_i. and dS_i. go to LDS ([64][8] each), O_i and dQ_i stay in registers
+//   column phase (token j): dV_j = sum_i P_ij dO_i,  dK_j = sum_i dS_ij Q_i   over the hyperedge's rows
+//   write phase:            O -> Fs, dQ/dK/dV over Q/K/V (after a barrier: the column phase reads Q and dO of other rows)
+// acc: this lane's running sums {dK_pad, dV_pad} x 8 features.
 template <int ML>
-__device__ __forceinline__ void attn_group_fb(float* __restrict__ Qs, float* __restrict__ Ks, float* __restrict__ Vs, float* __restrict__ Fs,
-                                              const float* __restrict__ kpad, const float* __restrict__ vpad, int li0, int k, int n_pad,
-                                              int sub, float inv_temp, float (&acc)[40]) {
+__device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs,
+                                            const float* __restrict__ Fs, const float* __restrict__ kpad, const float* __restrict__ vpad,
+                                            float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0, int k, int n_pad, int sub,
+                                            float inv_temp, float (&o)[8], float (&gq)[8], float (&acc)[16]) {
+  // Branch-free over the ML key slots: a wave almost always holds a hyperedge of the full width, so predicating the
+  // slots j >= k (clamped row, probability forced to 0) costs nothing and removes one branch per slot.
   const float padf = (float)n_pad;
   const bool hp = n_pad > 0;
-  float P[ML][ML], Pp[ML];
-  {
-    float q[ML][8], kk[ML][8], kp[8];
+  const int ii = li - li0;
+  float q[8], go[8], kk[ML][8], v[ML][8], kp[8], vp[8];
+  LD8(q, &Qs[li * kLd + 8 * sub]);
+  LD8(go, &Fs[li * kLd + 8 * sub]);
 #pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        LD8(q[i], &Qs[(li0 + i) * kLd + 8 * sub]);
-        LD8(kk[i], &Ks[(li0 + i) * kLd + 8 * sub]);
-      }
-    LD8(kp, kpad + 8 * sub);
-#pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        float mx = -3.4e38f;
-#pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) {
-            float a = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a += q[i][e] * kk[j][e];
-            float v = group_sum8_dpp(a) * inv_temp;
-            if (i == j) v = -1e32f;
-            P[i][j] = v;
-            mx = fmaxf(mx, v);
-          }
-        Pp[i] = 0.f;
-        if (hp) {
-          float a = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a += q[i][e] * kp[e];
-          Pp[i] = group_sum8_dpp(a) * inv_temp;
-          mx = fmaxf(mx, Pp[i]);
-        }
-        float den = 0.f;
-#pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) { P[i][j] = expf(P[i][j] - mx); den += P[i][j]; }
-        if (hp) { Pp[i] = expf(Pp[i] - mx); den += padf * Pp[i]; }
-        const float inv = 1.f / den;
-#pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) P[i][j] *= inv;
-        Pp[i] = hp ? Pp[i] * inv : 0.f;
-      }
+  for (int j = 0; j < ML; ++j) {
+    const int rj = li0 + (j < k ? j : 0);
+    LD8(kk[j], &Ks[rj * kLd + 8 * sub]);
+    LD8(v[j], &Vs[rj * kLd + 8 * sub]);
   }
-  float dS[ML][ML], dSp[ML];
-  {
-    float v[ML][8], go[ML][8], vp[8];
+  LD8(kp, kpad + 8 * sub);
+  LD8(vp, vpad + 8 * sub);
+  float p[ML], ds[ML], pp, dsp;
+  float mx = -3.4e38f;
 #pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        LD8(v[i], &Vs[(li0 + i) * kLd + 8 * sub]);
-        LD8(go[i], &Fs[(li0 + i) * kLd + 8 * sub]);
-      }
-    LD8(vp, vpad + 8 * sub);
-    // O_i (needed by the fc1 weight gradient) replaces dO_i in Fs
+  for (int j = 0; j < ML; ++j) {
+    float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = hp ? padf * Pp[i] * vp[e] : 0.f;
-#pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += P[i][j] * v[j][e];
-          }
-        ST8(&Fs[(li0 + i) * kLd + 8 * sub], o);
-      }
-    // dP -> dS
-#pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        float sig = 0.f;
-#pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) {
-            float a = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a += go[i][e] * v[j][e];
-            a = group_sum8_dpp(a);
-            dS[i][j] = a;
-            sig += P[i][j] * a;
-          }
-        dSp[i] = 0.f;
-        if (hp) {
-          float a = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a += go[i][e] * vp[e];
-          a = group_sum8_dpp(a);
-          dSp[i] = a;
-          sig += padf * Pp[i] * a;
-        }
-#pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) dS[i][j] = P[i][j] * (dS[i][j] - sig) * inv_temp;
-        dSp[i] = hp ? Pp[i] * (dSp[i] - sig) * inv_temp : 0.f;
-      }
-    // dV_j = sum_i P_ij dO_i ;  dV_pad += n_pad sum_i Pp_i dO_i
-#pragma unroll
-    for (int j = 0; j < ML; ++j)
-      if (j < k) {
-        float gv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gv[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < ML; ++i)
-          if (i < k) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] += P[i][j] * go[i][e];
-          }
-        ST8(&Vs[(li0 + j) * kLd + 8 * sub], gv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[16 + e] += gv[e];
-        if (hp) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[32 + e] += padf * Pp[j] * go[j][e];
-        }
-      }
+    for (int e = 0; e < 8; ++e) a += q[e] * kk[j][e];
+    a = group_sum8_dpp(a) * inv_temp;
+    a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
+    p[j] = a;
+    mx = (j < k) ? fmaxf(mx, a) : mx;
   }
   {
-    float q[ML][8], kk[ML][8], kp[8];
+    float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        LD8(q[i], &Qs[(li0 + i) * kLd + 8 * sub]);
-        LD8(kk[i], &Ks[(li0 + i) * kLd + 8 * sub]);
-      }
-    LD8(kp, kpad + 8 * sub);
+    for (int e = 0; e < 8; ++e) a += q[e] * kp[e];
+    pp = group_sum8_dpp(a) * inv_temp;
+    mx = hp ? fmaxf(mx, pp) : mx;
+  }
+  float den = 0.f;
 #pragma unroll
-    for (int i = 0; i < ML; ++i)
-      if (i < k) {
-        float gq[8], gk[8];
+  for (int j = 0; j < ML; ++j) {
+    p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
+    den += p[j];
+  }
+  pp = hp ? __expf(pp - mx) : 0.f;
+  den += padf * pp;
+  const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gq[e] = hp ? padf * dSp[i] * kp[e] : 0.f; gk[e] = 0.f; }
+  for (int j = 0; j < ML; ++j) p[j] *= inv;
+  pp *= inv;
+  // O_i
+  const float ppf = padf * pp;
 #pragma unroll
-        for (int j = 0; j < ML; ++j)
-          if (j < k) {
+  for (int e = 0; e < 8; ++e) o[e] = ppf * vp[e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              gq[e] += dS[i][j] * kk[j][e];      // dQ_i += dS_ij K_j
-              gk[e] += dS[j][i] * q[j][e];       // dK_i += dS_ji Q_j
-            }
-          }
-        ST8(&Qs[(li0 + i) * kLd + 8 * sub], gq);
-        ST8(&Ks[(li0 + i) * kLd + 8 * sub], gk);
+  for (int j = 0; j < ML; ++j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { acc[e] += gq[e]; acc[8 + e] += gk[e]; }
-        if (hp) {
+    for (int e = 0; e < 8; ++e) o[e] += p[j] * v[j][e];
+  }
+  // dP_i. -> dS_i.
+  float sig = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[24 + e] += padf * dSp[i] * q[i][e];
-        }
-      }
+  for (int j = 0; j < ML; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += go[e] * v[j][e];
+    a = group_sum8_dpp(a);
+    ds[j] = a;
+    sig += p[j] * a;
+  }
+  {
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += go[e] * vp[e];
+    dsp = group_sum8_dpp(a);
+    sig += ppf * dsp;
+  }
+#pragma unroll
+  for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
+  dsp = pp * (dsp - sig) * inv_temp;
+  // dQ_i
+  const float dspf = padf * dsp;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gq[e] = dspf * kp[e];
+#pragma unroll
+  for (int j = 0; j < ML; ++j) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gq[e] += ds[j] * kk[j][e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[e] += dspf * q[e]; acc[8 + e] += ppf * go[e]; }
+  // row i of P and dS for the column phase (every lane of the group holds the same values: lanes 0 / 1 write them)
+  if (sub < 2) {
+    float* dst = (sub == 0 ? Ps : dSs) + li * 8;
+    const float w0 = sub == 0 ? p[0] : ds[0], w1 = sub == 0 ? p[1 % ML] : ds[1 % ML];
+    const float w2 = sub == 0 ? p[2 % ML] : ds[2 % ML], w3 = sub == 0 ? p[3 % ML] : ds[3 % ML];
+    *reinterpret_cast<float4*>(dst) = make_float4(w0, w1, ML > 2 ? w2 : 0.f, ML > 3 ? w3 : 0.f);
+    if (ML > 4) {
+      const float w4 = sub == 0 ? p[4 % ML] : ds[4 % ML], w5 = sub == 0 ? p[5 % ML] : ds[5 % ML];
+      const float w6 = sub == 0 ? p[6 % ML] : ds[6 % ML], w7 = sub == 0 ? p[7 % ML] : ds[7 % ML];
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(w4, ML > 5 ? w5 : 0.f, ML > 6 ? w6 : 0.f, ML > 7 ? w7 : 0.f);
+    }
   }
 }
 
 template <int ML>
+__device__ __forceinline__ void attn_col_fb(const float* __restrict__ Qs, const float* __restrict__ Fs, const float* __restrict__ Ps,
+                                            const float* __restrict__ dSs, int li, int li0, int k, int sub, float (&gk)[8], float (&gv)[8]) {
+  const int jj = li - li0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gk[e] = 0.f; gv[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    const int ri = li0 + (i < k ? i : 0);
+    float q[8], go[8];
+    LD8(q, &Qs[ri * kLd + 8 * sub]);
+    LD8(go, &Fs[ri * kLd + 8 * sub]);
+    const float pij = (i < k) ? Ps[ri * 8 + jj] : 0.f, dsij = (i < k) ? dSs[ri * 8 + jj] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gv[e] += pij * go[e]; gk[e] += dsij * q[e]; }
+  }
+}
+
+// -DFB_TIMING: per-phase wall-clock (100 MHz) of workgroup 0, printed at the end -- development builds only
+#ifdef FB_TIMING
+#define FB_T(i) do { const long long now__ = wall_clock64(); tph[i] += now__ - tlast; tlast = now__; } while (0)
+#else
+#define FB_T(i) do { } while (0)
+#endif
+
+template <int ML>
 __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef FB_TIMING
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+#endif
   float* Wq = lds;
   float* Wk = lds + 1 * kTile;
   float* Wv = lds + 2 * kTile;
@@ -301,11 +281,13 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   float* Vs = lds + 7 * kTile;        // V -> dV
   float* Fs = lds + 8 * kTile;        // Wfc1 block -> dO -> O
   float* sm = lds + 9 * kTile;
-  int* roff = reinterpret_cast<int*>(sm);   // [<= 65]
-  float* cb = sm + 72;                // [3][64] folded projection biases of this head
+  int* tinfo = reinterpret_cast<int*>(sm);  // [64] per local token row: first row of its hyperedge | k << 8
+  float* cb = sm + 64;                // [3][64] folded projection biases of this head
   float* kpad = cb + 192;             // K / V rows of the shared padding token for this head
   float* vpad = kpad + 64;
   float* xpad = vpad + 64;
+  float* Ps = xpad + 64;              // [64][8] attention probabilities of the tile's rows
+  float* dSs = Ps + 512;              // [64][8] score gradients
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -360,90 +342,145 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   }
 
   f32x16 aWq = {0}, aWk = {0}, aWv = {0}, aWf = {0};
-  float accp[40];
+  float accp[16];                                    // dK_pad / dV_pad partials of this lane's feature slice
 #pragma unroll
-  for (int i = 0; i < 40; ++i) accp[i] = 0.f;
-  float4 fbs = make_float4(0.f, 0.f, 0.f, 0.f);      // fc1 bias gradient partial (head 0 only)
+  for (int i = 0; i < 16; ++i) accp[i] = 0.f;
+  float csq = 0.f, csk = 0.f, csv = 0.f, csd = 0.f;  // column sums of dQ, dK, dV, dDyn: fall out of the weight-gradient operand loads
+
+  // software pipeline: tile metadata two tiles ahead, X / dDyn rows one tile ahead in named registers (a struct passed
+  // by reference ends up in scratch memory: fused_fwd.hip)
+  const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
+  const int4 mzero = make_int4(0, 0, 0, 0);
+  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
+  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
+  float4 xn0, xn1, xn2, xn3, dn0, dn1, dn2, dn3;
+  int tpn = 0;
+#define FB_ROW_GLOAD(I, M)                                                                               \
+  do {                                                                                                   \
+    const int row__ = srow + 16 * (I);                                                                   \
+    const int64_t tok__ = (M).x + (row__ < (M).y ? row__ : ((M).y > 0 ? (M).y - 1 : 0));                 \
+    xn##I = *reinterpret_cast<const float4*>(g.X + tok__ * 64 + sc4);                                    \
+    dn##I = *reinterpret_cast<const float4*>(g.dDyn + tok__ * 64 + sc4);                                 \
+  } while (0)
+#define FB_ROWS_GLOAD(M)                                                                                 \
+  do {                                                                                                   \
+    FB_ROW_GLOAD(0, M); FB_ROW_GLOAD(1, M); FB_ROW_GLOAD(2, M); FB_ROW_GLOAD(3, M);                      \
+    if (tid < 64) tpn = g.tok_pos[(M).x + (tid < (M).y ? tid : ((M).y > 0 ? (M).y - 1 : 0))];           \
+  } while (0)
+#define FB_ROW_STAGE(I)                                                                                  \
+  do {                                                                                                   \
+    const int row__ = srow + 16 * (I);                                                                   \
+    const float msk__ = row__ < n_real ? 1.f : 0.f;                                                      \
+    const float4 xv__ = xn##I, dv__ = dn##I;                                                             \
+    const float mean__ = group_sum16_dpp((xv__.x + xv__.y) + (xv__.z + xv__.w)) * (1.f / 64.f);          \
+    const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
+    const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
+    const float rs__ = msk__ / sqrtf(q__ * (1.f / 64.f) + kEpsLn);                                       \
+    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
+    const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
+    *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
+  } while (0)
+  FB_ROWS_GLOAD(mc);
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int b0 = g.tile_b0[tile], b1 = g.tile_b0[tile + 1];
-    if (b0 >= b1) continue;
-    const int t0 = g.row_off[b0];
-    const int n_real = g.row_off[b1] - t0;
-    if (n_real <= 0) continue;
-    const int n_h = b1 - b0;
-    const bool lroff = n_h <= 64;
-    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
-    // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the local row offsets ----
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = srow + 16 * i;
-      const int rc = row < n_real ? row : n_real - 1;
-      const float msk = row < n_real ? 1.f : 0.f;
-      const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)(t0 + rc) * 64 + sc4);
-      const float4 dv = *reinterpret_cast<const float4*>(g.dDyn + (int64_t)(t0 + rc) * 64 + sc4);
-      float m, rs;
-      ln_row16(xv, m, rs);
-      rs *= msk;
-      *reinterpret_cast<float4*>(&Xs[row * kLd + sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
-      const float4 dm = make_float4(dv.x * msk, dv.y * msk, dv.z * msk, dv.w * msk);
-      *reinterpret_cast<float4*>(&Ds[row * kLd + sc4]) = dm;
-      fbs.x += dm.x; fbs.y += dm.y; fbs.z += dm.z; fbs.w += dm.w;
+    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
+    const int t0 = mc.x, n_real = mc.y;
+    if (n_real <= 0) {                                // no token starts in this window (all-padding rows only)
+      FB_ROWS_GLOAD(mn);
+      mc = mn; mn = mnn;
+      continue;
     }
+    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
+    FB_T(7);
+    // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the token -> hyperedge map ----
+    FB_ROW_STAGE(0); FB_ROW_STAGE(1); FB_ROW_STAGE(2); FB_ROW_STAGE(3);
     FB_LSTORE(Fs, fw);
-    if (lroff)
-      for (int i = tid; i <= n_h; i += 256) roff[i] = g.row_off[b0 + i] - t0;
+    if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
     __syncthreads();
+    FB_T(0);
     // ---- recompute Q, K, V; dO = dDyn . Wfc1[:, head block] ----
-    {
+    if (!(g.dbg & 2)) {
       f32x16 acc = {0};
       acc = gemm_nt(acc, Xs, Wq, wr, wc, r, h);
       quad_store(Qs, acc, cb, wr, wc, r, h);
     }
-    {
+    if (!(g.dbg & 2)) {
       f32x16 acc = {0};
       acc = gemm_nt(acc, Xs, Wk, wr, wc, r, h);
       quad_store(Ks, acc, cb + 64, wr, wc, r, h);
     }
-    {
+    if (!(g.dbg & 2)) {
       f32x16 acc = {0};
       acc = gemm_nt(acc, Xs, Wv, wr, wc, r, h);
       quad_store(Vs, acc, cb + 128, wr, wc, r, h);
     }
     {
       f32x16 acc = {0};
-      acc = gemm_nn(acc, Ds, Fs, wr, wc, r, h);
+      if (!(g.dbg & 2)) acc = gemm_nn(acc, Ds, Fs, wr, wc, r, h);
       __syncthreads();                                // every wave has read the fc1 block
       quad_store(Fs, acc, nullptr, wr, wc, r, h);
     }
     __syncthreads();
-    // ---- attention forward + backward, 8 lanes per hyperedge ----
-    for (int e0 = 0; e0 < n_h; e0 += 32) {
-      const int e = e0 + wave * 8 + (lane >> 3);
-      if (e < n_h) {
-        const int li0 = lroff ? roff[e] : g.row_off[b0 + e] - t0;
-        const int k = (lroff ? roff[e + 1] : g.row_off[b0 + e + 1] - t0) - li0;
-        if (k > 0) attn_group_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, li0, k, g.L - k, sub, inv_temp, accp);
+    FB_T(1);
+    // ---- attention forward + backward: 8 lanes per token, two passes of 32 tokens ----
+    {
+      float o0[8], q0[8], k0[8], v0[8], o1[8], q1[8], k1[8], v1[8];
+      const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int la = wave * 8 + (lane >> 3), lb = la + 32;
+      const bool acta = la < n_real && !(g.dbg & 1), actb = lb < n_real && !(g.dbg & 1);
+      int ia = 0, ib = 0;
+      if (acta) { ia = tinfo[la]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accp); }
+      if (actb) { ib = tinfo[lb]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, lb, ib & 255, ib >> 8, g.L - (ib >> 8), sub, inv_temp, o1, q1, accp); }
+      __syncthreads();
+      FB_T(2);
+      if (acta) attn_col_fb<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
+      if (actb) attn_col_fb<ML>(Qs, Fs, Ps, dSs, lb, ib & 255, ib >> 8, sub, k1, v1);
+      __syncthreads();
+      FB_T(3);
+      if (acta) {
+        ST8(&Fs[la * kLd + 8 * sub], o0); ST8(&Qs[la * kLd + 8 * sub], q0); ST8(&Ks[la * kLd + 8 * sub], k0); ST8(&Vs[la * kLd + 8 * sub], v0);
+      } else {                                        // rows past the tile's tokens: zero, the column sums below run over all 64 rows
+        ST8(&Qs[la * kLd + 8 * sub], zero8); ST8(&Ks[la * kLd + 8 * sub], zero8); ST8(&Vs[la * kLd + 8 * sub], zero8);
+      }
+      if (actb) {
+        ST8(&Fs[lb * kLd + 8 * sub], o1); ST8(&Qs[lb * kLd + 8 * sub], q1); ST8(&Ks[lb * kLd + 8 * sub], k1); ST8(&Vs[lb * kLd + 8 * sub], v1);
+      } else {
+        ST8(&Qs[lb * kLd + 8 * sub], zero8); ST8(&Ks[lb * kLd + 8 * sub], zero8); ST8(&Vs[lb * kLd + 8 * sub], zero8);
       }
     }
     __syncthreads();
+    FB_T(4);
+    // next tile's rows and the fc1 block for its staging: in flight during the GEMMs below
+    FB_ROWS_GLOAD(mn);
+    FB_GLOAD(fw, g.fc1_w + (int64_t)head * 64, 512);
     // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
-#pragma unroll 4
-    for (int m = 0; m < 32; ++m) {
-      const int t = 2 * m + h;
-      const float xk = Xs[t * kLd + 32 * wc + r];
-      const float ok = Fs[t * kLd + 32 * wc + r];
-      const float gq = Qs[t * kLd + 32 * wr + r];
-      const float gk = Ks[t * kLd + 32 * wr + r];
-      const float gv = Vs[t * kLd + 32 * wr + r];
-      const float gd = Ds[t * kLd + 32 * wr + r];
-      aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(gq, xk, aWq, 0, 0, 0);
-      aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(gk, xk, aWk, 0, 0, 0);
-      aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xk, aWv, 0, 0, 0);
-      aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(gd, ok, aWf, 0, 0, 0);
+    if (!(g.dbg & 4)) {
+#pragma unroll 1
+      for (int mm = 0; mm < 4; ++mm) {                // 8 contraction steps (16 tokens) per trip: operands first, then 32 MFMAs
+        float xk[8], ok[8], gq[8], gk[8], gv[8], gd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = 16 * mm + 2 * u + h;
+          xk[u] = Xs[t * kLd + 32 * wc + r];
+          ok[u] = Fs[t * kLd + 32 * wc + r];
+          gq[u] = Qs[t * kLd + 32 * wr + r];
+          gk[u] = Ks[t * kLd + 32 * wr + r];
+          gv[u] = Vs[t * kLd + 32 * wr + r];
+          gd[u] = Ds[t * kLd + 32 * wr + r];
+          csq += gq[u]; csk += gk[u]; csv += gv[u]; csd += gd[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(gq[u], xk[u], aWq, 0, 0, 0);
+          aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[u], xk[u], aWk, 0, 0, 0);
+          aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u], xk[u], aWv, 0, 0, 0);
+          aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(gd[u], ok[u], aWf, 0, 0, 0);
+        }
+      }
     }
+    FB_T(5);
     // ---- this head's share of d x_hat = dQ W'q + dK W'k + dV W'v ----
-    {
+    if (!(g.dbg & 8)) {
       f32x16 dx = {0};
       dx = gemm_nn(dx, Qs, Wq, wr, wc, r, h);
       dx = gemm_nn(dx, Ks, Wk, wr, wc, r, h);
@@ -455,10 +492,16 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
         if (row < n_real) out[(int64_t)row * 64] = dx[reg];
       }
     }
+    mc = mn; mn = mnn;
   }
 
   // ---- workgroup slab ----
   __syncthreads();
+#ifdef FB_TIMING
+  if (blockIdx.x == 0 && tid == 0)
+    printf("fused_bwd wg0 us: stage %.1f pre-gemm %.1f attn-row %.1f attn-col %.1f attn-write %.1f tn %.1f dx+wait %.1f (tiles %d)\n", tph[0] * 0.01,
+           tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
+#endif
   float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
   {
     const int col = 32 * wc + r;
@@ -471,31 +514,31 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       slab[3 * 4096 + row * 64 + col] = aWf[reg];
     }
   }
-  // per-lane attention sums: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
-  float* red = Xs;                      // [4][5][64]
+  // column sums: this lane covered the tokens of one parity for column 32 wr + r (waves with wc = 1 hold duplicates)
+  float* red = Xs;                      // [5][64]: dcq dck dcv dKpad dVpad
+  csq += __shfl_xor(csq, 32, 64); csk += __shfl_xor(csk, 32, 64); csv += __shfl_xor(csv, 32, 64); csd += __shfl_xor(csd, 32, 64);
+  float* red2 = Ds;                     // [64] fc1 bias gradient
+  if (wc == 0 && h == 0) {
+    red[0 * 64 + 32 * wr + r] = csq; red[1 * 64 + 32 * wr + r] = csk; red[2 * 64 + 32 * wr + r] = csv;
+    red2[32 * wr + r] = csd;
+  }
+  // dK_pad / dV_pad: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
+  float* redp = Xs + 3 * 64;            // [4][2][64]
 #pragma unroll
-  for (int i = 0; i < 40; ++i) {
+  for (int i = 0; i < 16; ++i) {
     float v = accp[i];
     v += __shfl_xor(v, 8, 64);
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if (lane < 8) red[(wave * 5 + (i >> 3)) * 64 + 8 * lane + (i & 7)] = v;
+    if (lane < 8) redp[(wave * 2 + (i >> 3)) * 64 + 8 * lane + (i & 7)] = v;
   }
-  float* red2 = Ds;                     // [16][64] fc1 bias partials of the staging rows
-  *reinterpret_cast<float4*>(&red2[srow * 64 + sc4]) = fbs;
   __syncthreads();
-  for (int i = tid; i < 320; i += 256) {
-    const int vec = i >> 6, f = i & 63;
-    slab[kVecOff + i] = ((red[(0 * 5 + vec) * 64 + f] + red[(1 * 5 + vec) * 64 + f]) + red[(2 * 5 + vec) * 64 + f]) + red[(3 * 5 + vec) * 64 + f];
+  if (tid < 192) slab[kVecOff + tid] = red[tid];
+  if (tid < 128) {
+    const int vec = tid >> 6, f = tid & 63;
+    slab[kVecOff + 192 + tid] = ((redp[(0 * 2 + vec) * 64 + f] + redp[(1 * 2 + vec) * 64 + f]) + redp[(2 * 2 + vec) * 64 + f]) + redp[(3 * 2 + vec) * 64 + f];
   }
-  if (tid < 64) {
-    float s = 0.f;
-    if (head == 0) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) s += red2[q * 64 + tid];
-    }
-    slab[kVecOff + 320 + tid] = s;
-  }
+  if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
 }
 
 // ---- slab reduction + un-folding of the LayerNorm affines -------------------------------------------------------
@@ -648,11 +691,12 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   {
     FusedBwdArgs g;
-    g.X = X; g.dDyn = dDyn; g.row_off = rg.row_off; g.count = rg.count; g.tile_b0 = rg.tile_b0; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
+    g.X = X; g.dDyn = dDyn; g.row_off = rg.row_off; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
     g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
     g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
     g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab;
-    const size_t lds = ((size_t)9 * kTile + 72 + 192 + 3 * 64) * sizeof(float);
+    { const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
+    const size_t lds = ((size_t)9 * kTile + 64 + 192 + 3 * 64 + 2 * 512) * sizeof(float);
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);

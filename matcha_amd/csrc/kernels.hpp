@@ -41,6 +41,8 @@ struct Ragged {
   int nblk;
   int32_t* tile_b0;    // [ntiles+1] first hyperedge of each fused-kernel tile (window 64 - L first-token indices)
   int ntiles;
+  int32_t* tok_pos;    // [T+1] position of the token inside its hyperedge | k << 8
+  int32_t* tile_meta;  // [ntiles + 2][4] {first token t0, number of tokens, first hyperedge b0, number of hyperedges}; zeros past the end
 };
 size_t ragged_bytes(int64_t B, int L);
 void ragged_carve(int64_t B, int L, char* base, Ragged& r);

@@ -12,6 +12,8 @@
 //                   the ones the oracle generates for the padded layout); tok_slot[Tr] = B*L
 //   tok_id [T+1]    node id of the compact token; tok_id[Tr] = 0 (padding id)
 //   count [2]       {Tr + 1, Tr}  -- device-side row counts consumed by every kernel through m_dev / t_dev
+//   tok_pos [T+1]   position of the compact token inside its hyperedge | k << 8 (fused kernels: token -> hyperedge rows)
+//   tile_b0, tile_meta   tiles of whole hyperedges (<= 63 tokens) for the fused d = 64 kernels
 #include "kernels.hpp"
 
 namespace matcha {
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(int32_t* __restrict__ bl
 
 __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict__ x, int64_t B, int L, const int32_t* __restrict__ blk_base,
                                                        const int32_t* __restrict__ count, int32_t* __restrict__ row_off,
-                                                       int32_t* __restrict__ tok_slot, int64_t* __restrict__ tok_id) {
+                                                       int32_t* __restrict__ tok_slot, int64_t* __restrict__ tok_id,
+                                                       int32_t* __restrict__ tok_pos) {
   __shared__ int lds4[4];
   const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * 4;
   int cnt = 0;
@@ -82,9 +85,12 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
     const int64_t b = b0 + i;
     if (b >= B) break;
     row_off[b] = pos;
+    int k = 0;
+    for (int l = 0; l < L; ++l) k += x[b * L + l] != 0 ? 1 : 0;
+    int nth = 0;
     for (int l = 0; l < L; ++l) {
       const int64_t id = x[b * L + l];
-      if (id != 0) { tok_slot[pos] = (int32_t)(b * L + l); tok_id[pos] = id; ++pos; }
+      if (id != 0) { tok_slot[pos] = (int32_t)(b * L + l); tok_id[pos] = id; tok_pos[pos] = nth | (k << 8); ++pos; ++nth; }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
     row_off[B] = tr;
     tok_slot[tr] = (int32_t)(B * L);
     tok_id[tr] = 0;
+    tok_pos[tr] = 0;
   }
 }
 
@@ -112,6 +119,22 @@ __global__ __launch_bounds__(256) void tile_plan_kernel(const int32_t* __restric
   }
 }
 
+// tile_meta[w] = {t0, n_real, b0, n_h}; entries past the last real tile are zero (n_real = 0: skipped by the kernels)
+__global__ __launch_bounds__(256) void tile_meta_kernel(const int32_t* __restrict__ row_off, const int32_t* __restrict__ tile_b0, int ntiles,
+                                                        int32_t* __restrict__ meta) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= ntiles + 2) return;
+  int4 m = make_int4(0, 0, 0, 0);
+  if (w < ntiles) {
+    const int b0 = tile_b0[w], b1 = tile_b0[w + 1];
+    if (b1 > b0) {
+      const int t0 = row_off[b0];
+      m = make_int4(t0, row_off[b1] - t0, b0, b1 - b0);
+    }
+  }
+  reinterpret_cast<int4*>(meta)[w] = m;
+}
+
 size_t ragged_bytes(int64_t B, int L) {
   const int64_t T = B * L;
   size_t n = 0;
@@ -121,6 +144,8 @@ size_t ragged_bytes(int64_t B, int L) {
   n += 256;                                        // count
   n += align_up((size_t)cdiv(B, kRowsPerBlock) * 4, 256);
   n += align_up((size_t)(cdiv(T + 1, 64 - L) + 2) * 4, 256);   // tile_b0
+  n += align_up((size_t)(T + 1) * 4, 256);        // tok_pos
+  n += align_up((size_t)(cdiv(T + 1, 64 - L) + 2) * 16, 256);  // tile_meta
   return n;
 }
 
@@ -136,6 +161,8 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.nblk = (int)cdiv(B, kRowsPerBlock);
   r.ntiles = (int)cdiv(T + 1, 64 - L);
   r.tile_b0 = (int32_t*)take((size_t)(r.ntiles + 2) * 4);
+  r.tok_pos = (int32_t*)take((size_t)(T + 1) * 4);
+  r.tile_meta = (int32_t*)take((size_t)(r.ntiles + 2) * 16);
 }
 
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st) {
@@ -143,10 +170,12 @@ int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipS
   MATCHA_CHECK_LAUNCH("row_count_kernel");
   hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, r.blk_sum, r.nblk, r.count);
   MATCHA_CHECK_LAUNCH("row_scan_kernel");
-  hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id);
+  hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
   hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, r.row_off, B, 64 - L, r.ntiles, r.tile_b0);
   MATCHA_CHECK_LAUNCH("tile_plan_kernel");
+  hipLaunchKernelGGL(tile_meta_kernel, dim3((unsigned)cdiv(r.ntiles + 2, 256)), dim3(256), 0, st, r.row_off, r.tile_b0, r.ntiles, r.tile_meta);
+  MATCHA_CHECK_LAUNCH("tile_meta_kernel");
   return MATCHA_OK;
 }
 
