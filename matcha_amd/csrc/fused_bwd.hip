@@ -15,7 +15,8 @@
 // one 256 B partial of d x_hat per head; lnhat_bwd_kernel sums the 8 partials and applies the LayerNorm backward.
 //
 // LDS: 9 tiles of 64 x 68 floats (W'q W'k W'v | x_hat dDyn | Q K V | F) = 153 KiB -> one workgroup per CU, 256 CUs =
-// 8 heads x 32 chunks.  F holds the fc1 block, then dO, then O.  Q/K/V are overwritten in place by dQ/dK/dV.
+// 8 heads x 32 chunks.  F holds dO, then O.  Q/K/V are overwritten in place by dQ/dK/dV.  The head's fc1 block lives in
+// registers as MFMA B fragments.
 #include <stdlib.h>
 
 #include "kernels.hpp"
@@ -78,6 +79,11 @@ struct FusedBwdArgs {
   do {                                                                                                   \
     *reinterpret_cast<float4*>(p) = make_float4(src[0], src[1], src[2], src[3]);                         \
     *reinterpret_cast<float4*>((p) + 4) = make_float4(src[4], src[5], src[6], src[7]);                   \
+  } while (0)
+#define ZR8(p)                                                                                           \
+  do {                                                                                                   \
+    *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+    *reinterpret_cast<float4*>((p) + 4) = make_float4(0.f, 0.f, 0.f, 0.f);                               \
   } while (0)
 
 // out[t][n] += A[t][k] . B[n][k]   (A rows and B rows in LDS)
@@ -142,30 +148,25 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
   const float padf = (float)n_pad;
   const bool hp = n_pad > 0;
   const int ii = li - li0;
-  float q[8], go[8], kk[ML][8], v[ML][8], kp[8], vp[8];
+  // three passes over the hyperedge's rows (K, then V, then K again) keep at most ML x 8 operand registers live
+  float q[8], p[ML], ds[ML], pp, dsp;
   LD8(q, &Qs[li * kLd + 8 * sub]);
-  LD8(go, &Fs[li * kLd + 8 * sub]);
-#pragma unroll
-  for (int j = 0; j < ML; ++j) {
-    const int rj = li0 + (j < k ? j : 0);
-    LD8(kk[j], &Ks[rj * kLd + 8 * sub]);
-    LD8(v[j], &Vs[rj * kLd + 8 * sub]);
-  }
-  LD8(kp, kpad + 8 * sub);
-  LD8(vp, vpad + 8 * sub);
-  float p[ML], ds[ML], pp, dsp;
   float mx = -3.4e38f;
-#pragma unroll
-  for (int j = 0; j < ML; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a += q[e] * kk[j][e];
-    a = group_sum8_dpp(a) * inv_temp;
-    a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
-    p[j] = a;
-    mx = (j < k) ? fmaxf(mx, a) : mx;
-  }
   {
+    float kk[ML][8], kp[8];
+#pragma unroll
+    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[(li0 + (j < k ? j : 0)) * kLd + 8 * sub]);
+    LD8(kp, kpad + 8 * sub);
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += q[e] * kk[j][e];
+      a = group_sum8_dpp(a) * inv_temp;
+      a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
+      p[j] = a;
+      mx = (j < k) ? fmaxf(mx, a) : mx;
+    }
     float a = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) a += q[e] * kp[e];
@@ -184,47 +185,62 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
 #pragma unroll
   for (int j = 0; j < ML; ++j) p[j] *= inv;
   pp *= inv;
-  // O_i
   const float ppf = padf * pp;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = ppf * vp[e];
-#pragma unroll
-  for (int j = 0; j < ML; ++j) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] += p[j] * v[j][e];
-  }
-  // dP_i. -> dS_i.
-  float sig = 0.f;
-#pragma unroll
-  for (int j = 0; j < ML; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a += go[e] * v[j][e];
-    a = group_sum8_dpp(a);
-    ds[j] = a;
-    sig += p[j] * a;
-  }
   {
-    float a = 0.f;
+    float go[8], v[ML][8], vp[8];
+    LD8(go, &Fs[li * kLd + 8 * sub]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a += go[e] * vp[e];
-    dsp = group_sum8_dpp(a);
-    sig += ppf * dsp;
+    for (int j = 0; j < ML; ++j) LD8(v[j], &Vs[(li0 + (j < k ? j : 0)) * kLd + 8 * sub]);
+    LD8(vp, vpad + 8 * sub);
+    // O_i
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ppf * vp[e];
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += p[j] * v[j][e];
+    }
+    // dP_i. -> dS_i.
+    float sig = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += go[e] * v[j][e];
+      a = group_sum8_dpp(a);
+      ds[j] = a;
+      sig += p[j] * a;
+    }
+    {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += go[e] * vp[e];
+      dsp = group_sum8_dpp(a);
+      sig += ppf * dsp;
+    }
+#pragma unroll
+    for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
+    dsp = pp * (dsp - sig) * inv_temp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[8 + e] += ppf * go[e];
   }
-#pragma unroll
-  for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
-  dsp = pp * (dsp - sig) * inv_temp;
   // dQ_i
   const float dspf = padf * dsp;
+  {
+    float kk[ML][8], kp[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) gq[e] = dspf * kp[e];
+    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[(li0 + (j < k ? j : 0)) * kLd + 8 * sub]);
+    LD8(kp, kpad + 8 * sub);
 #pragma unroll
-  for (int j = 0; j < ML; ++j) {
+    for (int e = 0; e < 8; ++e) gq[e] = dspf * kp[e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) gq[e] += ds[j] * kk[j][e];
+    for (int j = 0; j < ML; ++j) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] += ds[j] * kk[j][e];
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { acc[e] += dspf * q[e]; acc[8 + e] += ppf * go[e]; }
+  for (int e = 0; e < 8; ++e) acc[e] += dspf * q[e];
   // row i of P and dS for the column phase (every lane of the group holds the same values: lanes 0 / 1 write them)
   if (sub < 2) {
     float* dst = (sub == 0 ? Ps : dSs) + li * 8;
@@ -317,14 +333,17 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
 
   // ---- resident weights ----
   const int64_t wofs = (int64_t)head * 64 * 64;
-  float4 fw0, fw1, fw2, fw3;
+  float fcb[32];                      // B fragments of the head's fc1 block for dO = dDyn . Wfc1[:, head block] (constant per workgroup)
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) fcb[4 * c + x] = g.fc1_w[(int64_t)(8 * c + 4 * h + x) * 512 + head * 64 + 32 * wc + r];
   {
     float4 t0, t1, t2, t3;
     FB_GLOAD(t, g.wq + wofs, 64); FB_LSTORE(Wq, t);
     FB_GLOAD(t, g.wk + wofs, 64); FB_LSTORE(Wk, t);
     FB_GLOAD(t, g.wv + wofs, 64); FB_LSTORE(Wv, t);
   }
-  FB_GLOAD(fw, g.fc1_w + (int64_t)head * 64, 512);        // fc1_w[n][head*64 + k] as an [n][k] tile
   if (tid < 192) cb[tid] = (tid < 64 ? g.cq : (tid < 128 ? g.ck : g.cv))[head * 64 + (tid & 63)];
   if (tid < 16) {
     const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
@@ -394,11 +413,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     FB_T(7);
     // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the token -> hyperedge map ----
     FB_ROW_STAGE(0); FB_ROW_STAGE(1); FB_ROW_STAGE(2); FB_ROW_STAGE(3);
-    FB_LSTORE(Fs, fw);
     if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
     __syncthreads();
     FB_T(0);
-    // ---- recompute Q, K, V; dO = dDyn . Wfc1[:, head block] ----
+    // ---- recompute Q, K, V  (one accumulator at a time: fusing the three loops pushed hipcc into spilling) ----
     if (!(g.dbg & 2)) {
       f32x16 acc = {0};
       acc = gemm_nt(acc, Xs, Wq, wr, wc, r, h);
@@ -414,10 +432,19 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       acc = gemm_nt(acc, Xs, Wv, wr, wc, r, h);
       quad_store(Vs, acc, cb + 128, wr, wc, r, h);
     }
+    // ---- dO = dDyn . Wfc1[:, head block]  (B fragments in registers) ----
     {
       f32x16 acc = {0};
-      if (!(g.dbg & 2)) acc = gemm_nn(acc, Ds, Fs, wr, wc, r, h);
-      __syncthreads();                                // every wave has read the fc1 block
+      if (!(g.dbg & 2)) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float4 a = *reinterpret_cast<const float4*>(&Ds[(32 * wr + r) * kLd + 8 * c + 4 * h]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, fcb[4 * c + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, fcb[4 * c + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, fcb[4 * c + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, fcb[4 * c + 3], acc, 0, 0, 0);
+        }
+      }
       quad_store(Fs, acc, nullptr, wr, wc, r, h);
     }
     __syncthreads();
@@ -425,7 +452,6 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     // ---- attention forward + backward: 8 lanes per token, two passes of 32 tokens ----
     {
       float o0[8], q0[8], k0[8], v0[8], o1[8], q1[8], k1[8], v1[8];
-      const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const int la = wave * 8 + (lane >> 3), lb = la + 32;
       const bool acta = la < n_real && !(g.dbg & 1), actb = lb < n_real && !(g.dbg & 1);
       int ia = 0, ib = 0;
@@ -440,45 +466,19 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       if (acta) {
         ST8(&Fs[la * kLd + 8 * sub], o0); ST8(&Qs[la * kLd + 8 * sub], q0); ST8(&Ks[la * kLd + 8 * sub], k0); ST8(&Vs[la * kLd + 8 * sub], v0);
       } else {                                        // rows past the tile's tokens: zero, the column sums below run over all 64 rows
-        ST8(&Qs[la * kLd + 8 * sub], zero8); ST8(&Ks[la * kLd + 8 * sub], zero8); ST8(&Vs[la * kLd + 8 * sub], zero8);
+        ZR8(&Qs[la * kLd + 8 * sub]); ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
       }
       if (actb) {
         ST8(&Fs[lb * kLd + 8 * sub], o1); ST8(&Qs[lb * kLd + 8 * sub], q1); ST8(&Ks[lb * kLd + 8 * sub], k1); ST8(&Vs[lb * kLd + 8 * sub], v1);
       } else {
-        ST8(&Qs[lb * kLd + 8 * sub], zero8); ST8(&Ks[lb * kLd + 8 * sub], zero8); ST8(&Vs[lb * kLd + 8 * sub], zero8);
+        ZR8(&Qs[lb * kLd + 8 * sub]); ZR8(&Ks[lb * kLd + 8 * sub]); ZR8(&Vs[lb * kLd + 8 * sub]);
       }
     }
     __syncthreads();
     FB_T(4);
-    // next tile's rows and the fc1 block for its staging: in flight during the GEMMs below
+    // next tile's rows: in flight during the GEMMs below
     FB_ROWS_GLOAD(mn);
-    FB_GLOAD(fw, g.fc1_w + (int64_t)head * 64, 512);
-    // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
-    if (!(g.dbg & 4)) {
-#pragma unroll 1
-      for (int mm = 0; mm < 4; ++mm) {                // 8 contraction steps (16 tokens) per trip: operands first, then 32 MFMAs
-        float xk[8], ok[8], gq[8], gk[8], gv[8], gd[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = 16 * mm + 2 * u + h;
-          xk[u] = Xs[t * kLd + 32 * wc + r];
-          ok[u] = Fs[t * kLd + 32 * wc + r];
-          gq[u] = Qs[t * kLd + 32 * wr + r];
-          gk[u] = Ks[t * kLd + 32 * wr + r];
-          gv[u] = Vs[t * kLd + 32 * wr + r];
-          gd[u] = Ds[t * kLd + 32 * wr + r];
-          csq += gq[u]; csk += gk[u]; csv += gv[u]; csd += gd[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(gq[u], xk[u], aWq, 0, 0, 0);
-          aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[u], xk[u], aWk, 0, 0, 0);
-          aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u], xk[u], aWv, 0, 0, 0);
-          aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(gd[u], ok[u], aWf, 0, 0, 0);
-        }
-      }
-    }
-    FB_T(5);
+    // (stores first, weight gradients after: the stores are acknowledged long before the next tile waits on vmcnt)
     // ---- this head's share of d x_hat = dQ W'q + dK W'k + dV W'v ----
     if (!(g.dbg & 8)) {
       f32x16 dx = {0};
@@ -492,6 +492,48 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
         if (row < n_real) out[(int64_t)row * 64] = dx[reg];
       }
     }
+    FB_T(5);
+    // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
+    if (!(g.dbg & 4)) {
+      // 8 trips of 4 contraction steps (8 tokens); the operands of trip i + 1 are fetched before the 16 MFMAs of trip i.
+      // sched_barrier pins that order: left alone, the scheduler sinks every LDS read next to its MFMA to save
+      // registers and the wave then waits out the full LDS latency in front of each one.
+      float xa[4], oa[4], qa[4], ka[4], va[4], da[4], xb[4], ob[4], qb[4], kb[4], vb[4], db[4];
+      const float* px = Xs + h * kLd + 32 * wc + r;
+      const float* po = Fs + h * kLd + 32 * wc + r;
+      const float* pq = Qs + h * kLd + 32 * wr + r;
+      const float* pk = Ks + h * kLd + 32 * wr + r;
+      const float* pv = Vs + h * kLd + 32 * wr + r;
+      const float* pd = Ds + h * kLd + 32 * wr + r;
+#define FB_TN_LOAD(S, OFF)                                                                               \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                        \
+    x##S[u] = px[((OFF) + 2 * u) * kLd]; o##S[u] = po[((OFF) + 2 * u) * kLd];                            \
+    q##S[u] = pq[((OFF) + 2 * u) * kLd]; k##S[u] = pk[((OFF) + 2 * u) * kLd];                            \
+    v##S[u] = pv[((OFF) + 2 * u) * kLd]; d##S[u] = pd[((OFF) + 2 * u) * kLd];                            \
+  }
+#define FB_TN_MMA(S)                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                        \
+    csq += q##S[u]; csk += k##S[u]; csv += v##S[u]; csd += d##S[u];                                      \
+    aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(q##S[u], x##S[u], aWq, 0, 0, 0);                          \
+    aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(k##S[u], x##S[u], aWk, 0, 0, 0);                          \
+    aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(v##S[u], x##S[u], aWv, 0, 0, 0);                          \
+    aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(d##S[u], o##S[u], aWf, 0, 0, 0);                          \
+  }
+      FB_TN_LOAD(a, 0);
+#pragma unroll 1
+      for (int mm = 0; mm < 4; ++mm) {
+        FB_TN_LOAD(b, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        FB_TN_MMA(a);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = (mm == 3) ? -48 : 16;           // last trip: a harmless re-read of trip 0
+        px += nx * kLd; po += nx * kLd; pq += nx * kLd; pk += nx * kLd; pv += nx * kLd; pd += nx * kLd;
+        FB_TN_LOAD(a, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        FB_TN_MMA(b);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     mc = mn; mn = mnn;
   }
 
@@ -499,7 +541,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   __syncthreads();
 #ifdef FB_TIMING
   if (blockIdx.x == 0 && tid == 0)
-    printf("fused_bwd wg0 us: stage %.1f pre-gemm %.1f attn-row %.1f attn-col %.1f attn-write %.1f tn %.1f dx+wait %.1f (tiles %d)\n", tph[0] * 0.01,
+    printf("fused_bwd wg0 us: stage %.1f pre-gemm %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn+wait %.1f (tiles %d)\n", tph[0] * 0.01,
            tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
 #endif
   float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
