@@ -43,7 +43,8 @@ struct FusedFwdArgs {
   const int32_t* row_off;         // [B+1]
   const int32_t* tok_slot;        // [Tn]
   const int32_t* count;           // {Tr+1, Tr}
-  const int32_t* tile_b0;         // [ntiles+1]
+  const int32_t* tile_meta;       // [ntiles+2][4]
+  const int32_t* tok_pos;         // [Tn]
   int64_t B;
   int L;
   const float* wq; const float* wk; const float* wv;     // folded, [512, 64]
@@ -115,94 +116,70 @@ __device__ __forceinline__ void quad_store(float* __restrict__ Ts, const f32x16&
   }
 }
 
-// attention of one hyperedge for one head from LDS tiles; 8 lanes, lane `sub` owns features [8 sub, 8 sub + 8)
+// Attention output of ONE query token for one head from LDS tiles (8 lanes, lane `sub` owns features [8 sub, 8 sub + 8)):
+// a tile's <= 63 tokens fill the workgroup's 32 lane groups in two passes, and the work per group is O(k), not O(k^2).
+// Branch-free over the ML key slots (slots j >= k: clamped row, probability forced to 0).  O_i overwrites the token's own
+// Q row (no other task reads it).
 template <int ML>
-__device__ __forceinline__ void attn_group_fwd(float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs, int li0, int k,
-                                               int n_pad, int pad_row, int sub, float inv_temp) {
-  float q[ML][8], kk[ML][8], kp[8];
-#pragma unroll
-  for (int i = 0; i < ML; ++i)
-    if (i < k) {
-      const float4 a = *reinterpret_cast<const float4*>(&Qs[(li0 + i) * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Qs[(li0 + i) * kLdT + 8 * sub + 4]);
-      q[i][0] = a.x; q[i][1] = a.y; q[i][2] = a.z; q[i][3] = a.w; q[i][4] = b.x; q[i][5] = b.y; q[i][6] = b.z; q[i][7] = b.w;
-      const float4 c = *reinterpret_cast<const float4*>(&Ks[(li0 + i) * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[(li0 + i) * kLdT + 8 * sub + 4]);
-      kk[i][0] = c.x; kk[i][1] = c.y; kk[i][2] = c.z; kk[i][3] = c.w; kk[i][4] = e.x; kk[i][5] = e.y; kk[i][6] = e.z; kk[i][7] = e.w;
-    }
-  if (n_pad > 0) {
-    const float4 c = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub + 4]);
-    kp[0] = c.x; kp[1] = c.y; kp[2] = c.z; kp[3] = c.w; kp[4] = e.x; kp[5] = e.y; kp[6] = e.z; kp[7] = e.w;
-  }
-  float S[ML][ML], Sp[ML];
+__device__ __forceinline__ void attn_row_fwd(float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs, int li, int li0, int k,
+                                             int n_pad, int pad_row, int sub, float inv_temp) {
   const float padf = (float)n_pad;
+  const bool hp = n_pad > 0;
+  const int ii = li - li0;
+  float q[8], p[ML], pp;
+  {
+    const float4 a = *reinterpret_cast<const float4*>(&Qs[li * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Qs[li * kLdT + 8 * sub + 4]);
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+  }
+  float mx = -3.4e38f;
 #pragma unroll
-  for (int i = 0; i < ML; ++i)
-    if (i < k) {
-      float mx = -3.4e38f;
+  for (int j = 0; j < ML; ++j) {
+    const int rj = li0 + (j < k ? j : 0);
+    const float4 c = *reinterpret_cast<const float4*>(&Ks[rj * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[rj * kLdT + 8 * sub + 4]);
+    float a = ((q[0] * c.x + q[1] * c.y) + (q[2] * c.z + q[3] * c.w)) + ((q[4] * e.x + q[5] * e.y) + (q[6] * e.z + q[7] * e.w));
+    a = group_sum8_dpp(a) * inv_temp;
+    a = (j == ii) ? -1e32f : a;                       // masked diagonal (Modules.py:443-445)
+    p[j] = a;
+    mx = (j < k) ? fmaxf(mx, a) : mx;
+  }
+  {
+    const float4 c = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub + 4]);
+    const float a = ((q[0] * c.x + q[1] * c.y) + (q[2] * c.z + q[3] * c.w)) + ((q[4] * e.x + q[5] * e.y) + (q[6] * e.z + q[7] * e.w));
+    pp = group_sum8_dpp(a) * inv_temp;
+    mx = hp ? fmaxf(mx, pp) : mx;
+  }
+  float den = 0.f;
 #pragma unroll
-      for (int j = 0; j < ML; ++j)
-        if (j < k) {
-          float a = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a += q[i][e] * kk[j][e];
-          float v = group_sum8_dpp(a) * inv_temp;
-          if (i == j) v = -1e32f;
-          S[i][j] = v;
-          mx = fmaxf(mx, v);
-        }
-      Sp[i] = 0.f;
-      if (n_pad > 0) {
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a += q[i][e] * kp[e];
-        Sp[i] = group_sum8_dpp(a) * inv_temp;
-        mx = fmaxf(mx, Sp[i]);
-      }
-      float den = 0.f;
-#pragma unroll
-      for (int j = 0; j < ML; ++j)
-        if (j < k) { S[i][j] = expf(S[i][j] - mx); den += S[i][j]; }
-      if (n_pad > 0) { Sp[i] = expf(Sp[i] - mx); den += padf * Sp[i]; }
-      const float inv = 1.f / den;
-#pragma unroll
-      for (int j = 0; j < ML; ++j)
-        if (j < k) S[i][j] *= inv;
-      Sp[i] = n_pad > 0 ? Sp[i] * inv : 0.f;
-    }
-  // O_i = sum_j P_ij V_j + n_pad Pp_i V_pad   -> overwrites this hyperedge's own Q rows
-  float v[ML][8], vp[8];
-#pragma unroll
-  for (int j = 0; j < ML; ++j)
-    if (j < k) {
-      const float4 a = *reinterpret_cast<const float4*>(&Vs[(li0 + j) * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[(li0 + j) * kLdT + 8 * sub + 4]);
-      v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w; v[j][4] = b.x; v[j][5] = b.y; v[j][6] = b.z; v[j][7] = b.w;
-    }
-  if (n_pad > 0) {
+  for (int j = 0; j < ML; ++j) {
+    p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
+    den += p[j];
+  }
+  pp = hp ? __expf(pp - mx) : 0.f;
+  den += padf * pp;
+  const float inv = __builtin_amdgcn_rcpf(den);
+  const float ppf = padf * pp * inv;
+  float o[8];
+  {
     const float4 a = *reinterpret_cast<const float4*>(&Vs[pad_row * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[pad_row * kLdT + 8 * sub + 4]);
-    vp[0] = a.x; vp[1] = a.y; vp[2] = a.z; vp[3] = a.w; vp[4] = b.x; vp[5] = b.y; vp[6] = b.z; vp[7] = b.w;
+    o[0] = ppf * a.x; o[1] = ppf * a.y; o[2] = ppf * a.z; o[3] = ppf * a.w; o[4] = ppf * b.x; o[5] = ppf * b.y; o[6] = ppf * b.z; o[7] = ppf * b.w;
   }
 #pragma unroll
-  for (int i = 0; i < ML; ++i)
-    if (i < k) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (n_pad > 0) ? padf * Sp[i] * vp[e] : 0.f;
-#pragma unroll
-      for (int j = 0; j < ML; ++j)
-        if (j < k) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += S[i][j] * v[j][e];
-        }
-      *reinterpret_cast<float4*>(&Qs[(li0 + i) * kLdT + 8 * sub]) = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(&Qs[(li0 + i) * kLdT + 8 * sub + 4]) = make_float4(o[4], o[5], o[6], o[7]);
-    }
+  for (int j = 0; j < ML; ++j) {
+    const int rj = li0 + (j < k ? j : 0);
+    const float w = p[j] * inv;
+    const float4 a = *reinterpret_cast<const float4*>(&Vs[rj * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[rj * kLdT + 8 * sub + 4]);
+    o[0] += w * a.x; o[1] += w * a.y; o[2] += w * a.z; o[3] += w * a.w; o[4] += w * b.x; o[5] += w * b.y; o[6] += w * b.z; o[7] += w * b.w;
+  }
+  *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub]) = make_float4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub + 4]) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
 // LayerNorm statistics of a 64-float row held as one float4 per lane over 16 lanes
 __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rstd) {
-  const float s = group_sum<16>((v.x + v.y) + (v.z + v.w));
+  const float s = group_sum16_dpp((v.x + v.y) + (v.z + v.w));
   mean = s * (1.f / 64.f);
   const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
-  const float q = group_sum<16>((a * a + b * b) + (c * c + e * e));
+  const float q = group_sum16_dpp((a * a + b * b) + (c * c + e * e));
   rstd = 1.0f / sqrtf(q * (1.f / 64.f) + kEps);
 }
 __device__ __forceinline__ float4 ln_apply(const float4& v, float mean, float rstd, const float4& g, const float4& b) {
@@ -244,13 +221,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
 
   // ---- tile -> hyperedges [b0, b1), tokens [t0, t1) (+ the padding token as local row n_real) ----
   // window of first-token indices: a hyperedge starting at <= 63 - L ends at <= 63, so the tile holds <= 63 real tokens
-  const int b0 = g.tile_b0[blockIdx.x], b1 = g.tile_b0[blockIdx.x + 1];      // planned by ragged.hip (no search here)
-  if (b0 >= b1) return;                              // no hyperedge starts in this window
-  const int t0 = g.row_off[b0];
-  const int t1 = g.row_off[b1];
-  const int n_real = t1 - t0;                        // <= 63
+  const int4 meta = reinterpret_cast<const int4*>(g.tile_meta)[blockIdx.x];   // planned by ragged.hip
+  const int t0 = meta.x, n_real = meta.y, b0 = meta.z, n_h = meta.w;            // n_real <= 63
+  if (n_h <= 0) return;                              // no hyperedge starts in this window
   const int tok_pad = g.count[1];                    // Tr: index of the shared padding token
-  const int n_h = b1 - b0;
   const float inv_temp = 0.125f;                     // 1/sqrt(64)
 
   // weight tiles are fetched TWO phases ahead into two alternating register sets (A: Wq / Wv, B: Wk / Wfc1)
@@ -260,10 +234,15 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   // per-tile metadata in LDS: local row offsets of the tile's hyperedges and the folded projection biases of all heads
   // (small dependent global loads inside the head loop each cost a full L2 round trip at one or two waves per SIMD)
   int* roff = reinterpret_cast<int*>(lds + 4 * kTileF);          // [n_h + 1] (<= 64 hyperedges + 1)
-  float* cbias = lds + 4 * kTileF + 80;                           // [3][512]
+  int* tinfo = roff + 80;                                         // [64] per token row: first row of its hyperedge | k << 8
+  float* cbias = lds + 4 * kTileF + 144;                          // [3][512]
   const bool lroff = n_h <= 78;                                   // more only when many all-padding rows share the window
   if (lroff)
     for (int i = tid; i <= n_h; i += 256) roff[i] = g.row_off[b0 + i] - t0;
+  if (tid < n_real) {
+    const int tp = g.tok_pos[t0 + tid];
+    tinfo[tid] = (tid - (tp & 255)) | (tp & ~255);
+  }
   for (int i = tid; i < 3 * 512; i += 256) cbias[i] = (i < 512) ? g.cq[i] : (i < 1024 ? g.ck[i - 512] : g.cv[i - 1024]);
 
   // ---- x_hat fragments straight from global memory: lane (r, h) holds k = 8c + 4h .. +3 of row 32 wr + r; the other
@@ -331,14 +310,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     __syncthreads();                                   // Q, K, V tiles complete; Bs free
     TILE_LSTORE(Bs, wB);                               // fc1 block (read after the next barrier)
     TILE_GLOAD(wB, last ? g.p1w : g.wk + wofs + 64 * 64, 64);
-    // ---- attention: 8 lanes per hyperedge, 8 hyperedges per wave per pass ----
-    for (int e0 = 0; e0 < n_h && !(g.dbg & 1); e0 += 32) {
-      const int e = e0 + wave * 8 + (lane >> 3);
-      if (e < n_h) {
-        const int li0 = lroff ? roff[e] : g.row_off[b0 + e] - t0;
-        const int k = (lroff ? roff[e + 1] : g.row_off[b0 + e + 1] - t0) - li0;
-        if (k > 0) attn_group_fwd<ML>(Qs, Ks, Vs, li0, k, g.L - k, n_real, lane & 7, inv_temp);
-      }
+    // ---- attention: 8 lanes per query token, two passes of 32 tokens ----
+    if (!(g.dbg & 1)) {
+      const int la = wave * 8 + (lane >> 3), lb = la + 32;
+      if (la < n_real) { const int ti = tinfo[la]; attn_row_fwd<ML>(Qs, Ks, Vs, la, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp); }
+      if (lb < n_real) { const int ti = tinfo[lb]; attn_row_fwd<ML>(Qs, Ks, Vs, lb, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp); }
     }
     __syncthreads();
     // ---- dyn += O_h . Wfc1[:, head block]^T ----
@@ -431,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       ln_row16(xv, m, rs);
       const float4 sn = ln_apply(xv, m, rs, G2, B2);
       const float a = dn.x - sn.x, b = dn.y - sn.y, c = dn.z - sn.z, e = dn.w - sn.w;
-      const float o = group_sum<16>((a * a * Wc.x + b * b * Wc.y) + (c * c * Wc.z + e * e * Wc.w)) + bc;
+      const float o = group_sum16_dpp((a * a * Wc.x + b * b * Wc.y) + (c * c * Wc.z + e * e * Wc.w)) + bc;
       if ((tid & 15) == 0) outs[row] = o;
     }
   }
@@ -468,7 +444,7 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
                      hipStream_t st) {
   FusedFwdArgs g;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
-  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.tile_b0 = rg.tile_b0; g.B = B; g.L = L;
+  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.B = B; g.L = L;
   g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
   g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
   g.fc1_w = p.fc1_w; g.fc1_b = p.fc1_b; g.p0w = p.pff0_w; g.p0b = p.pff0_b; g.p1w = p.pff1_w; g.p1b = p.pff1_b;
@@ -477,7 +453,7 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   { static const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int ntiles = rg.ntiles;
-  const size_t lds = ((size_t)4 * kTileF + 80 + 3 * 512) * sizeof(float);
+  const size_t lds = ((size_t)4 * kTileF + 144 + 3 * 512) * sizeof(float);
   auto launch = [&](auto kfn) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);
