@@ -31,7 +31,10 @@ from matcha_amd import _lib, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA peak (no xf32/TF32 on gfx950)
-GEMM_CLASSES = ("gemm_nt", "gemm_nn", "gemm_tn")
+# MFMA-bound kernel classes.  The fused kernels count ALGORITHMIC GEMM flops only: fused_fwd 4 projections per
+# head + the two pff GEMMs; fused_bwd 8 GEMMs per head (dO, dWfc1, 3 dW', 3 d x_hat terms) -- the Q/K/V recompute of the
+# backward kernel and the O(k) attention arithmetic are not counted.
+GEMM_CLASSES = ("gemm_nt", "gemm_nn", "gemm_tn", "fused_fwd", "fused_bwd")
 
 
 def parse():

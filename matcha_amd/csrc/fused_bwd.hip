@@ -743,7 +743,8 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
     };
-    ProfScope ps(MATCHA_PROF_FUSED_BWD, 0.0, st);
+    // algorithmic flops: 8 heads x 8 GEMMs (dO, dWfc1, 3 dW', 3 d x_hat terms) of 2*64*64 per token; the Q/K/V recompute is not counted
+    ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
     switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
       case 2: launch(fused_bwd_kernel<2>); break;
       case 3: launch(fused_bwd_kernel<3>); break;

@@ -60,16 +60,6 @@ struct FusedFwdArgs {
   int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 = skip attention, 2 = skip projection GEMMs
 };
 
-__device__ __forceinline__ int lower_bound_rows(const int32_t* __restrict__ row_off, int64_t B, int target) {
-  // first b in [0, B] with row_off[b] >= target
-  int64_t lo = 0, hi = B;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (row_off[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  return (int)lo;
-}
-
 // stage a [64 x 64] fp32 block (row stride src_ld) into an LDS tile [64][68]
 __device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, int64_t src_ld) {
   const int srow = threadIdx.x >> 4, sc4 = (threadIdx.x & 15) * 4;
@@ -458,7 +448,8 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);
   };
-  ProfScope ps(MATCHA_PROF_FUSED_FWD, 0.0, st);
+  // algorithmic flops per token: 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
+  ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);
   switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
     case 2: launch(fused_fwd_kernel<2>); break;
     case 3: launch(fused_fwd_kernel<3>); break;
