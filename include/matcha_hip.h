@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MATCHA_ABI_VERSION 1
+#define MATCHA_ABI_VERSION 2
 
 #define MATCHA_OK 0
 #define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
@@ -148,7 +148,8 @@ size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L);
  *   x      int64 [B,L], 0 = padding
  *   y, w   float [B] labels / BCE weights, may be NULL (then no loss is computed)
  *   logits float [B]  (the reference returns [B,1] logits; callers apply sigmoid themselves)
- *   losses float [2]  {bce (mean over B), recon_loss}
+ *   losses float [3]  {bce (mean over B), recon_loss, m = rows the recon mean ran over (0 in table mode)} -- m lets
+ *                     data-parallel callers weight each rank's recon gradient by m_rank / m_global
  * Activations needed by matcha_backward stay in `ws`. */
 int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
                    const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L,

@@ -395,7 +395,7 @@ class _ClassifierFn(torch.autograd.Function):
         B, L = x.shape
         ws = rt.workspace(B, L)
         logits = torch.empty(B, dtype=torch.float32, device=rt.device)
-        losses = torch.zeros(2, dtype=torch.float32, device=rt.device)
+        losses = torch.zeros(3, dtype=torch.float32, device=rt.device)
         _lib.check(rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                          None, None, _lib.ptr(logits), _lib.ptr(losses), _lib.ptr(ws), ws.numel(), rt.stream()),
                    "matcha_forward")

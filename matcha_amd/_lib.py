@@ -104,7 +104,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.matcha_abi_version() != 1:
+    if lib.matcha_abi_version() != 2:
         raise MatchaHipError("libmatcha_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -436,7 +436,10 @@ __global__ __launch_bounds__(256) void adj_recon_final_kernel(const float* __res
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = m > 0 ? 100.f * red[0] / ((float)m * (float)n_r) : 0.f;
+  if (threadIdx.x == 0) {
+    out[0] = m > 0 ? 100.f * red[0] / ((float)m * (float)n_r) : 0.f;
+    out[1] = (float)m;                 // losses[2]: rows of the mean (data-parallel weighting)
+  }
 }
 
 // D *= g * 200 / (m * n_r)   with g = *drecon (autograd) or beta
@@ -521,7 +524,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
   }
   if (!recon_out) return MATCHA_OK;
   if (r < 0) {
-    if (hipMemsetAsync(recon_out, 0, sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    if (hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
     return MATCHA_OK;
   }
   // recon branch (Modules.py:192-199)

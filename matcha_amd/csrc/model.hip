@@ -222,7 +222,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
     MATCHA_TRY(launch_embed_fwd(ids, Tn, d, p.table, nullptr, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st, cnt));
-    if (recon_out && hipMemsetAsync(recon_out, 0, sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    if (recon_out && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
   } else {
     MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot));
     MATCHA_TRY(launch_embed_fwd(ids, Tn, d, nullptr, w.node, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st, cnt));

@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from .Modules import Classifier, _Runtime
-from .parallel import allreduce_gradients, broadcast_parameters
+from .parallel import allreduce_gradients, broadcast_parameters, recon_grad_weight
 
 
 class Trainer:
@@ -42,7 +42,7 @@ class Trainer:
         self.seg_step = torch.zeros(n_seg, dtype=torch.int32, device=dev)
         self.seg_coef = torch.zeros(3 * n_seg, dtype=torch.float32, device=dev)
         self.touched = torch.zeros(rt.n_touched, dtype=torch.int32, device=dev)
-        self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(3, dtype=torch.float32, device=dev)     # bce, recon, rows of the recon mean
         self.seed = torch.full((1,), int(base_seed), dtype=torch.int64, device=dev)
         self._ws = {}
         self._logits = {}
@@ -84,9 +84,13 @@ class Trainer:
         _lib.check(self.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                            _lib.ptr(y), _lib.ptr(w), _lib.ptr(logits), _lib.ptr(self.losses), _lib.ptr(ws), ws.numel(),
                                            st), "matcha_forward")
+        drecon = None
+        if (self.world > 1 or self.force_collectives) and rt.shape.mode == 1 and beta != 0.0:
+            # adj front end under data parallel: the recon loss is a mean over a rank-dependent number of rows
+            drecon = recon_grad_weight(self.losses[2:3], beta, self.pg)
         _lib.check(self.lib.matcha_backward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
-                                            _lib.ptr(y), _lib.ptr(w), None, None, C.byref(self.grads), _lib.ptr(self.touched),
-                                            _lib.ptr(ws), ws.numel(), st), "matcha_backward")
+                                            _lib.ptr(y), _lib.ptr(w), None, _lib.ptr(drecon) if drecon is not None else None,
+                                            C.byref(self.grads), _lib.ptr(self.touched), _lib.ptr(ws), ws.numel(), st), "matcha_backward")
         return logits
 
     def all_reduce(self):

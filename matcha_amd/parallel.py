@@ -42,6 +42,20 @@ def allreduce_gradients(gflat: torch.Tensor, touched: Optional[torch.Tensor], gr
     return 1.0 / world
 
 
+def recon_grad_weight(m_local: torch.Tensor, beta: float, group=None) -> torch.Tensor:
+    """Upstream gradient of the reconstruction loss for THIS rank so that the averaged gradient equals the single-rank
+    one on the global batch.  The reference's recon loss is a mean over the m "other" tokens of the
+    drawn chromosome (Modules.py:195-199); with m_r rows on rank r the global mean is sum_r(m_r * loss_r) / sum_r(m_r),
+    so rank r contributes with weight  beta * m_r / sum(m) * world  (the optimizer later divides the summed gradient by
+    world).  ``m_local`` is the 1-element device tensor ``losses[2:3]`` written by matcha_forward; no host sync."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return m_local.new_full((1,), float(beta))
+    world = dist.get_world_size(group)
+    total = m_local.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return float(beta) * world * m_local / torch.clamp(total, min=1.0)
+
+
 def broadcast_parameters(flat: torch.Tensor, src: int = 0, group=None):
     """Replicate rank ``src``'s flat parameter buffer (call once after building the model)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -188,3 +188,39 @@ def test_adj_backward_with_dropout_matches_oracle():
         ref = grads[n].numpy()
         assert p.grad is not None, n
         assert np.abs(p.grad.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+
+
+def test_recon_row_count_and_explicit_recon_gradient():
+    """matcha_forward reports the number of rows the recon mean ran over (losses[2]); feeding beta through the device-side
+    `drecon` pointer (the data-parallel weighting path, matcha_amd/parallel.py::recon_grad_weight) gives the same
+    gradients as the scalar beta."""
+    import ctypes as C
+    from matcha_amd import _lib
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["tiny"]
+    N = int(np.sum(num))
+    x, y, w = synth.make_batch(np.random.default_rng(3), N, [2, 3, 5], 20)
+    xt, yt, wt = (torch.from_numpy(a).cuda() for a in (x, y, w))
+    n2c = synth.node2chrom(num)[x]
+    grads = []
+    for explicit in (False, True):
+        clf, _ = hip_model(num, 16, "adj", 31)
+        clf.eval()
+        tr = Trainer(clf)
+        rt = tr.rt
+        B, L = xt.shape
+        ws, logits = tr._buffers(B, L)
+        opts = tr._opts(1.0, 0.25, 2)
+        yv, wv = yt.reshape(-1).contiguous(), wt.reshape(-1).contiguous()
+        _lib.check(tr.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(xt), B, L,
+                                         _lib.ptr(yv), _lib.ptr(wv), _lib.ptr(logits), _lib.ptr(tr.losses), _lib.ptr(ws), ws.numel(),
+                                         rt.stream()), "matcha_forward")
+        assert float(tr.losses[2]) == float(((n2c >= 0) & (n2c != 2)).sum())
+        drecon = torch.full((1,), 0.25, device="cuda") if explicit else None
+        _lib.check(tr.lib.matcha_backward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(xt), B, L,
+                                          _lib.ptr(yv), _lib.ptr(wv), None, _lib.ptr(drecon) if explicit else None, C.byref(tr.grads),
+                                          _lib.ptr(tr.touched), _lib.ptr(ws), ws.numel(), rt.stream()), "matcha_backward")
+        torch.cuda.synchronize()
+        grads.append(tr.gflat.clone())
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
