@@ -15,7 +15,7 @@ What it does
     main.py:630 builds it, and the reference's own save_embeddings / get_attributes /
     generate_negative (function bodies exec'd out of main.py's AST, because main.py has no
     __main__ guard and cannot be imported);
-  * writes G1..G5 of SURVEY.md §8(c2) + sampler statistics.
+  * writes G1..G5 of SURVEY.md §8(c2) + sampler statistics + G6 (inference consumers, §8 f1).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -281,6 +281,75 @@ def sampler_stats(M, U):
     np.savez_compressed(os.path.join(HERE, "sampler_stats.npz"), **out)
 
 
+def ref_functions(fname, names, glb):
+    """exec selected top-level function definitions of a reference script that cannot be imported (no __main__ guard)."""
+    tree = ast.parse(open(os.path.join(REF, fname)).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    exec(compile(ast.Module(body=body, type_ignores=[]), os.path.join(REF, fname), "exec"), glb)
+    return glb
+
+
+def g6_inference(M, U):
+    """G6: the inference consumers on the reference-pickled tiny models -- predict_multiway.py's
+    parse_file + predict (+ sigmoid) on a small text file, and denoise_contact.py's generate_pair_wise + predict +
+    proba2matrix for two chromosomes."""
+    from torch.nn.utils.rnn import pad_sequence
+    num = synth.LAYOUTS["tiny"]
+    cr = np.asarray(synth.chrom_range(num))
+    res = 1000000
+    names = [f"chr{i + 1}" for i in range(len(num))]
+    bin2node, node = {}, 1
+    for c, n in enumerate(num):
+        for b in range(n):
+            bin2node[f"{names[c]}:{b * res}"] = node
+            node += 1
+    rng = np.random.default_rng(66)
+    lines = []
+    for _ in range(40):
+        k = int(rng.integers(1, 7))
+        items = []
+        for _ in range(k):
+            c = int(rng.integers(0, len(num) + 1))                     # one value past the list: a chromosome to be skipped
+            cname = names[c] if c < len(num) else "chrX"
+            nb = num[c] if c < len(num) else 16
+            items.append(f"{cname}:{int(rng.integers(0, nb * res))}")   # unaligned position -> floor to the bin
+        if rng.random() < 0.3 and items:
+            items.append(items[0])                                     # duplicate bin inside a line
+        lines.append("\t".join(items))
+    text = "\n".join(lines) + "\n"
+    tmp = tempfile.mkdtemp(prefix="matcha_g6_")
+    np.save(os.path.join(tmp, "bin2node.npy"), bin2node)
+    with open(os.path.join(tmp, "in.txt"), "w") as f:
+        f.write(text)
+    common = dict(np=np, os=os, sys=sys, math=math, torch=torch, print=lambda *a, **k: None, trange=range,
+                  np2tensor_hyper=U.np2tensor_hyper, pad_sequence=pad_sequence, device=torch.device("cpu"))
+    pm = ref_functions("predict_multiway.py", {"parse_file", "predict"}, dict(common, temp_dir=tmp, chrom_list=names, res=res))
+    dc = ref_functions("denoise_contact.py", {"generate_pair_wise", "proba2matrix", "predict"}, dict(common, chrom_range=cr, min_dis=2))
+    parsed = pm["parse_file"](os.path.join(tmp, "in.txt"))
+    samples = np.empty(len(parsed), dtype=object)
+    for i, row in enumerate(parsed):
+        samples[i] = list(row)
+    out = {"text": np.array(text), "res": np.int64(res), "names": np.array(names),
+           "bin_keys": np.array(list(bin2node.keys())), "bin_vals": np.array(list(bin2node.values()), dtype=np.int64),
+           "n_samples": np.int64(len(parsed)), "sample_len": np.array([len(r) for r in parsed], dtype=np.int64),
+           "samples_pad": np.array([list(r) + [0] * (8 - len(r)) for r in parsed], dtype=np.int64)}
+    for mode in ("adj", "table"):
+        with redirect_stdout(io.StringIO()):
+            clf = torch.load(os.path.join(HERE, f"ref_model2load_tiny_{mode}"), map_location="cpu", weights_only=False)
+        # predict_multiway.py:104-112 (script body): predict in chunks of 1e4 rows, padded per chunk, then sigmoid
+        logits = pm["predict"](clf, samples)
+        out[f"multiway_proba_{mode}"] = torch.sigmoid(torch.from_numpy(logits)).numpy()
+        for cid in (0, 2):
+            pw = dc["generate_pair_wise"](cid)
+            lg = dc["predict"](clf, pw).reshape(-1)
+            proba = torch.sigmoid(torch.from_numpy(lg)).numpy()                       # denoise_contact.py:151-153
+            out[f"pairs_c{cid}"] = pw.copy()
+            out[f"pair_proba_{mode}_c{cid}"] = proba
+            out[f"pair_matrix_{mode}_c{cid}"] = dc["proba2matrix"](pw.copy(), None, proba)   # (mutates its first argument)
+    np.savez_compressed(os.path.join(HERE, "g6_inference_tiny.npz"), **out)
+    print("G6", len(parsed), "multiway samples;", {k: v.shape for k, v in out.items() if k.startswith("pair_matrix")})
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
@@ -296,6 +365,7 @@ def main():
     g3_train(M, "hg38_table_d64", synth.LAYOUTS["hg38_1mb"], 64, "table", 41, 1.0, 0.001, "phase2", n_steps=3, full=False)
     g3_train(M, "hg38_adj_d64", synth.LAYOUTS["hg38_1mb"], 64, "adj", 42, 1.0, 0.001, "phase2", n_steps=3, full=False)
     sampler_stats(M, U)
+    g6_inference(M, U)
 
 
 if __name__ == "__main__":
