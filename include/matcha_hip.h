@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MATCHA_ABI_VERSION 2
+#define MATCHA_ABI_VERSION 3
 
 #define MATCHA_OK 0
 #define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
@@ -139,6 +139,10 @@ typedef struct matcha_step_opts {
   const uint64_t* seed;      /* DEVICE pointer to the 64-bit dropout seed of this step (graph-replay safe) */
   int32_t forward_only;      /* 1: matcha_backward will NOT be called on this workspace (inference / no_grad): the
                                 forward may keep every intermediate on chip (fused kernel) and save nothing          */
+  int32_t loss_in_forward;   /* 1 (training step with y, w given; embed_dim 64): matcha_forward also runs the backward of the
+                                classifier tail for loss = alpha*bce (+ beta*recon) and keeps the result in the workspace;
+                                matcha_backward must then be called with the SAME opts and dlogits == NULL.  0: the
+                                backward pass starts from the saved activations (required for an arbitrary dlogits)   */
 } matcha_step_opts;
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */

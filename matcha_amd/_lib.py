@@ -46,7 +46,7 @@ class Frozen(C.Structure):
 class StepOpts(C.Structure):
     _fields_ = [("training", C.c_int32), ("random_chrom", C.c_int32), ("p_drop_adj", C.c_float),
                 ("p_drop_fc1", C.c_float), ("p_drop_pff", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
-                ("seed", _fp), ("forward_only", C.c_int32)]
+                ("seed", _fp), ("forward_only", C.c_int32), ("loss_in_forward", C.c_int32)]
 
 
 class GemmEpilogue(C.Structure):
@@ -104,7 +104,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.matcha_abi_version() != 2:
+    if lib.matcha_abi_version() != 3:
         raise MatchaHipError("libmatcha_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -58,7 +58,25 @@ struct FusedFwdArgs {
   const uint64_t* seed;
   float p_fc1, p_pff;
   int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 = skip attention, 2 = skip projection GEMMs
+  // training step with the loss known here (Trainer path): the kernel goes on with dL/dlogit = alpha w (sigmoid(z) - y) / B
+  // and runs the backward of the classifier tail and of pff_n1 while Y, H1, H2 are still in LDS
+  float* ddyn0;                   // [Tn, 64] gradient at the fc1 output (before bias; dropout / row mask applied); null: off
+  float* dXs;                     // [Tn, 64] gradient into X through the static branch (layer_norm2)
+  float* tslab;                   // [ntiles][kTailSlab] per-tile partials: dW1, dW0, 9 column-sum vectors, d bc
+  float alpha_over_B;
 };
+constexpr int kTailVec = 2 * 4096;                 // offset of the vectors inside a tile's slab
+constexpr int kTailSlab = 2 * 4096 + 10 * 64;      // {gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b} x 64, then bc (+ padding)
+
+// LayerNorm backward of a row held as one float4 per lane over 16 lanes: dx = rstd (dxh - mean(dxh) - xh mean(dxh xh))
+__device__ __forceinline__ float4 ln_bwd16(const float4& dxh, const float4& xh, float rstd) {
+  const float a = group_sum16_dpp((dxh.x + dxh.y) + (dxh.z + dxh.w)) * (1.f / 64.f);
+  const float b = group_sum16_dpp((dxh.x * xh.x + dxh.y * xh.y) + (dxh.z * xh.z + dxh.w * xh.w)) * (1.f / 64.f);
+  return make_float4(rstd * (dxh.x - a - xh.x * b), rstd * (dxh.y - a - xh.y * b), rstd * (dxh.z - a - xh.z * b), rstd * (dxh.w - a - xh.w * b));
+}
+#define F4_FMA(acc, a, b) do { acc.x += (a).x * (b).x; acc.y += (a).y * (b).y; acc.z += (a).z * (b).z; acc.w += (a).w * (b).w; } while (0)
+#define F4_ADD(acc, a) do { acc.x += (a).x; acc.y += (a).y; acc.z += (a).z; acc.w += (a).w; } while (0)
+#define F4_MUL(a, b) make_float4((a).x * (b).x, (a).y * (b).y, (a).z * (b).z, (a).w * (b).w)
 
 // stage a [64 x 64] fp32 block (row stride src_ld) into an LDS tile [64][68]
 __device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, int64_t src_ld) {
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   }
   __syncthreads();
   // ---- tail per token (16 lanes per row): out_t = sum_j (LN1(LN_pff(H2)) - LN2(X))_j^2 wc_j + bc ----
-  float* outs = Bs;                                     // [64] scratch (the weight tile is no longer needed)
+  float* outs = cbias;                                  // [64] per-token outputs (the folded biases are dead after the head loop)
+  float* douts = cbias + 64;                            // [64] per-token gradient of them (training step)
   {
     const float4 Gp = *reinterpret_cast<const float4*>(g.hp.gp + sc4), Bp = *reinterpret_cast<const float4*>(g.hp.bp + sc4);
     const float4 G1 = *reinterpret_cast<const float4*>(g.hp.g1 + sc4), B1 = *reinterpret_cast<const float4*>(g.hp.b1 + sc4);
@@ -412,6 +431,196 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     const float z = tot / ((float)k + 1e-15f);
     g.logits[b] = z;
     if (g.row_loss) g.row_loss[b] = g.w[b] * (fmaxf(z, 0.f) - z * g.y[b] + log1pf(expf(-fabsf(z))));
+    if (g.ddyn0) {                                     // main.py:56 backward: d bce / d z = w (sigmoid(z) - y) / B  (x alpha, main.py:166)
+      const float dz = g.alpha_over_B * g.w[b] * (1.f / (1.f + expf(-z)) - g.y[b]);
+      const float dout = dz / ((float)k + 1e-15f);
+      for (int i = 0; i < k; ++i) douts[li0 + i] = dout;
+    }
+  }
+  if (!g.ddyn0) return;
+
+  // =========== backward of the tail and of pff_n1 (Modules.py:290-311, :353-376), everything still in LDS ===========
+  TILE_GLOAD(wA, g.p0w, 64);                           // conv0 weight for the last phase; Bs still holds conv1's
+  __syncthreads();                                     // douts complete
+  float* tsl = g.tslab + (int64_t)blockIdx.x * kTailSlab;
+  float4 aGp = make_float4(0.f, 0.f, 0.f, 0.f), aBp = aGp, aG1 = aGp, aB1 = aGp, aG2 = aGp, aB2 = aGp, aWc = aGp;
+  float abc = 0.f;
+  {
+    const float4 Gp = *reinterpret_cast<const float4*>(g.hp.gp + sc4), Bp = *reinterpret_cast<const float4*>(g.hp.bp + sc4);
+    const float4 G1 = *reinterpret_cast<const float4*>(g.hp.g1 + sc4), B1 = *reinterpret_cast<const float4*>(g.hp.b1 + sc4);
+    const float4 G2 = *reinterpret_cast<const float4*>(g.hp.g2 + sc4), B2 = *reinterpret_cast<const float4*>(g.hp.b2 + sc4);
+    const float4 Wc = *reinterpret_cast<const float4*>(g.hp.wc + sc4);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      const float dout = row < n_real ? douts[row] : 0.f;
+      const float4 hv = *reinterpret_cast<const float4*>(&H2s[row * kLdT + sc4]);
+      float m, rh, ru, rx;
+      ln_row16(hv, m, rh);
+      const float4 hh = ln_apply(hv, m, rh, one4, zero4);
+      const float4 u = make_float4(hh.x * Gp.x + Bp.x, hh.y * Gp.y + Bp.y, hh.z * Gp.z + Bp.z, hh.w * Gp.w + Bp.w);
+      ln_row16(u, m, ru);
+      const float4 uh = ln_apply(u, m, ru, one4, zero4);
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      const float4 xv = *reinterpret_cast<const float4*>(g.X + tok * 64 + sc4);
+      ln_row16(xv, m, rx);
+      const float4 xh = ln_apply(xv, m, rx, one4, zero4);
+      const float4 df = make_float4((uh.x * G1.x + B1.x) - (xh.x * G2.x + B2.x), (uh.y * G1.y + B1.y) - (xh.y * G2.y + B2.y),
+                                    (uh.z * G1.z + B1.z) - (xh.z * G2.z + B2.z), (uh.w * G1.w + B1.w) - (xh.w * G2.w + B2.w));
+      aWc.x += df.x * df.x * dout; aWc.y += df.y * df.y * dout; aWc.z += df.z * df.z * dout; aWc.w += df.w * df.w * dout;
+      if ((tid & 15) == 0) abc += dout;
+      const float4 ddn = make_float4(2.f * df.x * Wc.x * dout, 2.f * df.y * Wc.y * dout, 2.f * df.z * Wc.z * dout, 2.f * df.w * Wc.w * dout);
+      const float4 dsn = make_float4(-ddn.x, -ddn.y, -ddn.z, -ddn.w);
+      // layer_norm1 (dynamic branch), then pff_n1.layer_norm
+      F4_FMA(aG1, ddn, uh); F4_ADD(aB1, ddn);
+      const float4 du = ln_bwd16(F4_MUL(ddn, G1), uh, ru);
+      F4_FMA(aGp, du, hh); F4_ADD(aBp, du);
+      const float4 dh = ln_bwd16(F4_MUL(du, Gp), hh, rh);
+      *reinterpret_cast<float4*>(&H2s[row * kLdT + sc4]) = dh;              // dH2 replaces H2 (zero rows past the tile's tokens)
+      // layer_norm2 (static branch) -> gradient into X
+      F4_FMA(aG2, dsn, xh); F4_ADD(aB2, dsn);
+      const float4 dxs = ln_bwd16(F4_MUL(dsn, G2), xh, rx);
+      if (row <= n_real) *reinterpret_cast<float4*>(g.dXs + tok * 64 + sc4) = dxs;   // the padding token's row is zero (dout = 0)
+    }
+  }
+  __syncthreads();
+  // ---- conv1: dW1[n][k] += sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2;  dZ1 = (dH2 W1) * dropmask * tanh' ----
+  float* dZs = H1s;
+  float cs1 = 0.f, cs0 = 0.f;
+  {
+    f32x16 aw = {0};
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+      const int t = 2 * m + h;
+      const float gh = H2s[t * kLdT + 32 * wr + r];
+      cs1 += gh;
+      aw = __builtin_amdgcn_mfma_f32_32x32x2f32(gh, H1s[t * kLdT + 32 * wc + r], aw, 0, 0, 0);
+    }
+    const int col = 32 * wc + r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) tsl[(32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + col] = aw[reg];
+  }
+  {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                      // dZ1[t][k] = sum_n dH2[t][n] W1[n][k]  (W1 stored [n][k]: column walk)
+      const float4 a = *reinterpret_cast<const float4*>(&H2s[(32 * wr + r) * kLdT + 8 * c + 4 * h]);
+      const float* wp = &Bs[(8 * c + 4 * h) * kLdT + 32 * wc + r];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wp[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wp[kLdT], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wp[2 * kLdT], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * kLdT], acc, 0, 0, 0);
+    }
+    __syncthreads();                                   // every wave is done reading H1 (weight gradient) and W1
+    const int col = 32 * wc + r;
+    const float unscale = drop2 ? 1.f - g.p_pff : 1.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const float hval = H1s[row * kLdT + col] * unscale;                   // tanh value (0 where dropped)
+      float v = acc[reg];
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      if (drop2) v = (rng_u32(key2, (uint32_t)g.tok_slot[tok], (uint32_t)col) >= thr2) ? v * ks2 : 0.f;
+      dZs[row * kLdT + col] = v * (1.f - hval * hval);
+    }
+    TILE_LSTORE(Bs, wA);                               // conv0 weight
+  }
+  __syncthreads();
+  // ---- conv0: dW0[n][k] += sum_t dZ1[t][n] Y[t][k];  d b0 = column sums of dZ1;  d dyn = (dZ1 W0 + dH2) * dropmask * rowmask ----
+  {
+    f32x16 aw = {0};
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+      const int t = 2 * m + h;
+      const float gz = dZs[t * kLdT + 32 * wr + r];
+      cs0 += gz;
+      aw = __builtin_amdgcn_mfma_f32_32x32x2f32(gz, Ys[t * kLdT + 32 * wc + r], aw, 0, 0, 0);
+    }
+    const int col = 32 * wc + r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) tsl[4096 + (32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + col] = aw[reg];
+  }
+  {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(&dZs[(32 * wr + r) * kLdT + 8 * c + 4 * h]);
+      const float* wp = &Bs[(8 * c + 4 * h) * kLdT + 32 * wc + r];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wp[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wp[kLdT], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wp[2 * kLdT], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * kLdT], acc, 0, 0, 0);
+    }
+    const int col = 32 * wc + r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row <= n_real) {
+        float v = 0.f;                                 // the padding token's row is masked (Modules.py:614)
+        const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+        if (row < n_real) {
+          v = acc[reg] + H2s[row * kLdT + col];        // residual: H2 = conv1(H1) + Y
+          if (drop1) v = (rng_u32(key1, (uint32_t)g.tok_slot[tok], (uint32_t)col) >= thr1) ? v * ks1 : 0.f;
+        }
+        g.ddyn0[tok * 64 + col] = v;
+      }
+    }
+  }
+  // ---- parameter-vector partials of this tile: rows of the 16 staging groups, then the two column sums ----
+  __syncthreads();                                     // all reads of the tiles are done: Qs is scratch now
+  float* red = Qs;                                     // [16][7][64]
+  *reinterpret_cast<float4*>(&red[(srow * 7 + 0) * 64 + sc4]) = aGp; *reinterpret_cast<float4*>(&red[(srow * 7 + 1) * 64 + sc4]) = aBp;
+  *reinterpret_cast<float4*>(&red[(srow * 7 + 2) * 64 + sc4]) = aG1; *reinterpret_cast<float4*>(&red[(srow * 7 + 3) * 64 + sc4]) = aB1;
+  *reinterpret_cast<float4*>(&red[(srow * 7 + 4) * 64 + sc4]) = aG2; *reinterpret_cast<float4*>(&red[(srow * 7 + 5) * 64 + sc4]) = aB2;
+  *reinterpret_cast<float4*>(&red[(srow * 7 + 6) * 64 + sc4]) = aWc;
+  float* redc = Qs + 16 * 7 * 64;                      // [2][64] column sums, [16] bc partials
+  cs1 += __shfl_xor(cs1, 32, 64);
+  cs0 += __shfl_xor(cs0, 32, 64);
+  if (wc == 0 && h == 0) { redc[32 * wr + r] = cs1; redc[64 + 32 * wr + r] = cs0; }
+  if ((tid & 15) == 0) redc[128 + srow] = abc;
+  __syncthreads();
+  for (int i = tid; i < 7 * 64; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q * 7 * 64 + i];
+    tsl[kTailVec + i] = t;
+  }
+  if (tid < 128) tsl[kTailVec + 7 * 64 + tid] = redc[tid];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int q = 0; q < 16; ++q) t += redc[128 + q];
+    tsl[kTailVec + 9 * 64] = t;
+  }
+}
+
+// Sum the per-tile slabs of the training forward in a fixed order and accumulate into the gradient tensors.
+struct TailReduceArgs {
+  const float* tslab; const int32_t* count; int L; int ntiles_cap;
+  float* dst[12];     // pff1_w, pff0_w, gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b, bc
+};
+__global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a) {
+  __shared__ float part[16][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;                   // element of the slab
+  const int win = 64 - a.L;
+  int nt = (a.count[1] + win - 1) / win;               // tiles that hold tokens (tiles of all-padding rows contribute zeros)
+  if (nt > a.ntiles_cap) nt = a.ntiles_cap;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < kTailSlab) {
+    int b = q;
+    for (; b + 16 < nt; b += 32) { s0 += a.tslab[(int64_t)b * kTailSlab + i]; s1 += a.tslab[(int64_t)(b + 16) * kTailSlab + i]; }
+    if (b < nt) s0 += a.tslab[(int64_t)b * kTailSlab + i];
+  }
+  part[q][o] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && i <= kTailVec + 9 * 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += part[t][o];
+    if (i < 4096) a.dst[0][i] += s;
+    else if (i < 8192) a.dst[1][i - 4096] += s;
+    else { const int v = (i - kTailVec) >> 6, j = (i - kTailVec) & 63; a.dst[2 + v][j] += s; }
   }
 }
 
@@ -429,10 +638,23 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
   return MATCHA_OK;
 }
 
+size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(cdiv(B * L + 1, 64 - L) + 2) * kTailSlab; }
+
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st) {
+  TailReduceArgs a;
+  a.tslab = tslab; a.count = rg.count; a.L = L; a.ntiles_cap = rg.ntiles;
+  float* dst[12] = {g_.pff1_w, g_.pff0_w, g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.pff1_b, g_.pff0_b, g_.cls_b};
+  for (int i = 0; i < 12; ++i) a.dst[i] = dst[i];
+  hipLaunchKernelGGL(tail_slab_reduce_kernel, dim3((unsigned)cdiv(kTailSlab, 64)), dim3(1024), 0, st, a);
+  MATCHA_CHECK_LAUNCH("tail_slab_reduce_kernel");
+  return MATCHA_OK;
+}
+
 int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                     hipStream_t st) {
+                     hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha) {
   FusedFwdArgs g;
+  g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.B = B; g.L = L;
   g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;

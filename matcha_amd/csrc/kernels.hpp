@@ -83,9 +83,14 @@ int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStre
 // fused_fwd.hip (embed_dim 64)
 size_t fused_fold_floats();
 int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st);
+// With ddyn0 != null (and y, w given) the kernel also runs the backward of the classifier tail and of pff_n1 for
+// loss = alpha * bce: it writes ddyn0 / dXs and per-tile partials of the 12 parameter gradients into tslab
+// (launch_tail_reduce accumulates them into the gradient tensors).
 int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                     hipStream_t st);
+                     hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f);
+size_t fused_tail_slab_floats(int64_t B, int L);
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st);
 
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)

@@ -64,6 +64,7 @@ struct Workspace {
   void* adj_ws;     size_t adj_ws_bytes;
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
+  float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
   size_t total;
 };
 
@@ -72,6 +73,10 @@ struct Workspace {
 //   MATCHA_DISABLE_FUSED_TRAIN  fused kernel only for no-grad forwards; training runs layer by layer
 static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && getenv("MATCHA_DISABLE_FUSED") == nullptr; }
 static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && getenv("MATCHA_DISABLE_FUSED_TRAIN") == nullptr; }
+//   MATCHA_DISABLE_LOSS_IN_FORWARD  the tail's backward as separate kernels even when opts->loss_in_forward is set
+static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
+  return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && getenv("MATCHA_DISABLE_LOSS_IN_FORWARD") == nullptr;
+}
 
 static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
   const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
@@ -121,6 +126,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
   w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
+  w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
   w.total = off;
   return off;
 }
@@ -236,10 +242,12 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   if (fused_enabled(s) && (opts->forward_only || fused_train_enabled(s))) {
     // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
     // token) and the backward pass recomputes the attention block from X (fused_bwd.hip)
-    const bool save = !opts->forward_only;
+    const bool lif = loss_in_forward(s, *opts, y, w_bce);            // the tail's backward runs in this kernel: nothing saved
+    const bool save = !opts->forward_only && !lif;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
     MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
-                                w.logits, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st));
+                                w.logits, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
+                                lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
     if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -306,6 +314,12 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   const int32_t* cnt = w.rg.count;             // the plan (row_off, tok_id, tok_slot, count) is still in the workspace
   const int64_t* ids = w.rg.tok_id;
 
+  const bool lif = loss_in_forward(s, *opts, y, w_bce);
+  MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
+  if (lif) {
+    // ddyn0 and dXs were produced by matcha_forward; only the per-tile parameter-gradient partials remain to be summed
+    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st));
+  } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   HeadParams ghp = {g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.cls_b};
@@ -325,6 +339,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     g.flags = MATCHA_EPI_RESIDUAL | MATCHA_EPI_ROWMASK; g.residual = w.dH2; g.row_ids = ids;
     if (drop_fc1) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
     MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
   }
   if (fused_train_enabled(s)) {
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;

@@ -68,6 +68,7 @@ class Trainer:
         o.alpha, o.beta = float(alpha), float(beta)
         o.random_chrom = int(random_chrom)
         o.seed = self.seed.data_ptr()
+        o.loss_in_forward = 1            # the loss is alpha*bce + beta*recon here: the tail's backward runs inside the forward kernel
         return o
 
     # ---- one step -------------------------------------------------------------------------------------

@@ -231,3 +231,40 @@ def test_fused_kernels_with_empty_rows():
             continue
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - res[1][1][n]).abs().max()) <= 2e-5 * scale + 1e-9, n
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+def test_loss_in_forward_matches_separate_tail_backward(mode):
+    """Trainer step (d = 64, dropout on): the tail's backward inside the forward kernel (opts.loss_in_forward) against
+    the separate head_bwd + pff GEMM kernels -- same weights, batch and dropout seed; gradients of every parameter."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(11)
+    x = _mixed_batch(N, [2, 3, 4, 5], 1500, rng)
+    y = (torch.rand(len(x), device="cuda") < 0.3).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    res = []
+    for separate in (True, False):
+        clf, _ = hip_model(num, 64, mode, 29)
+        clf.train(True)
+        tr = Trainer(clf, base_seed=77)
+        if separate:
+            os.environ["MATCHA_DISABLE_LOSS_IN_FORWARD"] = "1"
+        try:
+            tr.forward_backward(x, y, w, alpha=0.7, beta=0.01, random_chrom=3)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MATCHA_DISABLE_LOSS_IN_FORWARD", None)
+        res.append((tr.gflat.clone(), tr.losses.clone(), {n: (p.data_ptr() - tr.rt.flat.data_ptr()) // 4 for n, p in clf.named_parameters()
+                                                          if p.data_ptr() >= tr.rt.flat.data_ptr() and p.data_ptr() < tr.rt.flat.data_ptr() + tr.rt.n_flat * 4},
+                    {n: p.numel() for n, p in clf.named_parameters()}))
+    assert torch.equal(res[0][1][:2], res[1][1][:2])                 # same forward: identical losses
+    g0, g1, offs, sizes = res[0][0], res[1][0], res[1][2], res[1][3]
+    assert float(g0.abs().max()) > 0
+    for n, o in offs.items():
+        if n == GAUGE:
+            continue
+        a, b = g0[o:o + sizes[n]], g1[o:o + sizes[n]]
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
