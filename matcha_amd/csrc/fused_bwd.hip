@@ -322,9 +322,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     head = blockIdx.x & 7;
     chunk = blockIdx.x >> 3;
   }
-  const int win = 64 - g.L;
   const int tr = g.count[1];
-  int ntr = (tr + win - 1) / win;
+  int ntr = g.count[2];                                // tiles planned by ragged.hip
   if (ntr > g.ntiles) ntr = g.ntiles;
   const int per = (ntr + g.nchunks - 1) / g.nchunks;
   const int tile_lo = chunk * per;

@@ -8,7 +8,7 @@
 //
 // Work decomposition: one 256-thread workgroup per TILE of whole hyperedges, <= 63 real tokens + the shared padding token
 // as the last row (its K/V rows come out of the same projection GEMMs).  Tile i owns the hyperedges whose first token
-// index lies in [(64 - L) i, (64 - L)(i + 1)); ragged.hip plans the tiles (tile_b0).
+// ragged.hip packs the tiles greedily (tile_meta).
 // A 64x64x64 GEMM is split into four 32x32 quadrants, one per wave (32 f32 MFMAs each).
 // The three LayerNorm affines in front of Q/K/V are folded into the projection weights once per step
 // (W' = W * g, c = W . b), so one x_hat fragment set, held in registers for the whole tile, feeds all 24 projections.
@@ -603,8 +603,7 @@ __global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a
   __shared__ float part[16][64];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;                   // element of the slab
-  const int win = 64 - a.L;
-  int nt = (a.count[1] + win - 1) / win;               // tiles that hold tokens (tiles of all-padding rows contribute zeros)
+  int nt = a.count[2];                                 // tiles planned by ragged.hip (every one of them wrote its slab)
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
   float s0 = 0.f, s1 = 0.f;
   if (i < kTailSlab) {
@@ -638,7 +637,7 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
   return MATCHA_OK;
 }
 
-size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(cdiv(B * L + 1, 64 - L) + 2) * kTailSlab; }
+size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
 
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st) {
   TailReduceArgs a;

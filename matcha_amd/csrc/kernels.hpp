@@ -36,15 +36,18 @@ struct Ragged {
   int32_t* row_off;    // [B+1]
   int32_t* tok_slot;   // [T+1]
   int64_t* tok_id;     // [T+1]
-  int32_t* count;      // {Tr + 1, Tr}
+  int32_t* count;      // {Tr + 1, Tr, tiles}
   int32_t* blk_sum;
   int nblk;
-  int32_t* tile_b0;    // [ntiles+1] first hyperedge of each fused-kernel tile (window 64 - L first-token indices)
-  int ntiles;
+  int ntiles;          // capacity of tile_meta (upper bound of the tile count; the count itself is count[2])
   int32_t* tok_pos;    // [T+1] position of the token inside its hyperedge | k << 8
   int32_t* tile_meta;  // [ntiles + 2][4] {first token t0, number of tokens, first hyperedge b0, number of hyperedges}; zeros past the end
+  int32_t* sb_tiles;   // planning scratch: per-superblock tile lists
+  int32_t* sb_cnt;
+  int nsb, sb_cap;
 };
 size_t ragged_bytes(int64_t B, int L);
+int ragged_tiles_cap(int64_t B, int L);
 void ragged_carve(int64_t B, int L, char* base, Ragged& r);
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st);
 

@@ -11,9 +11,9 @@
 //   tok_slot [T+1]  compact token -> original slot b*L + l (dropout counters follow the original slots, so masks are
 //                   the ones the oracle generates for the padded layout); tok_slot[Tr] = B*L
 //   tok_id [T+1]    node id of the compact token; tok_id[Tr] = 0 (padding id)
-//   count [2]       {Tr + 1, Tr}  -- device-side row counts consumed by every kernel through m_dev / t_dev
+//   count [3]       {Tr + 1, Tr, number of tiles}  -- device-side counts consumed by every kernel through m_dev / t_dev
 //   tok_pos [T+1]   position of the compact token inside its hyperedge | k << 8 (fused kernels: token -> hyperedge rows)
-//   tile_b0, tile_meta   tiles of whole hyperedges (<= 63 tokens) for the fused d = 64 kernels
+//   tile_meta       tiles of whole hyperedges (<= 63 tokens) for the fused d = 64 kernels
 #include "kernels.hpp"
 
 namespace matcha {
@@ -102,38 +102,77 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
   }
 }
 
-// Tiles of the fused kernels: tile w owns the hyperedges whose first token index lies in [w*win, (w+1)*win), win = 64 - L
-// (<= 63 real tokens per tile).  tile_b0[w] = first hyperedge of tile w, tile_b0[ntiles] = B.  Consecutive hyperedges
-// start at most L < win tokens apart, so the window index grows by at most one per hyperedge.
-__global__ __launch_bounds__(256) void tile_plan_kernel(const int32_t* __restrict__ row_off, int64_t B, int win, int ntiles,
-                                                        int32_t* __restrict__ tile_b0) {
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b < B) {
-    const int w = row_off[b] / win;
-    const int wprev = b > 0 ? row_off[b - 1] / win : -1;
-    if (w != wprev && w <= ntiles) tile_b0[w] = (int32_t)b;
+// Tiles of the fused kernels: runs of whole consecutive hyperedges with at most 63 tokens (+ the shared padding token = 64
+// rows), packed greedily so the MFMA tiles are ~96 % full (fixed windows of 64 - L first-token indices gave 90 %).
+// Greedy packing is sequential, so it runs per SUPERBLOCK (the hyperedges whose first token lies in a window of kSuperTok
+// tokens, ~32 tiles): one wavefront per superblock loads 64 row lengths at a time and walks them with scalar code
+// (v_readlane); only the last tile of a superblock is partial.  A second kernel compacts the per-superblock lists.
+// tile_meta[w] = {first token t0, tokens, first hyperedge b0, hyperedges}; entries past the tile count are zero.
+constexpr int kTileTok = 63;
+constexpr int kSuperTok = 63 * 32;
+
+__device__ __forceinline__ int lower_bound_off(const int32_t* __restrict__ row_off, int64_t B, int target) {
+  int64_t lo = 0, hi = B;                              // first b in [0, B] with row_off[b] >= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (row_off[mid] < target) lo = mid + 1; else hi = mid;
   }
-  if (b == B - 1 || (B == 0 && b == 0)) {
-    const int wlast = B > 0 ? row_off[B - 1] / win : -1;
-    for (int w = wlast + 1; w <= ntiles; ++w) tile_b0[w] = (int32_t)B;
-  }
+  return (int)lo;
 }
 
-// tile_meta[w] = {t0, n_real, b0, n_h}; entries past the last real tile are zero (n_real = 0: skipped by the kernels)
-__global__ __launch_bounds__(256) void tile_meta_kernel(const int32_t* __restrict__ row_off, const int32_t* __restrict__ tile_b0, int ntiles,
-                                                        int32_t* __restrict__ meta) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  if (w >= ntiles + 2) return;
-  int4 m = make_int4(0, 0, 0, 0);
-  if (w < ntiles) {
-    const int b0 = tile_b0[w], b1 = tile_b0[w + 1];
-    if (b1 > b0) {
-      const int t0 = row_off[b0];
-      m = make_int4(t0, row_off[b1] - t0, b0, b1 - b0);
+__global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb,
+                                                       int32_t* __restrict__ sb_tiles, int32_t* __restrict__ sb_cnt) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int b_lo = lower_bound_off(row_off, B, s * kSuperTok);
+  const int b_hi = (s + 1 == nsb) ? (int)B : lower_bound_off(row_off, B, (s + 1) * kSuperTok);
+  int4* out = reinterpret_cast<int4*>(sb_tiles) + (int64_t)s * cap_per_sb;
+  int tile_b0 = b_lo, tile_t0 = b_lo < B ? row_off[b_lo] : 0, cur = 0, nt = 0;
+  for (int base = b_lo; base < b_hi; base += 64) {
+    const int kk = (base + lane < b_hi) ? row_off[base + lane + 1] - row_off[base + lane] : 0;
+    const int n = (b_hi - base < 64) ? b_hi - base : 64;
+    for (int i = 0; i < n; ++i) {
+      const int k = __builtin_amdgcn_readlane(kk, i);
+      if (cur + k > kTileTok) {                        // close the tile in front of hyperedge base + i
+        if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_t0, cur, tile_b0, base + i - tile_b0);
+        ++nt;
+        tile_b0 = base + i; tile_t0 += cur; cur = 0;
+      }
+      cur += k;
     }
   }
-  reinterpret_cast<int4*>(meta)[w] = m;
+  if (b_hi > tile_b0) {
+    if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_t0, cur, tile_b0, b_hi - tile_b0);
+    ++nt;
+  }
+  if (lane == 0) sb_cnt[s] = nt < cap_per_sb ? nt : cap_per_sb;
 }
+
+// exclusive scan of the superblock tile counts (one block; nsb is small), compaction, zero fill; count[2] = number of tiles
+__global__ __launch_bounds__(1024) void tile_compact_kernel(const int32_t* __restrict__ sb_tiles, int32_t* __restrict__ sb_cnt, int nsb,
+                                                            int cap_per_sb, int ntiles_cap, int32_t* __restrict__ meta, int32_t* __restrict__ count) {
+  __shared__ int total;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int s = 0; s < nsb; ++s) { const int c = sb_cnt[s]; sb_cnt[s] = run; run += c; }
+    total = run < ntiles_cap ? run : ntiles_cap;
+    count[2] = total;
+  }
+  __syncthreads();
+  const int4* src = reinterpret_cast<const int4*>(sb_tiles);
+  int4* dst = reinterpret_cast<int4*>(meta);
+  for (int i = threadIdx.x; i < nsb * cap_per_sb; i += 1024) {
+    const int s = i / cap_per_sb, j = i - s * cap_per_sb;
+    const int lo = sb_cnt[s], hi = (s + 1 < nsb) ? sb_cnt[s + 1] : total;
+    if (lo + j < hi && lo + j < ntiles_cap) dst[lo + j] = src[i];
+  }
+  for (int i = total + threadIdx.x; i < ntiles_cap + 2; i += 1024) dst[i] = make_int4(0, 0, 0, 0);
+}
+
+static inline int super_blocks(int64_t T) { return (int)cdiv(T + 1, kSuperTok); }
+static inline int super_cap(int L) { return (int)cdiv(kSuperTok + L, 64 - L) + 2; }
+static inline int tiles_cap(int64_t T, int L) { return (int)cdiv(T + 1, 64 - L) + super_blocks(T); }   // every tile but a superblock's last holds > 63 - L tokens
+
+int ragged_tiles_cap(int64_t B, int L) { return tiles_cap(B * L, L); }
 
 size_t ragged_bytes(int64_t B, int L) {
   const int64_t T = B * L;
@@ -143,9 +182,10 @@ size_t ragged_bytes(int64_t B, int L) {
   n += align_up((size_t)(T + 1) * 8, 256);        // tok_id
   n += 256;                                        // count
   n += align_up((size_t)cdiv(B, kRowsPerBlock) * 4, 256);
-  n += align_up((size_t)(cdiv(T + 1, 64 - L) + 2) * 4, 256);   // tile_b0
   n += align_up((size_t)(T + 1) * 4, 256);        // tok_pos
-  n += align_up((size_t)(cdiv(T + 1, 64 - L) + 2) * 16, 256);  // tile_meta
+  n += align_up((size_t)(tiles_cap(T, L) + 2) * 16, 256);                    // tile_meta
+  n += align_up((size_t)super_blocks(T) * super_cap(L) * 16, 256);           // sb_tiles
+  n += align_up((size_t)super_blocks(T) * 4, 256);                           // sb_cnt
   return n;
 }
 
@@ -159,10 +199,13 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.count = (int32_t*)take(256);
   r.blk_sum = (int32_t*)take((size_t)cdiv(B, kRowsPerBlock) * 4);
   r.nblk = (int)cdiv(B, kRowsPerBlock);
-  r.ntiles = (int)cdiv(T + 1, 64 - L);
-  r.tile_b0 = (int32_t*)take((size_t)(r.ntiles + 2) * 4);
+  r.ntiles = tiles_cap(T, L);
   r.tok_pos = (int32_t*)take((size_t)(T + 1) * 4);
   r.tile_meta = (int32_t*)take((size_t)(r.ntiles + 2) * 16);
+  r.nsb = super_blocks(T);
+  r.sb_cap = super_cap(L);
+  r.sb_tiles = (int32_t*)take((size_t)r.nsb * r.sb_cap * 16);
+  r.sb_cnt = (int32_t*)take((size_t)r.nsb * 4);
 }
 
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st) {
@@ -172,10 +215,10 @@ int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipS
   MATCHA_CHECK_LAUNCH("row_scan_kernel");
   hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
-  hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, r.row_off, B, 64 - L, r.ntiles, r.tile_b0);
-  MATCHA_CHECK_LAUNCH("tile_plan_kernel");
-  hipLaunchKernelGGL(tile_meta_kernel, dim3((unsigned)cdiv(r.ntiles + 2, 256)), dim3(256), 0, st, r.row_off, r.tile_b0, r.ntiles, r.tile_meta);
-  MATCHA_CHECK_LAUNCH("tile_meta_kernel");
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_tiles, r.sb_cnt);
+  MATCHA_CHECK_LAUNCH("tile_pack_kernel");
+  hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, st, r.sb_tiles, r.sb_cnt, r.nsb, r.sb_cap, r.ntiles, r.tile_meta, r.count);
+  MATCHA_CHECK_LAUNCH("tile_compact_kernel");
   return MATCHA_OK;
 }
 
