@@ -44,6 +44,7 @@ struct Ragged {
   int32_t* tile_meta;  // [ntiles + 2][4] {first token t0, number of tokens, first hyperedge b0, number of hyperedges}; zeros past the end
   int32_t* sb_tiles;   // planning scratch: per-superblock tile lists
   int32_t* sb_cnt;
+  int32_t* sb_first;   // [nsb + 1] first hyperedge of each planning superblock (B where none starts)
   int nsb, sb_cap;
 };
 size_t ragged_bytes(int64_t B, int L);

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void row_count_kernel(const int64_t* __restric
 }
 
 // exclusive scan of the block sums in place; count = {Tr + 1, Tr}
-__global__ __launch_bounds__(1024) void row_scan_kernel(int32_t* __restrict__ blk_sum, int nblk, int32_t* __restrict__ count) {
+__global__ __launch_bounds__(1024) void row_scan_kernel(int32_t* __restrict__ blk_sum, int nblk, int32_t* __restrict__ count,
+                                                        int32_t* __restrict__ sb_first, int nsb, int32_t n_rows) {
   __shared__ int part[1024];
+  for (int i = threadIdx.x; i <= nsb; i += 1024) sb_first[i] = n_rows;       // superblocks in which no hyperedge starts: empty range
   const int chunk = (nblk + 1023) / 1024;
   const int b0 = threadIdx.x * chunk, b1 = (b0 + chunk < nblk) ? b0 + chunk : nblk;
   int local = 0;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(int32_t* __restrict__ bl
 __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict__ x, int64_t B, int L, const int32_t* __restrict__ blk_base,
                                                        const int32_t* __restrict__ count, int32_t* __restrict__ row_off,
                                                        int32_t* __restrict__ tok_slot, int64_t* __restrict__ tok_id,
-                                                       int32_t* __restrict__ tok_pos) {
+                                                       int32_t* __restrict__ tok_pos, int32_t* __restrict__ sb_first, int super_tok) {
   __shared__ int lds4[4];
   const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * 4;
   int cnt = 0;
@@ -81,12 +83,20 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
     if (b0 + i < B)
       for (int l = 0; l < L; ++l) cnt += x[(b0 + i) * L + l] != 0 ? 1 : 0;
   int pos = blk_base[blockIdx.x] + block_exclusive_scan_256(cnt, lds4, nullptr);
+  int kprev = 0;
   for (int i = 0; i < 4; ++i) {
     const int64_t b = b0 + i;
     if (b >= B) break;
     row_off[b] = pos;
     int k = 0;
     for (int l = 0; l < L; ++l) k += x[b * L + l] != 0 ? 1 : 0;
+    // first hyperedge of a planning superblock: its first token lies in another window of super_tok tokens than its predecessor's
+    if (i == 0 && b > 0) {
+      kprev = 0;
+      for (int l = 0; l < L; ++l) kprev += x[(b - 1) * L + l] != 0 ? 1 : 0;
+    }
+    if (b == 0 || pos / super_tok != (pos - kprev) / super_tok) sb_first[pos / super_tok] = (int32_t)b;
+    kprev = k;
     int nth = 0;
     for (int l = 0; l < L; ++l) {
       const int64_t id = x[b * L + l];
@@ -105,59 +115,74 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
 // Tiles of the fused kernels: runs of whole consecutive hyperedges with at most 63 tokens (+ the shared padding token = 64
 // rows), packed greedily so the MFMA tiles are ~96 % full (fixed windows of 64 - L first-token indices gave 90 %).
 // Greedy packing is sequential, so it runs per SUPERBLOCK (the hyperedges whose first token lies in a window of kSuperTok
-// tokens, ~32 tiles): one wavefront per superblock loads 64 row lengths at a time and walks them with scalar code
-// (v_readlane); only the last tile of a superblock is partial.  A second kernel compacts the per-superblock lists.
+// tokens, ~32 tiles): one wavefront per superblock loads 64 row offsets at a time; a ballot finds the first hyperedge that
+// ends beyond the open tile, which closes it (about 4 closes per 64 hyperedges); only a superblock's last tile is partial.  A second kernel compacts the per-superblock lists.
 // tile_meta[w] = {first token t0, tokens, first hyperedge b0, hyperedges}; entries past the tile count are zero.
 constexpr int kTileTok = 63;
 constexpr int kSuperTok = 63 * 32;
 
-__device__ __forceinline__ int lower_bound_off(const int32_t* __restrict__ row_off, int64_t B, int target) {
-  int64_t lo = 0, hi = B;                              // first b in [0, B] with row_off[b] >= target
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (row_off[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  return (int)lo;
-}
-
 __global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb,
-                                                       int32_t* __restrict__ sb_tiles, int32_t* __restrict__ sb_cnt) {
+                                                       const int32_t* __restrict__ sb_first, int32_t* __restrict__ sb_tiles,
+                                                       int32_t* __restrict__ sb_cnt) {
   const int s = blockIdx.x, lane = threadIdx.x;
-  const int b_lo = lower_bound_off(row_off, B, s * kSuperTok);
-  const int b_hi = (s + 1 == nsb) ? (int)B : lower_bound_off(row_off, B, (s + 1) * kSuperTok);
+  const int b_lo = sb_first[s];                        // marked by row_fill_kernel (B: nothing starts here)
+  int b_hi = (int)B;
+  for (int q = s + 1; q < nsb; ++q)                    // next superblock that has a first hyperedge (normally s + 1)
+    if (sb_first[q] < (int)B) { b_hi = sb_first[q]; break; }
   int4* out = reinterpret_cast<int4*>(sb_tiles) + (int64_t)s * cap_per_sb;
-  int tile_b0 = b_lo, tile_t0 = b_lo < B ? row_off[b_lo] : 0, cur = 0, nt = 0;
-  for (int base = b_lo; base < b_hi; base += 64) {
-    const int kk = (base + lane < b_hi) ? row_off[base + lane + 1] - row_off[base + lane] : 0;
-    const int n = (b_hi - base < 64) ? b_hi - base : 64;
-    for (int i = 0; i < n; ++i) {
-      const int k = __builtin_amdgcn_readlane(kk, i);
-      if (cur + k > kTileTok) {                        // close the tile in front of hyperedge base + i
-        if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_t0, cur, tile_b0, base + i - tile_b0);
+  int nt = 0;
+  if (b_lo < b_hi) {
+    int tile_b0 = b_lo;
+    int tile_tok0 = __builtin_amdgcn_readfirstlane(row_off[b_lo]);
+    for (int base = b_lo; base < b_hi; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < b_hi;
+      const int so = valid ? row_off[idx] : 0;         // first token of hyperedge idx
+      const int eo = valid ? row_off[idx + 1] : 0;     // one past its last token (monotone over idx)
+      for (;;) {
+        const uint64_t over = __ballot(valid && eo - tile_tok0 > kTileTok);   // hyperedges that end beyond the open tile
+        if (over == 0) break;
+        const int i = __ffsll((long long)over) - 1;    // the first of them closes the tile and opens the next one
+        const int start = __builtin_amdgcn_readlane(so, i);
+        if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_tok0, start - tile_tok0, tile_b0, base + i - tile_b0);
         ++nt;
-        tile_b0 = base + i; tile_t0 += cur; cur = 0;
+        tile_b0 = base + i;
+        tile_tok0 = start;
       }
-      cur += k;
     }
-  }
-  if (b_hi > tile_b0) {
-    if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_t0, cur, tile_b0, b_hi - tile_b0);
+    const int end = __builtin_amdgcn_readfirstlane(row_off[b_hi]);
+    if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_tok0, end - tile_tok0, tile_b0, b_hi - tile_b0);
     ++nt;
   }
   if (lane == 0) sb_cnt[s] = nt < cap_per_sb ? nt : cap_per_sb;
 }
 
-// exclusive scan of the superblock tile counts (one block; nsb is small), compaction, zero fill; count[2] = number of tiles
+// exclusive scan of the superblock tile counts (one block, 1024 counts per pass), compaction, zero fill; count[2] = tiles
 __global__ __launch_bounds__(1024) void tile_compact_kernel(const int32_t* __restrict__ sb_tiles, int32_t* __restrict__ sb_cnt, int nsb,
                                                             int cap_per_sb, int ntiles_cap, int32_t* __restrict__ meta, int32_t* __restrict__ count) {
-  __shared__ int total;
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int s = 0; s < nsb; ++s) { const int c = sb_cnt[s]; sb_cnt[s] = run; run += c; }
-    total = run < ntiles_cap ? run : ntiles_cap;
-    count[2] = total;
-  }
+  __shared__ int buf[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
+  for (int base = 0; base < nsb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int c = i < nsb ? sb_cnt[i] : 0;
+    buf[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {               // Hillis-Steele inclusive scan
+      const int v = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (i < nsb) sb_cnt[i] = carry + buf[threadIdx.x] - c;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  const int total = carry < ntiles_cap ? carry : ntiles_cap;
+  if (threadIdx.x == 0) count[2] = total;
+  __syncthreads();                                     // sb_cnt (now offsets) written by this block: visible after the barrier
   const int4* src = reinterpret_cast<const int4*>(sb_tiles);
   int4* dst = reinterpret_cast<int4*>(meta);
   for (int i = threadIdx.x; i < nsb * cap_per_sb; i += 1024) {
@@ -186,6 +211,7 @@ size_t ragged_bytes(int64_t B, int L) {
   n += align_up((size_t)(tiles_cap(T, L) + 2) * 16, 256);                    // tile_meta
   n += align_up((size_t)super_blocks(T) * super_cap(L) * 16, 256);           // sb_tiles
   n += align_up((size_t)super_blocks(T) * 4, 256);                           // sb_cnt
+  n += align_up((size_t)(super_blocks(T) + 1) * 4, 256);                     // sb_first
   return n;
 }
 
@@ -206,16 +232,17 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.sb_cap = super_cap(L);
   r.sb_tiles = (int32_t*)take((size_t)r.nsb * r.sb_cap * 16);
   r.sb_cnt = (int32_t*)take((size_t)r.nsb * 4);
+  r.sb_first = (int32_t*)take((size_t)(r.nsb + 1) * 4);
 }
 
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st) {
   hipLaunchKernelGGL(row_count_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum);
   MATCHA_CHECK_LAUNCH("row_count_kernel");
-  hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, r.blk_sum, r.nblk, r.count);
+  hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, r.blk_sum, r.nblk, r.count, r.sb_first, r.nsb, (int32_t)B);
   MATCHA_CHECK_LAUNCH("row_scan_kernel");
-  hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos);
+  hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos, r.sb_first, kSuperTok);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_tiles, r.sb_cnt);
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_first, r.sb_tiles, r.sb_cnt);
   MATCHA_CHECK_LAUNCH("tile_pack_kernel");
   hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, st, r.sb_tiles, r.sb_cnt, r.nsb, r.sb_cap, r.ntiles, r.tile_meta, r.count);
   MATCHA_CHECK_LAUNCH("tile_compact_kernel");
