@@ -1,0 +1,235 @@
+// Fused backward of the encoder's front end for embed_dim 64 (training path of the metric's configuration):
+//   d x_hat = sum over the 8 per-head partials of fused_bwd.hip  ->  LayerNorm backward (no affine) + static-branch
+//   gradient + tanh'  = dZ0            (Modules.py:519-521 backward, :270)
+//   dX0 = dZ0 . Wn,  dWn += dZ0^T x0,  d bn += colsum(dZ0)                      (next_w, Modules.py:270)
+//   dWa += dX0^T attr_table[id],  d ba += colsum(dX0)                           (attribute_nn, :263-264)
+//   table front end: dtable[id] += dX0 (row 0 = padding_idx skipped);  adj front end: dX0 is handed to adj_backward.
+// One token-major kernel instead of lnhat_bwd + 2 GEMM_TN (+ slab reduces) + GEMM_NN + scatter: per token it reads the
+// 8 partials (2 KB), X, dXs, x0 (768 B), the id and its attribute row, and dZ0 / dX0 never reach HBM (table mode).
+// Persistent workgroups walk 64-token tiles; next_w stays in LDS, the two weight gradients in MFMA accumulators; one slab
+// per workgroup, summed in a fixed order by front_slab_reduce_kernel.  LDS 78 KB -> two workgroups per CU.
+#include "kernels.hpp"
+
+namespace matcha {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kLd = 68;
+constexpr int kTile = 64 * kLd;
+constexpr int kLdA = 36;                          // attribute tile row stride: 32 columns + 4
+constexpr int kAttrCols = 32;                     // attribute features handled by the fused kernel (n_attr <= 32, multiple of 4)
+constexpr int kFrontSlab = 4096 + 64 * kAttrCols + 128;     // dWn [64][64] | dWa [64][32] | d bn [64] | d ba [64]
+constexpr float kEps = 1e-5f;
+
+struct FrontBwdArgs {
+  const float* X; const float* dxh; int64_t tcap; const float* dxpad; const float* dXs; const float* x0;
+  const int64_t* ids; const float* attr_table; int n_attr;
+  const float* Wn;                                // next_w [64][64] ([out][in])
+  const int32_t* count;                           // {Tr + 1, Tr, tiles}
+  float* dX0;                                     // adj front end: [Tn, 64] output; table front end: null
+  float* dtable;                                  // table front end: scatter target; adj: null
+  float* slab;                                    // [gridDim.x][kFrontSlab]
+};
+
+__global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ws = lds;                                // next_w, resident
+  float* Zs = lds + 1 * kTile;                    // dZ0
+  float* X0s = lds + 2 * kTile;                   // x0
+  float* Ds = lds + 3 * kTile;                    // dX0
+  float* As = lds + 4 * kTile;                    // attribute rows [64][kLdA]
+  int* ids_s = reinterpret_cast<int*>(As + 64 * kLdA);   // [64] node id of each row (0: padding / past the end)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+  const int T = g.count[0];                       // real tokens + the shared padding token
+  const int ntiles = (T + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4*>(&Ws[(srow + 16 * i) * kLd + sc4]) = *reinterpret_cast<const float4*>(g.Wn + (srow + 16 * i) * 64 + sc4);
+  f32x16 aWn = {0}, aWa = {0};
+  float csz = 0.f, csd = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t t_base = (int64_t)tile * 64;
+    __syncthreads();                              // previous tile's GEMMs are done with the working tiles
+    // ---- stage: dZ0 (LayerNorm backward of the summed partials + static branch + tanh'), x0, ids, attribute rows ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      const int64_t t = t_base + row;
+      const bool valid = t < T;
+      const int64_t tc = valid ? t : (int64_t)T - 1;
+      const float4 xv = *reinterpret_cast<const float4*>(g.X + tc * 64 + sc4);
+      float4 d;
+      if (tc < T - 1) {
+        d = *reinterpret_cast<const float4*>(g.dxh + tc * 64 + sc4);
+#pragma unroll
+        for (int hd = 1; hd < MATCHA_N_HEAD; ++hd) {
+          const float4 v = *reinterpret_cast<const float4*>(g.dxh + ((int64_t)hd * g.tcap + tc) * 64 + sc4);
+          d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+        }
+      } else {
+        d = *reinterpret_cast<const float4*>(g.dxpad + sc4);        // the shared padding token (fb_unfold2_kernel)
+      }
+      const float mean = group_sum16_dpp((xv.x + xv.y) + (xv.z + xv.w)) * (1.f / 64.f);
+      const float a0 = xv.x - mean, a1 = xv.y - mean, a2 = xv.z - mean, a3 = xv.w - mean;
+      const float rs = 1.0f / sqrtf(group_sum16_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) * (1.f / 64.f) + kEps);
+      const float4 xh = make_float4(a0 * rs, a1 * rs, a2 * rs, a3 * rs);
+      const float ma = group_sum16_dpp((d.x + d.y) + (d.z + d.w)) * (1.f / 64.f);
+      const float mb = group_sum16_dpp((d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w)) * (1.f / 64.f);
+      const float4 s = *reinterpret_cast<const float4*>(g.dXs + tc * 64 + sc4);
+      const float m = valid ? 1.f : 0.f;
+      float4 z;
+      z.x = m * (rs * (d.x - ma - xh.x * mb) + s.x) * (1.f - xv.x * xv.x);
+      z.y = m * (rs * (d.y - ma - xh.y * mb) + s.y) * (1.f - xv.y * xv.y);
+      z.z = m * (rs * (d.z - ma - xh.z * mb) + s.z) * (1.f - xv.z * xv.z);
+      z.w = m * (rs * (d.w - ma - xh.w * mb) + s.w) * (1.f - xv.w * xv.w);
+      *reinterpret_cast<float4*>(&Zs[row * kLd + sc4]) = z;
+      const float4 x0v = *reinterpret_cast<const float4*>(g.x0 + tc * 64 + sc4);
+      *reinterpret_cast<float4*>(&X0s[row * kLd + sc4]) = make_float4(x0v.x * m, x0v.y * m, x0v.z * m, x0v.w * m);
+    }
+    if (tid < 64) ids_s[tid] = (t_base + tid < T) ? (int)g.ids[t_base + tid] : 0;
+    for (int i = tid; i < 64 * (kAttrCols / 4); i += 256) {         // 8 float4 slots per row
+      const int row = i >> 3, q = (i & 7) * 4;
+      const int64_t t = t_base + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T && q < g.n_attr) v = *reinterpret_cast<const float4*>(g.attr_table + g.ids[t] * g.n_attr + q);
+      *reinterpret_cast<float4*>(&As[row * kLdA + q]) = v;
+    }
+    __syncthreads();
+    // ---- dX0 = dZ0 . Wn  (Wn stored [n][k]: column walk) ----
+    {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(&Zs[(32 * wr + r) * kLd + 8 * c + 4 * h]);
+        const float* wp = &Ws[(8 * c + 4 * h) * kLd + 32 * wc + r];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wp[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wp[kLd], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wp[2 * kLd], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * kLd], acc, 0, 0, 0);
+      }
+      const int col = 32 * wc + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        Ds[row * kLd + col] = acc[reg];
+        const int64_t t = t_base + row;
+        if (g.dX0) {
+          if (t < T) g.dX0[t * 64 + col] = acc[reg];
+        } else {
+          const int id = ids_s[row];
+          if (id != 0) atomicAdd(g.dtable + (int64_t)id * 64 + col, acc[reg]);      // embedding backward (padding_idx = 0 skipped)
+        }
+      }
+    }
+    // ---- dWn[n][k] += sum_t dZ0[t][n] x0[t][k];  d bn = column sums of dZ0 ----
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+      const int t = 2 * m + h;
+      const float gz = Zs[t * kLd + 32 * wr + r];
+      csz += gz;
+      aWn = __builtin_amdgcn_mfma_f32_32x32x2f32(gz, X0s[t * kLd + 32 * wc + r], aWn, 0, 0, 0);
+    }
+    __syncthreads();                              // dX0 tile complete
+    // ---- dWa[n][a] += sum_t dX0[t][n] attr[t][a]  (a < 32: the waves with wc = 0);  d ba = column sums of dX0 ----
+    if (wc == 0) {
+#pragma unroll 8
+      for (int m = 0; m < 32; ++m) {
+        const int t = 2 * m + h;
+        const float gd = Ds[t * kLd + 32 * wr + r];
+        csd += gd;
+        aWa = __builtin_amdgcn_mfma_f32_32x32x2f32(gd, As[t * kLdA + r], aWa, 0, 0, 0);
+      }
+    }
+  }
+  // ---- workgroup slab ----
+  float* slab = g.slab + (int64_t)blockIdx.x * kFrontSlab;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    slab[row * 64 + 32 * wc + r] = aWn[reg];
+    if (wc == 0) slab[4096 + row * kAttrCols + r] = aWa[reg];
+  }
+  csz += __shfl_xor(csz, 32, 64);
+  csd += __shfl_xor(csd, 32, 64);
+  if (wc == 0 && h == 0) {
+    slab[4096 + 64 * kAttrCols + 32 * wr + r] = csz;
+    slab[4096 + 64 * kAttrCols + 64 + 32 * wr + r] = csd;
+  }
+}
+
+struct FrontReduceArgs {
+  const float* slab; int nwg; int n_attr;
+  float* dWn; float* dWa; float* dbn; float* dba;
+};
+// fixed-order sum over the workgroup slabs (64 outputs x 16 lanes per block), accumulated into the gradient tensors
+__global__ __launch_bounds__(1024) void front_slab_reduce_kernel(FrontReduceArgs a) {
+  __shared__ float part[16][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (i < kFrontSlab)
+    for (int b = q; b < a.nwg; b += 16) s += a.slab[(int64_t)b * kFrontSlab + i];
+  part[q][o] = s;
+  __syncthreads();
+  if (q == 0 && i < kFrontSlab) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += part[u][o];
+    if (i < 4096) a.dWn[i] += t;
+    else if (i < 4096 + 64 * kAttrCols) {
+      const int n = (i - 4096) / kAttrCols, c = (i - 4096) % kAttrCols;
+      if (c < a.n_attr) a.dWa[n * a.n_attr + c] += t;
+    } else if (i < 4096 + 64 * kAttrCols + 64) a.dbn[i - 4096 - 64 * kAttrCols] += t;
+    else a.dba[i - 4096 - 64 * kAttrCols - 64] += t;
+  }
+}
+
+int front_grid() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    n = 2 * cus;
+    if (n > 1024) n = 1024;
+  }
+  return n;
+}
+
+}  // namespace
+
+bool front_bwd_supported(int d, int n_attr) { return d == 64 && n_attr >= 4 && n_attr <= kAttrCols && n_attr % 4 == 0; }
+size_t front_bwd_ws_floats() { return (size_t)1024 * kFrontSlab; }
+
+int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
+                     const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
+                     matcha_tensors& grads, hipStream_t st) {
+  FrontBwdArgs g;
+  g.X = X; g.dxh = dxh; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr_table = attr_table; g.n_attr = n_attr;
+  g.Wn = p.next_w; g.count = rg.count; g.dX0 = dX0; g.dtable = dtable; g.slab = ws;
+  int grid = front_grid();
+  const int64_t max_tiles = cdiv(tcap, 64);
+  if (grid > max_tiles) grid = (int)max_tiles;
+  const size_t lds = ((size_t)4 * kTile + 64 * kLdA + 64) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(front_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    // algorithmic bytes per token: 8 partials + X + dXs + x0 (11 x 256 B), id, attribute row; table mode adds 256 B of atomics
+    ProfScope ps(MATCHA_PROF_LN3_BWD, (double)tcap * (11.0 * 256.0 + 8.0 + 4.0 * n_attr + 256.0), st);
+    hipLaunchKernelGGL(front_bwd_kernel, dim3(grid), dim3(256), lds, st, g);
+    MATCHA_CHECK_LAUNCH("front_bwd_kernel");
+  }
+  FrontReduceArgs a;
+  a.slab = ws; a.nwg = grid; a.n_attr = n_attr; a.dWn = grads.next_w; a.dWa = grads.attr_w; a.dbn = grads.next_b; a.dba = grads.attr_b;
+  hipLaunchKernelGGL(front_slab_reduce_kernel, dim3((unsigned)cdiv(kFrontSlab, 64)), dim3(1024), 0, st, a);
+  MATCHA_CHECK_LAUNCH("front_slab_reduce_kernel");
+  return MATCHA_OK;
+}
+
+}  // namespace matcha

@@ -717,6 +717,8 @@ int chunks_for(int ntiles) {
 
 }  // namespace
 
+const float* fused_bwd_dxpad(const float* ws) { return ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab + 32 * 3 * 3 * 64; }
+
 size_t fused_bwd_ws_floats(int64_t B, int L) {
   (void)B; (void)L;
   return (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab + (size_t)32 * 3 * 3 * 64 + 64;
@@ -772,8 +774,10 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     hipLaunchKernelGGL(fb_unfold2_kernel, dim3(1), dim3(512), 0, st, b);
     MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
   }
-  hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
-  MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
+  if (dZ0) {                                           // null: the caller's front-end backward kernel consumes dxh / dxpad itself
+    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
+    MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
+  }
   return MATCHA_OK;
 }
 

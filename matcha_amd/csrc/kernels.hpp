@@ -102,6 +102,16 @@ size_t fused_bwd_ws_floats(int64_t B, int L);
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st);
 
+const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
+
+// front_bwd.hip (embed_dim 64, n_attr <= 32): LayerNorm backward of the summed d x_hat partials, next_w and attribute_nn
+// backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel
+bool front_bwd_supported(int d, int n_attr);
+size_t front_bwd_ws_floats();
+int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
+                     const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
+                     matcha_tensors& grads, hipStream_t st);
+
 // attention.hip
 int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float* O, float* P,
                     hipStream_t st);

@@ -65,12 +65,14 @@ struct Workspace {
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
+  float* front_ws;                        // fused front-end backward: workgroup slabs
   size_t total;
 };
 
 // A/B switches for tests and profiling (read on every call so a test can flip them):
 //   MATCHA_DISABLE_FUSED        layer-by-layer kernels everywhere
 //   MATCHA_DISABLE_FUSED_TRAIN  fused kernel only for no-grad forwards; training runs layer by layer
+//   MATCHA_DISABLE_FUSED_FRONT  front-end backward (LayerNorm / next_w / attribute_nn / scatter) as separate kernels
 static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && getenv("MATCHA_DISABLE_FUSED") == nullptr; }
 static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && getenv("MATCHA_DISABLE_FUSED_TRAIN") == nullptr; }
 //   MATCHA_DISABLE_LOSS_IN_FORWARD  the tail's backward as separate kernels even when opts->loss_in_forward is set
@@ -127,6 +129,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
+  w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
   w.total = off;
   return off;
 }
@@ -344,7 +347,21 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   if (fused_train_enabled(s)) {
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
-    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, w.dZ0, st));
+    const bool front = front_bwd_supported(s.d, s.n_attr) && getenv("MATCHA_DISABLE_FUSED_FRONT") == nullptr;
+    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st));
+    if (front) {
+      // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
+      if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
+      MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
+                                  s.mode == 0 ? nullptr : w.dX0, s.mode == 0 ? g_.table : nullptr, w.front_ws, g_, st));
+      if (s.mode == 0) {
+        if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
+      } else {
+        MATCHA_TRY(adj_backward(s, p, *frozen, *opts, ids, Tn, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st,
+                                w.rg.tok_slot));
+      }
+      return MATCHA_OK;
+    }
   } else {
   // fc1: dW += ddyn0^T O ; db += colsum ; dO = ddyn0 Wfc1
   MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, g_.fc1_w, g_.fc1_b, d, hd, Tn, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
