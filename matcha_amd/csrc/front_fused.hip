@@ -1,4 +1,11 @@
-// Fused backward of the encoder's front end for embed_dim 64 (training path of the metric's configuration):
+// Fused front end of the encoder for embed_dim 64 (the metric's configuration), forward and backward.
+//
+// Forward (front_fwd_kernel): x0 = node_row + attribute_nn(attr_table[id])  (Modules.py:263-269),  X = tanh(next_w(x0))  (:270)
+// in one token-major kernel: the embedding rows are gathered straight into an LDS tile (coalesced 256-B rows), the
+// attribute Linear is a K = 32 MFMA GEMM on the gathered attribute rows, and the next_w GEMM consumes the x0 tile in
+// place; x0 (needed by the weight gradient) and X are the only writes.
+//
+// Backward (front_bwd_kernel):
 //   d x_hat = sum over the 8 per-head partials of fused_bwd.hip  ->  LayerNorm backward (no affine) + static-branch
 //   gradient + tanh'  = dZ0            (Modules.py:519-521 backward, :270)
 //   dX0 = dZ0 . Wn,  dWn += dZ0^T x0,  d bn += colsum(dZ0)                      (next_w, Modules.py:270)
@@ -162,6 +169,99 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
   }
 }
 
+struct FrontFwdArgs {
+  const int64_t* ids; const float* table; const float* dense;       // node rows: table[id] (table front end) or dense[t] (adj)
+  const float* attr_table; int n_attr;
+  const float* Wa; const float* ba; const float* Wn; const float* bn;
+  const int32_t* count;
+  float* x0; float* X;
+};
+
+__global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ws = lds;                                // next_w [n][k], resident
+  float* Es = lds + kTile;                        // node rows, then x0 in place
+  float* Was = lds + 2 * kTile;                   // attribute_nn.weight [64][kLdA] (columns >= n_attr zero), resident
+  float* As = Was + 64 * kLdA;                    // attribute rows [64][kLdA]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+  const int T = g.count[0];
+  const int ntiles = (T + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4*>(&Ws[(srow + 16 * i) * kLd + sc4]) = *reinterpret_cast<const float4*>(g.Wn + (srow + 16 * i) * 64 + sc4);
+  for (int i = tid; i < 64 * (kAttrCols / 4); i += 256) {
+    const int row = i >> 3, q = (i & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < g.n_attr) v = *reinterpret_cast<const float4*>(g.Wa + row * g.n_attr + q);
+    *reinterpret_cast<float4*>(&Was[row * kLdA + q]) = v;
+  }
+  const int col = 32 * wc + r;
+  const float bav = g.ba[col], bnv = g.bn[col];
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t t_base = (int64_t)tile * 64;
+    __syncthreads();
+    // ---- gather: node rows (16 lanes x float4 per 256-B row) and attribute rows ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      const int64_t t = t_base + row;
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T) e = g.table ? *reinterpret_cast<const float4*>(g.table + g.ids[t] * 64 + sc4) : *reinterpret_cast<const float4*>(g.dense + t * 64 + sc4);
+      *reinterpret_cast<float4*>(&Es[row * kLd + sc4]) = e;
+    }
+    for (int i = tid; i < 64 * (kAttrCols / 4); i += 256) {
+      const int row = i >> 3, q = (i & 7) * 4;
+      const int64_t t = t_base + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T && q < g.n_attr) v = *reinterpret_cast<const float4*>(g.attr_table + g.ids[t] * g.n_attr + q);
+      *reinterpret_cast<float4*>(&As[row * kLdA + q]) = v;
+    }
+    __syncthreads();
+    // ---- x0 = node_row + attr . Wa^T + ba   (K = 32) ----
+    {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int c = 0; c < kAttrCols / 8; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLdA + 8 * c + 4 * h]);
+        const float4 b = *reinterpret_cast<const float4*>(&Was[(32 * wc + r) * kLdA + 8 * c + 4 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const float v = acc[reg] + bav + Es[row * kLd + col];
+        Es[row * kLd + col] = v;                                      // in place: this lane owns the element
+        if (t_base + row < T) g.x0[(t_base + row) * 64 + col] = v;
+      }
+    }
+    __syncthreads();
+    // ---- X = tanh(x0 . Wn^T + bn) ----
+    {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(&Es[(32 * wr + r) * kLd + 8 * c + 4 * h]);
+        const float4 b = *reinterpret_cast<const float4*>(&Ws[(32 * wc + r) * kLd + 8 * c + 4 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (t_base + row < T) g.X[(t_base + row) * 64 + col] = tanhf(acc[reg] + bnv);
+      }
+    }
+  }
+}
+
 struct FrontReduceArgs {
   const float* slab; int nwg; int n_attr;
   float* dWn; float* dWa; float* dbn; float* dba;
@@ -204,6 +304,22 @@ int front_grid() {
 }
 
 }  // namespace
+
+int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st) {
+  FrontFwdArgs g;
+  g.ids = ids; g.table = table; g.dense = dense; g.attr_table = attr_table; g.n_attr = n_attr;
+  g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
+  int grid = front_grid();
+  const int64_t max_tiles = cdiv(tcap, 64);
+  if (grid > max_tiles) grid = (int)max_tiles;
+  const size_t lds = ((size_t)2 * kTile + 2 * 64 * kLdA) * sizeof(float);
+  // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
+  ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + 512.0), st);
+  hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);
+  MATCHA_CHECK_LAUNCH("front_fwd_kernel");
+  return MATCHA_OK;
+}
 
 bool front_bwd_supported(int d, int n_attr) { return d == 64 && n_attr >= 4 && n_attr <= kAttrCols && n_attr % 4 == 0; }
 size_t front_bwd_ws_floats() { return (size_t)1024 * kFrontSlab; }

@@ -104,9 +104,12 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 
-// front_bwd.hip (embed_dim 64, n_attr <= 32): LayerNorm backward of the summed d x_hat partials, next_w and attribute_nn
+// front_fused.hip (embed_dim 64, n_attr <= 32): forward = gather + attribute_nn + next_w + tanh in one kernel;
+// backward = LayerNorm backward of the summed d x_hat partials, next_w and attribute_nn
 // backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel
 bool front_bwd_supported(int d, int n_attr);
+int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st);
 size_t front_bwd_ws_floats();
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,

@@ -228,16 +228,21 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   MATCHA_TRY(launch_ragged_plan(x, B, L, w.rg, st));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
+  const bool front = fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && getenv("MATCHA_DISABLE_FUSED_FRONT") == nullptr;
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
-    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, p.table, nullptr, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st, cnt));
     if (recon_out && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
   } else {
     MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot));
-    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, nullptr, w.node, frozen->attr_table, s.n_attr, p.attr_w, p.attr_b, w.x0, st, cnt));
   }
-  // X = tanh(next_w(x0))   (Modules.py:270)
-  {
+  if (front) {
+    // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
+    MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, w.rg, Tn,
+                                w.x0, w.X, st));
+  } else {
+    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, p.attr_w,
+                                p.attr_b, w.x0, st, cnt));
+    // X = tanh(next_w(x0))   (Modules.py:270)
     GemmArgs g = gemm1(w, w.x0, p.next_w, w.X, Tn, d, d, false);
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
