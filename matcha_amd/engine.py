@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from .Modules import Classifier, _Runtime
-from .parallel import allreduce_gradients, broadcast_parameters, recon_grad_weight
+from .parallel import allreduce_bucket, broadcast_parameters, recon_grad_weight
 
 
 class Trainer:
@@ -33,7 +33,10 @@ class Trainer:
         self.lib = rt.lib
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         dev = rt.device
-        self.gflat = torch.zeros(rt.n_flat, dtype=torch.float32, device=dev)
+        # gradients + (data parallel) a float copy of the `touched` flags behind them: ONE all-reduce bucket per step
+        self._n_touched = rt.n_touched
+        self.gbuf = torch.zeros(rt.n_flat + rt.n_touched, dtype=torch.float32, device=dev)
+        self.gflat = self.gbuf[:rt.n_flat]
         self.exp_avg = torch.zeros_like(self.gflat)
         self.exp_avg_sq = torch.zeros_like(self.gflat)
         self.grads = rt.tensors_for(self.gflat)
@@ -95,9 +98,9 @@ class Trainer:
         return logits
 
     def all_reduce(self):
+        """One RCCL all-reduce per step over [gradients | touched flags] (matcha_amd/parallel.py::allreduce_bucket)."""
         if self.world > 1 or self.force_collectives:
-            torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-            torch.distributed.all_reduce(self.touched, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            allreduce_bucket(self.gbuf, self.rt.n_flat, self.touched, self.pg, force=self.force_collectives)
 
     def optimizer_step(self):
         rt = self.rt

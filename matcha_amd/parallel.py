@@ -42,6 +42,23 @@ def allreduce_gradients(gflat: torch.Tensor, touched: Optional[torch.Tensor], gr
     return 1.0 / world
 
 
+def allreduce_bucket(gbuf: torch.Tensor, n_flat: int, touched: torch.Tensor, group=None, force: bool = False) -> float:
+    """One collective per step: ``gbuf`` = [flat gradients (n_flat floats) | room for the touched flags].  The flags are
+    copied behind the gradients as floats, the whole buffer is summed across ranks, and a flag is set again where the sum
+    is positive -- "grad is None" is thereby decided on the GLOBAL batch.  Returns the 1/world scale the
+    optimizer applies.  ``force`` runs the collective even for a single rank (bench: exercise RCCL under a 1-rank launch)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return 1.0
+    tail = gbuf[n_flat:n_flat + touched.numel()]
+    tail.copy_(touched)
+    dist.all_reduce(gbuf, op=dist.ReduceOp.SUM, group=group)
+    touched.copy_(tail > 0)
+    return 1.0 / world
+
+
 def recon_grad_weight(m_local: torch.Tensor, beta: float, group=None) -> torch.Tensor:
     """Upstream gradient of the reconstruction loss for THIS rank so that the averaged gradient equals the single-rank
     one on the global batch.  The reference's recon loss is a mean over the m "other" tokens of the

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from matcha_amd import synth
-from matcha_amd.parallel import allreduce_gradients, broadcast_parameters, recon_grad_weight, shard_edges, shard_rows
+from matcha_amd.parallel import allreduce_bucket, allreduce_gradients, broadcast_parameters, recon_grad_weight, shard_edges, shard_rows
 from oracle import hypersagnn as O
 from tests.helpers import oracle_state
 
@@ -60,8 +60,13 @@ def _worker(rank, world, port, out_dir, mode):
     loss, bce, recon, logits, grads = O.loss_and_grads(P, fe, xs, ys, ws, 1.0, beta, random_chrom=1)
     gflat = _flatten(grads, names, P)
     touched = torch.tensor([1 if grads[n] is not None else 0 for n in names], dtype=torch.int32)
-    scale = allreduce_gradients(gflat, touched)
+    # the Trainer's path: one bucket [gradients | touched flags as floats], one SUM all-reduce
+    gbuf = torch.cat([gflat, torch.zeros(len(names))])
+    t2 = touched.clone()
+    assert allreduce_bucket(gbuf, gflat.numel(), t2) == 0.5
+    scale = allreduce_gradients(gflat, touched)          # the two-collective form (SUM + MAX) must agree with it
     assert scale == 0.5
+    assert torch.equal(gbuf[:gflat.numel()], gflat) and torch.equal(t2, touched)
     if rank == 0:
         torch.save({"g": gflat * scale, "names": names, "touched": touched}, os.path.join(out_dir, "dp.pt"))
     dist.barrier()
