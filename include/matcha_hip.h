@@ -275,6 +275,23 @@ int matcha_attn_bwd(const float* Q, const float* K, const float* V, const float*
                     const int32_t* row_off, int64_t B, int32_t L, int32_t d, float* dQ, float* dK, float* dV,
                     void* ws, size_t ws_bytes, matcha_stream_t stream);
 
+/* ---- k-mer generation (Code/generate_kmers.py:8-69, one k-mer size per call) -------------------------
+ * Every ascending k-subset of a cluster whose adjacent node gaps all exceed `min_dis` (generate_kmers.py:17, :24-32),
+ * counted over all clusters (:34-37), kept when seen >= `min_freq` times (:40).
+ *   ids, offsets   clusters in CSR form: cluster c = ids[offsets[c] .. offsets[c+1]), sorted unique node ids
+ *                  (process.py:66-77), device int32 / int64 [n_clusters + 1]
+ *   comb_off       device int64 [n_clusters + 1]: exclusive prefix sums of C(len_c, k) over the clusters with
+ *                  k <= len_c <= max_cluster_size (<= 64; generate_kmers.py:88) and 0 for the others -- the caller has the
+ *                  cluster lengths on the host; total_combos = comb_off[n_clusters] < 2^32 - 1
+ *   out_kmers      int64 [cap, k] rows in lexicographic order (the reference's order depends on worker scheduling),
+ *   out_freq       int64 [cap], n_out: device int64, the number of k-mers kept (if > cap only the first cap are written)
+ *   ws             matcha_kmer_workspace_bytes(total_combos, k, n_nodes) bytes */
+size_t matcha_kmer_workspace_bytes(int64_t total_combos, int32_t k, int32_t n_nodes);
+int matcha_kmer_generate(const int32_t* ids, const int64_t* offsets, const int64_t* comb_off, int64_t n_clusters,
+                         int64_t total_combos, int32_t k, int32_t n_nodes, int32_t min_dis, int32_t min_freq,
+                         int64_t* out_kmers, int64_t* out_freq, int64_t cap, int64_t* n_out, void* ws, size_t ws_bytes,
+                         matcha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

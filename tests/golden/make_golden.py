@@ -15,7 +15,7 @@ What it does
     main.py:630 builds it, and the reference's own save_embeddings / get_attributes /
     generate_negative (function bodies exec'd out of main.py's AST, because main.py has no
     __main__ guard and cannot be imported);
-  * writes G1..G5 of SURVEY.md §8(c2) + sampler statistics + G6 (inference consumers, §8 f1).
+  * writes G1..G5 of SURVEY.md §8(c2) + sampler statistics + G6 (inference consumers, §8 f1) + G7 (k-mer generation, §8 f2).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -350,6 +350,44 @@ def g6_inference(M, U):
     print("G6", len(parsed), "multiway samples;", {k: v.shape for k, v in out.items() if k.startswith("pair_matrix")})
 
 
+def g7_kmers(M, U):
+    """G7: generate_kmers.py's build_dict on a synthetic cluster file -- rows sorted lexicographically
+    (the script's own order depends on worker scheduling).  Clusters: sorted unique node lists as process.py:66-77 writes."""
+    from collections import Counter
+    from itertools import combinations
+    rng = np.random.default_rng(77)
+    n_nodes, max_size = 60, 9
+    clusters = []
+    for _ in range(400):
+        n = int(rng.integers(2, 13))                                    # some exceed max_size and must be skipped (:88)
+        # draw from a few "hot" neighbourhoods so that k-mers repeat across clusters
+        centre = int(rng.choice([8, 20, 33, 47]))
+        pool = np.clip(centre + rng.integers(-7, 8, size=3 * n), 1, n_nodes)
+        c = np.unique(pool)[:n]
+        if len(c) >= 2:
+            clusters.append(np.sort(c).astype(np.int64))
+    out = {"n_clusters": np.int64(len(clusters)), "cl_len": np.array([len(c) for c in clusters], dtype=np.int64),
+           "cl_flat": np.concatenate(clusters), "n_nodes": np.int64(n_nodes), "max_size": np.int64(max_size)}
+    for min_dis, cutoff in ((0, 2), (2, 1), (1, 3)):
+        for size in (2, 3, 4, 5):
+            new_data = [np.array(d) for d in clusters if (len(d) >= size) & (len(d) <= max_size)]      # generate_kmers.py:86-90
+            node2usefulindex = [[] for _ in range(n_nodes + 1)]
+            for i, datum in enumerate(new_data):                                                       # :92-95
+                for n in datum:
+                    node2usefulindex[n].append(i)
+            glb = dict(np=np, Counter=Counter, combinations=combinations, tqdm=lambda x: x, node2usefulindex=node2usefulindex,
+                       new_data=new_data, min_dis=min_dis, min_freq_cutoff=cutoff)
+            ref_functions("generate_kmers.py", {"build_dict"}, glb)
+            _, rows, freq = glb["build_dict"](size, list(range(n_nodes + 1)))
+            rows = np.asarray(rows, dtype=np.int64).reshape(-1, size)
+            freq = np.asarray(freq, dtype=np.int64).reshape(-1)
+            order = np.lexsort(rows.T[::-1]) if len(rows) else np.zeros(0, dtype=np.int64)
+            out[f"kmers_d{min_dis}_c{cutoff}_k{size}"] = rows[order]
+            out[f"freq_d{min_dis}_c{cutoff}_k{size}"] = freq[order]
+    np.savez_compressed(os.path.join(HERE, "g7_kmers.npz"), **out)
+    print("G7", {k: v.shape for k, v in out.items() if k.startswith("kmers_d0")})
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
@@ -366,6 +404,7 @@ def main():
     g3_train(M, "hg38_adj_d64", synth.LAYOUTS["hg38_1mb"], 64, "adj", 42, 1.0, 0.001, "phase2", n_steps=3, full=False)
     sampler_stats(M, U)
     g6_inference(M, U)
+    g7_kmers(M, U)
 
 
 if __name__ == "__main__":
