@@ -66,6 +66,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const int nchunk = per_lane / CH;
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
   const int64_t pad_base = (int64_t)row_off[B] * hd + (int64_t)head * d;
+  if (blockIdx.x == 0 && wave == 0) {
+    // the padding token's query is never evaluated, but its O row is a contraction row of the fc1 weight gradient
+    // (times a zero gradient): it must be finite, so zero it (the workspace is not initialised)
+    for (int c = 0; c < nchunk; ++c) {
+      Chunk<CH> z;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) z.v[e] = 0.f;
+      store_chunk<CH>(O + pad_base + c * (8 * CH) + sub * CH, z);
+    }
+  }
   for (int it = 0; it < kAttnRowsPerWave; ++it) {
     const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * kAttnRowsPerWave + it;
     if (b >= B) return;

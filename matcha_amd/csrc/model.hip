@@ -157,6 +157,29 @@ static GemmArgs gemm1(const Workspace& w, const float* A, const float* B, float*
   return g;
 }
 
+// MATCHA_DEBUG_NAN=1: after selected stages count the non-finite values in the VALID rows of a buffer and print them
+// (synchronises; development only -- it found reads of uninitialised workspace rows)
+__global__ void nan_count_kernel(const float* __restrict__ p, const int32_t* __restrict__ rows_dev, int64_t rows, int64_t width, int* __restrict__ out) {
+  if (rows_dev) rows = *rows_dev;
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * width; i += (int64_t)gridDim.x * blockDim.x)
+    bad += isfinite(p[i]) ? 0 : 1;
+  if (bad) atomicAdd(out, bad);
+}
+static void nan_check(const char* name, const float* p, const int32_t* rows_dev, int64_t rows, int64_t width, hipStream_t st) {
+  static const bool on = getenv("MATCHA_DEBUG_NAN") != nullptr;
+  if (!on || !p) return;
+  int* d = nullptr;
+  int h = 0;
+  if (hipMalloc(&d, sizeof(int)) != hipSuccess) return;
+  (void)hipMemsetAsync(d, 0, sizeof(int), st);
+  hipLaunchKernelGGL(nan_count_kernel, dim3(256), dim3(256), 0, st, p, rows_dev, rows, width, d);
+  (void)hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(d);
+  fprintf(stderr, "[matcha nan-check] %-10s %d non-finite values in the valid rows\n", name, h);
+}
+
 }  // namespace matcha
 
 using namespace matcha;
@@ -262,6 +285,8 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     }
     return MATCHA_OK;
   }
+  nan_check("x0", w.x0, cnt, 0, d, st);
+  nan_check("X", w.X, cnt, 0, d, st);
   // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
   MATCHA_TRY(launch_ln3_fwd(w.X, Tn, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st, cnt));
   {
@@ -271,7 +296,12 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     g.batch = 3;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
+  nan_check("qin", w.qin, cnt, 0, d, st);
+  nan_check("Q", w.Q, cnt, 0, hd, st);
+  nan_check("K", w.K, cnt, 0, hd, st);
+  nan_check("V", w.V, cnt, 0, hd, st);
   MATCHA_TRY(launch_attn_fwd(w.Q, w.K, w.V, w.rg.row_off, B, L, d, w.O, w.P, st));
+  nan_check("O", w.O, cnt + 1, 0, hd, st);
   // Y = (dropout(fc1(O))) * non_pad_mask    (Modules.py:572, :614); the mask only zeroes the shared padding token's row
   {
     GemmArgs g = gemm1(w, w.O, p.fc1_w, w.Y, Tn, d, hd, false);
@@ -291,6 +321,9 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_RESIDUAL; g.bias[0] = p.pff1_b; g.residual = w.Y;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
+  nan_check("Y", w.Y, cnt, 0, d, st);
+  nan_check("H1", w.H1, cnt, 0, d, st);
+  nan_check("H2", w.H2, cnt, 0, d, st);
   // LayerNorms, (dynamic-static)^2, Conv1d(d->1), masked mean, weighted BCE   (Modules.py:373-374, :290-311; main.py:56)
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   MATCHA_TRY(launch_head_fwd(w.rg.row_off, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, w.row_loss, losses, st));

@@ -268,3 +268,39 @@ def test_loss_in_forward_matches_separate_tail_backward(mode):
         a, b = g0[o:o + sizes[n]], g1[o:o + sizes[n]]
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("d,mode", [(16, "table"), (16, "adj"), (64, "table"), (64, "adj"), (128, "table")])
+def test_uninitialised_workspace_does_not_leak(d, mode):
+    """The workspace is caller-owned scratch and arrives uninitialised.  Poison it with NaN bit patterns: three optimiser
+    steps and an autograd forward/backward must stay finite (a contraction row multiplied by a zero gradient is still NaN
+    if the row was never written -- the padding token's attention output was such a row)."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["tiny"]
+    clf, _ = hip_model(num, d, mode, 3)
+    clf.train()
+    rt = clf._runtime()
+    orig = rt.workspace
+
+    def poisoned(B, L):
+        ws = orig(B, L)
+        ws.view(torch.int32).fill_(-1)                   # 0xFFFFFFFF: a NaN in every float slot
+        return ws
+    rt.workspace = poisoned
+    try:
+        x, y, w = synth.make_batch(np.random.default_rng(1), int(np.sum(num)), [2, 3, 5], 20)
+        xt, yt, wt = (torch.from_numpy(a).cuda() for a in (x, y, w))
+        lg, rc = clf(xt, return_recon=True)               # autograd path
+        (torch.nn.functional.binary_cross_entropy_with_logits(lg, yt, weight=wt) + 0.01 * rc.sum()).backward()
+        for n, p in clf.named_parameters():
+            assert p.grad is None or bool(torch.isfinite(p.grad).all()), n
+        clf.zero_grad()
+        tr = Trainer(clf)
+        for _ in range(3):
+            bce, _, lg = tr.step(xt, yt.reshape(-1), wt.reshape(-1), alpha=1.0, beta=0.001, random_chrom=1)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(bce)) and bool(torch.isfinite(lg).all())
+        for n, p in clf.named_parameters():
+            assert bool(torch.isfinite(p).all()), n
+    finally:
+        rt.workspace = orig
