@@ -304,3 +304,34 @@ def test_uninitialised_workspace_does_not_leak(d, mode):
             assert bool(torch.isfinite(p).all()), n
     finally:
         rt.workspace = orig
+
+
+@pytest.mark.parametrize("rows", [1, 2, 7, 65])
+def test_tiny_batches_fused_matches_layerwise(rows):
+    """Batches far smaller than one tile / one chunk (one hyperedge, one tile, just over a tile): fused d = 64 kernels against
+    the layer-by-layer kernels, forward and gradients."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, 64, "table", 41)
+    clf.train(False)
+    rng = np.random.default_rng(rows)
+    x = _mixed_batch(N, [2, 3, 5], 25, rng)[:rows].contiguous()
+    y = (torch.rand(rows, 1, device="cuda") < 0.5).float()
+    res = []
+    for layerwise in (True, False):
+        clf.zero_grad()
+        if layerwise:
+            os.environ["MATCHA_DISABLE_FUSED"] = "1"
+        try:
+            lg = clf(x)
+            torch.nn.functional.binary_cross_entropy_with_logits(lg, y).backward()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MATCHA_DISABLE_FUSED", None)
+        res.append((lg.detach().clone(), {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.grad is not None}))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
+    for n, a in res[0][1].items():
+        if n == GAUGE:
+            continue
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - res[1][1][n]).abs().max()) <= 2e-5 * scale + 1e-9, n
