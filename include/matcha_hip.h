@@ -65,6 +65,8 @@ int matcha_device_count(void);
 #define MATCHA_PROF_GATHER_ROWS 15
 #define MATCHA_PROF_FUSED_FWD 16
 #define MATCHA_PROF_FUSED_BWD 17
+#define MATCHA_PROF_FRONT_FWD 18   /* gather + attribute_nn + next_w + tanh (front_fused.hip) */
+#define MATCHA_PROF_FRONT_BWD 19   /* LayerNorm backward of the d x_hat partials + next_w / attribute_nn backward + scatter */
 int matcha_profile_select(int32_t kernel_class);
 int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
 

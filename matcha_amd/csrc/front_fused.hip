@@ -315,7 +315,7 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   if (grid > max_tiles) grid = (int)max_tiles;
   const size_t lds = ((size_t)2 * kTile + 2 * 64 * kLdA) * sizeof(float);
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
-  ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + 512.0), st);
+  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + 512.0), st);
   hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);
   MATCHA_CHECK_LAUNCH("front_fwd_kernel");
   return MATCHA_OK;
@@ -337,7 +337,7 @@ int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, 
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(front_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   {
     // algorithmic bytes per token: 8 partials + X + dXs + x0 (11 x 256 B), id, attribute row; table mode adds 256 B of atomics
-    ProfScope ps(MATCHA_PROF_LN3_BWD, (double)tcap * (11.0 * 256.0 + 8.0 + 4.0 * n_attr + 256.0), st);
+    ProfScope ps(MATCHA_PROF_FRONT_BWD, (double)tcap * (11.0 * 256.0 + 8.0 + 4.0 * n_attr + 256.0), st);
     hipLaunchKernelGGL(front_bwd_kernel, dim3(grid), dim3(256), lds, st, g);
     MATCHA_CHECK_LAUNCH("front_bwd_kernel");
   }

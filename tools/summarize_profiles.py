@@ -41,6 +41,10 @@ def cls(n):
         return "fused_fwd"
     if "fused_bwd_kernel" in n:
         return "fused_bwd"
+    if "front_fwd_kernel" in n:
+        return "front_fwd"
+    if "front_bwd_kernel" in n:
+        return "front_bwd"
     for k in ("attn_fwd", "attn_bwd", "embed_fwd", "embed_scatter", "ln3_fwd", "ln3_bwd", "head_fwd", "head_bwd", "adamw_kernel", "neg_sample", "adj_encode"):
         if k in n:
             return k.replace("_kernel", "")
