@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   const int tok_pad = g.count[1];                    // Tr: index of the shared padding token
   const float inv_temp = 0.125f;                     // 1/sqrt(64)
 
-  // weight tiles are fetched TWO phases ahead into two alternating register sets (A: Wq / Wv, B: Wk / Wfc1)
+  // weight tiles are fetched ahead of their use into two alternating register sets (A: Wq / Wv, B: Wk / Wfc1)
   float4 wA0, wA1, wA2, wA3, wB0, wB1, wB2, wB3;
   TILE_GLOAD(wA, g.wq, 64);
   TILE_GLOAD(wB, g.wk, 64);
@@ -285,28 +285,25 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   for (int hd = 0; hd < MATCHA_N_HEAD; ++hd) {
     const int64_t wofs = (int64_t)hd * 64 * 64;
     const bool last = hd + 1 == MATCHA_N_HEAD;
-    // ---- Q ----
-    __syncthreads();                                   // everyone is done with Bs (previous fc1 GEMM) and with Qs
+    // ---- Q and K: W'q staged in Bs, W'k in the V tile (free until V is computed) -> one barrier pair for two GEMMs ----
+    __syncthreads();                                   // everyone is done with Bs, Qs (previous fc1 GEMM) and Vs (attention)
     TILE_LSTORE(Bs, wA);
+    TILE_LSTORE(Vs, wB);
     TILE_GLOAD(wA, g.wv + wofs, 64);
+    TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
     __syncthreads();
     {
       f32x16 acc = {0};
       if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
       quad_store(Qs, acc, cbias + hd * 64, wr, wc, r, h);
     }
-    // ---- K ----
-    __syncthreads();
-    TILE_LSTORE(Bs, wB);
-    TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
-    __syncthreads();
     {
       f32x16 acc = {0};
-      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
+      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Vs, wc, r, h);
       quad_store(Ks, acc, cbias + 512 + hd * 64, wr, wc, r, h);
     }
     // ---- V ----
-    __syncthreads();
+    __syncthreads();                                   // both weight tiles consumed
     TILE_LSTORE(Bs, wA);
     TILE_GLOAD(wA, last ? g.p0w : g.wq + wofs + 64 * 64, 64);
     __syncthreads();
