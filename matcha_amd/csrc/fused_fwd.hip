@@ -2,13 +2,14 @@
 //   X  ->  x_hat  ->  per head { Q,K,V = x_hat.W'^T + c  ->  attention (diag masked, pads attended)  ->  dyn += O.Wfc1_h^T }
 //      ->  Y = mask*dropout(dyn + b)  ->  H1 = dropout(tanh(conv0 Y))  ->  H2 = conv1 H1 + Y
 //      ->  LN_pff, LN1, LN2(X), (dn - sn)^2 . wc + bc  ->  per-hyperedge mean  ->  logit (+ weighted BCE term)
-// (Modules.py:519-572, :353-376, :290-311; main.py:56).  Everything between X and the logits stays in LDS/registers:
-// per token the kernel reads 256 B (X) and, in training, writes 768 B (Y, H1, H2 for the backward pass) instead of the
-// ~20 KB of Q/K/V/O/... round trips of the layer-by-layer path.
+// (Modules.py:519-572, :353-376, :290-311; main.py:56).  Everything between X and the logits stays in LDS/registers.
+// Three modes: inference (nothing saved); autograd forward (Y, H1, H2 saved, 768 B per token, for a later backward with an
+// arbitrary dlogits); training step with the loss known here (opts.loss_in_forward): the kernel continues with
+// dL/dlogit = alpha w (sigmoid(z) - y) / B through the tail and pff_n1 BACKWARD while Y, H1, H2 are still in LDS and emits
+// d(dyn), dXs and per-tile partials of 12 parameter gradients -- nothing is saved.
 //
 // Work decomposition: one 256-thread workgroup per TILE of whole hyperedges, <= 63 real tokens + the shared padding token
-// as the last row (its K/V rows come out of the same projection GEMMs).  Tile i owns the hyperedges whose first token
-// ragged.hip packs the tiles greedily (tile_meta).
+// as the last row (its K/V rows come out of the same projection GEMMs); ragged.hip packs the tiles greedily (tile_meta).
 // A 64x64x64 GEMM is split into four 32x32 quadrants, one per wave (32 f32 MFMAs each).
 // The three LayerNorm affines in front of Q/K/V are folded into the projection weights once per step
 // (W' = W * g, c = W . b), so one x_hat fragment set, held in registers for the whole tile, feeds all 24 projections.
