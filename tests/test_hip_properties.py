@@ -335,3 +335,43 @@ def test_tiny_batches_fused_matches_layerwise(rows):
             continue
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - res[1][1][n]).abs().max()) <= 2e-5 * scale + 1e-9, n
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+def test_fused_front_end_matches_separate_kernels(mode):
+    """d = 64: the fused front-end kernels (gather + attribute_nn + next_w forward; LayerNorm backward + next_w +
+    attribute_nn + scatter backward) against the separate kernels they replace (MATCHA_DISABLE_FUSED_FRONT), which remain
+    the path for attribute tables wider than 32 columns."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(13)
+    x = _mixed_batch(N, [2, 3, 4, 5], 900, rng)
+    y = (torch.rand(len(x), device="cuda") < 0.3).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    res = []
+    for separate in (True, False):
+        clf, _ = hip_model(num, 64, mode, 37)
+        clf.train(True)
+        tr = Trainer(clf, base_seed=5)
+        if separate:
+            os.environ["MATCHA_DISABLE_FUSED_FRONT"] = "1"
+        try:
+            logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=2)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MATCHA_DISABLE_FUSED_FRONT", None)
+        res.append((logits.clone(), tr.gflat.clone()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
+    g0, g1 = res[0][1], res[1][1]
+    assert float(g0.abs().max()) > 0
+    # compare per parameter tensor (relative to that tensor's own scale)
+    clf, _ = hip_model(num, 64, mode, 37)
+    rt = clf._runtime()
+    for n, p in clf.named_parameters():
+        o = (p.data_ptr() - rt.flat.data_ptr()) // 4
+        if n == GAUGE or o < 0 or o >= rt.n_flat:
+            continue
+        a, b = g0[o:o + p.numel()], g1[o:o + p.numel()]
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
