@@ -392,13 +392,16 @@ __global__ __launch_bounds__(256) void adj_tanh_gather_kernel(const float* __res
   TH[i] = tanhf(node[(int64_t)other_map[j] * d + col]);
 }
 
-// D[j][col] = rec[j][col] - inter[x_j - 1][bounds[r] + col]  (in place; pad columns zeroed); per-block sums of D^2
+// D[j][col] = (rec[j][col] - inter[x_j - 1][bounds[r] + col]) * 200 / (m n_r)  (in place; pad columns zeroed): the gradient of
+// the recon loss w.r.t. rec up to the upstream factor g (beta or *drecon), which the backward pass folds into the outputs of
+// its two linear consumers.  Per-block sums of the unscaled squares for the loss itself.
 __global__ __launch_bounds__(256) void adj_recon_loss_kernel(float* __restrict__ rec, int64_t nr_pad, int n_r, int col0, const float* __restrict__ inter,
                                                              int64_t n_nodes, const int64_t* __restrict__ x, const int32_t* __restrict__ other_map,
                                                              const int32_t* __restrict__ counts, float* __restrict__ slab) {
   __shared__ float red[256];
   const int m = counts[0];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float gs = m > 0 ? 200.f / ((float)m * (float)n_r) : 0.f;
   float s = 0.f;
   // one wave per row, 64 rows per workgroup
   for (int rr = wave; rr < 64; rr += 4) {
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void adj_recon_loss_kernel(float* __restrict__
     for (int col = lane; col < nr_pad; col += 64) {
       float dv = 0.f;
       if (col < n_r) { dv = rrow[col] - trow[col]; s += dv * dv; }
-      rrow[col] = dv;
+      rrow[col] = dv * gs;
     }
   }
   red[threadIdx.x] = s;
@@ -442,26 +445,16 @@ __global__ __launch_bounds__(256) void adj_recon_final_kernel(const float* __res
   }
 }
 
-// D *= g * 200 / (m * n_r)   with g = *drecon (autograd) or beta
-__global__ __launch_bounds__(256) void adj_scale_kernel(float* __restrict__ D, int64_t nr_pad, int n_r, const int32_t* __restrict__ counts,
-                                                        const float* __restrict__ drecon, float beta) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int m = counts[0];
-  if (i >= (int64_t)m * nr_pad) return;
-  const float gscale = (drecon ? drecon[0] : beta) * 200.f / ((float)m * (float)n_r);
-  D[i] *= gscale;
-}
-
-// dnode[other_map[j]] += dTH[j] * (1 - TH[j]^2)
+// dnode[other_map[j]] += g * dTH[j] * (1 - TH[j]^2)      (g = *drecon from autograd, or beta)
 __global__ __launch_bounds__(256) void adj_recon_dnode_kernel(const float* __restrict__ dTH, const float* __restrict__ TH,
                                                               const int32_t* __restrict__ other_map, const int32_t* __restrict__ counts, int d,
-                                                              float* __restrict__ dnode) {
+                                                              float* __restrict__ dnode, const float* __restrict__ drecon, float beta) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t j = i / d;
   if (j >= counts[0]) return;
   const int col = (int)(i - j * d);
   const float t = TH[i];
-  dnode[(int64_t)other_map[j] * d + col] += dTH[i] * (1.f - t * t);
+  dnode[(int64_t)other_map[j] * d + col] += (drecon ? drecon[0] : beta) * dTH[i] * (1.f - t * t);
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------------
@@ -568,11 +561,10 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
   if (r >= 0 && (drecon || o.beta != 0.f)) {
     MATCHA_CHECK_ARG(g_.recon_w && g_.recon_b && f.bounds_host, "adj_backward: recon gradient buffers missing");
     const int lo_r = f.bounds_host[r], n_r = f.bounds_host[r + 1] - f.bounds_host[r];
-    hipLaunchKernelGGL(adj_scale_kernel, dim3((unsigned)cdiv(T * w.nr_pad, 256)), dim3(256), 0, st, w.rec, w.nr_pad, n_r, w.counts, drecon, o.beta);
-    MATCHA_CHECK_LAUNCH("adj_scale_kernel");
-    // dWr[n_r, d] += D^T TH ; dbr += colsum(D)
+    // w.rec holds D = (rec - target) * 200/(m n_r) since the forward pass; the upstream factor g scales the outputs
+    // dWr[n_r, d] += g D^T TH ; dbr += g colsum(D)
     MATCHA_TRY(launch_gemm_tn(w.rec, w.TH, g_.recon_w + (int64_t)d * lo_r, g_.recon_b + lo_r, n_r, d, T, w.nr_pad, d, nullptr, true, gemm_ws,
-                              gemm_ws_bytes, st, w.counts));
+                              gemm_ws_bytes, st, w.counts, drecon, drecon ? 1.f : o.beta));
     // dTH = D . Wr   (K = n_r)
     {
       GemmArgs g;
@@ -581,7 +573,7 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
       g.M = T; g.N = d; g.K = n_r; g.lda = w.nr_pad; g.ldb = d; g.ldc = d; g.aux_scale = 1.f; g.m_dev = w.counts;
       MATCHA_TRY(launch_gemm_rm(true, g, st));
     }
-    hipLaunchKernelGGL(adj_recon_dnode_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, w.dTH, w.TH, w.other_map, w.counts, d, dnode);
+    hipLaunchKernelGGL(adj_recon_dnode_kernel, dim3((unsigned)cdiv(T * d, 256)), dim3(256), 0, st, w.dTH, w.TH, w.other_map, w.counts, d, dnode, drecon, o.beta);
     MATCHA_CHECK_LAUNCH("adj_recon_dnode_kernel");
   }
   // ---- encoder ----

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
 // q, q+16, ... (ascending), then the 16 partial sums are added q = 0..15.  Coalesced 256-B reads per slab row.
 // Element i < n1 goes to out1[i], element n1 <= i < stride to out2[i - n1] (the column sums behind a TN slab).
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out1, int64_t n1,
-                                                           float* __restrict__ out2, int64_t stride, int P, int accumulate) {
+                                                           float* __restrict__ out2, int64_t stride, int P, int accumulate,
+                                                           const float* __restrict__ scale_dev, float scale) {
   __shared__ float part[16][64];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + o;
@@ -288,14 +289,17 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < 16; ++t) s += part[t][o];
     float* dst = i < n1 ? out1 + i : out2 + (i - n1);
+    s *= scale_dev ? scale_dev[0] * scale : scale;        // optional output scale (a device scalar times a host scalar)
     *dst = accumulate ? *dst + s : s;
   }
 }
 
-int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st) {
+int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st,
+                       const float* scale_dev, float scale) {
   const int64_t n = out2 ? stride : n1;
   if (n <= 0) return MATCHA_OK;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, slab, out1, n1, out2, stride, P, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, slab, out1, n1, out2, stride, P, accumulate ? 1 : 0,
+                     scale_dev, scale);
   MATCHA_CHECK_LAUNCH("slab_reduce_kernel");
   return MATCHA_OK;
 }
@@ -346,7 +350,7 @@ size_t gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t R) {
 // C[M,N] (+)= A[R,M]^T . B[R,N];  colsum[M] (+)= sum_r A[r,:]
 int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int64_t M, int64_t N, int64_t R,
                    int64_t lda, int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes,
-                   hipStream_t st, const int32_t* r_dev) {
+                   hipStream_t st, const int32_t* r_dev, const float* out_scale_dev, float out_scale) {
   if (M <= 0 || N <= 0) return MATCHA_OK;
   int tm, tn, P; int64_t rpb;
   tn_partition(M, N, R > 0 ? R : 1, &tm, &tn, &P, &rpb);
@@ -365,7 +369,7 @@ int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int6
     else hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(tm * tn, P), dim3(256), 0, st, g);
   }
   MATCHA_CHECK_LAUNCH("gemm_tn_kernel");
-  return launch_slab_reduce(g.slab, C, M * N, colsum, g.slab_stride, P, accumulate, st);
+  return launch_slab_reduce(g.slab, C, M * N, colsum, g.slab_stride, P, accumulate, st, out_scale_dev, out_scale);
 }
 
 }  // namespace matcha

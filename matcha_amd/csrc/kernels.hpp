@@ -61,8 +61,9 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st);
 size_t gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t R);
 int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int64_t M, int64_t N, int64_t R, int64_t lda,
                    int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-                   const int32_t* r_dev = nullptr);
-int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st);
+                   const int32_t* r_dev = nullptr, const float* out_scale_dev = nullptr, float out_scale = 1.f);   // C (+)= scale * A^T B
+int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st,
+                       const float* scale_dev = nullptr, float scale = 1.f);
 
 // token_kernels.hip
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
