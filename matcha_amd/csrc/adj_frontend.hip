@@ -235,18 +235,35 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
       const int kk = kc + lane;
       const int kcl = kk < n_c ? kk : n_c - 1;
       const float kmask = kk < n_c ? 1.f : 0.f;
-      for (int rr = wave; rr < 128; rr += 4) {
-        float v = g.feats[rowoff[rr] + kcl] * kmask;
-        if (drop) {
-          int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
-          if (g.slot_map) slot = g.slot_map[slot];
-          v = (rng_u32(key, (uint32_t)slot, (uint32_t)kk) >= thr) ? v * keep_scale : 0.f;   // counter = (token slot, column)
+      for (int i0 = 0; i0 < 32; i0 += 8) {            // 8 rows' loads in flight before the first is consumed
+        float fv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fv[u] = g.feats[rowoff[wave + 4 * (i0 + u)] + kcl];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = wave + 4 * (i0 + u);
+          float v = fv[u] * kmask;
+          if (drop) {
+            int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
+            if (g.slot_map) slot = g.slot_map[slot];
+            v = (rng_u32(key, (uint32_t)slot, (uint32_t)kk) >= thr) ? v * keep_scale : 0.f;   // counter = (token slot, column)
+          }
+          As[rr * kLdA + lane] = v;
         }
-        As[rr * kLdA + lane] = v;
       }
-      for (int j = wave; j < 32 * NT; j += 4) {
-        const int jc = j < g.d ? j : g.d - 1;
-        Bs[j * kLdA + lane] = (j < g.d) ? W0[(int64_t)jc * n_c + kcl] * kmask : 0.f;
+      for (int j0 = wave; j0 < 32 * NT; j0 += 32) {   // weight rows: 8 loads in flight
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + 4 * u;
+          const int jc = j < g.d ? j : g.d - 1;
+          wv[u] = W0[(int64_t)jc * n_c + kcl];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + 4 * u;
+          if (j < 32 * NT) Bs[j * kLdA + lane] = (j < g.d) ? wv[u] * kmask : 0.f;
+        }
       }
       __syncthreads();
       const float* arow = &As[(32 * wave + r) * kLdA + 4 * h];
@@ -278,6 +295,8 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
   }
 }
 
+constexpr size_t kAdjTnLds = (size_t)2 * 128 * 68 * sizeof(float);
+
 // ---- grouped weight gradients with atomics -----------------------------------------------------------------------
 //   MODE 0: dW1_c[j][k] += sum_p dnode[order[p]][j] * Hs[p][k]
 //   MODE 1: dW0_c[j][col] += sum_p dZ[p][j] * feats_c[x_p - lo_c][col] * dropmask(slot_p, col)
@@ -295,11 +314,19 @@ struct AdjTnArgs {
   const int32_t* slot_map;
 };
 
+// LDS-staged: per 128 sorted rows the workgroup resolves the row indices once (order -> slot -> feature row), stages the
+// A rows (64 columns of d) and the B rows (64 feature columns, dropout applied) with coalesced 256-B row reads, and every
+// wave accumulates its own 32x32 quadrant of the 64x64 output tile with the row index as the MFMA contraction index; a
+// chromosome's tile is added to the gradient with atomics straight from the accumulators (waves own distinct quadrants).
 template <int MODE>
-__global__ __launch_bounds__(256) void adj_tn_kernel(AdjTnArgs g) {
-  __shared__ float red[64 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
+__global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                              // [128][kLdA]
+  float* Bs = lds + 128 * kLdA;                 // [128][kLdA]
+  __shared__ int64_t rowoff[128];               // MODE 1: element offset of the feature row;  MODE 0: unused
+  __shared__ int rowslot[128];                  // token slot of the sorted row, -1 = past the range
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int mo0 = blockIdx.x * 64;             // output row tile (j)
   const int no0 = blockIdx.y * 64;             // output column tile (k or feature column)
   const int64_t nonpad = g.seg[g.C];
@@ -310,9 +337,8 @@ __global__ __launch_bounds__(256) void adj_tn_kernel(AdjTnArgs g) {
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
   if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
-  int am[2]; float amf[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) { am[t] = mo0 + 32 * t + r; amf[t] = am[t] < g.d ? 1.f : 0.f; if (am[t] >= g.d) am[t] = g.d - 1; }
+  const int acol = mo0 + lane, acolc = acol < g.d ? acol : g.d - 1;
+  const float amask = acol < g.d ? 1.f : 0.f;
   int c = 0;
   while (c < g.C && g.seg[c + 1] <= rb) ++c;
   for (; c < g.C && g.seg[c] < re; ++c) {
@@ -322,61 +348,59 @@ __global__ __launch_bounds__(256) void adj_tn_kernel(AdjTnArgs g) {
     const int lo = g.bounds[c], n_c = g.bounds[c + 1] - g.bounds[c];
     const int ncols = MODE == 0 ? g.d : n_c;
     if (no0 >= ncols) continue;
-    int bn[2]; float bnf[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { bn[t] = no0 + 32 * t + r; bnf[t] = bn[t] < ncols ? 1.f : 0.f; if (bn[t] >= ncols) bn[t] = ncols - 1; }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
-    for (int64_t r0 = p_lo + 8 * wave; r0 < p_hi; r0 += 32) {
-      float a[2][4], b[2][4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        int64_t p = r0 + 4 * h + cc;
-        const float rowf = p < p_hi ? 1.f : 0.f;
-        p = p < p_hi ? p : p_hi - 1;
-        const int slot = g.order[p];
-        const int64_t arow = MODE == 0 ? (int64_t)slot : p;
-        int64_t brow = 0;
-        if (MODE == 1) brow = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          a[t][cc] = g.A[arow * g.d + am[t]] * (amf[t] * rowf);
-          float bv = MODE == 0 ? g.Bd[p * g.d + bn[t]] : g.feats[brow + bn[t]];
-          if (drop) bv = (rng_u32(key, (uint32_t)(g.slot_map ? g.slot_map[slot] : slot), (uint32_t)bn[t]) >= thr) ? bv * keep_scale : 0.f;
-          b[t][cc] = bv * bnf[t];
-        }
-      }
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][cc], b[0][cc], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][cc], b[1][cc], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][cc], b[0][cc], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][cc], b[1][cc], acc[1][1], 0, 0, 0);
-      }
-    }
-    // combine the four waves (fixed order) and add the tile to the chromosome's gradient
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-              const int idx = (32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + 32 * j + r;
-              red[idx] = (w == 0) ? acc[i][j][reg] : red[idx] + acc[i][j][reg];
-            }
+    const int bcol = no0 + lane, bcolc = bcol < ncols ? bcol : ncols - 1;
+    const float bmask = bcol < ncols ? 1.f : 0.f;
+    f32x16 acc = {0};
+    for (int64_t p0 = p_lo; p0 < p_hi; p0 += 128) {
+      __syncthreads();                          // previous step's MFMAs are done with the tiles and the index arrays
+      if (tid < 128) {
+        const int64_t p = p0 + tid;
+        const bool in = p < p_hi;
+        const int slot = g.order[in ? p : p_hi - 1];
+        rowslot[tid] = in ? slot : -1;
+        if (MODE == 1) rowoff[tid] = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
       }
       __syncthreads();
+      // a wave-instruction reads 64 consecutive floats of one row; 8 rows' loads are issued before the first is consumed
+      // (one row per trip left every trip waiting out a full global-memory round trip: 32 serialised latencies per step)
+      for (int i0 = 0; i0 < 32; i0 += 8) {
+        float av[8], bv[8];
+        int sl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = wave + 4 * (i0 + u);
+          const int slot = rowslot[rr];
+          sl[u] = slot;
+          const int slc = slot >= 0 ? slot : 0;
+          const int64_t p = p0 + rr < p_hi ? p0 + rr : p_hi - 1;
+          const int64_t arow = MODE == 0 ? (int64_t)slc : p;
+          av[u] = g.A[arow * g.d + acolc];
+          bv[u] = MODE == 0 ? g.Bd[p * g.d + bcolc] : g.feats[rowoff[rr] + bcolc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = wave + 4 * (i0 + u);
+          const float rowm = sl[u] >= 0 ? 1.f : 0.f;
+          const int slc = sl[u] >= 0 ? sl[u] : 0;
+          float b = bv[u];
+          if (drop) b = (rng_u32(key, (uint32_t)(g.slot_map ? g.slot_map[slc] : slc), (uint32_t)bcol) >= thr) ? b * keep_scale : 0.f;
+          As[rr * kLdA + lane] = av[u] * (amask * rowm);
+          Bs[rr * kLdA + lane] = b * (bmask * rowm);
+        }
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int m = 0; m < 64; ++m) {
+        const int t = 2 * m + h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[t * kLdA + 32 * wr + r], Bs[t * kLdA + 32 * wc + r], acc, 0, 0, 0);
+      }
     }
     float* out = MODE == 0 ? g.out + (int64_t)c * g.d * g.d : g.out + (int64_t)g.d * lo;
-    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-      const int row = mo0 + idx / 64, col = no0 + idx % 64;
-      if (row < g.d && col < ncols) atomicAdd(out + (int64_t)row * ncols + col, red[idx]);
+    const int col = no0 + 32 * wc + r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = mo0 + 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row < g.d && col < ncols) atomicAdd(out + (int64_t)row * ncols + col, acc[reg]);
     }
   }
 }
@@ -584,7 +608,11 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     memset(&a, 0, sizeof(a));
     a.A = dnode; a.Bd = w.Hs; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
     a.out = g_.adj_w1; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = 0.f;
-    hipLaunchKernelGGL((adj_tn_kernel<0>), dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(d, 64), zblocks), dim3(256), 0, st, a);
+    auto k0 = adj_tn_kernel<0>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAdjTnLds) != hipSuccess) {
+      set_error("adj_tn_kernel: cannot raise the dynamic LDS limit"); return MATCHA_EHIP;
+    }
+    hipLaunchKernelGGL(k0, dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(d, 64), zblocks), dim3(256), kAdjTnLds, st, a);
     MATCHA_CHECK_LAUNCH("adj_tn_kernel<0>");
   }
   {   // dZ[p] = (dnode[order[p]] . W1_c) * (1 - Hs[p]^2)
@@ -602,7 +630,11 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     memset(&a, 0, sizeof(a));
     a.A = w.dZ; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
     a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
-    hipLaunchKernelGGL((adj_tn_kernel<1>), dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(s.max_bins, 64), zblocks), dim3(256), 0, st, a);
+    auto k1 = adj_tn_kernel<1>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAdjTnLds) != hipSuccess) {
+      set_error("adj_tn_kernel: cannot raise the dynamic LDS limit"); return MATCHA_EHIP;
+    }
+    hipLaunchKernelGGL(k1, dim3((unsigned)cdiv(d, 64), (unsigned)cdiv(s.max_bins, 64), zblocks), dim3(256), kAdjTnLds, st, a);
     MATCHA_CHECK_LAUNCH("adj_tn_kernel<1>");
   }
   return MATCHA_OK;
