@@ -244,8 +244,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   // (small dependent global loads inside the head loop each cost a full L2 round trip at one or two waves per SIMD)
   int* roff = reinterpret_cast<int*>(lds + 4 * kTileF);          // [n_h + 1] (<= 64 hyperedges + 1)
   int* tinfo = roff + 80;                                         // [64] per token row: first row of its hyperedge | k << 8
-  int* slots_s = tinfo + 64;                                      // [64] dropout counter row (original [B, L] slot) of each token row
-  float* cbias = lds + 4 * kTileF + 208;                          // [3][512]
+  // dropout: keep <=> lowbias32(col ^ lowbias32(slot ^ key)) >= threshold; the inner hash depends on the token row only
+  uint32_t* hrow1 = reinterpret_cast<uint32_t*>(tinfo + 64);       // [64] lowbias32(slot ^ key) for the fc1 dropout stream
+  uint32_t* hrow2 = hrow1 + 64;                                    // [64] ... for the pff dropout stream
+  float* cbias = lds + 4 * kTileF + 272;                          // [3][512]
   const bool lroff = n_h <= 78;                                   // more only when many all-padding rows share the window
   if (lroff)
     for (int i = tid; i <= n_h; i += 256) roff[i] = g.row_off[b0 + i] - t0;
@@ -253,7 +255,16 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     const int tp = g.tok_pos[t0 + tid];
     tinfo[tid] = (tid - (tp & 255)) | (tp & ~255);
   }
-  if (tid < 64) slots_s[tid] = g.tok_slot[tid < n_real ? t0 + tid : tok_pad];      // rows past the tokens: the padding token's slot
+  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
+  uint32_t thr1 = 0, thr2 = 0;
+  float ks1 = 1.f, ks2 = 1.f;
+  if (drop1) { thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
+  if (drop2) { thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
+  if (tid < 64 && (drop1 || drop2)) {
+    const uint32_t slot = (uint32_t)g.tok_slot[tid < n_real ? t0 + tid : tok_pad];      // rows past the tokens: the padding token's slot
+    hrow1[tid] = lowbias32(slot ^ rng_key(*g.seed, kStreamDropFc1));
+    hrow2[tid] = lowbias32(slot ^ rng_key(*g.seed, kStreamDropPff));
+  }
   for (int i = tid; i < 3 * 512; i += 256) cbias[i] = (i < 512) ? g.cq[i] : (i < 1024 ? g.ck[i - 512] : g.cv[i - 1024]);
 
   // ---- x_hat fragments straight from global memory: lane (r, h) holds k = 8c + 4h .. +3 of row 32 wr + r; the other
@@ -331,11 +342,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   __syncthreads();                                     // last fc1 GEMM done: Bs, Qs, Ks, Vs free
 
   // ---- Y = mask * dropout(dyn + b) -> Vs (+ global) ----
-  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
-  uint32_t key1 = 0, thr1 = 0, key2 = 0, thr2 = 0;
-  float ks1 = 1.f, ks2 = 1.f;
-  if (drop1) { key1 = rng_key(*g.seed, kStreamDropFc1); thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
-  if (drop2) { key2 = rng_key(*g.seed, kStreamDropPff); thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
+  uint32_t keep1 = 0, keep2 = 0;                        // this lane's 16 keep bits of the two dropout masks (reused by the backward part)
   float* Ys = Vs;
   float* H1s = Qs;
   float* H2s = Ks;
@@ -349,7 +356,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       float v = 0.f;
       if (row < n_real) {                              // the padding token's row (and unused rows) are masked to 0
         v = dyn[reg] + bv;
-        if (drop1) v = (rng_u32(key1, (uint32_t)slots_s[row], (uint32_t)col) >= thr1) ? v * ks1 : 0.f;
+        if (drop1) {
+          const bool kp = lowbias32((uint32_t)col ^ hrow1[row]) >= thr1;
+          keep1 |= kp ? (1u << reg) : 0u;
+          v = kp ? v * ks1 : 0.f;
+        }
         if (g.Y) g.Y[(int64_t)(t0 + row) * 64 + col] = v;
       } else if (row == n_real && g.Y) {
         g.Y[(int64_t)tok_pad * 64 + col] = 0.f;        // every tile writes the same zeros: benign
@@ -369,7 +380,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
       float v = tanhf(acc[reg] + bv);
       const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
-      if (drop2 && row <= n_real) v = (rng_u32(key2, (uint32_t)slots_s[row], (uint32_t)col) >= thr2) ? v * ks2 : 0.f;
+      if (drop2 && row <= n_real) {
+        const bool kp = lowbias32((uint32_t)col ^ hrow2[row]) >= thr2;
+        keep2 |= kp ? (1u << reg) : 0u;
+        v = kp ? v * ks2 : 0.f;
+      }
       if (g.H1 && row <= n_real) g.H1[tok * 64 + col] = v;
       H1s[row * kLdT + col] = v;
     }
@@ -521,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       const float hval = H1s[row * kLdT + col] * unscale;                   // tanh value (0 where dropped)
       float v = acc[reg];
       const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
-      if (drop2) v = (rng_u32(key2, (uint32_t)slots_s[row], (uint32_t)col) >= thr2) ? v * ks2 : 0.f;
+      if (drop2) v = ((keep2 >> reg) & 1u) ? v * ks2 : 0.f;        // the mask drawn in the forward part (rows past the tokens: v is 0)
       dZs[row * kLdT + col] = v * (1.f - hval * hval);
     }
     TILE_LSTORE(Bs, wA);                               // conv0 weight
@@ -561,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
         const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
         if (row < n_real) {
           v = acc[reg] + H2s[row * kLdT + col];        // residual: H2 = conv1(H1) + Y
-          if (drop1) v = (rng_u32(key1, (uint32_t)slots_s[row], (uint32_t)col) >= thr1) ? v * ks1 : 0.f;
+          if (drop1) v = ((keep1 >> reg) & 1u) ? v * ks1 : 0.f;
         }
         g.ddyn0[tok * 64 + col] = v;
       }
@@ -664,7 +679,7 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   { static const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int ntiles = rg.ntiles;
-  const size_t lds = ((size_t)4 * kTileF + 208 + 3 * 512) * sizeof(float);
+  const size_t lds = ((size_t)4 * kTileF + 272 + 3 * 512) * sizeof(float);
   auto launch = [&](auto kfn) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);
