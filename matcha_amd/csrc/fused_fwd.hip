@@ -101,6 +101,32 @@ __device__ __forceinline__ f32x16 quad_gemm_regA(f32x16 acc, const float4 (&afr)
   }
   return acc;
 }
+// Projection with the TRANSPOSED product (weight rows = MFMA row operand, token rows = column operand): lane (r, h) ends
+// with token row 32 wr + r and, in registers 4g..4g+3, the four consecutive features 32 wc + 8 g + 4 h + {0..3} -- one
+// ds_write_b128 per group instead of four ds_write_b32, and the bias is the accumulator's initial value (no adds).
+// VALU instructions are not free next to f32 MFMAs on this part (tools/ubench/mfma_valu.hip), so the epilogue matters.
+__device__ __forceinline__ void proj_store_T(float* __restrict__ Ts, const float4 (&afr)[8], const float* __restrict__ Bs, const float* __restrict__ bias,
+                                             int wr, int wc, int r, int h, bool skip) {
+  f32x16 acc;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const float4 bv = *reinterpret_cast<const float4*>(&bias[32 * wc + 8 * gq + 4 * h]);
+    acc[4 * gq] = bv.x; acc[4 * gq + 1] = bv.y; acc[4 * gq + 2] = bv.z; acc[4 * gq + 3] = bv.w;
+  }
+  if (!skip) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLdT + 8 * c + 4 * h]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, afr[c].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, afr[c].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, afr[c].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, afr[c].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq)
+    *reinterpret_cast<float4*>(&Ts[(32 * wr + r) * kLdT + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+}
 // same with the A tile in LDS ([row][k])
 __device__ __forceinline__ f32x16 quad_gemm_ldsA(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int r, int h) {
 #pragma unroll
@@ -306,26 +332,14 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     TILE_GLOAD(wA, g.wv + wofs, 64);
     TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
     __syncthreads();
-    {
-      f32x16 acc = {0};
-      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
-      quad_store(Qs, acc, cbias + hd * 64, wr, wc, r, h);
-    }
-    {
-      f32x16 acc = {0};
-      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Vs, wc, r, h);
-      quad_store(Ks, acc, cbias + 512 + hd * 64, wr, wc, r, h);
-    }
+    proj_store_T(Qs, afr, Bs, cbias + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0);
+    proj_store_T(Ks, afr, Vs, cbias + 512 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0);
     // ---- V ----
     __syncthreads();                                   // both weight tiles consumed
     TILE_LSTORE(Bs, wA);
     TILE_GLOAD(wA, last ? g.p0w : g.wq + wofs + 64 * 64, 64);
     __syncthreads();
-    {
-      f32x16 acc = {0};
-      if (!(g.dbg & 2)) acc = quad_gemm_regA(acc, afr, Bs, wc, r, h);
-      quad_store(Vs, acc, cbias + 1024 + hd * 64, wr, wc, r, h);
-    }
+    proj_store_T(Vs, afr, Bs, cbias + 1024 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0);
     __syncthreads();                                   // Q, K, V tiles complete; Bs free
     TILE_LSTORE(Bs, wB);                               // fc1 block (read after the next barrier)
     TILE_GLOAD(wB, last ? g.p1w : g.wk + wofs + 64 * 64, 64);
