@@ -112,6 +112,30 @@ __device__ __forceinline__ f32x16 gemm_nn(f32x16 acc, const float* __restrict__ 
   }
   return acc;
 }
+// Projection as a TRANSPOSED product (weight rows = MFMA row operand, token rows = column operand): lane (r, h) ends with
+// token row 32 wr + r and, in registers 4g..4g+3, the features 32 wc + 8 g + 4 h + {0..3}: the bias is the accumulator's
+// initial value and the tile is written with four ds_write_b128 (VALU work is not free next to f32 MFMAs on this part).
+__device__ __forceinline__ void proj_store_T(float* __restrict__ Ts, const float* __restrict__ As, const float* __restrict__ Bs,
+                                             const float* __restrict__ bias, int wr, int wc, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const float4 bv = *reinterpret_cast<const float4*>(&bias[32 * wc + 8 * gq + 4 * h]);
+    acc[4 * gq] = bv.x; acc[4 * gq + 1] = bv.y; acc[4 * gq + 2] = bv.z; acc[4 * gq + 3] = bv.w;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLd + 8 * c + 4 * h]);
+    const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLd + 8 * c + 4 * h]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq)
+    *reinterpret_cast<float4*>(&Ts[(32 * wr + r) * kLd + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+}
 __device__ __forceinline__ void quad_store(float* __restrict__ Ts, const f32x16& acc, const float* __restrict__ bias, int wr, int wc, int r, int h) {
   const int col = 32 * wc + r;
   const float bv = bias ? bias[col] : 0.f;
@@ -417,19 +441,9 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     FB_T(0);
     // ---- recompute Q, K, V  (one accumulator at a time: fusing the three loops pushed hipcc into spilling) ----
     if (!(g.dbg & 2)) {
-      f32x16 acc = {0};
-      acc = gemm_nt(acc, Xs, Wq, wr, wc, r, h);
-      quad_store(Qs, acc, cb, wr, wc, r, h);
-    }
-    if (!(g.dbg & 2)) {
-      f32x16 acc = {0};
-      acc = gemm_nt(acc, Xs, Wk, wr, wc, r, h);
-      quad_store(Ks, acc, cb + 64, wr, wc, r, h);
-    }
-    if (!(g.dbg & 2)) {
-      f32x16 acc = {0};
-      acc = gemm_nt(acc, Xs, Wv, wr, wc, r, h);
-      quad_store(Vs, acc, cb + 128, wr, wc, r, h);
+      proj_store_T(Qs, Xs, Wq, cb, wr, wc, r, h);
+      proj_store_T(Ks, Xs, Wk, cb + 64, wr, wc, r, h);
+      proj_store_T(Vs, Xs, Wv, cb + 128, wr, wc, r, h);
     }
     // ---- dO = dDyn . Wfc1[:, head block]  (B fragments in registers) ----
     {
