@@ -445,20 +445,22 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       proj_store_T(Ks, Xs, Wk, cb + 64, wr, wc, r, h);
       proj_store_T(Vs, Xs, Wv, cb + 128, wr, wc, r, h);
     }
-    // ---- dO = dDyn . Wfc1[:, head block]  (B fragments in registers) ----
+    // ---- dO = dDyn . Wfc1[:, head block]  (weight fragments in registers; transposed product like the projections) ----
     {
       f32x16 acc = {0};
       if (!(g.dbg & 2)) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const float4 a = *reinterpret_cast<const float4*>(&Ds[(32 * wr + r) * kLd + 8 * c + 4 * h]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, fcb[4 * c + 0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, fcb[4 * c + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, fcb[4 * c + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, fcb[4 * c + 3], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 0], a.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 1], a.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 2], a.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 3], a.w, acc, 0, 0, 0);
         }
       }
-      quad_store(Fs, acc, nullptr, wr, wc, r, h);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(&Fs[(32 * wr + r) * kLd + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
     }
     __syncthreads();
     FB_T(1);
