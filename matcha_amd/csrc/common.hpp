@@ -93,6 +93,14 @@ __device__ __forceinline__ float group_sum16_dpp(float v) {
   return v;
 }
 
+// tanh through one v_exp: (e^{2x} - 1) / (e^{2x} + 1).  Absolute error ~1e-7 (the parity bar is 1e-4 of the output scale);
+// libm's tanhf costs ~40 VALU instructions, which are not free next to the f32 MFMAs (tools/ubench/mfma_valu.hip).
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float xc = fminf(fmaxf(x, -15.f), 15.f);
+  const float e = __expf(2.f * xc);
+  return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
 #pragma unroll

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (t_base + row < T) g.X[(t_base + row) * 64 + col] = tanhf(acc[reg] + bnv);
+        if (t_base + row < T) g.X[(t_base + row) * 64 + col] = fast_tanh(acc[reg] + bnv);
       }
     }
   }

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      float v = tanhf(acc[reg] + bv);
+      float v = fast_tanh(acc[reg] + bv);
       const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
       if (drop2 && row <= n_real) {
         const bool kp = lowbias32((uint32_t)col ^ hrow2[row]) >= thr2;
