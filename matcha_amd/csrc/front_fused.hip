@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
       }
       const float mean = group_sum16_dpp((xv.x + xv.y) + (xv.z + xv.w)) * (1.f / 64.f);
       const float a0 = xv.x - mean, a1 = xv.y - mean, a2 = xv.z - mean, a3 = xv.w - mean;
-      const float rs = 1.0f / sqrtf(group_sum16_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) * (1.f / 64.f) + kEps);
+      const float rs = __builtin_amdgcn_rsqf(group_sum16_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) * (1.f / 64.f) + kEps);
       const float4 xh = make_float4(a0 * rs, a1 * rs, a2 * rs, a3 * rs);
       const float ma = group_sum16_dpp((d.x + d.y) + (d.z + d.w)) * (1.f / 64.f);
       const float mb = group_sum16_dpp((d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w)) * (1.f / 64.f);

@@ -151,7 +151,7 @@ __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rs
   mean = s * (1.f / 64.f);
   const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
   const float q = group_sum<16>((a * a + b * b) + (c * c + e * e));
-  rstd = 1.0f / sqrtf(q * (1.f / 64.f) + kEpsLn);
+  rstd = __builtin_amdgcn_rsqf(q * (1.f / 64.f) + kEpsLn);
 }
 
 // Attention forward + backward on LDS tiles, token-parallel: one 8-lane group per QUERY token (lane `sub` owns features
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     const float mean__ = group_sum16_dpp((xv__.x + xv__.y) + (xv__.z + xv__.w)) * (1.f / 64.f);          \
     const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
     const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
-    const float rs__ = msk__ / sqrtf(q__ * (1.f / 64.f) + kEpsLn);                                       \
+    const float rs__ = msk__ * __builtin_amdgcn_rsqf(q__ * (1.f / 64.f) + kEpsLn);                                     \
     *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
     const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
     *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
