@@ -174,12 +174,15 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
   const int ii = li - li0;
   // three passes over the hyperedge's rows (K, then V, then K again) keep at most ML x 8 operand registers live
   float q[8], p[ML], ds[ML], pp, dsp;
+  int ro[ML];                                            // element offset of key / value row j (clamped), shared by the three passes
+#pragma unroll
+  for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLd + 8 * sub;
   LD8(q, &Qs[li * kLd + 8 * sub]);
   float mx = -3.4e38f;
   {
     float kk[ML][8], kp[8];
 #pragma unroll
-    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[(li0 + (j < k ? j : 0)) * kLd + 8 * sub]);
+    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[ro[j]]);
     LD8(kp, kpad + 8 * sub);
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
@@ -214,7 +217,7 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
     float go[8], v[ML][8], vp[8];
     LD8(go, &Fs[li * kLd + 8 * sub]);
 #pragma unroll
-    for (int j = 0; j < ML; ++j) LD8(v[j], &Vs[(li0 + (j < k ? j : 0)) * kLd + 8 * sub]);
+    for (int j = 0; j < ML; ++j) LD8(v[j], &Vs[ro[j]]);
     LD8(vp, vpad + 8 * sub);
     // O_i
 #pragma unroll
@@ -253,7 +256,7 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
   {
     float kk[ML][8], kp[8];
 #pragma unroll
-    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[(li0 + (j < k ? j : 0)) * kLd + 8 * sub]);
+    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[ro[j]]);
     LD8(kp, kpad + 8 * sub);
 #pragma unroll
     for (int e = 0; e < 8; ++e) gq[e] = dspf * kp[e];
