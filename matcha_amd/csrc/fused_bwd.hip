@@ -162,42 +162,70 @@ __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rs
 //   column phase (token j): dV_j = sum_i P_ij dO_i,  dK_j = sum_i dS_ij Q_i   over the hyperedge's rows
 //   write phase:            O -> Fs, dQ/dK/dV over Q/K/V (after a barrier: the column phase reads Q and dO of other rows)
 // acc: this lane's running sums {dK_pad, dV_pad} x 8 features.
+// Eight consecutive floats as four packed pairs: dot products and axpys compile to v_pk_mul / v_pk_fma (two flops per lane
+// per instruction) instead of scalar chains the compiler re-packs with extra moves.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V8 { f2 a, b, c, d; };
+__device__ __forceinline__ V8 ld8(const float* __restrict__ p) {
+  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+  V8 v;
+  v.a = f2{x.x, x.y}; v.b = f2{x.z, x.w}; v.c = f2{y.x, y.y}; v.d = f2{y.z, y.w};
+  return v;
+}
+__device__ __forceinline__ void st8(float* __restrict__ p, const V8& v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v.a.x, v.a.y, v.b.x, v.b.y);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v.c.x, v.c.y, v.d.x, v.d.y);
+}
+__device__ __forceinline__ float dot8(const V8& u, const V8& v) {
+  f2 s = u.a * v.a;
+  s = __builtin_elementwise_fma(u.b, v.b, s);
+  s = __builtin_elementwise_fma(u.c, v.c, s);
+  s = __builtin_elementwise_fma(u.d, v.d, s);
+  return s.x + s.y;
+}
+__device__ __forceinline__ V8 scale8(float w, const V8& x) {
+  const f2 ww = {w, w};
+  V8 y;
+  y.a = ww * x.a; y.b = ww * x.b; y.c = ww * x.c; y.d = ww * x.d;
+  return y;
+}
+__device__ __forceinline__ void axpy8(V8& y, float w, const V8& x) {
+  const f2 ww = {w, w};
+  y.a = __builtin_elementwise_fma(ww, x.a, y.a); y.b = __builtin_elementwise_fma(ww, x.b, y.b);
+  y.c = __builtin_elementwise_fma(ww, x.c, y.c); y.d = __builtin_elementwise_fma(ww, x.d, y.d);
+}
+__device__ __forceinline__ V8 zero8() { V8 z; z.a = f2{0.f, 0.f}; z.b = z.a; z.c = z.a; z.d = z.a; return z; }
+
 template <int ML>
 __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs,
                                             const float* __restrict__ Fs, const float* __restrict__ kpad, const float* __restrict__ vpad,
                                             float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0, int k, int n_pad, int sub,
-                                            float inv_temp, float (&o)[8], float (&gq)[8], float (&acc)[16]) {
+                                            float inv_temp, V8& o, V8& gq, V8& accK, V8& accV) {
   // Branch-free over the ML key slots: a wave almost always holds a hyperedge of the full width, so predicating the
   // slots j >= k (clamped row, probability forced to 0) costs nothing and removes one branch per slot.
   const float padf = (float)n_pad;
   const bool hp = n_pad > 0;
   const int ii = li - li0;
   // three passes over the hyperedge's rows (K, then V, then K again) keep at most ML x 8 operand registers live
-  float q[8], p[ML], ds[ML], pp, dsp;
+  float p[ML], ds[ML], pp, dsp;
   int ro[ML];                                            // element offset of key / value row j (clamped), shared by the three passes
 #pragma unroll
   for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLd + 8 * sub;
-  LD8(q, &Qs[li * kLd + 8 * sub]);
+  const V8 q = ld8(&Qs[li * kLd + 8 * sub]);
   float mx = -3.4e38f;
   {
-    float kk[ML][8], kp[8];
+    V8 kk[ML];
 #pragma unroll
-    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[ro[j]]);
-    LD8(kp, kpad + 8 * sub);
+    for (int j = 0; j < ML; ++j) kk[j] = ld8(&Ks[ro[j]]);
+    const V8 kp = ld8(kpad + 8 * sub);
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
-      float a = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a += q[e] * kk[j][e];
-      a = group_sum8_dpp(a) * inv_temp;
+      float a = group_sum8_dpp(dot8(q, kk[j])) * inv_temp;
       a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
       p[j] = a;
       mx = (j < k) ? fmaxf(mx, a) : mx;
     }
-    float a = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a += q[e] * kp[e];
-    pp = group_sum8_dpp(a) * inv_temp;
+    pp = group_sum8_dpp(dot8(q, kp)) * inv_temp;
     mx = hp ? fmaxf(mx, pp) : mx;
   }
   float den = 0.f;
@@ -214,60 +242,42 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
   pp *= inv;
   const float ppf = padf * pp;
   {
-    float go[8], v[ML][8], vp[8];
-    LD8(go, &Fs[li * kLd + 8 * sub]);
+    const V8 go = ld8(&Fs[li * kLd + 8 * sub]);
+    V8 v[ML];
 #pragma unroll
-    for (int j = 0; j < ML; ++j) LD8(v[j], &Vs[ro[j]]);
-    LD8(vp, vpad + 8 * sub);
+    for (int j = 0; j < ML; ++j) v[j] = ld8(&Vs[ro[j]]);
+    const V8 vp = ld8(vpad + 8 * sub);
     // O_i
+    o = scale8(ppf, vp);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = ppf * vp[e];
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += p[j] * v[j][e];
-    }
+    for (int j = 0; j < ML; ++j) axpy8(o, p[j], v[j]);
     // dP_i. -> dS_i.
     float sig = 0.f;
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
-      float a = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a += go[e] * v[j][e];
-      a = group_sum8_dpp(a);
+      const float a = group_sum8_dpp(dot8(go, v[j]));
       ds[j] = a;
       sig += p[j] * a;
     }
-    {
-      float a = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a += go[e] * vp[e];
-      dsp = group_sum8_dpp(a);
-      sig += ppf * dsp;
-    }
+    dsp = group_sum8_dpp(dot8(go, vp));
+    sig += ppf * dsp;
 #pragma unroll
     for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
     dsp = pp * (dsp - sig) * inv_temp;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[8 + e] += ppf * go[e];
+    axpy8(accV, ppf, go);
   }
   // dQ_i
   const float dspf = padf * dsp;
   {
-    float kk[ML][8], kp[8];
+    V8 kk[ML];
 #pragma unroll
-    for (int j = 0; j < ML; ++j) LD8(kk[j], &Ks[ro[j]]);
-    LD8(kp, kpad + 8 * sub);
+    for (int j = 0; j < ML; ++j) kk[j] = ld8(&Ks[ro[j]]);
+    const V8 kp = ld8(kpad + 8 * sub);
+    gq = scale8(dspf, kp);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) gq[e] = dspf * kp[e];
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gq[e] += ds[j] * kk[j][e];
-    }
+    for (int j = 0; j < ML; ++j) axpy8(gq, ds[j], kk[j]);
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] += dspf * q[e];
+  axpy8(accK, dspf, q);
   // row i of P and dS for the column phase (every lane of the group holds the same values: lanes 0 / 1 write them)
   if (sub < 2) {
     float* dst = (sub == 0 ? Ps : dSs) + li * 8;
@@ -284,19 +294,17 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
 
 template <int ML>
 __device__ __forceinline__ void attn_col_fb(const float* __restrict__ Qs, const float* __restrict__ Fs, const float* __restrict__ Ps,
-                                            const float* __restrict__ dSs, int li, int li0, int k, int sub, float (&gk)[8], float (&gv)[8]) {
+                                            const float* __restrict__ dSs, int li, int li0, int k, int sub, V8& gk, V8& gv) {
   const int jj = li - li0;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { gk[e] = 0.f; gv[e] = 0.f; }
+  gk = zero8();
+  gv = zero8();
 #pragma unroll
   for (int i = 0; i < ML; ++i) {
     const int ri = li0 + (i < k ? i : 0);
-    float q[8], go[8];
-    LD8(q, &Qs[ri * kLd + 8 * sub]);
-    LD8(go, &Fs[ri * kLd + 8 * sub]);
+    const V8 q = ld8(&Qs[ri * kLd + 8 * sub]), go = ld8(&Fs[ri * kLd + 8 * sub]);
     const float pij = (i < k) ? Ps[ri * 8 + jj] : 0.f, dsij = (i < k) ? dSs[ri * 8 + jj] : 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { gv[e] += pij * go[e]; gk[e] += dsij * q[e]; }
+    axpy8(gv, pij, go);
+    axpy8(gk, dsij, q);
   }
 }
 
@@ -387,9 +395,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   }
 
   f32x16 aWq = {0}, aWk = {0}, aWv = {0}, aWf = {0};
-  float accp[16];                                    // dK_pad / dV_pad partials of this lane's feature slice
-#pragma unroll
-  for (int i = 0; i < 16; ++i) accp[i] = 0.f;
+  V8 accK = zero8(), accV = zero8();                 // dK_pad / dV_pad partials of this lane's feature slice
   float csq = 0.f, csk = 0.f, csv = 0.f, csd = 0.f;  // column sums of dQ, dK, dV, dDyn: fall out of the weight-gradient operand loads
 
   // software pipeline: tile metadata two tiles ahead, X / dDyn rows one tile ahead in named registers (a struct passed
@@ -469,12 +475,12 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     FB_T(1);
     // ---- attention forward + backward: 8 lanes per token, two passes of 32 tokens ----
     {
-      float o0[8], q0[8], k0[8], v0[8], o1[8], q1[8], k1[8], v1[8];
+      V8 o0, q0, k0, v0, o1, q1, k1, v1;
       const int la = wave * 8 + (lane >> 3), lb = la + 32;
       const bool acta = la < n_real && !(g.dbg & 1), actb = lb < n_real && !(g.dbg & 1);
       int ia = 0, ib = 0;
-      if (acta) { ia = tinfo[la]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accp); }
-      if (actb) { ib = tinfo[lb]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, lb, ib & 255, ib >> 8, g.L - (ib >> 8), sub, inv_temp, o1, q1, accp); }
+      if (acta) { ia = tinfo[la]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
+      if (actb) { ib = tinfo[lb]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, lb, ib & 255, ib >> 8, g.L - (ib >> 8), sub, inv_temp, o1, q1, accK, accV); }
       __syncthreads();
       FB_T(2);
       if (acta) attn_col_fb<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
@@ -482,12 +488,12 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       __syncthreads();
       FB_T(3);
       if (acta) {
-        ST8(&Fs[la * kLd + 8 * sub], o0); ST8(&Qs[la * kLd + 8 * sub], q0); ST8(&Ks[la * kLd + 8 * sub], k0); ST8(&Vs[la * kLd + 8 * sub], v0);
+        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0); st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
       } else {                                        // rows past the tile's tokens: zero, the column sums below run over all 64 rows
         ZR8(&Qs[la * kLd + 8 * sub]); ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
       }
       if (actb) {
-        ST8(&Fs[lb * kLd + 8 * sub], o1); ST8(&Qs[lb * kLd + 8 * sub], q1); ST8(&Ks[lb * kLd + 8 * sub], k1); ST8(&Vs[lb * kLd + 8 * sub], v1);
+        st8(&Fs[lb * kLd + 8 * sub], o1); st8(&Qs[lb * kLd + 8 * sub], q1); st8(&Ks[lb * kLd + 8 * sub], k1); st8(&Vs[lb * kLd + 8 * sub], v1);
       } else {
         ZR8(&Qs[lb * kLd + 8 * sub]); ZR8(&Ks[lb * kLd + 8 * sub]); ZR8(&Vs[lb * kLd + 8 * sub]);
       }
@@ -584,6 +590,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   }
   // dK_pad / dV_pad: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
   float* redp = Xs + 3 * 64;            // [4][2][64]
+  const float accp[16] = {accK.a.x, accK.a.y, accK.b.x, accK.b.y, accK.c.x, accK.c.y, accK.d.x, accK.d.y,
+                          accV.a.x, accV.a.y, accV.b.x, accV.b.y, accV.c.x, accV.c.y, accV.d.x, accV.d.y};
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     float v = accp[i];
