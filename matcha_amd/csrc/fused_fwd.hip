@@ -155,34 +155,49 @@ __device__ __forceinline__ void quad_store(float* __restrict__ Ts, const f32x16&
 // a tile's <= 63 tokens fill the workgroup's 32 lane groups in two passes, and the work per group is O(k), not O(k^2).
 // Branch-free over the ML key slots (slots j >= k: clamped row, probability forced to 0).  O_i overwrites the token's own
 // Q row (no other task reads it).
+// Eight consecutive floats as four packed pairs: dot products and axpys compile to v_pk_mul / v_pk_fma.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V8 { f2 a, b, c, d; };
+__device__ __forceinline__ V8 ld8(const float* __restrict__ p) {
+  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+  V8 v;
+  v.a = f2{x.x, x.y}; v.b = f2{x.z, x.w}; v.c = f2{y.x, y.y}; v.d = f2{y.z, y.w};
+  return v;
+}
+__device__ __forceinline__ float dot8(const V8& u, const V8& v) {
+  f2 s = u.a * v.a;
+  s = __builtin_elementwise_fma(u.b, v.b, s);
+  s = __builtin_elementwise_fma(u.c, v.c, s);
+  s = __builtin_elementwise_fma(u.d, v.d, s);
+  return s.x + s.y;
+}
+__device__ __forceinline__ void axpy8(V8& y, float w, const V8& x) {
+  const f2 ww = {w, w};
+  y.a = __builtin_elementwise_fma(ww, x.a, y.a); y.b = __builtin_elementwise_fma(ww, x.b, y.b);
+  y.c = __builtin_elementwise_fma(ww, x.c, y.c); y.d = __builtin_elementwise_fma(ww, x.d, y.d);
+}
+
 template <int ML>
 __device__ __forceinline__ void attn_row_fwd(float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs, int li, int li0, int k,
                                              int n_pad, int pad_row, int sub, float inv_temp) {
   const float padf = (float)n_pad;
   const bool hp = n_pad > 0;
   const int ii = li - li0;
-  float q[8], p[ML], pp;
-  {
-    const float4 a = *reinterpret_cast<const float4*>(&Qs[li * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Qs[li * kLdT + 8 * sub + 4]);
-    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
-  }
+  float p[ML], pp;
+  int ro[ML];                                         // element offset of key / value row j (slots j >= k: clamped)
+#pragma unroll
+  for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLdT + 8 * sub;
+  const V8 q = ld8(&Qs[li * kLdT + 8 * sub]);
   float mx = -3.4e38f;
 #pragma unroll
   for (int j = 0; j < ML; ++j) {
-    const int rj = li0 + (j < k ? j : 0);
-    const float4 c = *reinterpret_cast<const float4*>(&Ks[rj * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[rj * kLdT + 8 * sub + 4]);
-    float a = ((q[0] * c.x + q[1] * c.y) + (q[2] * c.z + q[3] * c.w)) + ((q[4] * e.x + q[5] * e.y) + (q[6] * e.z + q[7] * e.w));
-    a = group_sum8_dpp(a) * inv_temp;
+    float a = group_sum8_dpp(dot8(q, ld8(&Ks[ro[j]]))) * inv_temp;
     a = (j == ii) ? -1e32f : a;                       // masked diagonal (Modules.py:443-445)
     p[j] = a;
     mx = (j < k) ? fmaxf(mx, a) : mx;
   }
-  {
-    const float4 c = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub]), e = *reinterpret_cast<const float4*>(&Ks[pad_row * kLdT + 8 * sub + 4]);
-    const float a = ((q[0] * c.x + q[1] * c.y) + (q[2] * c.z + q[3] * c.w)) + ((q[4] * e.x + q[5] * e.y) + (q[6] * e.z + q[7] * e.w));
-    pp = group_sum8_dpp(a) * inv_temp;
-    mx = hp ? fmaxf(mx, pp) : mx;
-  }
+  pp = group_sum8_dpp(dot8(q, ld8(&Ks[pad_row * kLdT + 8 * sub]))) * inv_temp;
+  mx = hp ? fmaxf(mx, pp) : mx;
   float den = 0.f;
 #pragma unroll
   for (int j = 0; j < ML; ++j) {
@@ -192,21 +207,16 @@ __device__ __forceinline__ void attn_row_fwd(float* __restrict__ Qs, const float
   pp = hp ? __expf(pp - mx) : 0.f;
   den += padf * pp;
   const float inv = __builtin_amdgcn_rcpf(den);
-  const float ppf = padf * pp * inv;
-  float o[8];
+  V8 o;
   {
-    const float4 a = *reinterpret_cast<const float4*>(&Vs[pad_row * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[pad_row * kLdT + 8 * sub + 4]);
-    o[0] = ppf * a.x; o[1] = ppf * a.y; o[2] = ppf * a.z; o[3] = ppf * a.w; o[4] = ppf * b.x; o[5] = ppf * b.y; o[6] = ppf * b.z; o[7] = ppf * b.w;
+    const V8 vp = ld8(&Vs[pad_row * kLdT + 8 * sub]);
+    const f2 w = {padf * pp * inv, padf * pp * inv};
+    o.a = w * vp.a; o.b = w * vp.b; o.c = w * vp.c; o.d = w * vp.d;
   }
 #pragma unroll
-  for (int j = 0; j < ML; ++j) {
-    const int rj = li0 + (j < k ? j : 0);
-    const float w = p[j] * inv;
-    const float4 a = *reinterpret_cast<const float4*>(&Vs[rj * kLdT + 8 * sub]), b = *reinterpret_cast<const float4*>(&Vs[rj * kLdT + 8 * sub + 4]);
-    o[0] += w * a.x; o[1] += w * a.y; o[2] += w * a.z; o[3] += w * a.w; o[4] += w * b.x; o[5] += w * b.y; o[6] += w * b.z; o[7] += w * b.w;
-  }
-  *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub]) = make_float4(o[0], o[1], o[2], o[3]);
-  *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+  for (int j = 0; j < ML; ++j) axpy8(o, p[j] * inv, ld8(&Vs[ro[j]]));
+  *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub]) = make_float4(o.a.x, o.a.y, o.b.x, o.b.y);
+  *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub + 4]) = make_float4(o.c.x, o.c.y, o.d.x, o.d.y);
 }
 
 // LayerNorm statistics of a 64-float row held as one float4 per lane over 16 lanes
