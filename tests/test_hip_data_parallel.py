@@ -1,0 +1,79 @@
+"""The Trainer's data-parallel step on the GPU with two ranks.  Both ranks share cuda:0 and talk over
+gloo (one MI355X on the test box, so RCCL cannot place two ranks; the collective calls are the same torch.distributed ops
+the RCCL launch uses): broadcast of rank 0's weights, per-rank shard of the batch, ONE all-reduce bucket of gradients +
+touched flags, recon-gradient weighting in adj mode.  The result must equal the single-rank step on the global batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from matcha_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(num):
+    x, y, w = synth.make_batch(np.random.default_rng(4), int(np.sum(num)), [2, 3, 5], 40)      # 120 rows
+    return x, y.reshape(-1), w.reshape(-1)
+
+
+def _worker(rank, world, port, out_dir, mode, d):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from matcha_amd.engine import Trainer
+    from matcha_amd.parallel import shard_rows
+    from tests.test_hip_model import hip_model
+    num = synth.LAYOUTS["tiny"]
+    clf, _ = hip_model(num, d, mode, 50)                   # same frozen features everywhere (they are data, not parameters)
+    clf.eval()                                              # no dropout: masks are indexed by the LOCAL batch slot
+    if rank == 1:                                           # different weights on rank 1: the Trainer must broadcast rank 0's
+        with torch.no_grad():
+            clf._runtime().flat.add_(0.25)
+    tr = Trainer(clf, lr=1e-3)
+    x, y, w = _batch(num)
+    idx = shard_rows(len(x), rank, world)
+    xs, ys, ws = (torch.from_numpy(a[idx]).cuda() for a in (x, y, w))
+    for _ in range(2):
+        tr.step(xs, ys, ws, alpha=1.0, beta=0.3, random_chrom=1)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({n: p.detach().cpu() for n, p in clf.named_parameters()}, os.path.join(out_dir, "dp.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,d", [("table", 64), ("adj", 64), ("adj", 16)])
+def test_two_rank_trainer_equals_single_rank_on_global_batch(tmp_path, mode, d):
+    from matcha_amd.engine import Trainer
+    from tests.test_hip_model import GAUGE, hip_model
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode, d), nprocs=2, join=True)
+    got = torch.load(os.path.join(tmp_path, "dp.pt"), weights_only=False)
+    num = synth.LAYOUTS["tiny"]
+    clf, _ = hip_model(num, d, mode, 50)
+    clf.eval()
+    tr = Trainer(clf, lr=1e-3)
+    x, y, w = _batch(num)
+    xt, yt, wt = (torch.from_numpy(a).cuda() for a in (x, y, w))
+    for _ in range(2):
+        tr.step(xt, yt, wt, alpha=1.0, beta=0.3, random_chrom=1)
+    torch.cuda.synchronize()
+    for n, p in clf.named_parameters():
+        if n == GAUGE:
+            continue
+        a, b = p.detach().cpu(), got[n]
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), (n, float((a - b).abs().max()))
