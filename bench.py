@@ -235,6 +235,18 @@ def main():
                 roof["traffic"] = round(pmc["hbm_bytes_per_launch"], 1)
         except (OSError, ValueError, KeyError):
             pass
+    # the model step alone (forward + backward [+ all-reduce] + AdamW on the last batch; no positive
+    # gather, no negative sampling) -- reported beside the headline, never as `value`
+    model_only_ms = None
+    if not args.graph:
+        k2 = max(1, args.steps)
+        trainer.step(x, y, w, alpha=1.0, beta=0.001, random_chrom=0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            trainer.step(x, y, w, alpha=1.0, beta=0.001, random_chrom=0)
+        barrier()
+        model_only_ms = (time.perf_counter() - t1) / k2 * 1e3
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -255,6 +267,7 @@ def main():
                    "parallelism": f"dp{world}", "hipgraph": bool(args.graph)},
         "positives_per_s": round(P * world * args.steps / elapsed, 1),
         "last_bce": round(losses[0], 5),
+        "model_step_only": None if model_only_ms is None else {"ms_per_step": round(model_only_ms, 4), "hyperedges_per_s": round(B * world / (model_only_ms * 1e-3), 1)},
         "roofline": roof,
         "kernel_class_ms_per_step": {k: round(v, 4) for k, v in sorted(class_ms.items(), key=lambda kv: -kv[1])},
     }
