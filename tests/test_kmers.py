@@ -63,3 +63,30 @@ def test_hip_kmers_split_launches_and_random_clusters(monkeypatch):
     # nothing qualifies: empty result with the right shapes
     rows, freq = KM.generate_kmers(cl, 5, 1000, 12, 1, n_nodes=300)
     assert rows.shape == (0, 5) and freq.shape == (0,)
+
+
+@pytest.mark.gpu
+def test_kmers_cli_writes_the_files_train_reads(tmp_path):
+    """python -m matcha_amd.kmers: config.JSON + temp_dir/{edge_list,chrom_range}.npy -> all_<k>_counter.npy / _freq_counter.npy
+    (generate_kmers.py:133-139), the inputs of matcha_amd.train.load_kmers."""
+    import json
+    import os
+    from matcha_amd import kmers as KM
+    g = gold("g7_kmers.npz")
+    cl = _clusters(g)
+    temp = os.path.join(tmp_path, "Temp")
+    os.makedirs(temp)
+    obj = np.empty(len(cl), dtype=object)
+    for i, c in enumerate(cl):
+        obj[i] = list(map(int, c))
+    np.save(os.path.join(temp, "edge_list.npy"), obj, allow_pickle=True)
+    np.save(os.path.join(temp, "chrom_range.npy"), np.array([[1, 31], [31, int(g["n_nodes"]) + 1]]))
+    cfg = {"temp_dir": temp, "max_cluster_size": int(g["max_size"]), "k-mer_size": [2, 3, 5], "min_distance": 0, "min_freq_cutoff": 2}
+    path = os.path.join(tmp_path, "config.JSON")
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    KM.main(["--config", path])
+    for k in (2, 3, 5):
+        rows = np.load(os.path.join(temp, "all_%d_counter.npy" % k))
+        freq = np.load(os.path.join(temp, "all_%d_freq_counter.npy" % k))
+        assert np.array_equal(rows, g[f"kmers_d0_c2_k{k}"]) and np.array_equal(freq, g[f"freq_d0_c2_k{k}"])

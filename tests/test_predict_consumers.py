@@ -102,3 +102,30 @@ def test_pairwise_sweep_full_chromosome_properties():
     assert m.shape == (n, n) and torch.equal(m, m.T)
     band = torch.triu(torch.ones(n, n, device=m.device), 0) * torch.tril(torch.ones(n, n, device=m.device), 1)
     assert float((m * band).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_predict_cli_multiway_and_pairwise(tmp_path, monkeypatch):
+    """python -m matcha_amd.predict {multiway, pairwise}: config.JSON + temp_dir/{model2load, bin2node.npy, chrom_range.npy},
+    the files the reference's scripts read (predict_multiway.py:93-112, denoise_contact.py:91-99)."""
+    import json
+    import shutil
+    import Modules  # noqa: F401
+    g, bin2node, samples = _g6()
+    temp = os.path.join(tmp_path, "Temp")
+    os.makedirs(temp)
+    shutil.copy(os.path.join(GOLD, "ref_model2load_tiny_table"), os.path.join(temp, "model2load"))
+    np.save(os.path.join(temp, "bin2node.npy"), bin2node, allow_pickle=True)
+    np.save(os.path.join(temp, "chrom_range.npy"), np.asarray(synth.chrom_range(synth.LAYOUTS["tiny"])))
+    cfg = {"temp_dir": temp, "resolution": int(g["res"]), "chrom_list": [str(n) for n in g["names"]], "min_distance": 2}
+    cpath = os.path.join(tmp_path, "config.JSON")
+    with open(cpath, "w") as f:
+        json.dump(cfg, f)
+    inp, out = os.path.join(tmp_path, "in.txt"), os.path.join(tmp_path, "out.txt")
+    with open(inp, "w") as f:
+        f.write(str(g["text"]))
+    PR.main(["multiway", "-i", inp, "-o", out, "--config", cpath])
+    assert rel_err(np.loadtxt(out).reshape(-1, 1), g["multiway_proba_table"]) < TOL
+    mout = os.path.join(tmp_path, "chr1.npy")
+    PR.main(["pairwise", "--chrom", "0", "-o", mout, "--config", cpath])
+    assert rel_err(np.load(mout), g["pair_matrix_table_c0"]) < TOL
