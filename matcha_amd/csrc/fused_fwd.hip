@@ -644,13 +644,18 @@ __global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a
   const int i = blockIdx.x * 64 + o;                   // element of the slab
   int nt = a.count[2];                                 // tiles planned by ragged.hip (every one of them wrote its slab)
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;        // four independent chains: four loads in flight per lane
   if (i < kTailSlab) {
     int b = q;
-    for (; b + 16 < nt; b += 32) { s0 += a.tslab[(int64_t)b * kTailSlab + i]; s1 += a.tslab[(int64_t)(b + 16) * kTailSlab + i]; }
-    if (b < nt) s0 += a.tslab[(int64_t)b * kTailSlab + i];
+    for (; b + 48 < nt; b += 64) {
+      s0 += a.tslab[(int64_t)b * kTailSlab + i];
+      s1 += a.tslab[(int64_t)(b + 16) * kTailSlab + i];
+      s2 += a.tslab[(int64_t)(b + 32) * kTailSlab + i];
+      s3 += a.tslab[(int64_t)(b + 48) * kTailSlab + i];
+    }
+    for (; b < nt; b += 16) s0 += a.tslab[(int64_t)b * kTailSlab + i];
   }
-  part[q][o] = s0 + s1;
+  part[q][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (q == 0 && i <= kTailVec + 9 * 64) {
     float s = 0.f;
