@@ -625,9 +625,24 @@ __global__ __launch_bounds__(256) void fb_unfold_kernel(UnfoldArgs a) {
   const int row = slice * 16 + rl;
   const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlab;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int c = 0; c < a.nchunks; ++c) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * kWgSlab + mat * 4096 + row * 64 + c4);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  {
+    float4 t0 = s, t1 = s, t2 = s, t3 = s;             // four independent chains: four loads in flight per lane
+    const float* pb = base + mat * 4096 + row * 64 + c4;
+    int c = 0;
+    for (; c + 3 < a.nchunks; c += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(pb + (int64_t)c * kWgSlab), v1 = *reinterpret_cast<const float4*>(pb + (int64_t)(c + 1) * kWgSlab);
+      const float4 v2 = *reinterpret_cast<const float4*>(pb + (int64_t)(c + 2) * kWgSlab), v3 = *reinterpret_cast<const float4*>(pb + (int64_t)(c + 3) * kWgSlab);
+      t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
+      t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
+      t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w;
+      t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
+    }
+    for (; c < a.nchunks; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(pb + (int64_t)c * kWgSlab);
+      t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
+    }
+    s.x = (t0.x + t1.x) + (t2.x + t3.x); s.y = (t0.y + t1.y) + (t2.y + t3.y);
+    s.z = (t0.z + t1.z) + (t2.z + t3.z); s.w = (t0.w + t1.w) + (t2.w + t3.w);
   }
   if (mat == 3) {       // dfc1[n][head*64 + k]
     float4* o = reinterpret_cast<float4*>(a.gfc1 + (int64_t)row * 512 + head * 64 + c4);
