@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    FB_T(6);
     mc = mn; mn = mnn;
   }
 
@@ -565,8 +566,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   __syncthreads();
 #ifdef FB_TIMING
   if (blockIdx.x == 0 && tid == 0)
-    printf("fused_bwd wg0 us: stage %.1f pre-gemm %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn+wait %.1f (tiles %d)\n", tph[0] * 0.01,
-           tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
+    printf("fused_bwd wg0 us: stage %.1f pre-gemm %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (tiles %d)\n",
+           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
 #endif
   float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
   {
