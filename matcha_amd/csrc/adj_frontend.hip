@@ -329,25 +329,25 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int mo0 = blockIdx.x * 64;             // output row tile (j)
   const int no0 = blockIdx.y * 64;             // output column tile (k or feature column)
-  const int64_t nonpad = g.seg[g.C];
-  const int64_t rb = (int64_t)blockIdx.z * g.rows_per_block;
-  if (rb >= nonpad) return;
-  const int64_t re = rb + g.rows_per_block < nonpad ? rb + g.rows_per_block : nonpad;
+  // blockIdx.z = chromosome * splits + split: the chromosomes run in parallel (a small batch used to walk all of them
+  // serially inside two workgroups), each cut into `splits` equal row ranges (g.rows_per_block carries `splits`)
+  const int splits = g.rows_per_block;
   const bool drop = MODE == 1 && g.p_drop > 0.f;
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
   if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
   const int acol = mo0 + lane, acolc = acol < g.d ? acol : g.d - 1;
   const float amask = acol < g.d ? 1.f : 0.f;
-  int c = 0;
-  while (c < g.C && g.seg[c + 1] <= rb) ++c;
-  for (; c < g.C && g.seg[c] < re; ++c) {
-    const int64_t p_lo = g.seg[c] > rb ? g.seg[c] : rb;
-    const int64_t p_hi = g.seg[c + 1] < re ? g.seg[c + 1] : re;
-    if (p_lo >= p_hi) continue;
+  {
+    const int c = blockIdx.z / splits, sp = blockIdx.z - c * splits;
+    const int64_t c_lo = g.seg[c], c_hi = g.seg[c + 1];
+    const int64_t per = ((c_hi - c_lo + splits - 1) / splits + 127) / 128 * 128;      // whole 128-row steps per split
+    const int64_t p_lo = c_lo + sp * per;
+    const int64_t p_hi = p_lo + per < c_hi ? p_lo + per : c_hi;
+    if (p_lo >= p_hi) return;
     const int lo = g.bounds[c], n_c = g.bounds[c + 1] - g.bounds[c];
     const int ncols = MODE == 0 ? g.d : n_c;
-    if (no0 >= ncols) continue;
+    if (no0 >= ncols) return;
     const int bcol = no0 + lane, bcolc = bcol < ncols ? bcol : ncols - 1;
     const float bmask = bcol < ncols ? 1.f : 0.f;
     f32x16 acc = {0};
@@ -601,8 +601,10 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     MATCHA_CHECK_LAUNCH("adj_recon_dnode_kernel");
   }
   // ---- encoder ----
-  const int rpb = 1024;
-  const unsigned zblocks = (unsigned)cdiv(T, rpb);
+  int splits = (int)cdiv(T, (int64_t)C * 1024);      // ~1024 rows per workgroup at an even spread of the tokens over the chromosomes
+  if (splits < 1) splits = 1;
+  const int rpb = splits;
+  const unsigned zblocks = (unsigned)(C * splits);
   {
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));
