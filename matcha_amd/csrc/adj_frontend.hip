@@ -187,6 +187,7 @@ struct AdjEncArgs {
   float* Hs;
   int64_t T;
   int C, d;
+  int splits;                  // workgroups per chromosome (grid = C * splits); a workgroup takes every splits-th 128-row step
   const uint64_t* seed;
   float p_drop;
   const int32_t* slot_map;     // token index -> original slot (dropout counter); null = identity
@@ -201,20 +202,17 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
   __shared__ int rowslot[128];                  // token slot (dropout counter), -1 = row not in this sub-range
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * 128;
-  const int64_t nonpad = g.seg[g.C];
-  if (m0 >= nonpad) return;
-  const int64_t m_end = m0 + 128 < nonpad ? m0 + 128 : nonpad;
+  // chromosome-major: workgroup (c, sp) takes the 128-row steps sp, sp + splits, ... of chromosome c, so a small batch
+  // spreads over C workgroups instead of walking several chromosomes serially inside a few
+  const int c = blockIdx.x / g.splits, sp = blockIdx.x - c * g.splits;
   const bool drop = g.p_drop > 0.f;
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
   if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
-  int c_lo = 0;
-  while (c_lo < g.C && g.seg[c_lo + 1] <= m0) ++c_lo;
-  for (int c = c_lo; c < g.C && g.seg[c] < m_end; ++c) {
-    const int64_t row_lo = g.seg[c] > m0 ? g.seg[c] : m0;
-    const int64_t row_hi = g.seg[c + 1] < m_end ? g.seg[c + 1] : m_end;
-    if (row_lo >= row_hi) continue;
+  const int64_t c_lo = g.seg[c], c_hi = g.seg[c + 1];
+  for (int64_t m0 = c_lo + (int64_t)sp * 128; m0 < c_hi; m0 += (int64_t)g.splits * 128) {
+    const int64_t row_lo = m0;
+    const int64_t row_hi = m0 + 128 < c_hi ? m0 + 128 : c_hi;
     const int lo = g.bounds[c], n_c = g.bounds[c + 1] - g.bounds[c];
     const float* W0 = g.w0 + (int64_t)g.d * lo;                 // [d, n_c] row-major
     __syncthreads();
@@ -520,7 +518,9 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
     a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats; a.w0 = p.adj_w0;
     a.Hs = w.Hs; a.T = T; a.C = C; a.d = d; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
     const int nt = (int)cdiv(d, 32);
-    dim3 grid((unsigned)cdiv(T, 128));
+    a.splits = (int)cdiv(T, (int64_t)C * 128);
+    if (a.splits < 1) a.splits = 1;
+    dim3 grid((unsigned)(C * a.splits));
     ProfScope ps(MATCHA_PROF_ADJ_ENCODE, 0.0, st);
     if (nt <= 1) hipLaunchKernelGGL((adj_encode_fwd_kernel<1>), grid, dim3(256), (size_t)(128 + 32) * kLdA * 4, st, a);
     else if (nt == 2) hipLaunchKernelGGL((adj_encode_fwd_kernel<2>), grid, dim3(256), (size_t)(128 + 64) * kLdA * 4, st, a);
