@@ -294,6 +294,20 @@ int matcha_kmer_generate(const int32_t* ids, const int64_t* offsets, const int64
                          int64_t* out_kmers, int64_t* out_freq, int64_t cap, int64_t* n_out, void* ws, size_t ws_bytes,
                          matcha_stream_t stream);
 
+/* ---- positive-weight preprocessing (Code/main.py:555, :653) -------------------------------------------
+ * The uniform quantile transform of one float32 column of k-mer frequencies: what
+ * sklearn.preprocessing.QuantileTransformer(n_quantiles, output_distribution='uniform').fit_transform computes when it fits
+ * on every row (subsample=None; above 10 000 rows scikit-learn's default fits on a random subsample -- the reference's only
+ * non-determinism here, deliberately not reproduced).  Bit-identical to oracle/positives.py.
+ *   freq           device float32 [n], 1 <= n < 2^31, no NaNs (frequencies are counts)
+ *   n_quantiles    1 .. 4096 (the reference uses 1000); clamped to n as scikit-learn does
+ *   out            device float32 [n] in [0, 1]; must not alias freq
+ *   quantiles_out  optional device float64 [min(n_quantiles, n)]: the fitted landmarks (QuantileTransformer.quantiles_)
+ *   ws             matcha_quantile_workspace_bytes(n) bytes */
+size_t matcha_quantile_workspace_bytes(int64_t n);
+int matcha_quantile_uniform(const float* freq, int64_t n, int32_t n_quantiles, float* out, double* quantiles_out, void* ws,
+                            size_t ws_bytes, matcha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,8 @@ SIGNATURES = {
     "matcha_attn_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _I64, _I32, _I32, _fp, _fp, _fp, _fp, _SZ, _fp]),
     "matcha_kmer_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "matcha_kmer_generate": (C.c_int, [_fp, _fp, _fp, _I64, _I64, _I32, _I32, _I32, _I32, _fp, _fp, _I64, _fp, _fp, _SZ, _fp]),
+    "matcha_quantile_workspace_bytes": (_SZ, [_I64]),
+    "matcha_quantile_uniform": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _SZ, _fp]),
 }
 
 _lib = None

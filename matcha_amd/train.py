@@ -45,18 +45,11 @@ def get_attributes(num: List[int]) -> np.ndarray:
 
 def load_kmers(temp_dir: str, size_list: List[int], cutoff: float) -> Tuple[np.ndarray, np.ndarray]:
     """all_<k>_counter.npy / all_<k>_freq_counter.npy -> (edges int64 [M, max_k] zero-padded, weights float32 [M]) keeping
-    rows whose quantile-transformed frequency exceeds ``cutoff`` (main.py:551-566, :649-660)."""
-    from sklearn.preprocessing import QuantileTransformer
-    L = max(size_list)
-    edges, weights = [], []
-    for k in size_list:
-        data = np.load(os.path.join(temp_dir, "all_%d_counter.npy" % k)).astype(np.int64)
-        freq = np.load(os.path.join(temp_dir, "all_%d_freq_counter.npy" % k)).astype("float32")
-        q = QuantileTransformer(n_quantiles=1000, output_distribution="uniform").fit_transform(freq.reshape(-1, 1)).reshape(-1)
-        keep = q > cutoff
-        edges.append(np.pad(data[keep], ((0, 0), (0, L - k))))
-        weights.append(q[keep].astype(np.float32))
-    return np.concatenate(edges, axis=0), np.concatenate(weights, axis=0)
+    rows whose quantile-transformed frequency exceeds ``cutoff`` (main.py:551-566, :649-660).  The transform runs on the
+    device (positives.py / csrc/quantile.hip), fitted on every row -- no scikit-learn, no random subsample."""
+    from . import positives
+    edges, weights = positives.load_kmers(temp_dir, size_list, cutoff)
+    return edges.cpu().numpy(), weights.cpu().numpy()
 
 
 def build_features(temp_dir: str, chrom_range: np.ndarray):

@@ -388,6 +388,60 @@ def g7_kmers(M, U):
     print("G7", {k: v.shape for k, v in out.items() if k.startswith("kmers_d0")})
 
 
+def g8_positives(M, U):
+    """G8: main.py:551-566 / :594-597 on synthetic frequency columns -- scikit-learn's own
+    QuantileTransformer(n_quantiles=1000, output_distribution='uniform').fit_transform as the reference constructs it
+    (deterministic up to 10 000 rows), and with subsample=None above that (every row fitted; the default would draw a random
+    subsample).  Inputs are stored too: they are small and heavy-tailed counts are awkward to regenerate bit for bit."""
+    import warnings
+    import sklearn
+    from sklearn.preprocessing import QuantileTransformer
+    rng = np.random.default_rng(88)
+    cols = {
+        "counts_u": rng.integers(2, 50, size=5000).astype("float32"),                  # synth k-mer frequencies (SURVEY §8 d2)
+        "counts_heavy": (np.floor(rng.pareto(1.2, size=9999)) + 2).astype("float32"),  # heavy tail, most rows tied at 2
+        "short": (np.floor(rng.pareto(1.0, size=700)) + 1).astype("float32"),          # fewer rows than quantiles
+        "real": rng.gamma(2.0, 1.0, size=10000).astype("float32"),                     # no ties
+        "constant": np.full(37, 3.0, dtype="float32"),
+        "single": np.array([5.0], dtype="float32"),
+        "pair": np.array([1.0, 5.0], dtype="float32"),
+        "big_counts": (np.floor(rng.pareto(1.2, size=60000)) + 2).astype("float32"),   # > 10 000 rows: subsample=None
+        "big_real": rng.gamma(2.0, 1.0, size=40000).astype("float32"),
+    }
+    out = {"sklearn_version": np.array(sklearn.__version__), "numpy_version": np.array(np.__version__)}
+    for name, col in cols.items():
+        kw = {"subsample": None} if len(col) > 10000 else {}
+        qt = QuantileTransformer(n_quantiles=1000, output_distribution="uniform", **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                                             # "n_quantiles is greater than ..." for the short columns
+            w = qt.fit_transform(col.copy().reshape((-1, 1))).reshape((-1))            # main.py:555
+        out[f"{name}_freq"] = col
+        out[f"{name}_weight"] = w.astype("float32")
+        out[f"{name}_quantiles"] = qt.quantiles_[:, 0].astype("float64")
+    # the selection + normalisation of main.py:551-566, :594-597 for two sizes (script-level statements of main.py, which
+    # cannot be exec'd in isolation: restated here statement by statement around scikit-learn's transform)
+    neg_num = 3
+    for size, name in ((2, "counts_u"), (3, "counts_heavy")):
+        out[f"sel_data_k{size}"] = np.sort(rng.integers(1, 200, size=(len(cols[name]), size)), axis=1).astype("int")
+    for cutoff in (0.6, 0.4):
+        data_list, weight_list = [], []
+        for size, name in ((2, "counts_u"), (3, "counts_heavy")):
+            data = out[f"sel_data_k{size}"]
+            weight = QuantileTransformer(n_quantiles=1000, output_distribution="uniform").fit_transform(cols[name].copy().reshape((-1, 1))).reshape((-1))
+            mask = weight > cutoff
+            data, weight = data[mask], weight[mask]
+            data_list.append(np.pad(data, ((0, 0), (0, 3 - size))))
+            weight_list.append(weight)
+        weight = np.concatenate(weight_list, axis=0)
+        out[f"sel_rows_c{cutoff}"] = np.concatenate(data_list, axis=0)
+        out[f"sel_weight_c{cutoff}"] = weight.copy()
+        weight /= np.mean(weight)
+        weight *= neg_num
+        out[f"sel_norm_c{cutoff}"] = weight
+    np.savez_compressed(os.path.join(HERE, "g8_positives.npz"), **out)
+    print("G8", {k: v.shape for k, v in out.items() if k.endswith("_weight")})
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
@@ -405,6 +459,7 @@ def main():
     sampler_stats(M, U)
     g6_inference(M, U)
     g7_kmers(M, U)
+    g8_positives(M, U)
 
 
 if __name__ == "__main__":

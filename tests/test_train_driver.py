@@ -41,10 +41,6 @@ def test_host_helpers(tmp_path):
     assert np.array_equal(T.get_attributes(synth.LAYOUTS["tiny"]), g["attr"])           # main.py:497-512 via the reference
     cfg, num = _write_temp_dir(str(tmp_path))
     assert U.get_config(os.path.join(tmp_path, "config.JSON"))["embed_dim"] == 16
-    e, w = T.load_kmers(cfg["temp_dir"], [2, 3], 0.6)
-    assert e.shape[1] == 3 and len(e) == len(w) and (w > 0.6).all()
-    assert 0.3 * 800 < len(e) < 0.5 * 800                                                # ~40 % of rows pass the 0.6 quantile
-    assert ((e != 0).sum(1) >= 2).all() and (np.diff(np.where(e == 0, 10 ** 9, e), axis=1) > 0).all()
     feats, inter = T.build_features(cfg["temp_dir"], synth.chrom_range(num))
     assert [f.shape for f in feats] == [(n, n) for n in num] and not np.isnan(np.concatenate([f.ravel() for f in feats])).any()
     # utils surface
@@ -59,6 +55,17 @@ def test_host_helpers(tmp_path):
     assert U.accuracy(p, y, s) == "2 1.000 3 1.000 "
     auc, aupr = U.roc_auc_cuda(y, p, s, 3)
     assert auc.startswith("all 1.000") and aupr.split(" ")[-2] == "3"                    # the label main.py:313 parses
+
+
+@pytest.mark.gpu
+def test_load_kmers_on_device(tmp_path):
+    """main.py:551-566 through the device quantile transform (tests/test_positives.py holds its parity tests)."""
+    from matcha_amd import train as T
+    cfg, num = _write_temp_dir(str(tmp_path))
+    e, w = T.load_kmers(cfg["temp_dir"], [2, 3], 0.6)
+    assert e.shape[1] == 3 and len(e) == len(w) and (w > 0.6).all()
+    assert 0.3 * 800 < len(e) < 0.5 * 800                                                # ~40 % of rows pass the 0.6 quantile
+    assert ((e != 0).sum(1) >= 2).all() and (np.diff(np.where(e == 0, 10 ** 9, e), axis=1) > 0).all()
 
 
 @pytest.mark.gpu
