@@ -308,6 +308,26 @@ size_t matcha_quantile_workspace_bytes(int64_t n);
 int matcha_quantile_uniform(const float* freq, int64_t n, int32_t n_quantiles, float* out, double* quantiles_out, void* ws,
                             size_t ws_bytes, matcha_stream_t stream);
 
+/* ---- feature construction from contact maps ----------------------------------------------------------
+ * matcha_pixels_to_adj   Code/process.py:144-172: cooler pixels -> adjacency.  For every pixel i whose two bins map to nodes
+ *   (index2node[bin] >= 1; 0 = chromosome outside chrom_list) and whose count is not NaN: M[n1-1][n2-1] += count and
+ *   M[n2-1][n1-1] += count, M = intra when node2chrom[n1] == node2chrom[n2], else inter.  Adds into the caller's matrices
+ *   (zero them first; call repeatedly to stream a large pixel table).
+ *     bin1, bin2 device int64 [n_pixels]; count device float64 [n_pixels]; index2node device int32 [n_index];
+ *     node2chrom device int32 [n_nodes + 1] (entry 0 unused); intra, inter device float64 [n_nodes, n_nodes]
+ * matcha_corrcoef_block  Code/main.py:571-575: np.corrcoef of one chromosome's intra block, NaN -> 0.
+ *     adj device float32, the block's top-left element, row stride ld (elements); out device float32 [n, n];
+ *     ws matcha_corrcoef_workspace_bytes(n) bytes.  float64 arithmetic; differs from numpy only by summation order.
+ * matcha_zscore_rows     Code/Modules.py:146-152: every row of a float32 [rows, cols] matrix, in place: strictly positive
+ *     entries -> (x - mean) / std (ddof 0) over those entries, then NaN -> 0. */
+int matcha_pixels_to_adj(const int64_t* bin1, const int64_t* bin2, const double* count, int64_t n_pixels,
+                         const int32_t* index2node, int64_t n_index, const int32_t* node2chrom, int32_t n_nodes,
+                         double* intra, double* inter, matcha_stream_t stream);
+size_t matcha_corrcoef_workspace_bytes(int32_t n);
+int matcha_corrcoef_block(const float* adj, int64_t ld, int32_t n, float* out, void* ws, size_t ws_bytes,
+                          matcha_stream_t stream);
+int matcha_zscore_rows(float* matrix, int64_t rows, int64_t cols, matcha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

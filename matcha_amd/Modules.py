@@ -81,7 +81,10 @@ class SparseEmbedding(nn.Module):
             raise NotImplementedError("sparse (scipy) feature matrices are not supported on the HIP path")
         w = embedding_weight.todense() if hasattr(embedding_weight, "todense") else embedding_weight
         self.sparse = False
-        self.embedding = torch.from_numpy(np.ascontiguousarray(np.asarray(w))).to(_default_device())
+        if isinstance(w, torch.Tensor):                      # features built on the device (matcha_amd.features)
+            self.embedding = w.detach().contiguous().to(_default_device())
+        else:
+            self.embedding = torch.from_numpy(np.ascontiguousarray(np.asarray(w))).to(_default_device())
 
     forward = _no_submodule_forward
 
@@ -216,7 +219,10 @@ class MultipleEmbedding(nn.Module):
         self.num_list = torch.tensor([0] + [int(v) for v in list(num_list)]).to(dev)
         self.dim = dim
         self.embeddings = [SparseEmbedding(w, sparse) for w in embedding_weights]
-        if inter_initial is not None:
+        if isinstance(inter_initial, torch.Tensor):          # raw inter matrix already on the device: z-score there, in place
+            from . import features
+            self.inter_initial = SparseEmbedding(features.zscore_rows_(inter_initial), sparse)
+        elif inter_initial is not None:                      # numpy input: the reference's own host statements
             for i in range(len(inter_initial)):
                 row = inter_initial[i, :]
                 pos = row > 0

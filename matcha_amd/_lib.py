@@ -85,6 +85,10 @@ SIGNATURES = {
     "matcha_kmer_generate": (C.c_int, [_fp, _fp, _fp, _I64, _I64, _I32, _I32, _I32, _I32, _fp, _fp, _I64, _fp, _fp, _SZ, _fp]),
     "matcha_quantile_workspace_bytes": (_SZ, [_I64]),
     "matcha_quantile_uniform": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _SZ, _fp]),
+    "matcha_pixels_to_adj": (C.c_int, [_fp, _fp, _fp, _I64, _fp, _I64, _fp, _I32, _fp, _fp, _fp]),
+    "matcha_corrcoef_workspace_bytes": (_SZ, [_I32]),
+    "matcha_corrcoef_block": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _SZ, _fp]),
+    "matcha_zscore_rows": (C.c_int, [_fp, _I64, _I64, _fp]),
 }
 
 _lib = None

@@ -53,16 +53,10 @@ def load_kmers(temp_dir: str, size_list: List[int], cutoff: float) -> Tuple[np.n
 
 
 def build_features(temp_dir: str, chrom_range: np.ndarray):
-    """Per-chromosome np.corrcoef of the intra-chromosomal contact block, NaN -> 0 (main.py:569-577) + raw inter matrix."""
-    inter = np.load(os.path.join(temp_dir, "inter_adj.npy")).astype("float32")
-    adj = np.load(os.path.join(temp_dir, "intra_adj.npy")).astype("float32")
-    feats = []
-    for lo, hi in chrom_range:
-        with np.errstate(invalid="ignore", divide="ignore"):
-            c = np.corrcoef(adj[lo - 1:hi - 1, lo - 1:hi - 1]).astype("float32")
-        c[np.isnan(c)] = 0.0
-        feats.append(c)
-    return feats, inter
+    """Per-chromosome np.corrcoef of the intra-chromosomal contact block, NaN -> 0 (main.py:569-577) + raw inter matrix, both
+    built and kept on the device (features.py / csrc/features.hip); ``MultipleEmbedding`` z-scores the inter rows there."""
+    from . import features
+    return features.build_features(temp_dir, chrom_range)
 
 
 @torch.no_grad()

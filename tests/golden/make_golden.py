@@ -442,6 +442,130 @@ def g8_positives(M, U):
     print("G8", {k: v.shape for k, v in out.items() if k.endswith("_weight")})
 
 
+class _NpProxy:
+    """numpy for the exec'd process.py functions: np.save of a ragged python list (process.py:87) needs an explicit object
+    array on numpy >= 1.24 (shim 2); np.load of the pickled dicts needs allow_pickle."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def save(path, obj):
+        try:
+            arr = np.asanyarray(obj)
+        except ValueError:
+            arr = np.empty(len(obj), dtype=object)
+            for i, o in enumerate(obj):
+                arr[i] = o
+        np.save(path, arr, allow_pickle=True)
+
+    @staticmethod
+    def load(path, **kw):
+        kw["allow_pickle"] = True
+        return np.load(path, **kw)
+
+
+def g9_process(M, U):
+    """G9: process.py's build_node_dict, parse_file and parse_cool_contact exec'd from the reference on a
+    synthetic genome (3 listed chromosomes + 1 unlisted), a synthetic cluster file and a synthetic cooler -- h5py is not
+    installed, so ``h5py.File`` is a dict of the arrays a cooler holds (dev-only stand-in, like the pybloom_live one) --
+    plus main.py:571-575 (np.corrcoef per chromosome) and Modules.py:146-152 (scipy zscore of the positive inter entries) on
+    the resulting matrices."""
+    import math
+    import shutil
+    import types
+    import pandas as pd
+    import scipy.stats
+    rng = np.random.default_rng(99)
+    tmp = tempfile.mkdtemp(prefix="matcha_g9_")
+    res = 1000000
+    chrom_list = ["chr1", "chr2", "chrX"]
+    size_lines = [("chr1", 9000000), ("chr1", 12300000), ("chr2", 8000000), ("chrY", 3000000), ("chrX", 5500001)]
+    size_text = "".join("%s\t%d\n" % kv for kv in size_lines)
+    with open(os.path.join(tmp, "sizes.txt"), "w") as f:
+        f.write(size_text)
+    sizes = {"chr1": 12300000, "chr2": 8000000, "chrX": 5500001, "chrY": 3000000}
+    lines = []
+    for c in range(300):
+        n = int(rng.integers(1, 12))
+        items = []
+        for _ in range(n):
+            chrom = str(rng.choice(["chr1", "chr1", "chr2", "chr2", "chrX", "chrY"]))
+            items.append("%s:%d" % (chrom, int(rng.integers(0, sizes[chrom]))))
+        if c % 17 == 0:
+            items = items + items[:2]                                   # repeated items collapse (process.py:67)
+        lines.append("\t".join(["cluster%d" % c] + items))
+    lines.append("\t".join(["huge"] + ["chr1:%d" % int(rng.integers(0, sizes["chr1"])) for _ in range(6 * 50 + 1)]))   # > 50 * max: skipped unparsed
+    lines.append("single\tchr1:5")
+    lines.append("")
+    cluster_text = "\n".join(lines) + "\n"
+    with open(os.path.join(tmp, "x.cluster"), "w") as f:
+        f.write(cluster_text)
+    # a cooler: bins of every chromosome of the file (chrY included, unlisted), upper-triangle pixels, some NaN weights
+    names = ["chr1", "chr2", "chrY", "chrX"]
+    b_chrom, b_start = [], []
+    for ci, c in enumerate(names):
+        for b in range(math.ceil(sizes[c] / res)):
+            b_chrom.append(ci)
+            b_start.append(b * res)
+    nb = len(b_chrom)
+    iu, ju = np.triu_indices(nb)
+    pick = rng.random(len(iu)) < 0.55
+    bin1, bin2 = iu[pick].astype(np.int64), ju[pick].astype(np.int64)
+    balanced = rng.gamma(2.0, 1.0, size=len(bin1)) / (np.abs(bin1 - bin2) + 1.0)
+    balanced[rng.random(len(bin1)) < 0.05] = np.nan
+    counts = rng.integers(1, 40, size=len(bin1)).astype(np.int32)
+    out = {"sizes_text": np.array(size_text), "cluster_text": np.array(cluster_text), "bins_chrom": np.array(b_chrom, dtype=np.int32),
+           "bins_start": np.array(b_start, dtype=np.int64), "chrom_names": np.array(names), "bin1": bin1, "bin2": bin2,
+           "balanced": balanced, "count": counts, "max_cluster_size": np.int64(6)}
+    for key, pixels in (("balanced", {"bin1_id": bin1, "bin2_id": bin2, "balanced": balanced, "count": counts}),
+                        ("count", {"bin1_id": bin1, "bin2_id": bin2, "count": counts})):
+        cooler = {"resolutions": {str(res): {"bins": {"chrom": np.array(b_chrom), "start": np.array(b_start)},
+                                             "chroms": {"name": np.array([n.encode() for n in names])}, "pixels": pixels}}}
+        glb = dict(np=_NpProxy(), pd=pd, math=math, os=os, sys=sys, tqdm=lambda x: x, trange=range, print=lambda *a, **k: None,
+                   h5py=types.SimpleNamespace(File=lambda path, mode: cooler), chrom_size=os.path.join(tmp, "sizes.txt"),
+                   chrom_list=chrom_list, res=res, temp_dir=tmp, cluster_path=os.path.join(tmp, "x.cluster"), mcool_path="x.mcool",
+                   max_cluster_size=6)
+        ref_functions("process.py", {"build_node_dict", "parse_file", "parse_cool_contact"}, glb)
+        with redirect_stdout(io.StringIO()):
+            glb["build_node_dict"]()
+            glb["parse_file"]()
+            glb["parse_cool_contact"]()
+        out[f"intra_{key}"] = np.load(os.path.join(tmp, "intra_adj.npy"))
+        out[f"inter_{key}"] = np.load(os.path.join(tmp, "inter_adj.npy"))
+    chrom_range = np.load(os.path.join(tmp, "chrom_range.npy"))
+    bin2node = np.load(os.path.join(tmp, "bin2node.npy"), allow_pickle=True).item()
+    node2chrom = np.load(os.path.join(tmp, "node2chrom.npy"), allow_pickle=True).item()
+    node2bin = np.load(os.path.join(tmp, "node2bin.npy"), allow_pickle=True).item()
+    edge_list = np.load(os.path.join(tmp, "edge_list.npy"), allow_pickle=True)
+    N = int(np.max(chrom_range)) - 1
+    out["chrom_range"] = chrom_range
+    out["bin2node_keys"] = np.array(list(bin2node.keys()))
+    out["bin2node_vals"] = np.array(list(bin2node.values()), dtype=np.int64)
+    out["node2chrom"] = np.array([node2chrom[i] for i in range(1, N + 1)], dtype=np.int64)
+    out["node2bin"] = np.array([node2bin[i] for i in range(1, N + 1)])
+    out["edge_len"] = np.array([len(e) for e in edge_list], dtype=np.int64)
+    out["edge_flat"] = np.concatenate([np.asarray(e, dtype=np.int64) for e in edge_list])
+    # main.py:568-575 and Modules.py:146-152 on the balanced matrices
+    inter_initial = out["inter_balanced"].astype("float32")
+    adj = out["intra_balanced"].astype("float32")
+    for ci, v in enumerate(chrom_range):
+        temp = adj[v[0] - 1:v[1] - 1, v[0] - 1:v[1] - 1]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            temp = np.corrcoef(temp).astype("float32")
+        temp[np.isnan(temp)] = 0.0
+        out[f"corr_{ci}"] = temp
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(len(inter_initial)):
+            temp = inter_initial[i, :]
+            inter_initial[i, temp > 0] = scipy.stats.mstats.zscore(temp[temp > 0]).astype("float32")
+    inter_initial[np.isnan(inter_initial)] = 0.0
+    out["inter_zscore"] = inter_initial
+    np.savez_compressed(os.path.join(HERE, "g9_process.npz"), **out)
+    shutil.rmtree(tmp)
+    print("G9", "N =", N, "clusters kept", len(edge_list), "pixels", len(bin1), {k: out[k].shape for k in ("intra_balanced", "corr_0")})
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
@@ -460,6 +584,7 @@ def main():
     g6_inference(M, U)
     g7_kmers(M, U)
     g8_positives(M, U)
+    g9_process(M, U)
 
 
 if __name__ == "__main__":

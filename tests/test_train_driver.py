@@ -41,8 +41,6 @@ def test_host_helpers(tmp_path):
     assert np.array_equal(T.get_attributes(synth.LAYOUTS["tiny"]), g["attr"])           # main.py:497-512 via the reference
     cfg, num = _write_temp_dir(str(tmp_path))
     assert U.get_config(os.path.join(tmp_path, "config.JSON"))["embed_dim"] == 16
-    feats, inter = T.build_features(cfg["temp_dir"], synth.chrom_range(num))
-    assert [f.shape for f in feats] == [(n, n) for n in num] and not np.isnan(np.concatenate([f.ravel() for f in feats])).any()
     # utils surface
     assert isinstance(U.np2tensor_hyper([[1, 2], [3, 4]]), torch.Tensor)
     ragged = U.np2tensor_hyper([[1, 2], [3, 4, 5]])
@@ -66,6 +64,9 @@ def test_load_kmers_on_device(tmp_path):
     assert e.shape[1] == 3 and len(e) == len(w) and (w > 0.6).all()
     assert 0.3 * 800 < len(e) < 0.5 * 800                                                # ~40 % of rows pass the 0.6 quantile
     assert ((e != 0).sum(1) >= 2).all() and (np.diff(np.where(e == 0, 10 ** 9, e), axis=1) > 0).all()
+    feats, inter = T.build_features(cfg["temp_dir"], synth.chrom_range(num))
+    assert [tuple(f.shape) for f in feats] == [(n, n) for n in num] and not any(torch.isnan(f).any() for f in feats)
+    assert inter.is_cuda and inter.shape == (sum(num), sum(num))
 
 
 @pytest.mark.gpu
