@@ -145,3 +145,35 @@ def save_adj(temp_dir: str, intra: torch.Tensor, inter: torch.Tensor):
     """process.py:175-176."""
     np.save(os.path.join(temp_dir, "intra_adj.npy"), intra.cpu().numpy())
     np.save(os.path.join(temp_dir, "inter_adj.npy"), inter.cpu().numpy())
+
+
+def main(argv=None):
+    """The script body of process.py:229-242: node dictionaries, edge_list.npy and -- when h5py is importable, it is not part
+    of this image -- the adjacency matrices from ``mcool_path``, streamed through the device 16 M pixels at a time."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(description="process.py on the MI355X path")
+    ap.add_argument("--config", default="./config.JSON")
+    args = ap.parse_args(argv)
+    with open(args.config) as f:
+        config = json.load(f)
+    res, chrom_list, temp_dir = config["resolution"], config["chrom_list"], config["temp_dir"]
+    bin2node, _, node2chrom, chrom_range = build_node_dict(config["chrom_size"], chrom_list, res, temp_dir)
+    clusters = parse_clusters(config["cluster_path"], bin2node, chrom_list, res, config["max_cluster_size"], temp_dir)
+    print("%d nodes, %d clusters" % (int(chrom_range.max()) - 1, len(clusters)))
+    try:
+        import h5py
+    except ImportError:
+        raise SystemExit("h5py is not installed: load the cooler's bins / pixels yourself and call process.pixels_to_adj")
+    f = h5py.File(config["mcool_path"], "r")["resolutions"][str(res)]
+    i2n = cool_index2node(np.array(f["bins"]["chrom"]), np.array(f["bins"]["start"]), np.array(f["chroms"]["name"]).astype("str"),
+                          chrom_list, bin2node)
+    weights = f["pixels"]["balanced"] if "balanced" in f["pixels"].keys() else f["pixels"]["count"]       # process.py:147-150
+    N, out, step = int(chrom_range.max()) - 1, None, 1 << 24
+    for s in range(0, len(weights), step):
+        out = pixels_to_adj(f["pixels"]["bin1_id"][s:s + step], f["pixels"]["bin2_id"][s:s + step], weights[s:s + step], i2n, node2chrom, N, out=out)
+    save_adj(temp_dir, *out)
+
+
+if __name__ == "__main__":
+    main()
