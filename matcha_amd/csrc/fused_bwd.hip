@@ -24,6 +24,7 @@
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -50,6 +51,7 @@ struct FusedBwdArgs {
   float* dxh;                     // [8][tcap][64]
   int64_t tcap;
   float* wslab;                   // [8][nchunks][kWgSlab]
+  const float* qkv;               // [ntiles][8][3][4096] Q, K, V register images left by the training forward (null: recompute them)
   int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 attention, 2 recompute GEMMs, 4 weight-grad GEMMs, 8 dx_hat GEMMs
 };
 
@@ -431,13 +433,35 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
     *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
   } while (0)
+  // Q, K, V tiles of the forward pass: reloaded thread for thread (the register image proj_store_T of fused_fwd.hip wrote)
+  // instead of recomputed -- 1.4 GB per 65 536-row step through an HBM that is otherwise idle, against 96 MFMAs per wave and tile
+  const bool img = g.qkv != nullptr;
+  f32x4 qi0, qi1, qi2, qi3, ki0, ki1, ki2, ki3, vi0, vi1, vi2, vi3;
+  const int img_lane = ((wr * 2 + wc) * 4) * 64 + lane;
+#define FB_QKV_GLOAD(TILE)                                                                               \
+  do {                                                                                                   \
+    const f32x4* b__ = reinterpret_cast<const f32x4*>(g.qkv + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * 3 * 4096) + img_lane; \
+    qi0 = __builtin_nontemporal_load(b__); qi1 = __builtin_nontemporal_load(b__ + 64);                   \
+    qi2 = __builtin_nontemporal_load(b__ + 128); qi3 = __builtin_nontemporal_load(b__ + 192);            \
+    ki0 = __builtin_nontemporal_load(b__ + 1024); ki1 = __builtin_nontemporal_load(b__ + 1088);          \
+    ki2 = __builtin_nontemporal_load(b__ + 1152); ki3 = __builtin_nontemporal_load(b__ + 1216);          \
+    vi0 = __builtin_nontemporal_load(b__ + 2048); vi1 = __builtin_nontemporal_load(b__ + 2112);          \
+    vi2 = __builtin_nontemporal_load(b__ + 2176); vi3 = __builtin_nontemporal_load(b__ + 2240);          \
+  } while (0)
+#define FB_IMG_STAGE(TS, R0, R1, R2, R3)                                                                 \
+  do {                                                                                                   \
+    f32x4* d__ = reinterpret_cast<f32x4*>(&(TS)[(32 * wr + r) * kLd + 32 * wc + 4 * h]);                 \
+    d__[0] = R0; d__[2] = R1; d__[4] = R2; d__[6] = R3;                                                  \
+  } while (0)
   FB_ROWS_GLOAD(mc);
+  if (img && tile_lo < tile_hi) FB_QKV_GLOAD(tile_lo);
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
     const int t0 = mc.x, n_real = mc.y;
     if (n_real <= 0) {                                // no token starts in this window (all-padding rows only)
       FB_ROWS_GLOAD(mn);
+      if (img && tile + 1 < tile_hi) FB_QKV_GLOAD(tile + 1);
       mc = mn; mn = mnn;
       continue;
     }
@@ -446,10 +470,16 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the token -> hyperedge map ----
     FB_ROW_STAGE(0); FB_ROW_STAGE(1); FB_ROW_STAGE(2); FB_ROW_STAGE(3);
     if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
+    if (img) {
+      FB_IMG_STAGE(Qs, qi0, qi1, qi2, qi3);
+      FB_IMG_STAGE(Ks, ki0, ki1, ki2, ki3);
+      FB_IMG_STAGE(Vs, vi0, vi1, vi2, vi3);
+    }
     __syncthreads();
     FB_T(0);
-    // ---- recompute Q, K, V  (one accumulator at a time: fusing the three loops pushed hipcc into spilling) ----
-    if (!(g.dbg & 2)) {
+    // ---- recompute Q, K, V when the forward pass did not leave them (one accumulator at a time: fusing the three loops
+    //      pushed hipcc into spilling) ----
+    if (!img && !(g.dbg & 2)) {
       proj_store_T(Qs, Xs, Wq, cb, wr, wc, r, h);
       proj_store_T(Ks, Xs, Wk, cb + 64, wr, wc, r, h);
       proj_store_T(Vs, Xs, Wv, cb + 128, wr, wc, r, h);
@@ -517,6 +547,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       }
     }
     FB_T(5);
+    if (img && tile + 1 < tile_hi) FB_QKV_GLOAD(tile + 1);     // next tile's Q, K, V: in flight during the weight-gradient GEMMs
     // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
     if (!(g.dbg & 4)) {
       // 8 trips of 4 contraction steps (8 tokens); the operands of trip i + 1 are fetched before the 16 MFMAs of trip i.
@@ -768,7 +799,7 @@ size_t fused_bwd_ws_floats(int64_t B, int L) {
 }
 
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
-                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st) {
+                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv) {
   const int64_t tcap = B * L + 1;
   const int nchunks = chunks_for(rg.ntiles);
   float* wslab = ws;
@@ -780,7 +811,7 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     g.X = X; g.dDyn = dDyn; g.row_off = rg.row_off; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
     g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
     g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
-    g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab;
+    g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.qkv = qkv;
     { const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
     const size_t lds = ((size_t)9 * kTile + 64 + 192 + 3 * 64 + 2 * 512) * sizeof(float);
     auto launch = [&](auto kfn) {

@@ -20,6 +20,7 @@
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTM = 64;          // tile rows (tokens)
 constexpr int kLdT = 68;         // LDS row stride (floats)
@@ -65,6 +66,7 @@ struct FusedFwdArgs {
   float* dXs;                     // [Tn, 64] gradient into X through the static branch (layer_norm2)
   float* tslab;                   // [ntiles][kTailSlab] per-tile partials: dW1, dW0, 9 column-sum vectors, d bc
   float alpha_over_B;
+  float* qkv;                     // [ntiles][8 heads][3][4096] register images of the Q, K, V tiles for fused_bwd (null: not saved)
 };
 constexpr int kTailVec = 2 * 4096;                 // offset of the vectors inside a tile's slab
 constexpr int kTailSlab = 2 * 4096 + 10 * 64;      // {gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b} x 64, then bc (+ padding)
@@ -105,8 +107,10 @@ __device__ __forceinline__ f32x16 quad_gemm_regA(f32x16 acc, const float4 (&afr)
 // with token row 32 wr + r and, in registers 4g..4g+3, the four consecutive features 32 wc + 8 g + 4 h + {0..3} -- one
 // ds_write_b128 per group instead of four ds_write_b32, and the bias is the accumulator's initial value (no adds).
 // VALU instructions are not free next to f32 MFMAs on this part (tools/ubench/mfma_valu.hip), so the epilogue matters.
+// `gimg` (training): the same registers also go to global memory, 16 KB per tile in (wave quadrant, group, lane) order -- the
+// backward kernel reloads them thread for thread instead of recomputing the projection (fused_bwd.hip).
 __device__ __forceinline__ void proj_store_T(float* __restrict__ Ts, const float4 (&afr)[8], const float* __restrict__ Bs, const float* __restrict__ bias,
-                                             int wr, int wc, int r, int h, bool skip) {
+                                             int wr, int wc, int r, int h, bool skip, float* __restrict__ gimg) {
   f32x16 acc;
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
@@ -126,6 +130,12 @@ __device__ __forceinline__ void proj_store_T(float* __restrict__ Ts, const float
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq)
     *reinterpret_cast<float4*>(&Ts[(32 * wr + r) * kLdT + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+  if (gimg) {
+    f32x4* dst = reinterpret_cast<f32x4*>(gimg) + ((wr * 2 + wc) * 4) * 64 + 32 * h + r;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)          // written once, read ~1 ms later by another kernel: keep it out of the caches
+      __builtin_nontemporal_store((f32x4){acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]}, dst + gq * 64);
+  }
 }
 // same with the A tile in LDS ([row][k])
 __device__ __forceinline__ f32x16 quad_gemm_ldsA(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int r, int h) {
@@ -342,14 +352,15 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     TILE_GLOAD(wA, g.wv + wofs, 64);
     TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
     __syncthreads();
-    proj_store_T(Qs, afr, Bs, cbias + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0);
-    proj_store_T(Ks, afr, Vs, cbias + 512 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0);
+    float* img = g.qkv ? g.qkv + ((int64_t)blockIdx.x * MATCHA_N_HEAD + hd) * 3 * 4096 : nullptr;
+    proj_store_T(Qs, afr, Bs, cbias + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img);
+    proj_store_T(Ks, afr, Vs, cbias + 512 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img ? img + 4096 : nullptr);
     // ---- V ----
     __syncthreads();                                   // both weight tiles consumed
     TILE_LSTORE(Bs, wA);
     TILE_GLOAD(wA, last ? g.p0w : g.wq + wofs + 64 * 64, 64);
     __syncthreads();
-    proj_store_T(Vs, afr, Bs, cbias + 1024 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0);
+    proj_store_T(Vs, afr, Bs, cbias + 1024 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img ? img + 8192 : nullptr);
     __syncthreads();                                   // Q, K, V tiles complete; Bs free
     TILE_LSTORE(Bs, wB);                               // fc1 block (read after the next barrier)
     TILE_GLOAD(wB, last ? g.p1w : g.wk + wofs + 64 * 64, 64);
@@ -682,6 +693,7 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
 }
 
 size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
+size_t fused_qkv_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * MATCHA_N_HEAD * 3 * 4096; }
 
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st) {
   TailReduceArgs a;
@@ -695,9 +707,9 @@ int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tenso
 
 int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                     hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha) {
+                     hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv) {
   FusedFwdArgs g;
-  g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B;
+  g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B; g.qkv = qkv;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.B = B; g.L = L;
   g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;

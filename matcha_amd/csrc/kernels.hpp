@@ -93,7 +93,7 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st);
 // (launch_tail_reduce accumulates them into the gradient tensors).
 int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                     hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f);
+                     hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr);
 size_t fused_tail_slab_floats(int64_t B, int L);
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st);
 
@@ -101,7 +101,8 @@ int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tenso
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)
 size_t fused_bwd_ws_floats(int64_t B, int L);
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
-                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st);
+                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
+size_t fused_qkv_floats(int64_t B, int L);         // Q/K/V register images the training forward leaves for the fused backward
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 

@@ -65,6 +65,7 @@ struct Workspace {
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
+  float* qkv;                             // training forward -> fused backward: Q, K, V tiles of every (tile, head), 384 KB per tile
   float* front_ws;                        // fused front-end backward: workgroup slabs
   size_t total;
 };
@@ -79,6 +80,10 @@ static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s)
 static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
   return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && getenv("MATCHA_DISABLE_LOSS_IN_FORWARD") == nullptr;
 }
+
+//   MATCHA_DISABLE_QKV_SAVE  the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
+//                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
+static bool save_qkv() { static const bool on = getenv("MATCHA_DISABLE_QKV_SAVE") == nullptr; return on; }
 
 static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
   const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
@@ -129,6 +134,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
+  w.qkv = take(s.d == 64 && save_qkv() ? fused_qkv_floats(B, L) : 0);
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
   w.total = off;
   return off;
@@ -278,7 +284,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
     MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                 w.logits, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha));
+                                lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, (!opts->forward_only && save_qkv()) ? w.qkv : nullptr));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
     if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -386,7 +392,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
     const bool front = front_bwd_supported(s.d, s.n_attr) && getenv("MATCHA_DISABLE_FUSED_FRONT") == nullptr;
-    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st));
+    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, save_qkv() ? w.qkv : nullptr));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
