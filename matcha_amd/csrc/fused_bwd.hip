@@ -51,7 +51,7 @@ struct FusedBwdArgs {
   float* dxh;                     // [8][tcap][64]
   int64_t tcap;
   float* wslab;                   // [8][nchunks][kWgSlab]
-  const float* qkv;               // [ntiles][8][3][4096] Q, K, V register images left by the training forward (null: recompute them)
+  const float* qkv;               // [ntiles][8][kImgRec] Q, K, V register images + attention probabilities left by the training forward (null: recompute)
   int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 attention, 2 recompute GEMMs, 4 weight-grad GEMMs, 8 dx_hat GEMMs
 };
 
@@ -202,7 +202,7 @@ template <int ML>
 __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs,
                                             const float* __restrict__ Fs, const float* __restrict__ kpad, const float* __restrict__ vpad,
                                             float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0, int k, int n_pad, int sub,
-                                            float inv_temp, V8& o, V8& gq, V8& accK, V8& accV) {
+                                            float inv_temp, V8& o, V8& gq, V8& accK, V8& accV, bool have_p) {
   // Branch-free over the ML key slots: a wave almost always holds a hyperedge of the full width, so predicating the
   // slots j >= k (clamped row, probability forced to 0) costs nothing and removes one branch per slot.
   const float padf = (float)n_pad;
@@ -214,34 +214,42 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
 #pragma unroll
   for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLd + 8 * sub;
   const V8 q = ld8(&Qs[li * kLd + 8 * sub]);
-  float mx = -3.4e38f;
-  {
-    V8 kk[ML];
+  if (have_p) {                                          // the forward pass left row i of P in Ps (slot 7: the padding probability)
+    const float4 pa = *reinterpret_cast<const float4*>(&Ps[li * 8]), pb = *reinterpret_cast<const float4*>(&Ps[li * 8 + 4]);
+    const float w[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-    for (int j = 0; j < ML; ++j) kk[j] = ld8(&Ks[ro[j]]);
-    const V8 kp = ld8(kpad + 8 * sub);
+    for (int j = 0; j < ML; ++j) p[j] = (j < k) ? w[j] : 0.f;
+    pp = hp ? w[7] : 0.f;
+  } else {
+    float mx = -3.4e38f;
+    {
+      V8 kk[ML];
+#pragma unroll
+      for (int j = 0; j < ML; ++j) kk[j] = ld8(&Ks[ro[j]]);
+      const V8 kp = ld8(kpad + 8 * sub);
+#pragma unroll
+      for (int j = 0; j < ML; ++j) {
+        float a = group_sum8_dpp(dot8(q, kk[j])) * inv_temp;
+        a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
+        p[j] = a;
+        mx = (j < k) ? fmaxf(mx, a) : mx;
+      }
+      pp = group_sum8_dpp(dot8(q, kp)) * inv_temp;
+      mx = hp ? fmaxf(mx, pp) : mx;
+    }
+    float den = 0.f;
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
-      float a = group_sum8_dpp(dot8(q, kk[j])) * inv_temp;
-      a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
-      p[j] = a;
-      mx = (j < k) ? fmaxf(mx, a) : mx;
+      p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
+      den += p[j];
     }
-    pp = group_sum8_dpp(dot8(q, kp)) * inv_temp;
-    mx = hp ? fmaxf(mx, pp) : mx;
-  }
-  float den = 0.f;
+    pp = hp ? __expf(pp - mx) : 0.f;
+    den += padf * pp;
+    const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
-  for (int j = 0; j < ML; ++j) {
-    p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
-    den += p[j];
+    for (int j = 0; j < ML; ++j) p[j] *= inv;
+    pp *= inv;
   }
-  pp = hp ? __expf(pp - mx) : 0.f;
-  den += padf * pp;
-  const float inv = __builtin_amdgcn_rcpf(den);
-#pragma unroll
-  for (int j = 0; j < ML; ++j) p[j] *= inv;
-  pp *= inv;
   const float ppf = padf * pp;
   {
     const V8 go = ld8(&Fs[li * kLd + 8 * sub]);
@@ -281,7 +289,7 @@ __device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const 
   }
   axpy8(accK, dspf, q);
   // row i of P and dS for the column phase (every lane of the group holds the same values: lanes 0 / 1 write them)
-  if (sub < 2) {
+  if (have_p ? sub == 1 : sub < 2) {
     float* dst = (sub == 0 ? Ps : dSs) + li * 8;
     const float w0 = sub == 0 ? p[0] : ds[0], w1 = sub == 0 ? p[1 % ML] : ds[1 % ML];
     const float w2 = sub == 0 ? p[2 % ML] : ds[2 % ML], w3 = sub == 0 ? p[3 % ML] : ds[3 % ML];
@@ -436,11 +444,13 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   // Q, K, V tiles of the forward pass: reloaded thread for thread (the register image proj_store_T of fused_fwd.hip wrote)
   // instead of recomputed -- 1.4 GB per 65 536-row step through an HBM that is otherwise idle, against 96 MFMAs per wave and tile
   const bool img = g.qkv != nullptr;
-  f32x4 qi0, qi1, qi2, qi3, ki0, ki1, ki2, ki3, vi0, vi1, vi2, vi3;
+  f32x4 qi0, qi1, qi2, qi3, ki0, ki1, ki2, ki3, vi0, vi1, vi2, vi3, pn = {0.f, 0.f, 0.f, 0.f};
   const int img_lane = ((wr * 2 + wc) * 4) * 64 + lane;
 #define FB_QKV_GLOAD(TILE)                                                                               \
   do {                                                                                                   \
-    const f32x4* b__ = reinterpret_cast<const f32x4*>(g.qkv + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * 3 * 4096) + img_lane; \
+    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.qkv + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * kImgRec);  \
+    const f32x4* b__ = r__ + img_lane;                                                                   \
+    if (tid < 128) pn = __builtin_nontemporal_load(r__ + 3072 + tid);                                    \
     qi0 = __builtin_nontemporal_load(b__); qi1 = __builtin_nontemporal_load(b__ + 64);                   \
     qi2 = __builtin_nontemporal_load(b__ + 128); qi3 = __builtin_nontemporal_load(b__ + 192);            \
     ki0 = __builtin_nontemporal_load(b__ + 1024); ki1 = __builtin_nontemporal_load(b__ + 1088);          \
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       FB_IMG_STAGE(Qs, qi0, qi1, qi2, qi3);
       FB_IMG_STAGE(Ks, ki0, ki1, ki2, ki3);
       FB_IMG_STAGE(Vs, vi0, vi1, vi2, vi3);
+      if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;          // rows of P: the row phase starts from them
     }
     __syncthreads();
     FB_T(0);
@@ -509,8 +520,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       const int la = wave * 8 + (lane >> 3), lb = la + 32;
       const bool acta = la < n_real && !(g.dbg & 1), actb = lb < n_real && !(g.dbg & 1);
       int ia = 0, ib = 0;
-      if (acta) { ia = tinfo[la]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
-      if (actb) { ib = tinfo[lb]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, lb, ib & 255, ib >> 8, g.L - (ib >> 8), sub, inv_temp, o1, q1, accK, accV); }
+      if (acta) { ia = tinfo[la]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV, img); }
+      if (actb) { ib = tinfo[lb]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, lb, ib & 255, ib >> 8, g.L - (ib >> 8), sub, inv_temp, o1, q1, accK, accV, img); }
       __syncthreads();
       FB_T(2);
       if (acta) attn_col_fb<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);

@@ -66,7 +66,7 @@ struct FusedFwdArgs {
   float* dXs;                     // [Tn, 64] gradient into X through the static branch (layer_norm2)
   float* tslab;                   // [ntiles][kTailSlab] per-tile partials: dW1, dW0, 9 column-sum vectors, d bc
   float alpha_over_B;
-  float* qkv;                     // [ntiles][8 heads][3][4096] register images of the Q, K, V tiles for fused_bwd (null: not saved)
+  float* qkv;                     // [ntiles][8 heads][kImgRec]: register images of the Q, K, V tiles + attention probabilities for fused_bwd (null: not saved)
 };
 constexpr int kTailVec = 2 * 4096;                 // offset of the vectors inside a tile's slab
 constexpr int kTailSlab = 2 * 4096 + 10 * 64;      // {gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b} x 64, then bc (+ padding)
@@ -189,7 +189,7 @@ __device__ __forceinline__ void axpy8(V8& y, float w, const V8& x) {
 
 template <int ML>
 __device__ __forceinline__ void attn_row_fwd(float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs, int li, int li0, int k,
-                                             int n_pad, int pad_row, int sub, float inv_temp) {
+                                             int n_pad, int pad_row, int sub, float inv_temp, float* __restrict__ pimg) {
   const float padf = (float)n_pad;
   const bool hp = n_pad > 0;
   const int ii = li - li0;
@@ -227,6 +227,17 @@ __device__ __forceinline__ void attn_row_fwd(float* __restrict__ Qs, const float
   for (int j = 0; j < ML; ++j) axpy8(o, p[j] * inv, ld8(&Vs[ro[j]]));
   *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub]) = make_float4(o.a.x, o.a.y, o.b.x, o.b.y);
   *reinterpret_cast<float4*>(&Qs[li * kLdT + 8 * sub + 4]) = make_float4(o.c.x, o.c.y, o.d.x, o.d.y);
+  // training: row i of P for the backward pass -- slots 0..k-1 the real keys, slot 7 the per-slot padding probability (a
+  // hyperedge with 8 real nodes has no padding slot, so the two never collide); the 8 lanes hold the same values
+  if (pimg && sub == 0) {
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = j < ML ? p[j < ML ? j : 0] * inv : 0.f;
+    if (hp) w[7] = pp * inv;
+    f32x4* dst = reinterpret_cast<f32x4*>(pimg + li * 8);
+    __builtin_nontemporal_store((f32x4){w[0], w[1], w[2], w[3]}, dst);
+    __builtin_nontemporal_store((f32x4){w[4], w[5], w[6], w[7]}, dst + 1);
+  }
 }
 
 // LayerNorm statistics of a 64-float row held as one float4 per lane over 16 lanes
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     TILE_GLOAD(wA, g.wv + wofs, 64);
     TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
     __syncthreads();
-    float* img = g.qkv ? g.qkv + ((int64_t)blockIdx.x * MATCHA_N_HEAD + hd) * 3 * 4096 : nullptr;
+    float* img = g.qkv ? g.qkv + ((int64_t)blockIdx.x * MATCHA_N_HEAD + hd) * kImgRec : nullptr;
     proj_store_T(Qs, afr, Bs, cbias + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img);
     proj_store_T(Ks, afr, Vs, cbias + 512 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img ? img + 4096 : nullptr);
     // ---- V ----
@@ -367,8 +378,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     // ---- attention: 8 lanes per query token, two passes of 32 tokens ----
     if (!(g.dbg & 1)) {
       const int la = wave * 8 + (lane >> 3), lb = la + 32;
-      if (la < n_real) { const int ti = tinfo[la]; attn_row_fwd<ML>(Qs, Ks, Vs, la, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp); }
-      if (lb < n_real) { const int ti = tinfo[lb]; attn_row_fwd<ML>(Qs, Ks, Vs, lb, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp); }
+      float* pimg = img ? img + 3 * 4096 : nullptr;
+      if (la < n_real) { const int ti = tinfo[la]; attn_row_fwd<ML>(Qs, Ks, Vs, la, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp, pimg); }
+      if (lb < n_real) { const int ti = tinfo[lb]; attn_row_fwd<ML>(Qs, Ks, Vs, lb, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp, pimg); }
     }
     __syncthreads();
     // ---- dyn += O_h . Wfc1[:, head block]^T ----
@@ -693,7 +705,7 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
 }
 
 size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
-size_t fused_qkv_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * MATCHA_N_HEAD * 3 * 4096; }
+size_t fused_qkv_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRec; }
 
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st) {
   TailReduceArgs a;

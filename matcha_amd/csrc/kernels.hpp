@@ -102,7 +102,8 @@ int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tenso
 size_t fused_bwd_ws_floats(int64_t B, int L);
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
-size_t fused_qkv_floats(int64_t B, int L);         // Q/K/V register images the training forward leaves for the fused backward
+size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
+constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 
