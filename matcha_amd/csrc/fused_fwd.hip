@@ -667,18 +667,22 @@ __global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a
   const int i = blockIdx.x * 64 + o;                   // element of the slab
   int nt = a.count[2];                                 // tiles planned by ragged.hip (every one of them wrote its slab)
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;        // four independent chains: four loads in flight per lane
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;   // eight independent chains: the walk is latency-bound
   if (i < kTailSlab) {
     int b = q;
-    for (; b + 48 < nt; b += 64) {
+    for (; b + 112 < nt; b += 128) {
       s0 += a.tslab[(int64_t)b * kTailSlab + i];
       s1 += a.tslab[(int64_t)(b + 16) * kTailSlab + i];
       s2 += a.tslab[(int64_t)(b + 32) * kTailSlab + i];
       s3 += a.tslab[(int64_t)(b + 48) * kTailSlab + i];
+      s4 += a.tslab[(int64_t)(b + 64) * kTailSlab + i];
+      s5 += a.tslab[(int64_t)(b + 80) * kTailSlab + i];
+      s6 += a.tslab[(int64_t)(b + 96) * kTailSlab + i];
+      s7 += a.tslab[(int64_t)(b + 112) * kTailSlab + i];
     }
     for (; b < nt; b += 16) s0 += a.tslab[(int64_t)b * kTailSlab + i];
   }
-  part[q][o] = (s0 + s1) + (s2 + s3);
+  part[q][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   __syncthreads();
   if (q == 0 && i <= kTailVec + 9 * 64) {
     float s = 0.f;
