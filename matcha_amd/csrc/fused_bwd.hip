@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
 
   f32x16 aWq = {0}, aWk = {0}, aWv = {0}, aWf = {0};
   V8 accK = zero8(), accV = zero8();                 // dK_pad / dV_pad partials of this lane's feature slice
-  float csq = 0.f, csk = 0.f, csv = 0.f, csd = 0.f;  // column sums of dQ, dK, dV, dDyn: fall out of the weight-gradient operand loads
+  f2 csq2 = {0.f, 0.f}, csk2 = csq2, csv2 = csq2, csd2 = csq2;   // column sums of dQ, dK, dV, dDyn (even / odd token pairs): fall out of the weight-gradient operand loads
 
   // software pipeline: tile metadata two tiles ahead, X / dDyn rows one tile ahead in named registers (a struct passed
   // by reference ends up in scratch memory: fused_fwd.hip)
@@ -546,15 +546,48 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     // (stores first, weight gradients after: the stores are acknowledged long before the next tile waits on vmcnt)
     // ---- this head's share of d x_hat = dQ W'q + dK W'k + dV W'v ----
     if (!(g.dbg & 8)) {
+      // d x_hat^T: 24 contraction steps (3 products x 8) as one software pipeline: the operands of step s + 1 are read from LDS before
+      // the four MFMAs of step s, and sched_barrier keeps it that way (left alone the reads sink next to their MFMA and
+      // each one waits out the LDS latency: 40 ns per MFMA instead of 27)
       f32x16 dx = {0};
-      dx = gemm_nn(dx, Qs, Wq, wr, wc, r, h);
-      dx = gemm_nn(dx, Ks, Wk, wr, wc, r, h);
-      dx = gemm_nn(dx, Vs, Wv, wr, wc, r, h);
-      float* out = g.dxh + ((int64_t)head * g.tcap + t0) * 64 + 32 * wc + r;
+      const float* arow = Qs + (32 * wr + r) * kLd + 4 * h;
+      const float* wcol = Wq + (4 * h) * kLd + 32 * wc + r;
+      float4 a0 = *reinterpret_cast<const float4*>(arow), a1;
+      float w00 = wcol[0], w01 = wcol[kLd], w02 = wcol[2 * kLd], w03 = wcol[3 * kLd], w10, w11, w12, w13;
+#define FB_DX_LOAD(A, W, S)                                                                              \
+  do {                                                                                                   \
+    constexpr int m__ = (S) / 8, c__ = (S) % 8;                                                          \
+    const float* ap__ = arow + m__ * kTile + 8 * c__;                                                    \
+    const float* wp__ = wcol + m__ * kTile + (8 * c__) * kLd;                                            \
+    A = *reinterpret_cast<const float4*>(ap__);                                                          \
+    W##0 = wp__[0]; W##1 = wp__[kLd]; W##2 = wp__[2 * kLd]; W##3 = wp__[3 * kLd];                        \
+  } while (0)
+#define FB_DX_MMA(A, W)                                                                                  \
+  do {                                                                                                   \
+    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##0, A.x, dx, 0, 0, 0);                                   \
+    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##1, A.y, dx, 0, 0, 0);                                   \
+    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##2, A.z, dx, 0, 0, 0);                                   \
+    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##3, A.w, dx, 0, 0, 0);                                   \
+  } while (0)
+#define FB_DX_PAIR(S)                                                                                    \
+  do {                                                                                                   \
+    FB_DX_LOAD(a1, w1, (S) + 1);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FB_DX_MMA(a0, w0);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if ((S) + 2 < 24) FB_DX_LOAD(a0, w0, ((S) + 2 < 24 ? (S) + 2 : 0));                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FB_DX_MMA(a1, w1);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+      FB_DX_PAIR(0); FB_DX_PAIR(2); FB_DX_PAIR(4); FB_DX_PAIR(6); FB_DX_PAIR(8); FB_DX_PAIR(10);
+      FB_DX_PAIR(12); FB_DX_PAIR(14); FB_DX_PAIR(16); FB_DX_PAIR(18); FB_DX_PAIR(20); FB_DX_PAIR(22);
+      // transposed product (weights = MFMA row operand): lane (r, h) holds token row 32 wr + r and, in registers 4g..4g+3,
+      // features 32 wc + 8 g + 4 h + {0..3} -- four 16-byte stores under one predicate instead of sixteen predicated dwords
+      if (32 * wr + r < n_real) {
+        f32x4* out = reinterpret_cast<f32x4*>(g.dxh + ((int64_t)head * g.tcap + t0 + 32 * wr + r) * 64 + 32 * wc + 4 * h);
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (row < n_real) out[(int64_t)row * 64] = dx[reg];
+        for (int gq = 0; gq < 4; ++gq) out[2 * gq] = (f32x4){dx[4 * gq], dx[4 * gq + 1], dx[4 * gq + 2], dx[4 * gq + 3]};
       }
     }
     FB_T(5);
@@ -564,27 +597,33 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       // 8 trips of 4 contraction steps (8 tokens); the operands of trip i + 1 are fetched before the 16 MFMAs of trip i.
       // sched_barrier pins that order: left alone, the scheduler sinks every LDS read next to its MFMA to save
       // registers and the wave then waits out the full LDS latency in front of each one.
-      float xa[4], oa[4], qa[4], ka[4], va[4], da[4], xb[4], ob[4], qb[4], kb[4], vb[4], db[4];
+      // operands as (u, u + 1) pairs = the two destinations of one ds_read2_b32; the column sums then are v_pk_add_f32 on
+      // exactly those pairs (scalar adds made hipcc pair q with k instead and shuffle ~45 registers per trip to do so)
+      f2 xa01, xa23, oa01, oa23, qa01, qa23, ka01, ka23, va01, va23, da01, da23;
+      f2 xb01, xb23, ob01, ob23, qb01, qb23, kb01, kb23, vb01, vb23, db01, db23;
       const float* px = Xs + h * kLd + 32 * wc + r;
       const float* po = Fs + h * kLd + 32 * wc + r;
       const float* pq = Qs + h * kLd + 32 * wr + r;
       const float* pk = Ks + h * kLd + 32 * wr + r;
       const float* pv = Vs + h * kLd + 32 * wr + r;
       const float* pd = Ds + h * kLd + 32 * wr + r;
+#define FB_TN_LD2(P, OFF) (f2){(P)[(OFF) * kLd], (P)[((OFF) + 2) * kLd]}
 #define FB_TN_LOAD(S, OFF)                                                                               \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                        \
-    x##S[u] = px[((OFF) + 2 * u) * kLd]; o##S[u] = po[((OFF) + 2 * u) * kLd];                            \
-    q##S[u] = pq[((OFF) + 2 * u) * kLd]; k##S[u] = pk[((OFF) + 2 * u) * kLd];                            \
-    v##S[u] = pv[((OFF) + 2 * u) * kLd]; d##S[u] = pd[((OFF) + 2 * u) * kLd];                            \
-  }
+  x##S##01 = FB_TN_LD2(px, OFF); x##S##23 = FB_TN_LD2(px, (OFF) + 4);                                    \
+  o##S##01 = FB_TN_LD2(po, OFF); o##S##23 = FB_TN_LD2(po, (OFF) + 4);                                    \
+  q##S##01 = FB_TN_LD2(pq, OFF); q##S##23 = FB_TN_LD2(pq, (OFF) + 4);                                    \
+  k##S##01 = FB_TN_LD2(pk, OFF); k##S##23 = FB_TN_LD2(pk, (OFF) + 4);                                    \
+  v##S##01 = FB_TN_LD2(pv, OFF); v##S##23 = FB_TN_LD2(pv, (OFF) + 4);                                    \
+  d##S##01 = FB_TN_LD2(pd, OFF); d##S##23 = FB_TN_LD2(pd, (OFF) + 4);
+#define FB_TN_MMA4(S, PR, E)                                                                             \
+  aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(q##S##PR.E, x##S##PR.E, aWq, 0, 0, 0);                      \
+  aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(k##S##PR.E, x##S##PR.E, aWk, 0, 0, 0);                      \
+  aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(v##S##PR.E, x##S##PR.E, aWv, 0, 0, 0);                      \
+  aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(d##S##PR.E, o##S##PR.E, aWf, 0, 0, 0);
 #define FB_TN_MMA(S)                                                                                     \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                        \
-    csq += q##S[u]; csk += k##S[u]; csv += v##S[u]; csd += d##S[u];                                      \
-    aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(q##S[u], x##S[u], aWq, 0, 0, 0);                          \
-    aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(k##S[u], x##S[u], aWk, 0, 0, 0);                          \
-    aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(v##S[u], x##S[u], aWv, 0, 0, 0);                          \
-    aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(d##S[u], o##S[u], aWf, 0, 0, 0);                          \
-  }
+  csq2 += q##S##01; csk2 += k##S##01; csv2 += v##S##01; csd2 += d##S##01;                                \
+  csq2 += q##S##23; csk2 += k##S##23; csv2 += v##S##23; csd2 += d##S##23;                                \
+  FB_TN_MMA4(S, 01, x) FB_TN_MMA4(S, 01, y) FB_TN_MMA4(S, 23, x) FB_TN_MMA4(S, 23, y)
       FB_TN_LOAD(a, 0);
 #pragma unroll 1
       for (int mm = 0; mm < 4; ++mm) {
@@ -625,6 +664,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   }
   // column sums: this lane covered the tokens of one parity for column 32 wr + r (waves with wc = 1 hold duplicates)
   float* red = Xs;                      // [5][64]: dcq dck dcv dKpad dVpad
+  float csq = csq2.x + csq2.y, csk = csk2.x + csk2.y, csv = csv2.x + csv2.y, csd = csd2.x + csd2.y;
   csq += __shfl_xor(csq, 32, 64); csk += __shfl_xor(csk, 32, 64); csv += __shfl_xor(csv, 32, 64); csd += __shfl_xor(csd, 32, 64);
   float* red2 = Ds;                     // [64] fc1 bias gradient
   if (wc == 0 && h == 0) {
