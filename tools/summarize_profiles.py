@@ -15,7 +15,7 @@ rows = list(csv.DictReader(open(src)))
 with open(f"profiles/{rnd}_kernel_stats.md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats ({rnd})\n\n")
     f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 "
-            "--prof none --no-cpu-baseline`\n(7 steps of 65536 rows; hg38-1Mb, table front end, d=64, L=5; raw CSV next to this file)\n\n")
+            "--prof none --no-cpu-baseline`\n(65536 rows per step; calls = warm-up + timed steps of the end-to-end leg and of the model-step-only leg; hg38-1Mb, table front end, d=64, L=5; raw CSV next to this file)\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows[:26]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
@@ -71,3 +71,28 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pass
            "classes": out}, open(f"profiles/{rnd}_pmc_traffic.json", "w"), indent=1)
 for c, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"]):
     print(f"{c:14s} x{v['launches_per_step']:2d}  {v['hbm_bytes_per_launch']/1e6:9.1f} MB/launch")
+
+
+# ---- matrix-core utilisation (two more PMC passes, when collected) --------------------------------------------------
+if glob.glob(f"gpurun_out/{tag}_mfma1/*/*_counter_collection.csv"):
+    names1, names2 = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"]
+    res = collections.OrderedDict()
+    for d, names in (("mfma1", names1), ("mfma2", names2)):
+        for name in names:
+            vals = load(d, name)
+            ids = sorted(vals)
+            start = max(i for i in ids if "neg_sample" in vals[i][0])
+            for i in ids:
+                c = cls(vals[i][0])
+                if i >= start and c in ("fused_fwd", "fused_bwd", "front_fwd", "front_bwd"):
+                    res.setdefault(c, collections.OrderedDict())
+                    res[c][name] = res[c].get(name, 0.0) + vals[i][1]
+    for c, v in res.items():
+        v["MfmaUtil_percent"] = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 1)
+    json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --prof none "
+                          "--no-cpu-baseline  (second pass: --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES); tools/collect_profiles.sh",
+               "note": "sums over the launches of one step; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so MfmaUtil = 100 * MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs); "
+                       "SQ_VALU_MFMA_COEXEC_CYCLES counts cycles in which vector and matrix instructions execute together",
+               "kernels": res}, open(f"profiles/{rnd}_pmc_mfma.json", "w"), indent=1)
+    for c, v in res.items():
+        print(f"{c:10s} MfmaUtil {v['MfmaUtil_percent']} %  coexec {v.get('SQ_VALU_MFMA_COEXEC_CYCLES')}")
