@@ -83,7 +83,7 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
 
 //   MATCHA_DISABLE_QKV_SAVE  the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
-static bool save_qkv() { static const bool on = getenv("MATCHA_DISABLE_QKV_SAVE") == nullptr; return on; }
+static bool save_qkv() { return getenv("MATCHA_DISABLE_QKV_SAVE") == nullptr; }
 
 static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
   const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
@@ -134,7 +134,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
-  w.qkv = take(s.d == 64 && save_qkv() ? fused_qkv_floats(B, L) : 0);
+  w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever MATCHA_DISABLE_QKV_SAVE says: the layout must not depend on a switch read per call
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
   w.total = off;
   return off;

@@ -375,3 +375,43 @@ def test_fused_front_end_matches_separate_kernels(mode):
         a, b = g0[o:o + p.numel()], g1[o:o + p.numel()]
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+@pytest.mark.parametrize("ks", [[2, 3, 4, 5], [8, 3], [2]])
+def test_saved_tiles_backward_matches_recompute(mode, ks):
+    """d = 64 training step: the fused backward fed by the Q/K/V tiles and attention probabilities the training forward saved
+    against the same kernel recomputing them (MATCHA_DISABLE_QKV_SAVE): same weights, same dropout seed, same batch.  The
+    workspace keeps its size in both cases (the switch only changes which path runs), so one Trainer per case."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(31)
+    x = _mixed_batch(N, ks, 800, rng)
+    y = (torch.rand(len(x), device="cuda") < 0.3).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    res = []
+    for recompute in (True, False):
+        clf, _ = hip_model(num, 64, mode, 41)
+        clf.train(True)
+        tr = Trainer(clf, base_seed=8)
+        if recompute:
+            os.environ["MATCHA_DISABLE_QKV_SAVE"] = "1"
+        try:
+            logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MATCHA_DISABLE_QKV_SAVE", None)
+        res.append((logits.clone(), tr.gflat.clone()))
+    assert torch.equal(res[0][0], res[1][0])                 # the forward pass computes the same thing either way
+    g0, g1 = res[0][1], res[1][1]
+    assert float(g0.abs().max()) > 0
+    clf, _ = hip_model(num, 64, mode, 41)
+    rt = clf._runtime()
+    for n, p in clf.named_parameters():
+        o = (p.data_ptr() - rt.flat.data_ptr()) // 4
+        if n == GAUGE or o < 0 or o >= rt.n_flat:
+            continue
+        a, b = g0[o:o + p.numel()], g1[o:o + p.numel()]
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
