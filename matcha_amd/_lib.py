@@ -91,6 +91,8 @@ SIGNATURES = {
     "matcha_zscore_rows": (C.c_int, [_fp, _I64, _I64, _fp]),
 }
 
+ABI_VERSION = 3             # MATCHA_ABI_VERSION of include/matcha_hip.h
+
 _lib = None
 
 
@@ -112,7 +114,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.matcha_abi_version() != 3:
+    if lib.matcha_abi_version() != ABI_VERSION:
         raise MatchaHipError("libmatcha_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -35,6 +35,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.matcha_device_count() >= 0
 
 
+def test_graft_build_entry_point_runs():
+    """The driver's "does it build" check: __graft_entry__.build() (make is a no-op when the library is up to date) must
+    pass, including its ABI-version assertion against include/matcha_hip.h."""
+    import re
+    import __graft_entry__ as G
+    G.build()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "matcha_hip.h")).read()
+    assert int(re.search(r"#define MATCHA_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
+
+
 def test_ctypes_structs_match_header_field_order():
     src = open(os.path.join(ROOT, "include", "matcha_hip.h")).read()
     body = src[src.index("typedef struct matcha_tensors {"):src.index("} matcha_tensors;")]
