@@ -149,6 +149,10 @@ typedef struct matcha_step_opts {
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */
 size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L);
+/* Scratch (bytes) that is enough for matcha_forward with opts->forward_only = 1 (inference: predict(), the pairwise sweep,
+ * save_embeddings).  At embed_dim 64 only the ragged plan, two [tokens, d] buffers and the front end's buffers exist
+ * (~1 KB per token instead of ~27 KB); for other shapes it equals matcha_workspace_bytes. */
+size_t matcha_workspace_bytes_forward(const matcha_shape* shp, int64_t B, int32_t L);
 
 /* Classifier.forward(x, return_recon=True) (Modules.py:278-318) + the weighted BCE of main.py:56.
  *   x      int64 [B,L], 0 = padding

@@ -383,8 +383,9 @@ class _Runtime:
     def still_packed(self) -> bool:
         return all(p.data_ptr() == e for p, e in zip(self.live, self.expected_ptrs))
 
-    def workspace(self, B: int, L: int) -> torch.Tensor:
-        n = self.lib.matcha_workspace_bytes(C.byref(self.shape), B, L)
+    def workspace(self, B: int, L: int, forward_only: bool = False) -> torch.Tensor:
+        query = self.lib.matcha_workspace_bytes_forward if forward_only else self.lib.matcha_workspace_bytes
+        n = query(C.byref(self.shape), B, L)
         if n == 0:
             raise _lib.MatchaHipError(self.lib.matcha_last_error().decode())
         return torch.empty(n, dtype=torch.uint8, device=self.device)
@@ -399,7 +400,7 @@ class _ClassifierFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rt: _Runtime, opts: "_lib.StepOpts", seed_t, *live):
         B, L = x.shape
-        ws = rt.workspace(B, L)
+        ws = rt.workspace(B, L, forward_only=bool(opts.forward_only))      # inference: ~1 KB per token instead of ~27 KB
         logits = torch.empty(B, dtype=torch.float32, device=rt.device)
         losses = torch.zeros(3, dtype=torch.float32, device=rt.device)
         _lib.check(rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,

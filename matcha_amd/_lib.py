@@ -63,6 +63,7 @@ SIGNATURES = {
     "matcha_profile_select": (C.c_int, [_I32]),
     "matcha_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "matcha_workspace_bytes": (_SZ, [C.POINTER(Shape), _I64, _I32]),
+    "matcha_workspace_bytes_forward": (_SZ, [C.POINTER(Shape), _I64, _I32]),
     "matcha_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,
                                  _I32, _fp, _fp, _fp, _fp, _fp, _SZ, _fp]),
     "matcha_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,

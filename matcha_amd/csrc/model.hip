@@ -85,28 +85,31 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
 static bool save_qkv() { return getenv("MATCHA_DISABLE_QKV_SAVE") == nullptr; }
 
-static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w) {
+// `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
+// x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
+static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspace& w, bool compact = false) {
   const int64_t Tn = B * L + 1, d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;      // upper bound of token rows
   size_t off = 0;
-  auto take = [&](size_t n_floats) {
+  auto take_always = [&](size_t n_floats) {
     float* p = base ? (float*)(base + off) : nullptr;
     off += align_up(n_floats * sizeof(float), 256);
     return p;
   };
+  auto take = [&](size_t n_floats) { return compact ? (float*)nullptr : take_always(n_floats); };
   {
     const size_t rb = ragged_bytes(B, L);
     if (base) ragged_carve(B, L, base + off, w.rg);
     off += align_up(rb, 256);
   }
-  w.x0 = take(Tn * d); w.X = take(Tn * d);
+  w.x0 = take_always(Tn * d); w.X = take_always(Tn * d);
   w.qin = take(Tn * d); w.kin = take(Tn * d); w.vin = take(Tn * d);
   w.stats = take(Tn * 2);
   w.Q = take(Tn * hd); w.K = take(Tn * hd); w.V = take(Tn * hd);
   w.P = take(B * MATCHA_N_HEAD * L * L);
   w.O = take(Tn * hd);
   w.Y = take(Tn * d); w.H1 = take(Tn * d); w.H2 = take(Tn * d);
-  w.row_loss = take(B); w.logits = take(B);
-  w.node = take(s.mode == 1 ? Tn * d : 0);
+  w.row_loss = take_always(B); w.logits = take_always(B);
+  w.node = take_always(s.mode == 1 ? Tn * d : 0);
   w.dH2 = take(Tn * d); w.dXs = take(Tn * d); w.dZ1 = take(Tn * d); w.ddyn0 = take(Tn * d);
   w.dO = take(Tn * hd); w.dQ = take(Tn * hd); w.dK = take(Tn * hd); w.dV = take(Tn * hd);
   w.dqin = take(Tn * d); w.dkin = take(Tn * d); w.dvin = take(Tn * d);
@@ -130,8 +133,8 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   }
   w.gemm_ws_bytes = gb; w.gemm_ws = take(gb / sizeof(float));
   w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, Tn) : 0;
-  w.adj_ws = take(w.adj_ws_bytes / sizeof(float));
-  w.folded = take(s.d == 64 ? fused_fold_floats() : 0);
+  w.adj_ws = take_always(w.adj_ws_bytes / sizeof(float));
+  w.folded = take_always(s.d == 64 ? fused_fold_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
   w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever MATCHA_DISABLE_QKV_SAVE says: the layout must not depend on a switch read per call
@@ -227,6 +230,14 @@ extern "C" size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int
   return carve(*shp, B, L, nullptr, w);
 }
 
+// a forward with opts->forward_only set needs no more than this (equal to matcha_workspace_bytes when the shape has no fused path)
+static bool compact_forward(const matcha_shape& s, const matcha_step_opts& o) { return o.forward_only && fused_enabled(s); }
+extern "C" size_t matcha_workspace_bytes_forward(const matcha_shape* shp, int64_t B, int32_t L) {
+  if (check_shape(shp, B, L) != MATCHA_OK) return 0;
+  Workspace w;
+  return carve(*shp, B, L, nullptr, w, fused_enabled(*shp));
+}
+
 extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
                               const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, const float* y,
                               const float* w_bce, float* logits, float* losses, void* ws, size_t ws_bytes,
@@ -238,7 +249,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   const matcha_tensors& p = *params;
   hipStream_t st = (hipStream_t)stream;
   Workspace w;
-  const size_t need = carve(s, B, L, (char*)ws, w);
+  const size_t need = carve(s, B, L, (char*)ws, w, compact_forward(s, *opts));
   if (ws_bytes < need) { set_error("matcha_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
   const int64_t Tn = B * L + 1;                 // upper bound; the true count is *w.rg.count
   const int d = s.d;

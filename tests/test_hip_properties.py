@@ -282,8 +282,8 @@ def test_uninitialised_workspace_does_not_leak(d, mode):
     rt = clf._runtime()
     orig = rt.workspace
 
-    def poisoned(B, L):
-        ws = orig(B, L)
+    def poisoned(B, L, **kw):
+        ws = orig(B, L, **kw)
         ws.view(torch.int32).fill_(-1)                   # 0xFFFFFFFF: a NaN in every float slot
         return ws
     rt.workspace = poisoned
@@ -415,3 +415,46 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
         a, b = g0[o:o + p.numel()], g1[o:o + p.numel()]
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+def test_forward_only_workspace_is_compact_and_equivalent(mode):
+    """d = 64 inference: matcha_workspace_bytes_forward is a small fraction of the training workspace, and a forward run in it
+    gives bit-identical logits (and recon loss) to the same forward run in the full workspace."""
+    import ctypes as C
+    from matcha_amd import _lib
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, 64, mode, 19)
+    clf.eval()
+    rt = clf._runtime()
+    x = _mixed_batch(N, [2, 3, 4, 5], 2000, np.random.default_rng(6))
+    B, L = x.shape
+    full = rt.lib.matcha_workspace_bytes(C.byref(rt.shape), B, L)
+    small = rt.lib.matcha_workspace_bytes_forward(C.byref(rt.shape), B, L)
+    assert 0 < small < full / 8
+    np.random.seed(3)
+    with torch.no_grad():
+        lg, rc = clf(x, return_recon=True)                                     # compact workspace (Modules.py asks for it)
+    np.random.seed(3)
+    first_chrom = int(np.random.choice(np.arange(rt.n_chrom), 1)[0]) if mode == "adj" else 0   # what that call drew (Modules.py:192)
+    opts, _ = clf._opts(rt, True)
+    opts.random_chrom = first_chrom
+    opts.forward_only = 1
+    out = []
+    for nbytes in (small, full):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        ws.fill_(0xFF)                                                         # NaN patterns: nothing may be read before it is written
+        logits = torch.empty(B, device="cuda")
+        losses = torch.zeros(3, device="cuda")
+        _lib.check(rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L, None, None,
+                                         _lib.ptr(logits), _lib.ptr(losses), _lib.ptr(ws), nbytes, rt.stream()), "matcha_forward")
+        out.append((logits.clone(), losses.clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert bool(torch.isfinite(out[0][0]).all()) and torch.allclose(out[0][0], lg.view(-1), rtol=0, atol=1e-6)
+    # a forward that will be differentiated does not fit in the compact workspace: loud error, not a silent overrun
+    opts.forward_only = 0
+    ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+    rc_ = rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L, None, None,
+                                _lib.ptr(logits), _lib.ptr(losses), _lib.ptr(ws), small, rt.stream())
+    assert rc_ != 0 and b"workspace" in rt.lib.matcha_last_error()
