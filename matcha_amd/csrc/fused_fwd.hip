@@ -736,7 +736,8 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   { static const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
   const int ntiles = rg.ntiles;
-  const size_t lds = ((size_t)4 * kTileF + 272 + 3 * 512) * sizeof(float);
+  size_t lds = ((size_t)4 * kTileF + 272 + 3 * 512) * sizeof(float);
+  { const char* e = getenv("MATCHA_FWD_LDS_PAD"); if (e) lds += (size_t)atoi(e); }      // occupancy experiment: 1 workgroup per CU
   auto launch = [&](auto kfn) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);
