@@ -24,6 +24,8 @@ namespace matcha {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBM = 128, kBN = 64, kBK = 64, kLd = 68;   // kLd: padded LDS row stride (floats), 16-B aligned rows
+// K > 64 walks 32-deep chunks instead (BK = 32, row stride 36): 2 x A + 2 x B = 54 KiB, so two workgroups share a CU -- with
+// 64-deep double-buffered chunks (102 KiB) a CU held one workgroup = one wave per SIMD and every barrier and LDS latency showed
 
 int launch_gemm_rm_direct(bool b_kn, const GemmArgs& g, hipStream_t st);   // gemm_f32.hip (unaligned fallback)
 
@@ -37,9 +39,15 @@ struct StageRegs {
   float4 a[8];
   float4 b[4];
 };
+// B tile in LDS: NT: [n = 64][k = BK] (stride BK + 4);  NN (B_KN): [k = BK][n = 64] (stride 68)
 
-template <bool B_KN, int FLAGS>
+template <bool B_KN, int FLAGS, int BK>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_per_block) {
+  constexpr int LDK = BK + 4;                        // row stride of the k-major tiles (A, and B in NT mode)
+  constexpr int F4 = BK / 4;                         // float4 per k-row segment
+  constexpr int RPP = 256 / F4;                      // rows staged per pass (16 or 32)
+  constexpr int APASS = kBM / RPP, BPASS = kBN / RPP;
+  constexpr int B_SZ = B_KN ? BK * kLd : kBN * LDK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -51,12 +59,13 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
   const int64_t m0 = (int64_t)blockIdx.y * kBM;
   if (m0 >= M) return;
   const int64_t m_end = (m0 + kBM < M) ? m0 + kBM : M;
-  const int srow = tid >> 4, sc4 = (tid & 15) * 4;      // staging: thread -> (row within 16-row slab, float4 column)
-  const bool kmulti = K > kBK;
+  const int srow = tid / F4, sc4 = (tid % F4) * 4;      // staging of k-major tiles: thread -> (row within a slab, float4 column)
+  const int nrow = tid >> 4, nc4 = (tid & 15) * 4;      // staging of the [k][n] tile (NN): 16 k-rows per pass
+  const bool kmulti = K > BK;
   float* const As0 = lds;
-  float* const As1 = kmulti ? lds + kBM * kLd : lds;
-  float* const Bs0 = lds + (kmulti ? 2 : 1) * kBM * kLd;
-  float* const Bs1 = Bs0 + kBN * kLd;
+  float* const As1 = kmulti ? lds + kBM * LDK : lds;
+  float* const Bs0 = lds + (kmulti ? 2 : 1) * kBM * LDK;
+  float* const Bs1 = Bs0 + B_SZ;
 
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
@@ -66,17 +75,17 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
     keep_scale = 1.f / (1.f - g.p_drop);
   }
   const float* bias = g.bias[z];
-  const int nkc = (int)((K + kBK - 1) / kBK);
+  const int nkc = (int)((K + BK - 1) / BK);
   const int64_t tiles_n = (N + kBN - 1) / kBN;
   int n_nt = n_tiles_per_block;
   if ((int64_t)blockIdx.x * n_tiles_per_block + n_nt > tiles_n) n_nt = (int)(tiles_n - (int64_t)blockIdx.x * n_tiles_per_block);
   const int nsteps = n_nt * nkc;
 
   // A row pointers of this thread's 8 staging rows (constant over steps)
-  const float* arow_ptr[8];
+  const float* arow_ptr[APASS];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int64_t gm = m0 + srow + 16 * i; gm = gm < M ? gm : M - 1;
+  for (int i = 0; i < APASS; ++i) {
+    int64_t gm = m0 + srow + RPP * i; gm = gm < M ? gm : M - 1;
     if (g.a_row_map) gm = g.a_row_map[gm];
     arow_ptr[i] = A + gm * g.lda + sc4;
   }
@@ -104,12 +113,12 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
     // ---- global -> registers for step s -------------------------------------------------------------------
     auto gload = [&](int s, StageRegs& rg, bool with_a) {
       const int nt_i = s / nkc;
-      const int64_t kc = (int64_t)(s - nt_i * nkc) * kBK;
+      const int64_t kc = (int64_t)(s - nt_i * nkc) * BK;
       const int64_t n0 = ((int64_t)blockIdx.x * n_tiles_per_block + nt_i) * kBN;
-      const bool full_k = kc + kBK <= K;
+      const bool full_k = kc + BK <= K;
       if (with_a) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < APASS; ++i) {
           const float* src = arow_ptr[i] + kc;
           float4 v;
           if (full_k) v = *reinterpret_cast<const float4*>(src);
@@ -122,10 +131,10 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
           rg.a[i] = v;
         }
       }
-      if (!B_KN) {                                         // B[n][k]: 64 rows x 16 float4
+      if (!B_KN) {                                         // B[n][k]: 64 rows x F4 float4
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int64_t gn = n0 + srow + 16 * i; gn = gn < N ? gn : N - 1;
+        for (int i = 0; i < BPASS; ++i) {
+          int64_t gn = n0 + srow + RPP * i; gn = gn < N ? gn : N - 1;
           const float* src = B + gn * g.ldb + kc + sc4;
           float4 v;
           if (full_k) v = *reinterpret_cast<const float4*>(src);
@@ -136,20 +145,20 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
           }
           rg.b[i] = v;
         }
-      } else {                                             // B[k][n]: 64 k-rows x 16 float4 along n
+      } else {                                             // B[k][n]: BK k-rows x 16 float4 along n
         const bool full_n = n0 + kBN <= N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t gk = kc + srow + 16 * i;
+        for (int i = 0; i < BK / 16; ++i) {
+          const int64_t gk = kc + nrow + 16 * i;
           const int64_t gkc = gk < K ? gk : K - 1;
           float4 v;
-          if (full_n) v = *reinterpret_cast<const float4*>(B + gkc * g.ldb + n0 + sc4);
+          if (full_n) v = *reinterpret_cast<const float4*>(B + gkc * g.ldb + n0 + nc4);
           else {
             const float* src = B + gkc * g.ldb;
-            v.x = (n0 + sc4 + 0 < N) ? src[n0 + sc4 + 0] : 0.f;
-            v.y = (n0 + sc4 + 1 < N) ? src[n0 + sc4 + 1] : 0.f;
-            v.z = (n0 + sc4 + 2 < N) ? src[n0 + sc4 + 2] : 0.f;
-            v.w = (n0 + sc4 + 3 < N) ? src[n0 + sc4 + 3] : 0.f;
+            v.x = (n0 + nc4 + 0 < N) ? src[n0 + nc4 + 0] : 0.f;
+            v.y = (n0 + nc4 + 1 < N) ? src[n0 + nc4 + 1] : 0.f;
+            v.z = (n0 + nc4 + 2 < N) ? src[n0 + nc4 + 2] : 0.f;
+            v.w = (n0 + nc4 + 3 < N) ? src[n0 + nc4 + 3] : 0.f;
           }
           if (gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
           rg.b[i] = v;
@@ -159,10 +168,15 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
     auto lstore = [&](const StageRegs& rg, float* As, float* Bs, bool with_a) {
       if (with_a) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&As[(srow + 16 * i) * kLd + sc4]) = rg.a[i];
+        for (int i = 0; i < APASS; ++i) *reinterpret_cast<float4*>(&As[(srow + RPP * i) * LDK + sc4]) = rg.a[i];
       }
+      if (!B_KN) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[(srow + 16 * i) * kLd + sc4]) = rg.b[i];
+        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[(srow + RPP * i) * LDK + sc4]) = rg.b[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < BK / 16; ++i) *reinterpret_cast<float4*>(&Bs[(nrow + 16 * i) * kLd + nc4]) = rg.b[i];
+      }
     };
 
     StageRegs rg;
@@ -183,15 +197,15 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
       if (kci == 0) { acc0 = (f32x16){0}; acc1 = (f32x16){0}; }
       const float* As = (kmulti && buf) ? As1 : As0;
       const float* Bs = buf ? Bs1 : Bs0;
-      // ---- 32 rows x 64 columns x 64 deep per wave: 64 MFMAs ----
-      const float* arow = &As[(32 * wave + r) * kLd + 4 * h];
+      // ---- 32 rows x 64 columns x BK deep per wave: BK MFMAs ----
+      const float* arow = &As[(32 * wave + r) * LDK + 4 * h];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < BK / 8; ++c) {
         const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
         float4 b0, b1;
         if (!B_KN) {
-          b0 = *reinterpret_cast<const float4*>(&Bs[r * kLd + 8 * c + 4 * h]);
-          b1 = *reinterpret_cast<const float4*>(&Bs[(32 + r) * kLd + 8 * c + 4 * h]);
+          b0 = *reinterpret_cast<const float4*>(&Bs[r * LDK + 8 * c + 4 * h]);
+          b1 = *reinterpret_cast<const float4*>(&Bs[(32 + r) * LDK + 8 * c + 4 * h]);
         } else {
           const float* bp = &Bs[(8 * c + 4 * h) * kLd + r];
           b0 = make_float4(bp[0], bp[kLd], bp[2 * kLd], bp[3 * kLd]);
@@ -242,9 +256,11 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
   }
 }
 
-template <bool B_KN, int FLAGS>
-static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, size_t lds_bytes, hipStream_t st) {
-  auto kfn = gemm_lds_kernel<B_KN, FLAGS>;
+template <bool B_KN, int FLAGS, int BK>
+static void launch_bk(const GemmArgs& g, dim3 grid, int ntpb, hipStream_t st) {
+  auto kfn = gemm_lds_kernel<B_KN, FLAGS, BK>;
+  const size_t b_sz = B_KN ? (size_t)BK * kLd : (size_t)kBN * (BK + 4);
+  const size_t lds_bytes = ((size_t)(g.K > BK ? 2 : 1) * kBM * (BK + 4) + 2 * b_sz) * sizeof(float);
   if (lds_bytes > 64 * 1024) {
     static bool configured = false;      // per instantiation
     if (!configured) {
@@ -253,6 +269,11 @@ static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, size_t lds_bytes,
     }
   }
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds_bytes, st, g, ntpb);
+}
+template <bool B_KN, int FLAGS>
+static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, size_t, hipStream_t st) {
+  if (g.K > kBK) launch_bk<B_KN, FLAGS, 32>(g, grid, ntpb, st);      // several k chunks: 32 deep, two workgroups per CU
+  else launch_bk<B_KN, FLAGS, 64>(g, grid, ntpb, st);                // K <= 64: the activation tile stays resident
 }
 
 int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
