@@ -289,7 +289,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   }
   if (fused_enabled(s) && (opts->forward_only || fused_train_enabled(s))) {
     // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
-    // token) and the backward pass recomputes the attention block from X (fused_bwd.hip)
+    // token); every training forward also leaves its Q/K/V tiles and attention probabilities for the fused backward (w.qkv)
     const bool lif = loss_in_forward(s, *opts, y, w_bce);            // the tail's backward runs in this kernel: nothing saved
     const bool save = !opts->forward_only && !lif;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
