@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MATCHA_ABI_VERSION 3
+#define MATCHA_ABI_VERSION 4
 
 #define MATCHA_OK 0
 #define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
@@ -69,6 +69,29 @@ int matcha_device_count(void);
 #define MATCHA_PROF_FRONT_BWD 19   /* LayerNorm backward of the d x_hat partials + next_w / attribute_nn backward + scatter */
 int matcha_profile_select(int32_t kernel_class);
 int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
+
+/* A/B switches for tests and profiling.  Each option is read from the environment variable MATCHA_<NAME> (upper case) ONCE,
+ * when the library is loaded, and can be changed afterwards only through matcha_set_option -- no entry point reads the
+ * environment per call.  Names: "disable_fused" (layer-by-layer kernels at every embed_dim), "disable_fused_train" (fused
+ * kernels only for forwards that will not be differentiated), "disable_fused_front" (front end as separate kernels),
+ * "disable_loss_in_forward", "disable_qkv_save" (the fused backward recomputes Q/K/V instead of reloading saved tiles),
+ * "disable_sorted_scatter" (table gradient through float atomics instead of the sort + segmented sum), "debug_nan",
+ * "fused_dbg", "fwd_lds_pad".  Returns MATCHA_EINVAL for an unknown name; matcha_get_option returns -1 for one.
+ * Process-global: flip them only while no call is in flight. */
+int matcha_set_option(const char* name, int32_t value);
+int32_t matcha_get_option(const char* name);
+
+/* Device-side status word of the entry points that index memory by node id.  `status` is a caller-owned DEVICE int32[4],
+ * zeroed by the caller; kernels OR / add into it and the caller inspects it whenever it synchronises anyway (no entry point
+ * syncs).  Ids that would index out of bounds are replaced by 0 (the padding id) so that no kernel reads or writes outside
+ * its buffers; the reference raises IndexError there (nn.Embedding, Modules.py:34/:67).
+ *   status[0]  bit 0: a node id of x / ids was outside [0, n_nodes];  bit 1: the sampler met a node without a chromosome
+ *              (node2chrom < 0 or >= n_chrom) and kept it unchanged
+ *   status[1]  number of negatives whose 65 536 trials were exhausted (the row is returned equal to its positive; the
+ *              reference would loop forever, main.py:392)
+ *   status[2..3] reserved */
+#define MATCHA_STATUS_BAD_ID 1
+#define MATCHA_STATUS_BAD_CHROM 2
 
 /* ------------------------------------------------------------------------------------------
  * Model description: shapes + one pointer per LIVE tensor of the reference's
@@ -145,6 +168,10 @@ typedef struct matcha_step_opts {
                                 classifier tail for loss = alpha*bce (+ beta*recon) and keeps the result in the workspace;
                                 matcha_backward must then be called with the SAME opts and dlogits == NULL.  0: the
                                 backward pass starts from the saved activations (required for an arbitrary dlogits)   */
+  int32_t* status;           /* optional DEVICE int32[4] status word (see above); NULL = not reported                   */
+  int32_t sparse_table_grad; /* table mode, matcha_backward: 1 = do NOT add the table gradient into grads->table; leave it as
+                                (unique node ids, summed gradient rows) in the workspace for matcha_table_grad_rows (the
+                                row-sparse data-parallel exchange); 0 = dense grads->table as usual      */
 } matcha_step_opts;
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */
@@ -178,10 +205,44 @@ int matcha_backward(const matcha_shape* shp, const matcha_tensors* params, const
                     matcha_tensors* grads, int32_t* touched,
                     void* ws, size_t ws_bytes, matcha_stream_t stream);
 
-/* model.get_node_embeddings(x) (Modules.py:252-259), eval mode: rows float [T,d] for ids int64 [T]. */
+/* model.get_node_embeddings(x) (Modules.py:252-259), eval mode: rows float [T,d] for ids int64 [T].
+ * `status`: optional device status word (ids outside [0, n_nodes] are flagged and read as id 0). */
 int matcha_node_embeddings(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
                            const int64_t* ids, int64_t T, float* rows, void* ws, size_t ws_bytes,
-                           matcha_stream_t stream);
+                           int32_t* status, matcha_stream_t stream);
+
+/* Classifier.get_embedding(x) (Modules.py:261-276): the encoder's two outputs in the reference's padded layout,
+ *   dynamic float [B,L,d] = pff_n1(...) * non_pad_mask (Modules.py:614; zero rows at padding slots)
+ *   static  float [B,L,d] = tanh(next_w(node + attribute))  (:270; padding slots hold tanh(next_w(attribute_nn.bias)))
+ *   attn    float [B,8,L,L], optional (may be NULL): attention probabilities in the ragged form of matcha_attn_fwd -- row i of
+ *           hyperedge b and head h holds the probabilities of its k_b real keys in columns j < k_b and the probability of EACH
+ *           padding slot in column k_b (all L - k_b padding keys are equal); rows i >= k_b (padding queries) are not computed
+ * computed by the layer-by-layer kernels; opts as for matcha_forward (training = dropout with opts->seed).  `ws` needs
+ * matcha_workspace_bytes(shp, B, L) bytes.  Not differentiable through this entry point. */
+int matcha_get_embedding(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                         const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, float* dynamic,
+                         float* static_, float* attn, float* losses /* [3] as matcha_forward (bce unused), may be NULL */,
+                         void* ws, size_t ws_bytes, matcha_stream_t stream);
+
+/* Row-sparse view of the table gradient of the LAST matcha_backward on `ws` that ran with opts->sparse_table_grad = 1
+ * (table mode): one (node id, gradient row) pair per token of the batch, NOT yet summed per node (at 1 M nodes a batch holds
+ * few repeated ids, so the per-token list is what the data-parallel exchange ships; the receiver sums, matcha_scatter_rows).
+ * Pointers into `ws` (valid until the next call on it):
+ *   *ids      device int32 [cap]    node id of each list entry; 0 = unused entry (skip)
+ *   *rows     device float [cap,d]  gradient row of each entry (rows of unused entries hold garbage)
+ *   *n_tokens device int32 [1]      number of used entries (they are the first *n_tokens[0] ones); may be passed NULL
+ *   *cap      = B*L + 1 entries (the host-known bound a fixed-size all-gather is sized for). */
+int matcha_table_grad_rows(const matcha_shape* shp, int64_t B, int32_t L, void* ws, size_t ws_bytes,
+                           const int32_t** ids, const float** rows, const int32_t** n_tokens, int64_t* cap);
+
+/* Sum (ids, rows) lists into a dense gradient table deterministically: the n entries (ids int32 [n], 0 = unused entry;
+ * rows float [n,d]) -- e.g. the all-gathered lists of every rank, concatenated in rank order -- are stably sorted by id, the
+ * rows of equal ids are added in list order, and each sum is added to dtable[id] by ONE writer (plain stores, no atomics):
+ * bitwise reproducible.  Rows of ids that do not occur are not touched.  `ws`: matcha_scatter_rows_workspace_bytes bytes,
+ * 256-byte aligned.  This is also the embedding backward of matcha_backward in table mode (nn.Embedding, Modules.py:29-34). */
+size_t matcha_scatter_rows_workspace_bytes(int64_t n, int32_t d, int32_t n_nodes);
+int matcha_scatter_rows(const int32_t* ids, const float* rows, int64_t n, int32_t d, int32_t n_nodes, float* dtable,
+                        void* ws, size_t ws_bytes, matcha_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * torch.optim.AdamW(lr=1e-3) as main.py:630/:671 builds it, fused over one flat buffer.
@@ -211,12 +272,14 @@ int matcha_hashset_contains(const void* set, const int64_t* edges, int32_t L_set
                             int64_t n, int32_t L, int32_t* out, matcha_stream_t stream);
 /* generate_negative: for each positive row (int64 [P,L], zero-padded) emit `neg_num` corrupted copies into
  * neg int64 [P*neg_num, L] (row P*? layout: negatives of positive j at rows neg_num*j .. neg_num*j+neg_num-1,
- * main.py:383-428).  node2chrom int32 [N+1]; chrom_range int32 [C,2] = [start,end) ids; an EMPTY set
- * (n_set_edges == 0) reproduces the reference's phase-1 quirk: negatives == positives (main.py:589). */
+ * main.py:383-428).  node2chrom int32 [n_nodes+1]; chrom_range int32 [n_chrom,2] = [start,end) ids; an EMPTY set
+ * (n_set_edges == 0) reproduces the reference's phase-1 quirk: negatives == positives (main.py:589).
+ * `status` (optional device int32[4]): nodes outside [1, n_nodes] or without a chromosome are kept unchanged and flagged;
+ * status[1] counts the negatives whose trials were exhausted (returned equal to the positive). */
 int matcha_neg_sample(const void* set, const int64_t* set_edges, int64_t n_set_edges, int32_t L_set,
                       const int64_t* pos, int64_t P, int32_t L, int32_t neg_num, int32_t min_dis,
-                      const int32_t* node2chrom, const int32_t* chrom_range, const uint64_t* seed,
-                      int64_t* neg, matcha_stream_t stream);
+                      const int32_t* node2chrom, int32_t n_nodes, const int32_t* chrom_range, int32_t n_chrom,
+                      const uint64_t* seed, int64_t* neg, int32_t* status, matcha_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Op-level entry points (the kernels behind matcha_forward/backward, exposed so that each one is
@@ -253,6 +316,20 @@ size_t matcha_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int matcha_gemm(int32_t op, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K,
                 const matcha_gemm_epilogue* epi, float* colsum, const int64_t* b_row_gather,
                 void* ws, size_t ws_bytes, matcha_stream_t stream);
+
+/* The ragged execution plan of a batch (csrc/ragged.hip): the real slots (x != 0, get_non_pad_mask Modules.py:12-14) of the
+ * zero-padded x [B,L] (pad_sequence, main.py:435-437) compacted into a CSR token list + ONE shared padding token, and tiles of
+ * whole hyperedges (<= 63 tokens) for the fused kernels.  matcha_forward builds it inside its workspace; this entry point
+ * builds it alone so that it can be compared bit for bit with the C restatement oracle/c/ragged_plan.c.
+ *   view->row_off  int32 [B+1]; tok_slot, tok_key, tok_pos int32 [B*L+1]; tok_id int64 [B*L+1]; count int32 [3] = {Tr+1, Tr,
+ *   tiles}; tile_meta int32 [tiles_cap][4] = {first token, tokens, first hyperedge, hyperedges} -- device pointers into `ws`. */
+typedef struct matcha_ragged_view {
+  const int32_t* row_off; const int32_t* tok_slot; const int64_t* tok_id; const int32_t* tok_key; const int32_t* tok_pos;
+  const int32_t* count; const int32_t* tile_meta; int64_t tiles_cap;
+} matcha_ragged_view;
+size_t matcha_ragged_plan_bytes(int64_t B, int32_t L);
+int matcha_ragged_plan(const int64_t* x, int64_t B, int32_t L, int32_t n_nodes, int32_t* status, void* ws, size_t ws_bytes,
+                       matcha_ragged_view* view, matcha_stream_t stream);
 
 /* K1 + K6: x0[t] = rows[t] + attr_table[x[t]] . attr_w^T + attr_b, rows[t] = table[x[t]] (table != NULL) or
  * dense[t] (Modules.py:34, :263-269).  Backward: scatter-add into dtable (row 0 skipped, padding_idx=0). */

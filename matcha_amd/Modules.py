@@ -261,8 +261,11 @@ def _gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     ten = _lib.Tensors()
     ten.table = table.data_ptr()
     fro = _lib.Frozen()
+    status = torch.zeros(4, dtype=torch.int32, device=table.device)
     _lib.check(lib.matcha_node_embeddings(C.byref(shp), C.byref(ten), C.byref(fro), _lib.ptr(ids), ids.numel(), _lib.ptr(out),
-                                          None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "matcha_node_embeddings")
+                                          None, 0, _lib.ptr(status), C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)),
+               "matcha_node_embeddings")
+    _lib.raise_on_status(status.tolist(), "Wrap_Embedding.forward")
     return out.view(*ids.shape, d)
 
 
@@ -372,6 +375,21 @@ class _Runtime:
         self.params = self.tensors_for(self.flat)
         self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
         self.seed_counter = 0
+        self.status = torch.zeros(4, dtype=torch.int32, device=dev)       # device status word of the id-indexed kernels
+
+    def check_status(self, what: str):
+        """Read the device status word (ONE small device-to-host copy, i.e. a synchronisation), clear it and raise what the
+        reference raises for a node id outside the tables (IndexError from nn.Embedding, Modules.py:34/:67)."""
+        st = self.status.tolist()
+        if st[0]:
+            self.status.zero_()
+            _lib.raise_on_status(st, what)
+
+    def field_off_after(self, field: str) -> int:
+        """Element offset of the first ABI field behind ``field`` in the flat buffer (fields start on 16-byte boundaries)."""
+        offs = sorted(self.field_off.values())
+        i = offs.index(self.field_off[field])
+        return offs[i + 1] if i + 1 < len(offs) else self.n_flat
 
     def tensors_for(self, flat: torch.Tensor) -> "_lib.Tensors":
         t = _lib.Tensors()
@@ -403,6 +421,7 @@ class _ClassifierFn(torch.autograd.Function):
         ws = rt.workspace(B, L, forward_only=bool(opts.forward_only))      # inference: ~1 KB per token instead of ~27 KB
         logits = torch.empty(B, dtype=torch.float32, device=rt.device)
         losses = torch.zeros(3, dtype=torch.float32, device=rt.device)
+        opts.status = rt.status.data_ptr()
         _lib.check(rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                          None, None, _lib.ptr(logits), _lib.ptr(losses), _lib.ptr(ws), ws.numel(), rt.stream()),
                    "matcha_forward")
@@ -461,6 +480,15 @@ class Classifier(nn.Module):
         self.attribute_nn = nn.Linear(table.shape[-1], bottle_neck)
         self.attribute_dict = self.attribute_dict_embedding
 
+    # Node ids are validated on the device (ids outside [0, N] are flagged and read as the padding id, so no kernel indexes out
+    # of bounds); with check_ids the flag is read back after every call -- one 16-byte device-to-host copy -- and raised as the
+    # reference's IndexError.  Bulk callers that issue many forwards back to back (predict.py's sweeps) switch it off and call
+    # check_status() once at the end.  Class attribute, so that models pickled by the reference get it too.
+    check_ids = True
+
+    def check_status(self):
+        self._runtime().check_status("Classifier")
+
     # ---- runtime plumbing ---------------------------------------------------------------------------
     def __getstate__(self):
         st = self.__dict__.copy()
@@ -512,6 +540,8 @@ class Classifier(nn.Module):
             raise ValueError(f"hyperedges wider than {_lib.MAX_L} are not supported")
         opts, seed_t = self._opts(rt, return_recon)
         logits, recon = _ClassifierFn.apply(x, rt, opts, seed_t, *rt.live)
+        if self.check_ids and not torch.cuda.is_current_stream_capturing():
+            rt.check_status("Classifier.forward")          # IndexError for ids outside [0, N], like the reference's nn.Embedding
         return (logits, recon) if return_recon else logits
 
     def get_node_embeddings(self, x, return_recon=False):
@@ -528,14 +558,52 @@ class Classifier(nn.Module):
             np.random.choice(np.arange(rt.n_chrom), 1)      # keep numpy's global stream in step with Modules.py:192
             ws = rt.workspace(sz_b, len_seq)
         _lib.check(rt.lib.matcha_node_embeddings(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), _lib.ptr(ids), ids.numel(),
-                                                 _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), rt.stream()),
+                                                 _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.ptr(rt.status),
+                                                 rt.stream()),
                    "matcha_node_embeddings")
+        if self.check_ids and not torch.cuda.is_current_stream_capturing():
+            rt.check_status("Classifier.get_node_embeddings")
         out = out.view(sz_b, len_seq, -1)
         return (out, recon) if return_recon else out
 
     def get_embedding(self, x, slf_attn_mask=None, non_pad_mask=None, return_recon=False):
-        raise NotImplementedError("get_embedding's intermediates (dynamic, static, attn) stay on chip in the fused path; "
-                                  "use forward() / get_node_embeddings()")
+        """(dynamic, static, attn[, recon_loss]) of the encoder in the reference's padded layout (reference Modules.py:261-276):
+        dynamic [B,L,d] = encode1's pff_n1 output (zero at padding slots), static [B,L,d] = tanh(next_w(node + attribute)),
+        attn [8*B, L, L] head-major like the reference's (index h*B + b; key columns as they stand in x).  The two mask
+        arguments are accepted and ignored exactly as far as the reference ignores them: non_pad_mask is recomputed from x, the
+        key-pad mask never reaches the softmax (SURVEY.md headline fact 7).  Runs the layer-by-layer kernels (the fused path
+        keeps these tensors on chip); inference surface, not differentiable.  Rows of padding QUERIES in ``attn`` are zero
+        (the reference computes a softmax there that nothing reads)."""
+        rt = self._runtime()
+        x = torch.as_tensor(x).to(device=rt.device, dtype=torch.long).contiguous()
+        B, L = x.shape
+        opts, seed_t = self._opts(rt, return_recon)
+        opts.forward_only = 0
+        opts.status = rt.status.data_ptr()
+        ws = rt.workspace(B, L)
+        dyn = torch.empty(B, L, rt.d, dtype=torch.float32, device=rt.device)
+        sta = torch.empty_like(dyn)
+        praw = torch.zeros(B, _lib.N_HEAD, L, L, dtype=torch.float32, device=rt.device)
+        losses = torch.zeros(3, dtype=torch.float32, device=rt.device)
+        _lib.check(rt.lib.matcha_get_embedding(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
+                                               _lib.ptr(dyn), _lib.ptr(sta), _lib.ptr(praw), _lib.ptr(losses), _lib.ptr(ws), ws.numel(),
+                                               rt.stream()),
+                   "matcha_get_embedding")
+        if self.check_ids and not torch.cuda.is_current_stream_capturing():
+            rt.check_status("Classifier.get_embedding")
+        # ragged probabilities -> the reference's [8B, L, L]: key slot l of a real key reads its compact column, every padding
+        # slot reads the shared padding column k_b
+        real = x != 0
+        k = real.sum(1)
+        col = torch.where(real, torch.cumsum(real.long(), 1) - 1, k.unsqueeze(1))                 # [B, L] compact column of slot l
+        row = torch.where(real, torch.cumsum(real.long(), 1) - 1, torch.zeros_like(col))          # compact row of a real query slot
+        p = praw.gather(3, col.view(B, 1, 1, L).expand(B, _lib.N_HEAD, L, L))                     # columns in slot order
+        p = p.gather(2, row.view(B, 1, L, 1).expand(B, _lib.N_HEAD, L, L))                        # rows in slot order
+        p = p * real.view(B, 1, L, 1).to(p.dtype)
+        attn = p.permute(1, 0, 2, 3).reshape(_lib.N_HEAD * B, L, L)
+        if return_recon:
+            return dyn, sta, attn, losses[1:2]
+        return dyn, sta, attn
 
 
 class DataGenerator:

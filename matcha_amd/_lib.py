@@ -46,7 +46,13 @@ class Frozen(C.Structure):
 class StepOpts(C.Structure):
     _fields_ = [("training", C.c_int32), ("random_chrom", C.c_int32), ("p_drop_adj", C.c_float),
                 ("p_drop_fc1", C.c_float), ("p_drop_pff", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
-                ("seed", _fp), ("forward_only", C.c_int32), ("loss_in_forward", C.c_int32)]
+                ("seed", _fp), ("forward_only", C.c_int32), ("loss_in_forward", C.c_int32), ("status", _fp),
+                ("sparse_table_grad", C.c_int32)]
+
+
+class RaggedView(C.Structure):
+    _fields_ = [("row_off", _fp), ("tok_slot", _fp), ("tok_id", _fp), ("tok_key", _fp), ("tok_pos", _fp), ("count", _fp),
+                ("tile_meta", _fp), ("tiles_cap", C.c_int64)]
 
 
 class GemmEpilogue(C.Structure):
@@ -68,12 +74,22 @@ SIGNATURES = {
                                  _I32, _fp, _fp, _fp, _fp, _fp, _SZ, _fp]),
     "matcha_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,
                                   _I32, _fp, _fp, _fp, _fp, C.POINTER(Tensors), _fp, _fp, _SZ, _fp]),
-    "matcha_node_embeddings": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), _fp, _I64, _fp, _fp, _SZ, _fp]),
+    "matcha_node_embeddings": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), _fp, _I64, _fp, _fp, _SZ, _fp, _fp]),
+    "matcha_get_embedding": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64, _I32,
+                                       _fp, _fp, _fp, _fp, _fp, _SZ, _fp]),
+    "matcha_table_grad_rows": (C.c_int, [C.POINTER(Shape), _I64, _I32, _fp, _SZ, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "matcha_scatter_rows_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
+    "matcha_scatter_rows": (C.c_int, [_fp, _fp, _I64, _I32, _I32, _fp, _fp, _SZ, _fp]),
+    "matcha_ragged_plan_bytes": (_SZ, [_I64, _I32]),
+    "matcha_ragged_plan": (C.c_int, [_fp, _I64, _I32, _I32, _fp, _fp, _SZ, C.POINTER(RaggedView), _fp]),
+    "matcha_set_option": (C.c_int, [C.c_char_p, _I32]),
+    "matcha_get_option": (C.c_int32, [C.c_char_p]),
     "matcha_adamw_step": (C.c_int, [_fp, _fp, _fp, _fp, _I64, _fp, _I32, _fp, _fp, _fp, _fp, _D, _D, _D, _D, _D, _D, _fp]),
     "matcha_hashset_bytes": (_SZ, [_I64]),
     "matcha_hashset_build": (C.c_int, [_fp, _SZ, _fp, _I64, _I32, _fp]),
     "matcha_hashset_contains": (C.c_int, [_fp, _fp, _I32, _fp, _I64, _I32, _fp, _fp]),
-    "matcha_neg_sample": (C.c_int, [_fp, _fp, _I64, _I32, _fp, _I64, _I32, _I32, _I32, _fp, _fp, _fp, _fp, _fp]),
+    "matcha_neg_sample": (C.c_int, [_fp, _fp, _I64, _I32, _fp, _I64, _I32, _I32, _I32, _fp, _I32, _fp, _I32, _fp, _fp, _fp, _fp]),
     "matcha_gemm_tn_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "matcha_gemm": (C.c_int, [_I32, _fp, _fp, _fp, _I64, _I64, _I64, C.POINTER(GemmEpilogue), _fp, _fp, _fp, _SZ, _fp]),
     "matcha_embed_fwd": (C.c_int, [_fp, _I64, _I32, _fp, _fp, _fp, _I32, _fp, _fp, _fp, _fp]),
@@ -92,7 +108,7 @@ SIGNATURES = {
     "matcha_zscore_rows": (C.c_int, [_fp, _I64, _I64, _fp]),
 }
 
-ABI_VERSION = 3             # MATCHA_ABI_VERSION of include/matcha_hip.h
+ABI_VERSION = 4             # MATCHA_ABI_VERSION of include/matcha_hip.h
 
 _lib = None
 
@@ -130,3 +146,36 @@ def check(rc: int, what: str = ""):
 def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+STATUS_BAD_ID, STATUS_BAD_CHROM = 1, 2      # bits of status[0] (include/matcha_hip.h)
+
+
+def set_option(name: str, value: int = 1) -> int:
+    """Flip one of the library's process-wide A/B switches (matcha_set_option); returns the previous value."""
+    lib = load()
+    old = lib.matcha_get_option(name.encode())
+    check(lib.matcha_set_option(name.encode(), int(value)), "matcha_set_option")
+    return old
+
+
+class option:
+    """``with _lib.option("disable_fused"): ...`` -- switch on for the block, restore afterwards (tests)."""
+
+    def __init__(self, name: str, value: int = 1):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *a):
+        set_option(self.name, self.old)
+
+
+def raise_on_status(status_host, what: str):
+    """Translate a status word read back from the device (list of 4 ints) into the exception the reference raises."""
+    if status_host[0] & STATUS_BAD_ID:
+        raise IndexError(f"{what}: node id outside [0, n_nodes] (the reference's nn.Embedding raises 'index out of range in self')")
+    if status_host[0] & STATUS_BAD_CHROM:
+        raise KeyError(f"{what}: a node without a chromosome (node2chrom < 0) reached the negative sampler")

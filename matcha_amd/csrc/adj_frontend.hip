@@ -65,7 +65,7 @@ size_t adj_workspace_bytes(const matcha_shape& s, int64_t T) {
 }
 
 __device__ __forceinline__ int chrom_of(int64_t id, const int32_t* __restrict__ bounds, int C) {
-  if (id == 0) return C;                          // padding bucket
+  if (id <= 0 || id > bounds[C]) return C;        // padding bucket; ids outside [1, N] land there too (flagged by the caller's status word), so nothing indexes out of bounds
   int c = 0;
   while (c + 1 < C && id > bounds[c + 1]) ++c;   // ids of chromosome c: bounds[c]+1 .. bounds[c+1]
   return c;

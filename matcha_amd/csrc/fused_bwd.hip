@@ -863,7 +863,7 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
     g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
     g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.qkv = qkv;
-    { const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
+    g.dbg = options().fused_dbg;
     const size_t lds = ((size_t)9 * kTile + 64 + 192 + 3 * 64 + 2 * 512) * sizeof(float);
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

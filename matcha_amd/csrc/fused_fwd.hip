@@ -734,10 +734,10 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
   g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
-  { static const char* e = getenv("MATCHA_FUSED_DBG"); g.dbg = e ? atoi(e) : 0; }
+  g.dbg = options().fused_dbg;
   const int ntiles = rg.ntiles;
   size_t lds = ((size_t)4 * kTileF + 272 + 3 * 512) * sizeof(float);
-  { const char* e = getenv("MATCHA_FWD_LDS_PAD"); if (e) lds += (size_t)atoi(e); }      // occupancy experiment: 1 workgroup per CU
+  lds += (size_t)options().fwd_lds_pad;      // occupancy experiment: 1 workgroup per CU
   auto launch = [&](auto kfn) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, dim3(ntiles), dim3(256), lds, st, g);

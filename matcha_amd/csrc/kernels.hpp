@@ -41,6 +41,7 @@ struct Ragged {
   int nblk;
   int ntiles;          // capacity of tile_meta (upper bound of the tile count; the count itself is count[2])
   int32_t* tok_pos;    // [T+1] position of the token inside its hyperedge | k << 8
+  int32_t* tok_key;    // [T+1] node id as int32, 0 in unused slots (table-gradient list)
   int32_t* tile_meta;  // [ntiles + 2][4] {first token t0, number of tokens, first hyperedge b0, number of hyperedges}; zeros past the end
   int32_t* sb_tiles;   // planning scratch: per-superblock tile lists
   int32_t* sb_cnt;
@@ -50,7 +51,7 @@ struct Ragged {
 size_t ragged_bytes(int64_t B, int L);
 int ragged_tiles_cap(int64_t B, int L);
 void ragged_carve(int64_t B, int L, char* base, Ragged& r);
-int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st);
+int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st);
 
 struct HeadParams {
   const float *gp, *bp, *g1, *b1, *g2, *b2, *wc, *bc;
@@ -69,7 +70,21 @@ int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, 
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev = nullptr);
 int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st, const int32_t* t_dev = nullptr);
-int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, float* rows, hipStream_t st);
+int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, int64_t n_nodes, float* rows, int32_t* status, hipStream_t st);
+int launch_check_ids(const int64_t* ids, int64_t T, int64_t n_nodes, int32_t* status, hipStream_t st);
+int launch_expand_embedding(const int64_t* x, int64_t B, int L, int d, const int32_t* row_off, const float* H2, const float* X, const float* gp,
+                            const float* bp, float* dynamic, float* static_, hipStream_t st);
+
+// table_grad.hip: deterministic embedding backward -- stable sort of (id, row) pairs by id + one writer per table row
+size_t table_grad_ws_bytes(int64_t n, int n_nodes);
+int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, int n_nodes, float* dtable, void* ws, size_t ws_bytes, hipStream_t st);
+
+// process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
+struct Options {
+  int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save, disable_sorted_scatter;
+  int debug_nan, fused_dbg, fwd_lds_pad;
+};
+Options& options();
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
 int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const float* bq, const float* gk, const float* bk,
                    const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st,

@@ -67,23 +67,49 @@ struct Workspace {
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
   float* qkv;                             // training forward -> fused backward: Q, K, V tiles of every (tile, head), 384 KB per tile
   float* front_ws;                        // fused front-end backward: workgroup slabs
+  void* tg_ws;      size_t tg_ws_bytes;   // table mode: sort scratch of the deterministic table gradient (table_grad.hip)
   size_t total;
 };
 
-// A/B switches for tests and profiling (read on every call so a test can flip them):
-//   MATCHA_DISABLE_FUSED        layer-by-layer kernels everywhere
-//   MATCHA_DISABLE_FUSED_TRAIN  fused kernel only for no-grad forwards; training runs layer by layer
-//   MATCHA_DISABLE_FUSED_FRONT  front-end backward (LayerNorm / next_w / attribute_nn / scatter) as separate kernels
-static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && getenv("MATCHA_DISABLE_FUSED") == nullptr; }
-static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && getenv("MATCHA_DISABLE_FUSED_TRAIN") == nullptr; }
-//   MATCHA_DISABLE_LOSS_IN_FORWARD  the tail's backward as separate kernels even when opts->loss_in_forward is set
-static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
-  return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && getenv("MATCHA_DISABLE_LOSS_IN_FORWARD") == nullptr;
-}
-
-//   MATCHA_DISABLE_QKV_SAVE  the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
+// A/B switches for tests and profiling (include/matcha_hip.h, matcha_set_option): ONE process-wide struct whose initial values
+// come from the environment (MATCHA_DISABLE_FUSED, ...) when it is first touched; no entry point calls getenv per call.
+//   disable_fused            layer-by-layer kernels everywhere
+//   disable_fused_train      fused kernel only for no-grad forwards; training runs layer by layer
+//   disable_fused_front      front end (gather + attribute_nn + next_w; its backward) as separate kernels
+//   disable_loss_in_forward  the tail's backward as separate kernels even when opts->loss_in_forward is set
+//   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
-static bool save_qkv() { return getenv("MATCHA_DISABLE_QKV_SAVE") == nullptr; }
+//   disable_sorted_scatter   table gradient through float atomics instead of table_grad.hip's sort + segmented sum
+struct OptionName { const char* name; int Options::*field; };
+static const OptionName kOptionNames[] = {
+    {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
+    {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
+    {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_sorted_scatter", &Options::disable_sorted_scatter},
+    {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
+Options& options() {
+  static Options o = [] {
+    Options v;
+    memset(&v, 0, sizeof(v));
+    for (const OptionName& n : kOptionNames) {
+      char env[64] = "MATCHA_";
+      size_t k = strlen(env);
+      for (const char* c = n.name; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+      env[k] = 0;
+      const char* e = getenv(env);
+      if (e) v.*(n.field) = (*e == 0) ? 1 : atoi(e);       // "MATCHA_X=" (set, empty) counts as on, like the old getenv != NULL test
+      if (e && v.*(n.field) == 0 && strcmp(e, "0") != 0) v.*(n.field) = 1;
+    }
+    return v;
+  }();
+  return o;
+}
+static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && !options().disable_fused; }
+static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && !options().disable_fused_train; }
+static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
+  return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && !options().disable_loss_in_forward;
+}
+static bool save_qkv() { return !options().disable_qkv_save; }
+static bool sorted_scatter() { return !options().disable_sorted_scatter; }
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
 // x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
@@ -139,8 +165,19 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
   w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever MATCHA_DISABLE_QKV_SAVE says: the layout must not depend on a switch read per call
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
+  w.tg_ws_bytes = (s.mode == 0 && !compact) ? table_grad_ws_bytes(Tn, s.n_nodes) : 0;
+  w.tg_ws = take(w.tg_ws_bytes / sizeof(float));
   w.total = off;
   return off;
+}
+
+// Table mode, after the backward pass left one gradient row per compact token in w.dX0 (ids in w.rg.tok_key): add them into the
+// dense table gradient deterministically (table_grad.hip) -- unless the caller asked for the row-sparse form
+// (opts.sparse_table_grad: the list stays in the workspace for matcha_table_grad_rows / the data-parallel exchange).
+static int table_gradient(const matcha_shape& s, const matcha_step_opts& o, const Workspace& w, int64_t Tn, matcha_tensors& g, hipStream_t st) {
+  if (o.sparse_table_grad) return MATCHA_OK;
+  if (!sorted_scatter()) return MATCHA_OK;                // the front-end kernel already added the rows with float atomics
+  return launch_table_grad(w.rg.tok_key, w.dX0, Tn, s.d, s.n_nodes, g.table, w.tg_ws, w.tg_ws_bytes, st);
 }
 
 static int check_shape(const matcha_shape* s, int64_t B, int32_t L) {
@@ -150,6 +187,11 @@ static int check_shape(const matcha_shape* s, int64_t B, int32_t L) {
   MATCHA_CHECK_ARG(s->d % 4 == 0, "d must be a multiple of 4");
   MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L, "L=%d outside 1..%d", L, MATCHA_MAX_L);
   MATCHA_CHECK_ARG(B >= 1 && B * (int64_t)L < (1ll << 31) - 2, "B=%lld must be >= 1 and B*L < 2^31", (long long)B);
+  // the layer-by-layer kernels (every embed_dim but 64) put token tiles on grid.y (<= 65 535 tiles of 128 tokens) and launch
+  // T * d / 256 workgroups on grid.x: 8.38 M token rows is what they support
+  MATCHA_CHECK_ARG(s->d == 64 || B * (int64_t)L + 1 <= 65535ll * 128, "B*L=%lld exceeds the %lld token rows the layer-by-layer kernels (embed_dim != 64) launch",
+                   (long long)(B * (int64_t)L), 65535ll * 128);
+  MATCHA_CHECK_ARG(s->n_nodes >= 1, "n_nodes=%d must be >= 1", s->n_nodes);
   MATCHA_CHECK_ARG(s->mode == 0 || s->mode == 1, "mode=%d must be 0 (table) or 1 (adj)", s->mode);
   MATCHA_CHECK_ARG(s->n_attr >= 1 && (size_t)s->n_attr * s->d * 4 <= 160 * 1024, "n_attr=%d does not fit the LDS staging", s->n_attr);
   return MATCHA_OK;
@@ -176,8 +218,7 @@ __global__ void nan_count_kernel(const float* __restrict__ p, const int32_t* __r
   if (bad) atomicAdd(out, bad);
 }
 static void nan_check(const char* name, const float* p, const int32_t* rows_dev, int64_t rows, int64_t width, hipStream_t st) {
-  static const bool on = getenv("MATCHA_DEBUG_NAN") != nullptr;
-  if (!on || !p) return;
+  if (!options().debug_nan || !p) return;
   int* d = nullptr;
   int h = 0;
   if (hipMalloc(&d, sizeof(int)) != hipSuccess) return;
@@ -238,10 +279,12 @@ extern "C" size_t matcha_workspace_bytes_forward(const matcha_shape* shp, int64_
   return carve(*shp, B, L, nullptr, w, fused_enabled(*shp));
 }
 
-extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
-                              const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, const float* y,
-                              const float* w_bce, float* logits, float* losses, void* ws, size_t ws_bytes,
-                              matcha_stream_t stream) {
+// force_layerwise: run the separate kernels whatever the shape (matcha_get_embedding needs H2 and X in HBM);
+// stop_before_head: return after pff_n1 (no logits, no loss)
+static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                        const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, const float* y,
+                        const float* w_bce, float* logits, float* losses, void* ws, size_t ws_bytes,
+                        matcha_stream_t stream, bool force_layerwise, bool stop_before_head) {
   MATCHA_TRY(check_shape(shp, B, L));
   MATCHA_CHECK_ARG(params && frozen && opts && x && ws, "matcha_forward: null pointer");
   MATCHA_CHECK_ARG(((uintptr_t)ws) % 256 == 0, "matcha_forward: workspace must be 256-byte aligned");
@@ -249,7 +292,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   const matcha_tensors& p = *params;
   hipStream_t st = (hipStream_t)stream;
   Workspace w;
-  const size_t need = carve(s, B, L, (char*)ws, w, compact_forward(s, *opts));
+  const size_t need = carve(s, B, L, (char*)ws, w, !force_layerwise && compact_forward(s, *opts));
   if (ws_bytes < need) { set_error("matcha_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
   const int64_t Tn = B * L + 1;                 // upper bound; the true count is *w.rg.count
   const int d = s.d;
@@ -265,10 +308,10 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   const int64_t* ids = w.rg.tok_id;
 
   // CSR plan: real tokens + one shared padding token
-  MATCHA_TRY(launch_ragged_plan(x, B, L, w.rg, st));
+  MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
-  const bool front = fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && getenv("MATCHA_DISABLE_FUSED_FRONT") == nullptr;
+  const bool front = !force_layerwise && fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
     if (recon_out && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
@@ -287,7 +330,7 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
-  if (fused_enabled(s) && (opts->forward_only || fused_train_enabled(s))) {
+  if (!force_layerwise && fused_enabled(s) && (opts->forward_only || fused_train_enabled(s))) {
     // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
     // token); every training forward also leaves its Q/K/V tiles and attention probabilities for the fused backward (w.qkv)
     const bool lif = loss_in_forward(s, *opts, y, w_bce);            // the tail's backward runs in this kernel: nothing saved
@@ -341,12 +384,66 @@ extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* par
   nan_check("Y", w.Y, cnt, 0, d, st);
   nan_check("H1", w.H1, cnt, 0, d, st);
   nan_check("H2", w.H2, cnt, 0, d, st);
+  if (stop_before_head) return MATCHA_OK;
   // LayerNorms, (dynamic-static)^2, Conv1d(d->1), masked mean, weighted BCE   (Modules.py:373-374, :290-311; main.py:56)
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   MATCHA_TRY(launch_head_fwd(w.rg.row_off, w.H2, w.X, B, L, d, hp, y, w_bce, w.logits, w.row_loss, losses, st));
   if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
     set_error("logits copy failed"); return MATCHA_EHIP;
   }
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                              const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, const float* y,
+                              const float* w_bce, float* logits, float* losses, void* ws, size_t ws_bytes,
+                              matcha_stream_t stream) {
+  return forward_impl(shp, params, frozen, opts, x, B, L, y, w_bce, logits, losses, ws, ws_bytes, stream, false, false);
+}
+
+extern "C" int matcha_get_embedding(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
+                                    const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L, float* dynamic,
+                                    float* static_, float* attn, float* losses, void* ws, size_t ws_bytes, matcha_stream_t stream) {
+  MATCHA_CHECK_ARG(dynamic && static_ && opts, "matcha_get_embedding: null pointer");
+  matcha_step_opts o = *opts;
+  o.forward_only = 0;                  // full workspace layout: the layer-by-layer path keeps H2 and X in HBM
+  o.loss_in_forward = 0;
+  MATCHA_TRY(forward_impl(shp, params, frozen, &o, x, B, L, nullptr, nullptr, nullptr, losses, ws, ws_bytes, stream, true, true));
+  Workspace w;
+  carve(*shp, B, L, (char*)ws, w);
+  if (attn && hipMemcpyAsync(attn, w.P, (size_t)B * MATCHA_N_HEAD * L * L * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_error("matcha_get_embedding: attention copy failed"); return MATCHA_EHIP;
+  }
+  return launch_expand_embedding(x, B, L, shp->d, w.rg.row_off, w.H2, w.X, params->pff_ln_g, params->pff_ln_b, dynamic, static_, (hipStream_t)stream);
+}
+
+extern "C" int matcha_set_option(const char* name, int32_t value) {
+  MATCHA_CHECK_ARG(name, "matcha_set_option: null name");
+  for (const OptionName& n : kOptionNames)
+    if (strcmp(n.name, name) == 0) { options().*(n.field) = value; return MATCHA_OK; }
+  set_error("matcha_set_option: unknown option '%s'", name);
+  return MATCHA_EINVAL;
+}
+
+extern "C" int32_t matcha_get_option(const char* name) {
+  if (!name) return -1;
+  for (const OptionName& n : kOptionNames)
+    if (strcmp(n.name, name) == 0) return options().*(n.field);
+  return -1;
+}
+
+extern "C" int matcha_table_grad_rows(const matcha_shape* shp, int64_t B, int32_t L, void* ws, size_t ws_bytes,
+                                      const int32_t** ids, const float** rows, const int32_t** n_tokens, int64_t* cap) {
+  MATCHA_TRY(check_shape(shp, B, L));
+  MATCHA_CHECK_ARG(ws && ids && rows && cap, "matcha_table_grad_rows: null pointer");
+  MATCHA_CHECK_ARG(shp->mode == 0, "matcha_table_grad_rows: table mode only");
+  Workspace w;
+  const size_t need = carve(*shp, B, L, (char*)ws, w);
+  if (ws_bytes < need) { set_error("matcha_table_grad_rows: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
+  *ids = w.rg.tok_key;
+  *rows = w.dX0;
+  if (n_tokens) *n_tokens = w.rg.count + 1;
+  *cap = B * (int64_t)L + 1;
   return MATCHA_OK;
 }
 
@@ -402,14 +499,16 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   if (fused_train_enabled(s)) {
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
-    const bool front = front_bwd_supported(s.d, s.n_attr) && getenv("MATCHA_DISABLE_FUSED_FRONT") == nullptr;
+    const bool front = front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
     MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, save_qkv() ? w.qkv : nullptr));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
+      const bool rows_out = s.mode == 1 || sorted_scatter() || opts->sparse_table_grad;     // dX0 rows instead of float atomics
       MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
-                                  s.mode == 0 ? nullptr : w.dX0, s.mode == 0 ? g_.table : nullptr, w.front_ws, g_, st));
+                                  rows_out ? w.dX0 : nullptr, rows_out ? nullptr : g_.table, w.front_ws, g_, st));
       if (s.mode == 0) {
+        MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));
         if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
       } else {
         MATCHA_TRY(adj_backward(s, p, *frozen, *opts, ids, Tn, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st,
@@ -452,7 +551,8 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   // node embedding
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
-    MATCHA_TRY(launch_embed_scatter(ids, Tn, d, w.dX0, g_.table, st, cnt));
+    if (sorted_scatter() || opts->sparse_table_grad) MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));
+    else MATCHA_TRY(launch_embed_scatter(ids, Tn, d, w.dX0, g_.table, st, cnt));
     if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
   } else {
     MATCHA_TRY(adj_backward(s, p, *frozen, *opts, ids, Tn, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st,
@@ -463,14 +563,16 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
 
 extern "C" int matcha_node_embeddings(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
                                       const int64_t* ids, int64_t T, float* rows, void* ws, size_t ws_bytes,
-                                      matcha_stream_t stream) {
+                                      int32_t* status, matcha_stream_t stream) {
   MATCHA_CHECK_ARG(shp && params && frozen && ids && rows, "matcha_node_embeddings: null pointer");
+  MATCHA_CHECK_ARG(shp->d >= 4 && shp->d <= 256 && shp->d % 4 == 0, "matcha_node_embeddings: d=%d", shp->d);
   hipStream_t st = (hipStream_t)stream;
   if (shp->mode == 0) {
     // Wrap_Embedding: plain row gather (Modules.py:33-34)
     MATCHA_CHECK_ARG(params->table, "matcha_node_embeddings: null table");
-    return launch_gather_rows(ids, T, shp->d, params->table, rows, st);
+    return launch_gather_rows(ids, T, shp->d, params->table, shp->n_nodes, rows, status, st);
   }
+  MATCHA_TRY(launch_check_ids(ids, T, shp->n_nodes, status, st));      // out-of-range ids land in the padding bucket (chrom_of)
   matcha_step_opts o;
   memset(&o, 0, sizeof(o));
   o.random_chrom = -1;   // no reconstruction branch

@@ -10,7 +10,10 @@
 //   row_off [B+1]   first compact token of hyperedge b (exclusive prefix sum of k_b); row_off[B] = Tr
 //   tok_slot [T+1]  compact token -> original slot b*L + l (dropout counters follow the original slots, so masks are
 //                   the ones the oracle generates for the padded layout); tok_slot[Tr] = B*L
-//   tok_id [T+1]    node id of the compact token; tok_id[Tr] = 0 (padding id)
+//   tok_id [T+1]    node id of the compact token; tok_id[Tr] = 0 (padding id).  Ids outside [0, n_nodes] are flagged in the
+//                   caller's status word and replaced by 0, so that no later kernel indexes out of bounds
+//   tok_key [T+1]   the same ids as int32 with 0 in every unused slot (the (id, gradient row) list of table_grad.hip and of
+//                   the row-sparse data-parallel exchange)
 //   count [3]       {Tr + 1, Tr, number of tiles}  -- device-side counts consumed by every kernel through m_dev / t_dev
 //   tok_pos [T+1]   position of the compact token inside its hyperedge | k << 8 (fused kernels: token -> hyperedge rows)
 //   tile_meta       tiles of whole hyperedges (<= 63 tokens) for the fused d = 64 kernels
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(int32_t* __restrict__ bl
 __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict__ x, int64_t B, int L, const int32_t* __restrict__ blk_base,
                                                        const int32_t* __restrict__ count, int32_t* __restrict__ row_off,
                                                        int32_t* __restrict__ tok_slot, int64_t* __restrict__ tok_id,
-                                                       int32_t* __restrict__ tok_pos, int32_t* __restrict__ sb_first, int super_tok) {
+                                                       int32_t* __restrict__ tok_pos, int32_t* __restrict__ sb_first, int super_tok,
+                                                       int32_t* __restrict__ tok_key, int64_t n_nodes, int32_t* __restrict__ status) {
   __shared__ int lds4[4];
   const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * 4;
   int cnt = 0;
@@ -99,8 +103,14 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
     kprev = k;
     int nth = 0;
     for (int l = 0; l < L; ++l) {
-      const int64_t id = x[b * L + l];
-      if (id != 0) { tok_slot[pos] = (int32_t)(b * L + l); tok_id[pos] = id; tok_pos[pos] = nth | (k << 8); ++pos; ++nth; }
+      int64_t id = x[b * L + l];
+      if (id != 0) {
+        if (id < 0 || id > n_nodes) {                  // the reference raises IndexError here (nn.Embedding, Modules.py:34)
+          if (status) atomicOr(status, MATCHA_STATUS_BAD_ID);
+          id = 0;
+        }
+        tok_slot[pos] = (int32_t)(b * L + l); tok_id[pos] = id; tok_key[pos] = (int32_t)id; tok_pos[pos] = nth | (k << 8); ++pos; ++nth;
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -208,6 +218,7 @@ size_t ragged_bytes(int64_t B, int L) {
   n += 256;                                        // count
   n += align_up((size_t)cdiv(B, kRowsPerBlock) * 4, 256);
   n += align_up((size_t)(T + 1) * 4, 256);        // tok_pos
+  n += align_up((size_t)(T + 1) * 4, 256);        // tok_key
   n += align_up((size_t)(tiles_cap(T, L) + 2) * 16, 256);                    // tile_meta
   n += align_up((size_t)super_blocks(T) * super_cap(L) * 16, 256);           // sb_tiles
   n += align_up((size_t)super_blocks(T) * 4, 256);                           // sb_cnt
@@ -227,6 +238,7 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.nblk = (int)cdiv(B, kRowsPerBlock);
   r.ntiles = tiles_cap(T, L);
   r.tok_pos = (int32_t*)take((size_t)(T + 1) * 4);
+  r.tok_key = (int32_t*)take((size_t)(T + 1) * 4);
   r.tile_meta = (int32_t*)take((size_t)(r.ntiles + 2) * 16);
   r.nsb = super_blocks(T);
   r.sb_cap = super_cap(L);
@@ -235,12 +247,14 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.sb_first = (int32_t*)take((size_t)(r.nsb + 1) * 4);
 }
 
-int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipStream_t st) {
+int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st) {
+  if (hipMemsetAsync(r.tok_key, 0, (size_t)(B * L + 1) * 4, st) != hipSuccess) { set_error("ragged plan: memset failed"); return MATCHA_EHIP; }
   hipLaunchKernelGGL(row_count_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum);
   MATCHA_CHECK_LAUNCH("row_count_kernel");
   hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, r.blk_sum, r.nblk, r.count, r.sb_first, r.nsb, (int32_t)B);
   MATCHA_CHECK_LAUNCH("row_scan_kernel");
-  hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos, r.sb_first, kSuperTok);
+  hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos, r.sb_first, kSuperTok,
+                     r.tok_key, n_nodes, status);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
   hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_first, r.sb_tiles, r.sb_cnt);
   MATCHA_CHECK_LAUNCH("tile_pack_kernel");
@@ -250,3 +264,24 @@ int launch_ragged_plan(const int64_t* x, int64_t B, int L, const Ragged& r, hipS
 }
 
 }  // namespace matcha
+
+using namespace matcha;
+
+extern "C" size_t matcha_ragged_plan_bytes(int64_t B, int32_t L) {
+  if (B < 1 || L < 1 || L > MATCHA_MAX_L || B * (int64_t)L >= (1ll << 31) - 2) return 0;
+  return ragged_bytes(B, L);
+}
+
+extern "C" int matcha_ragged_plan(const int64_t* x, int64_t B, int32_t L, int32_t n_nodes, int32_t* status, void* ws, size_t ws_bytes,
+                                  matcha_ragged_view* view, matcha_stream_t stream) {
+  MATCHA_CHECK_ARG(x && ws && view, "matcha_ragged_plan: null pointer");
+  MATCHA_CHECK_ARG(B >= 1 && L >= 1 && L <= MATCHA_MAX_L && B * (int64_t)L < (1ll << 31) - 2, "matcha_ragged_plan: B=%lld L=%d", (long long)B, L);
+  MATCHA_CHECK_ARG(n_nodes >= 1, "matcha_ragged_plan: n_nodes=%d", n_nodes);
+  MATCHA_CHECK_ARG(((uintptr_t)ws) % 256 == 0, "matcha_ragged_plan: workspace must be 256-byte aligned");
+  if (ws_bytes < ragged_bytes(B, L)) { set_error("matcha_ragged_plan: workspace %zu < %zu bytes", ws_bytes, ragged_bytes(B, L)); return MATCHA_ENOMEM; }
+  Ragged r;
+  ragged_carve(B, L, (char*)ws, r);
+  view->row_off = r.row_off; view->tok_slot = r.tok_slot; view->tok_id = r.tok_id; view->tok_key = r.tok_key; view->tok_pos = r.tok_pos;
+  view->count = r.count; view->tile_meta = r.tile_meta; view->tiles_cap = r.ntiles;
+  return launch_ragged_plan(x, B, L, n_nodes, status, r, (hipStream_t)stream);
+}

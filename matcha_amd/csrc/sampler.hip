@@ -84,9 +84,9 @@ __global__ void hashset_contains_kernel(const int32_t* __restrict__ set, const i
 // one thread per negative
 __global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restrict__ set, const int64_t* __restrict__ set_edges,
                                                          int64_t n_set, int L_set, const int64_t* __restrict__ pos, int64_t P,
-                                                         int L, int neg_num, int min_dis, const int32_t* __restrict__ node2chrom,
-                                                         const int32_t* __restrict__ chrom_range, const uint64_t* __restrict__ seed,
-                                                         int64_t* __restrict__ neg) {
+                                                         int L, int neg_num, int min_dis, const int32_t* __restrict__ node2chrom, int n_nodes,
+                                                         const int32_t* __restrict__ chrom_range, int n_chrom,
+                                                         const uint64_t* __restrict__ seed, int64_t* __restrict__ neg, int32_t* __restrict__ status) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P * neg_num) return;
   const int64_t j = n / neg_num;
@@ -111,10 +111,16 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restri
       for (int i = 0; i < MATCHA_MAX_L; ++i) {
         cand[i] = orig[i];
         if (i < k && ((mask >> i) & 1u)) {
-          const int c = node2chrom[orig[i]];
-          const int64_t start = chrom_range[2 * c], end = chrom_range[2 * c + 1];
-          const uint32_t r = rng_u32(key, (uint32_t)n, (uint32_t)(8 * trial + i));
-          cand[i] = start + (int64_t)(((uint64_t)r * (uint64_t)(end - start)) >> 32);
+          // a node outside [1, n_nodes] or without a chromosome (node2chrom = -1, the default fill of train.run) cannot be
+          // redrawn: it is kept and the call is flagged (the reference raises KeyError / IndexError at main.py:401-403)
+          const int c = (orig[i] >= 1 && orig[i] <= n_nodes) ? node2chrom[orig[i]] : -1;
+          if (c >= 0 && c < n_chrom) {
+            const int64_t start = chrom_range[2 * c], end = chrom_range[2 * c + 1];
+            const uint32_t r = rng_u32(key, (uint32_t)n, (uint32_t)(8 * trial + i));
+            cand[i] = start + (int64_t)(((uint64_t)r * (uint64_t)(end - start)) >> 32);
+          } else if (status && trial == 0) {
+            atomicOr(status, MATCHA_STATUS_BAD_CHROM);
+          }
         }
       }
       // sort ascending (k <= 8), then reject duplicates / close neighbours / known hyperedges (main.py:410-421, :392)
@@ -134,6 +140,9 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restri
       }
       if (ok && !set_contains(set, set_edges, L_set, cand, L)) done = true;
     }
+    // trials exhausted (tiny chromosome, large min_dis, dense known set): the row is returned equal to its positive and counted;
+    // the reference would loop forever (main.py:392)
+    if (!done && status) atomicAdd(status + 1, 1);
   }
   for (int i = 0; i < L; ++i) out[i] = done ? cand[i] : orig[i];
 }
@@ -182,16 +191,17 @@ extern "C" int matcha_hashset_contains(const void* set, const int64_t* edges, in
 
 extern "C" int matcha_neg_sample(const void* set, const int64_t* set_edges, int64_t n_set_edges, int32_t L_set,
                                  const int64_t* pos, int64_t P, int32_t L, int32_t neg_num, int32_t min_dis,
-                                 const int32_t* node2chrom, const int32_t* chrom_range, const uint64_t* seed, int64_t* neg,
-                                 matcha_stream_t stream) {
+                                 const int32_t* node2chrom, int32_t n_nodes, const int32_t* chrom_range, int32_t n_chrom,
+                                 const uint64_t* seed, int64_t* neg, int32_t* status, matcha_stream_t stream) {
   MATCHA_CHECK_ARG(pos && neg && node2chrom && chrom_range && seed, "matcha_neg_sample: null pointer");
+  MATCHA_CHECK_ARG(n_nodes >= 1 && n_chrom >= 1, "matcha_neg_sample: n_nodes=%d n_chrom=%d", n_nodes, n_chrom);
   MATCHA_CHECK_ARG(n_set_edges == 0 || (set && set_edges), "matcha_neg_sample: non-empty set without buffers");
   MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L && neg_num >= 1, "matcha_neg_sample: L=%d neg_num=%d", L, neg_num);
   if (P <= 0) return MATCHA_OK;
   ProfScope ps(MATCHA_PROF_NEG_SAMPLE, (double)P * L * 8.0 * (1.0 + neg_num), (hipStream_t)stream);
   hipLaunchKernelGGL(neg_sample_kernel, dim3((unsigned)cdiv(P * neg_num, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const int32_t*)set, set_edges, n_set_edges, L_set > 0 ? L_set : L, pos, P, L, neg_num, min_dis, node2chrom,
-                     chrom_range, seed, neg);
+                     (const int32_t*)set, set_edges, n_set_edges, L_set > 0 ? L_set : L, pos, P, L, neg_num, min_dis, node2chrom, n_nodes,
+                     chrom_range, n_chrom, seed, neg, status);
   MATCHA_CHECK_LAUNCH("neg_sample_kernel");
   return MATCHA_OK;
 }

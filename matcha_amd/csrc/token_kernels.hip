@@ -213,15 +213,84 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 }
 
 // K1 alone: rows[t] = table[ids[t]]   (Wrap_Embedding.forward, Modules.py:33-34; save_embeddings main.py:471)
+// A 16-lane group gathers TWO rows per trip (both rows' loads are issued before the first store: twice the bytes in
+// flight per wave) and writes them with non-temporal stores -- the output is read by somebody else much later, and plain
+// stores made the write-back compete with the table rows for L2 (tools/ubench/gather_variants.hip: 33.5 -> 37.6 % of the
+// HBM-read roof on a 4 GB table, 39.1 -> 42.7 % on a 256 MB one).  A materialising gather moves as many bytes out as in,
+// so it is bound by the ~6.3 TB/s read+write copy ceiling, i.e. ~39 % of the 8 TB/s read roof.
+// Ids outside [0, n_nodes] are flagged in `status` and read as row 0 (the reference raises IndexError, Modules.py:34).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int NCH>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ ids, int64_t T, int d,
-                                                          const float* __restrict__ table, float* __restrict__ rows) {
+                                                          const float* __restrict__ table, int64_t n_nodes, float* __restrict__ rows,
+                                                          int32_t* __restrict__ status) {
   const int s = threadIdx.x & 15;
-  const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (t >= T) return;
-  Row e;
-  load_row<NCH>(table + ids[t] * d, s, d, e);
-  store_row<NCH>(rows + t * d, s, d, e);
+  const int64_t t0 = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 4)) * 2;
+  if (t0 >= T) return;
+  const bool two = t0 + 1 < T;
+  int64_t id0 = ids[t0], id1 = two ? ids[t0 + 1] : 0;
+  if (id0 < 0 || id0 > n_nodes || id1 < 0 || id1 > n_nodes) {
+    if (status) atomicOr(status, MATCHA_STATUS_BAD_ID);
+    if (id0 < 0 || id0 > n_nodes) id0 = 0;
+    if (id1 < 0 || id1 > n_nodes) id1 = 0;
+  }
+  Row e0, e1;
+  load_row<NCH>(table + id0 * d, s, d, e0);
+  load_row<NCH>(table + id1 * d, s, d, e1);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = 4 * s + 64 * c;
+    if (j < d) {
+      const f32x4_t v0 = {e0.v[c].x, e0.v[c].y, e0.v[c].z, e0.v[c].w};
+      __builtin_nontemporal_store(v0, reinterpret_cast<f32x4_t*>(rows + t0 * d + j));
+      if (two) {
+        const f32x4_t v1 = {e1.v[c].x, e1.v[c].y, e1.v[c].z, e1.v[c].w};
+        __builtin_nontemporal_store(v1, reinterpret_cast<f32x4_t*>(rows + (t0 + 1) * d + j));
+      }
+    }
+  }
+}
+
+// flag ids outside [0, n_nodes] (entry points that hand raw ids to kernels which bucket them instead of indexing a table)
+__global__ __launch_bounds__(256) void check_ids_kernel(const int64_t* __restrict__ ids, int64_t T, int64_t n_nodes, int32_t* __restrict__ status) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < T) {
+    const int64_t id = ids[t];
+    if (id < 0 || id > n_nodes) atomicOr(status, MATCHA_STATUS_BAD_ID);
+  }
+}
+
+// Classifier.get_embedding's outputs in the reference's padded [B, L, d] layout (Modules.py:261-276, :611-617) from the ragged
+// activations: dynamic[b,l] = LayerNorm_pff(H2[t]) for a real slot (token t), 0 for a padding slot (the * non_pad_mask of :614);
+// static[b,l] = X[t], or the shared padding token's X for a padding slot.  16 lanes per slot.
+template <int NCH>
+__global__ __launch_bounds__(256) void expand_embedding_kernel(const int64_t* __restrict__ x, int64_t B, int L, int d,
+                                                               const int32_t* __restrict__ row_off, const float* __restrict__ H2,
+                                                               const float* __restrict__ X, const float* __restrict__ gp,
+                                                               const float* __restrict__ bp, float* __restrict__ dynamic,
+                                                               float* __restrict__ static_) {
+  const int s = threadIdx.x & 15;
+  const int64_t slot = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (slot >= B * L) return;
+  const int64_t b = slot / L;
+  const int l = (int)(slot - b * L);
+  int nth = 0;
+  for (int i = 0; i < l; ++i) nth += x[b * L + i] != 0 ? 1 : 0;
+  const bool real = x[slot] != 0;
+  const int64_t t = real ? (int64_t)row_off[b] + nth : (int64_t)row_off[B];      // row_off[B] = the shared padding token
+  Row xs, h, hh, u;
+  load_row<NCH>(X + t * d, s, d, xs);
+  store_row<NCH>(static_ + slot * d, s, d, xs);
+  if (real) {
+    Row G, Bb;
+    load_row<NCH>(gp, s, d, G); load_row<NCH>(bp, s, d, Bb);
+    float m, r;
+    load_row<NCH>(H2 + t * d, s, d, h);
+    row_stats<NCH>(h, s, d, m, r); normalize<NCH>(h, s, d, m, r, hh); affine<NCH>(hh, G, Bb, u);
+  } else {
+    zero_row<NCH>(u);
+  }
+  store_row<NCH>(dynamic + slot * d, s, d, u);
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
@@ -532,13 +601,30 @@ int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, con
   return MATCHA_OK;
 }
 
-int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, float* rows, hipStream_t st) {
+int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, int64_t n_nodes, float* rows, int32_t* status, hipStream_t st) {
   if (T <= 0) return MATCHA_OK;
-  dim3 grid((unsigned)cdiv(T, 16));
-  // gather read bytes = 4d + 8 per row (+ 4d written because the rows are materialised here)
-  ProfScope ps(MATCHA_PROF_GATHER_ROWS, (double)T * (8.0 + 8.0 * d), st);
-  DISPATCH_NCH(d, hipLaunchKernelGGL((gather_rows_kernel<NCH>), grid, dim3(256), 0, st, ids, T, d, table, rows));
+  dim3 grid((unsigned)cdiv(T, 32));
+  // ALGORITHMIC gather read bytes = 4d + 8 per row (the rows are also written, 4d more, because this entry
+  // point materialises them; bench.py reports the read fraction and the read + write total separately)
+  ProfScope ps(MATCHA_PROF_GATHER_ROWS, (double)T * (8.0 + 4.0 * d), st);
+  DISPATCH_NCH(d, hipLaunchKernelGGL((gather_rows_kernel<NCH>), grid, dim3(256), 0, st, ids, T, d, table, n_nodes, rows, status));
   MATCHA_CHECK_LAUNCH("gather_rows_kernel");
+  return MATCHA_OK;
+}
+
+int launch_check_ids(const int64_t* ids, int64_t T, int64_t n_nodes, int32_t* status, hipStream_t st) {
+  if (T <= 0 || !status) return MATCHA_OK;
+  hipLaunchKernelGGL(check_ids_kernel, dim3((unsigned)cdiv(T, 256)), dim3(256), 0, st, ids, T, n_nodes, status);
+  MATCHA_CHECK_LAUNCH("check_ids_kernel");
+  return MATCHA_OK;
+}
+
+int launch_expand_embedding(const int64_t* x, int64_t B, int L, int d, const int32_t* row_off, const float* H2, const float* X, const float* gp,
+                            const float* bp, float* dynamic, float* static_, hipStream_t st) {
+  if (B <= 0) return MATCHA_OK;
+  dim3 grid((unsigned)cdiv(B * L, 16));
+  DISPATCH_NCH(d, hipLaunchKernelGGL((expand_embedding_kernel<NCH>), grid, dim3(256), 0, st, x, B, L, d, row_off, H2, X, gp, bp, dynamic, static_));
+  MATCHA_CHECK_LAUNCH("expand_embedding_kernel");
   return MATCHA_OK;
 }
 

@@ -21,12 +21,18 @@ import torch
 
 from . import _lib
 from .Modules import Classifier, _Runtime
-from .parallel import allreduce_bucket, broadcast_parameters, recon_grad_weight
+from .parallel import allreduce_bucket, broadcast_parameters, exchange_table_rows, recon_grad_weight, sparse_exchange_pays
 
 
 class Trainer:
     def __init__(self, model: Classifier, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, process_group=None, base_seed: int = 0):
+                 weight_decay: float = 1e-2, process_group=None, base_seed: int = 0, table_exchange: str = "auto"):
+        """``table_exchange`` (data parallel, table front end): "dense" = the table gradient rides in the flat all-reduce bucket,
+        "sparse" = all-gather of per-token (id, row) lists + a deterministic local sum, "auto" = whichever
+        moves fewer bytes for the batch shape (parallel.sparse_exchange_pays)."""
+        if table_exchange not in ("auto", "dense", "sparse"):
+            raise ValueError("table_exchange must be 'auto', 'dense' or 'sparse'")
+        self.table_exchange = table_exchange
         self.model = model
         self.rt: _Runtime = model._runtime()
         rt = self.rt
@@ -46,15 +52,24 @@ class Trainer:
         self.seg_coef = torch.zeros(3 * n_seg, dtype=torch.float32, device=dev)
         self.touched = torch.zeros(rt.n_touched, dtype=torch.int32, device=dev)
         self.losses = torch.zeros(3, dtype=torch.float32, device=dev)     # bce, recon, rows of the recon mean
-        self.seed = torch.full((1,), int(base_seed), dtype=torch.int64, device=dev)
         self._ws = {}
         self._logits = {}
+        self._xws = {}
         self.pg = process_group
         self.world = 1
+        rank = 0
         self.force_collectives = False      # bench.py sets it under a 1-rank torchrun launch to exercise the RCCL path
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            rank = torch.distributed.get_rank(process_group)
             broadcast_parameters(rt.flat, 0, process_group)      # every rank starts from rank 0's weights
+        # dropout masks are a function of (seed, row slot): ranks must not share a seed or every rank would drop the same
+        # units of its own rows (rank folded in here so that callers cannot forget it)
+        self.seed = torch.full((1,), (int(base_seed) + 0x9E3779B97F4A7C15 * rank) & 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=dev)
+        # table front end: the table is the FIRST field of the flat buffer; with the row-sparse exchange the all-reduce bucket
+        # starts behind it
+        self._n_table = (rt.field_off_after("table") if rt.mode == 0 else 0)
+        self._sparse = False
 
     # ---- buffers ------------------------------------------------------------------------------------
     def _buffers(self, B: int, L: int):
@@ -72,7 +87,23 @@ class Trainer:
         o.random_chrom = int(random_chrom)
         o.seed = self.seed.data_ptr()
         o.loss_in_forward = 1            # the loss is alpha*bce + beta*recon here: the tail's backward runs inside the forward kernel
+        o.status = self.rt.status.data_ptr()
+        o.sparse_table_grad = 1 if self._sparse else 0
         return o
+
+    def _use_sparse(self, B: int, L: int) -> bool:
+        rt = self.rt
+        if rt.mode != 0 or not (self.world > 1 or self.force_collectives):
+            return False
+        if self.table_exchange != "auto":
+            return self.table_exchange == "sparse"
+        return sparse_exchange_pays(rt.n_nodes, rt.d, B * L + 1, self.world)
+
+    def check_status(self):
+        """Synchronising check of the device status word: raises IndexError if a node id outside [0, N] reached a step since
+        the last check (the kernels read such ids as the padding id; the reference's nn.Embedding raises at once).  Call it
+        where the loop synchronises anyway (end of an epoch: train.train_epoch does)."""
+        self.rt.check_status("Trainer.step")
 
     # ---- one step -------------------------------------------------------------------------------------
     def forward_backward(self, x, y, w, alpha=1.0, beta=0.001, random_chrom: int = 0):
@@ -82,6 +113,8 @@ class Trainer:
             raise _lib.MatchaHipError("model parameters moved after the Trainer was built; create a new Trainer")
         B, L = x.shape
         ws, logits = self._buffers(B, L)
+        self._sparse = self._use_sparse(B, L)
+        self._last_shape = (B, L)
         opts = self._opts(alpha, beta, random_chrom)
         st = rt.stream()
         self.seed.add_(1)                                   # new dropout masks every step (graph-replay safe)
@@ -98,9 +131,33 @@ class Trainer:
         return logits
 
     def all_reduce(self):
-        """One RCCL all-reduce per step over [gradients | touched flags] (matcha_amd/parallel.py::allreduce_bucket)."""
-        if self.world > 1 or self.force_collectives:
-            allreduce_bucket(self.gbuf, self.rt.n_flat, self.touched, self.pg, force=self.force_collectives)
+        """One RCCL all-reduce per step over [gradients | touched flags] (matcha_amd/parallel.py::allreduce_bucket).  With the
+        row-sparse table exchange the bucket starts BEHIND the table gradient, and the table's (id, row) lists are all-gathered
+        and summed locally in a fixed order instead (matcha_scatter_rows): every rank ends with the same dense table gradient."""
+        if not (self.world > 1 or self.force_collectives):
+            return
+        rt = self.rt
+        if not self._sparse:
+            allreduce_bucket(self.gbuf, rt.n_flat, self.touched, self.pg, force=self.force_collectives)
+            return
+        allreduce_bucket(self.gbuf[self._n_table:], rt.n_flat - self._n_table, self.touched, self.pg, force=self.force_collectives)
+        B, L = self._last_shape
+        ws = self._ws[(B, L)]
+        p_ids, p_rows, p_n, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.matcha_table_grad_rows(C.byref(rt.shape), B, L, _lib.ptr(ws), ws.numel(), C.byref(p_ids), C.byref(p_rows),
+                                                   C.byref(p_n), C.byref(cap)), "matcha_table_grad_rows")
+        cap, d, base = int(cap.value), rt.d, ws.data_ptr()
+        ids = ws[p_ids.value - base:p_ids.value - base + 4 * cap].view(torch.int32)
+        rows = ws[p_rows.value - base:p_rows.value - base + 4 * cap * d].view(torch.float32).view(cap, d)
+        ids_all, rows_all = exchange_table_rows(ids, rows, self.pg)
+        n = ids_all.numel()
+        key = (n, d)
+        if key not in self._xws:
+            self._xws[key] = torch.empty(self.lib.matcha_scatter_rows_workspace_bytes(n, d, rt.n_nodes), dtype=torch.uint8, device=rt.device)
+        xws = self._xws[key]
+        self._keep = (ids_all, rows_all)               # alive until the kernels that read them have run
+        _lib.check(self.lib.matcha_scatter_rows(_lib.ptr(ids_all), _lib.ptr(rows_all), n, d, rt.n_nodes, _lib.ptr(self.gflat), _lib.ptr(xws),
+                                                xws.numel(), rt.stream()), "matcha_scatter_rows")
 
     def optimizer_step(self):
         rt = self.rt
@@ -125,6 +182,12 @@ class Trainer:
         Refill ``x``, ``y``, ``w`` in place between replays."""
         if self.world > 1:
             raise RuntimeError("capture() covers the single-GPU step; with DP the all-reduce sits between two graphs")
+        if self.rt.mode == 1 and beta != 0.0:
+            # random_chrom is a launch-shape parameter of the reconstruction branch (its bounds are read on the host), so a graph
+            # would replay ONE chromosome forever and only recon[r] would ever train; the reference draws a new one per
+            # forward (Modules.py:192)
+            raise RuntimeError("capture() would freeze random_chrom (adj front end with beta != 0): replay the step eagerly, "
+                               "or capture with beta = 0.  alpha and beta are baked into a captured graph as well.")
         x = x.contiguous()
         y = y.reshape(-1).contiguous()
         w = w.reshape(-1).contiguous()

@@ -59,6 +59,30 @@ def allreduce_bucket(gbuf: torch.Tensor, n_flat: int, touched: torch.Tensor, gro
     return 1.0 / world
 
 
+def sparse_exchange_pays(n_nodes: int, d: int, cap: int, world: int) -> bool:
+    """Row-sparse exchange of the table gradient or dense all-reduce?  Bytes a rank receives: the
+    all-gather of (id, row) lists is (world - 1) * cap * (d + 1) * 4; a ring all-reduce of the dense [N + 1, d] gradient moves
+    2 * (world - 1) / world * (N + 1) * d * 4.  hg38 1 Mb (N = 3067) stays dense (1.4 MB against 0.6 GB of lists at 65 536
+    rows per rank); BASELINE config 5 (1 M nodes, d = 256) goes sparse (0.94 GB of lists at 16 384 x 8 slots per rank on 8
+    ranks against 1.8 GB)."""
+    if world <= 1:
+        return False
+    return (world - 1) * cap * (d + 1) < 2 * (world - 1) / world * (n_nodes + 1) * d
+
+
+def exchange_table_rows(ids: torch.Tensor, rows: torch.Tensor, group=None):
+    """All-gather every rank's (node id, gradient row) list: ids int32 [cap] (0 = unused entry), rows float [cap, d] ->
+    (ids_all [world * cap], rows_all [world * cap, d]) in rank order on every rank.  Fixed-size lists, so no host
+    synchronisation is needed to size the collective; xGMI is point-to-point, and an all-gather sends each list once to each
+    peer (one hop), where a ring all-reduce of the dense table would forward 2 (world - 1) / world table copies."""
+    world = dist.get_world_size(group)
+    ids_all = ids.new_empty(world * ids.numel())
+    rows_all = rows.new_empty((world * rows.shape[0], rows.shape[1]))
+    dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=group)
+    dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=group)
+    return ids_all, rows_all
+
+
 def recon_grad_weight(m_local: torch.Tensor, beta: float, group=None) -> torch.Tensor:
     """Upstream gradient of the reconstruction loss for THIS rank so that the averaged gradient equals the single-rank
     one on the global batch.  The reference's recon loss is a mean over the m "other" tokens of the

@@ -52,6 +52,11 @@ class NegativeSampler:
         self.node2chrom = torch.as_tensor(np.asarray(node2chrom, dtype=np.int32), device=dev)
         self.chrom_range = torch.as_tensor(np.asarray(chrom_range, dtype=np.int32), device=dev).contiguous()
         self.seed = torch.full((1,), int(seed), dtype=torch.int64, device=dev)
+        self.n_nodes = int(self.node2chrom.numel()) - 1
+        self.n_chrom = int(self.chrom_range.shape[0])
+        # device status word (include/matcha_hip.h): [0] bit 1 = a node without a chromosome was met, [1] = negatives whose
+        # trials were exhausted (returned equal to their positive); read it with check_status() at a point that syncs anyway
+        self.status = torch.zeros(4, dtype=torch.int32, device=dev)
 
     def sample_into(self, pos: torch.Tensor, neg_out: torch.Tensor):
         """pos int64 [P,L] -> neg_out int64 [P*neg_num, L]; negatives of positive j at rows neg_num*j ... (main.py:383-428).
@@ -61,9 +66,18 @@ class NegativeSampler:
         st = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
         self.seed.add_(1)
         _lib.check(lib.matcha_neg_sample(_lib.ptr(self.hset.table), _lib.ptr(self.hset.edges), self.hset.n, self.hset.L, _lib.ptr(pos), P, L,
-                                         self.neg_num, self.min_dis, _lib.ptr(self.node2chrom), _lib.ptr(self.chrom_range),
-                                         _lib.ptr(self.seed), _lib.ptr(neg_out), st), "matcha_neg_sample")
+                                         self.neg_num, self.min_dis, _lib.ptr(self.node2chrom), self.n_nodes, _lib.ptr(self.chrom_range),
+                                         self.n_chrom, _lib.ptr(self.seed), _lib.ptr(neg_out), _lib.ptr(self.status), st), "matcha_neg_sample")
         return neg_out
+
+    def check_status(self) -> int:
+        """Synchronising read of the status word: raises KeyError if a node without a chromosome reached the sampler (the
+        reference's ``chrom_range[node2chrom[node]]`` raises there, main.py:401-403); returns the number of negatives whose
+        65 536 redraws were exhausted since the last call (the reference would still be looping, main.py:392)."""
+        st = self.status.tolist()
+        self.status.zero_()
+        _lib.raise_on_status(st, "NegativeSampler")
+        return int(st[1])
 
     def sample(self, pos: torch.Tensor) -> torch.Tensor:
         pos = pos.to(torch.long).contiguous()

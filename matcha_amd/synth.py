@@ -23,8 +23,10 @@ HG38_100KB = [int(np.ceil(mb * 10)) + 1 for mb in _HG38_MB]
 LAYOUTS = {
     "tiny": [16, 16, 16, 16],          # golden-fixture size
     "c1": [128, 128, 128, 128],        # BASELINE.json configs[0]: 512 bins
+    "c23": [12, 11, 10, 9, 8, 8, 8, 7, 7, 7, 6, 6, 6, 6, 5, 5, 5, 5, 4, 4, 4, 4, 3],   # 23 chromosomes (n_attr = 24 like hg38), 150 bins: full d = 64 goldens
     "hg38_1mb": HG38_1MB,              # configs[1], configs[2]: N = 3067
     "hg38_100kb": HG38_100KB,          # configs[3]: N ~ 30.4 k
+    "c5": [50000] * 20,                # configs[4]: 1 M nodes (20 synthetic chromosomes of 50 000 bins; table front end only)
 }
 
 
@@ -181,3 +183,57 @@ def make_batch(rng: np.random.Generator, n_nodes: int, ks: List[int], rows_per_k
     y = (rng.random((len(x), 1)) < 0.25).astype(np.float32)
     w = np.where(y > 0, rng.uniform(0.5, 4.0, size=y.shape), 1.0).astype(np.float32)
     return x, y, w
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] ("C5"): 1 M nodes, up to 100 M hyperedges with k uniform in {2..8}, built ON THE DEVICE
+# (node ids uniform -- the worst case for caches --, int32 CSR shards per rank).
+# ------------------------------------------------------------------------------------------------------------------
+def make_edges_device(n_nodes: int, n_edges: int, ks=(2, 3, 4, 5, 6, 7, 8), seed: int = 5, device="cuda", chunk: int = 1 << 24):
+    """int64 [n_edges, max(ks)] zero-padded rows on ``device``: k uniform over ``ks``, the k nodes a uniform k-subset of
+    1..n_nodes in ascending order.  Built without rejection: k sorted draws u_0 <= ... <= u_{k-1} from [0, n_nodes - k] plus
+    their rank i are strictly ascending and uniform over the k-subsets (the classic bijection between k-multisets of
+    [0, n - k] and k-subsets of [0, n - 1]).  Duplicate ROWS are possible (k = 2: ~1e-4 of 100 M rows at 1 M nodes) and
+    harmless: the hash set keeps one copy.  Generated in chunks so that the sort's scratch stays small."""
+    import torch
+    L = max(ks)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ks_t = torch.tensor(list(ks), device=device)
+    out = torch.empty((n_edges, L), dtype=torch.long, device=device)
+    col = torch.arange(L, device=device).view(1, L)
+    for lo in range(0, n_edges, chunk):
+        m = min(chunk, n_edges - lo)
+        k = ks_t[torch.randint(len(ks), (m,), generator=g, device=device)].view(m, 1)
+        u = (torch.rand((m, L), generator=g, device=device, dtype=torch.float64) * (n_nodes - k + 1).to(torch.float64)).long()
+        u = torch.minimum(u, (n_nodes - k).expand(m, L))
+        u = torch.where(col < k, u, torch.full_like(u, n_nodes + L))            # unused slots sort to the end
+        u, _ = torch.sort(u, dim=1)
+        out[lo:lo + m] = torch.where(col < k, u + col + 1, torch.zeros_like(u))
+    return out
+
+
+def edges_to_csr(edges, rank: int = 0, world: int = 1):
+    """The rank's shard of a zero-padded edge list as int32 CSR: rows rank, rank + world, ... ->
+    (offsets int64 [m + 1], ids int32 [nnz]) on the same device."""
+    import torch
+    e = edges[rank::world]
+    k = (e != 0).sum(1)
+    offsets = torch.zeros(len(e) + 1, dtype=torch.long, device=e.device)
+    torch.cumsum(k, 0, out=offsets[1:])
+    ids = e[e != 0].to(torch.int32)
+    return offsets, ids
+
+
+def csr_to_padded(offsets, ids, L: int, rows=None):
+    """Rows ``rows`` (LongTensor of row indices; default all) of a CSR shard as int64 [m, L] zero-padded -- what the sampler
+    and the model take (main.py:433 hands int64; 0 = padding)."""
+    import torch
+    if rows is None:
+        rows = torch.arange(len(offsets) - 1, device=offsets.device)
+    lo, hi = offsets[rows], offsets[rows + 1]
+    col = torch.arange(L, device=offsets.device).view(1, L)
+    idx = lo.view(-1, 1) + col
+    valid = idx < hi.view(-1, 1)
+    out = ids[torch.where(valid, idx, torch.zeros_like(idx))].to(torch.long)
+    return torch.where(valid, out, torch.zeros_like(out))

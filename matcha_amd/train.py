@@ -8,6 +8,13 @@ the GPU, negatives are drawn by the device sampler, and one step is forward+back
 (matcha_amd.engine.Trainer) with no per-step host synchronisation.
 
     cd <dir with config.JSON> && python -m matcha_amd.train [--front-end adj|table] [--epochs1 3 --epochs2 30]
+
+Data parallel (the reference is single-process): launched with
+``python -m torch.distributed.run --nproc-per-node N -m matcha_amd.train ...`` every rank runs this same flow on its own GPU.
+Everything drawn from numpy's global generator -- the 80/20 split, the epoch shuffles, ``random_chrom`` -- is identical on
+every rank (rank 0's seed is broadcast), each global batch of ``world * 96`` positives is cut strided by rank
+(parallel.shard_rows), each rank draws its own negatives, gradients are exchanged inside ``Trainer.step``, and only rank 0
+writes files.
 """
 from __future__ import annotations
 
@@ -24,7 +31,20 @@ import torch
 from . import utils as U
 from .Modules import Classifier, DataGenerator, MultipleEmbedding, Wrap_Embedding
 from .engine import Trainer
+from .parallel import shard_rows
 from .sampler import HyperedgeSet, NegativeSampler
+
+
+def _dist():
+    """(rank, world) of the initialised default process group, (0, 1) without one."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def _barrier():
+    if _dist()[1] > 1:
+        torch.distributed.barrier()
 
 NEG_NUM = 3          # main.py:527
 BATCH_SIZE = 96      # main.py:528 (positives per step)
@@ -96,6 +116,7 @@ class Session:
         self.min_size, self.max_size, self.min_dis = min_size, max_size, min_dis
         self.node2chrom, self.chrom_range = node2chrom, chrom_range
         self.n_chrom = len(chrom_range)
+        self.rank, self.world = _dist()
         self.trainer = Trainer(model, lr=1e-3, base_seed=seed)                    # AdamW(lr=1e-3), main.py:630
         self.set_known(None)
         self.rng = np.random.default_rng(seed)
@@ -110,8 +131,9 @@ class Session:
             hs = HyperedgeSet.empty(self.dev, self.max_size)
         else:
             hs = HyperedgeSet(torch.from_numpy(np.ascontiguousarray(edges)).to(self.dev))
+        # the draw is rank-shared (numpy's global stream is); the rank offset gives every rank its own negative stream
         self.sampler = NegativeSampler(hs, self.node2chrom, self.chrom_range, neg_num=NEG_NUM, min_dis=self.min_dis,
-                                       seed=int(np.random.randint(1 << 30)))
+                                       seed=int(np.random.randint(1 << 30)) + 7919 * self.rank)
 
     def make_batch(self, pos: torch.Tensor, pos_w: torch.Tensor):
         """generate_negative's output (main.py:443-448): x = [pos; neg], y = [1..; 0..], w = [pos_w..; 1..]."""
@@ -134,14 +156,16 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
     model.train()
     e = torch.from_numpy(edges).to(dev)
     w = torch.from_numpy(weights.astype(np.float32)).to(dev)
-    perm = torch.randperm(len(e), device=dev)                                   # sync_shuffle, utils.py:142-149
+    perm = torch.from_numpy(np.random.permutation(len(e))).to(dev)              # sync_shuffle, utils.py:142-149 (rank-shared stream)
     e, w = e[perm], w[perm]
-    n_batch = len(e) // batch_size
+    gb = batch_size * sess.world                                                # global batch: every rank steps on batch_size positives
+    n_batch = len(e) // gb
+    mine = torch.from_numpy(shard_rows(gb, sess.rank, sess.world)).to(dev)      # this rank's rows of a global batch (strided)
     bce_sum = torch.zeros((), device=dev)
     rec_sum = torch.zeros((), device=dev)
     preds, labels, sizes = [], [], []
     for i in range(n_batch):
-        pos, pw = e[i * batch_size:(i + 1) * batch_size], w[i * batch_size:(i + 1) * batch_size]
+        pos, pw = e[i * gb:(i + 1) * gb][mine], w[i * gb:(i + 1) * gb][mine]
         x, y, ww, s = sess.make_batch(pos, pw)
         bce, recon, logits = sess.trainer.step(x, y, ww, alpha=alpha, beta=beta, random_chrom=sess.random_chrom())
         bce_sum += bce
@@ -149,7 +173,15 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
         preds.append(torch.sigmoid(logits).clone())                             # main.py:58
         labels.append(y)
         sizes.append(s)
-    pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()
+    if sess.world > 1:                                                           # epoch means over all ranks; metrics below: this rank's rows
+        both = torch.stack([bce_sum, rec_sum])
+        torch.distributed.all_reduce(both)
+        bce_sum, rec_sum = both[0] / sess.world, both[1] / sess.world
+    pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()     # the epoch's one synchronisation
+    sess.trainer.check_status()                                                  # IndexError if a node id outside [0, N] reached a step
+    exhausted = sess.sampler.check_status()                                      # KeyError for nodes without a chromosome
+    if exhausted:
+        print(f"warning: {exhausted} negatives could not be redrawn within 65536 trials and were returned equal to their positive")
     auc, aupr = U.roc_auc_cuda(label, pred, size, sess.max_size)
     acc = U.accuracy(pred, label, size, sess.max_size)
     return float(bce_sum) / max(n_batch, 1), float(rec_sum) / max(n_batch, 1), acc, auc, aupr
@@ -165,7 +197,7 @@ def eval_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, batch_size
     from . import _lib
     e = torch.from_numpy(edges).to(dev)
     w = torch.from_numpy(weights.astype(np.float32)).to(dev)
-    perm = torch.randperm(len(e), device=dev)[:max_rows]
+    perm = torch.from_numpy(np.random.permutation(len(e))[:max_rows]).to(dev)   # rank-shared stream: every rank evaluates the same rows
     e, w = e[perm], w[perm]
     n_batch = len(e) // batch_size
     bce_sum, rec_sum = 0.0, 0.0
@@ -193,9 +225,13 @@ def train(sess: Session, training_data, validation_data, epochs: int, alpha: flo
     so every epoch is saved.)"""
     edges, weights = training_data
     rows = [r[r != 0] for r in edges]
-    gen = DataGenerator(rows, weights, int(batch_size), batches_per_epoch, min_size=sess.min_size, max_size=sess.max_size)
+    root = sess.rank == 0
+    log = log if root else (lambda *a, **k: None)
+    # an "iteration" serves batches_per_epoch GLOBAL batches: world times the rows of the single-process run, same number of steps
+    gen = DataGenerator(rows, weights, int(batch_size) * sess.world, batches_per_epoch, min_size=sess.min_size, max_size=sess.max_size)
     for epoch in range(epochs):
-        save_embeddings(sess.model, n_nodes, emb_path)
+        if root:
+            save_embeddings(sess.model, n_nodes, emb_path)
         t0 = time.time()
         e_part, w_part = gen.next_iter()
         bce, rec, acc, auc, aupr = train_epoch(sess, e_part, w_part, alpha, beta, batch_size)
@@ -204,15 +240,41 @@ def train(sess: Session, training_data, validation_data, epochs: int, alpha: flo
         t0 = time.time()
         vb, vr, vacc, vauc, vaupr = eval_epoch(sess, validation_data[0], validation_data[1], batch_size)
         log(f"  - (Validation-hyper) bce: {vb:7.4f}, recon: {vr:7.4f},  acc: {vacc}, auc: {vauc}, aupr: {vaupr}, elapse: {time.time() - t0:3.3f} s")
-        torch.save({"model_link": sess.model.state_dict(), "epoch": epoch}, os.path.join(temp_dir, MODEL_NAME))   # main.py:316-321
-        torch.save(sess.model, os.path.join(temp_dir, "model2load"))                                               # main.py:322
+        if root:
+            torch.save({"model_link": sess.model.state_dict(), "epoch": epoch}, os.path.join(temp_dir, MODEL_NAME))   # main.py:316-321
+            torch.save(sess.model, os.path.join(temp_dir, "model2load"))                                               # main.py:322
+    _barrier()                                                                  # rank 0's checkpoint is on disk
     ck = torch.load(os.path.join(temp_dir, MODEL_NAME), map_location=sess.dev, weights_only=False)              # main.py:326-327
     sess.model.load_state_dict(ck["model_link"])
 
 
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, str]:
+    """Join the process group a ``torch.distributed.run`` launch describes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the
+    environment): one process per GPU, backend "nccl" (= RCCL on ROCm) unless MATCHA_DIST_BACKEND / ``backend`` says otherwise
+    (the two-ranks-on-one-GPU test uses gloo).  Returns (rank, world, device); (0, 1, "cuda") outside such a launch."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or "RANK" not in os.environ:
+        return 0, 1, "cuda"
+    backend = backend or os.environ.get("MATCHA_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else int(os.environ.get("MATCHA_LOCAL_DEVICE", "0"))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not torch.distributed.is_initialized():
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        torch.distributed.init_process_group(backend, **kw)
+    return torch.distributed.get_rank(), world, f"cuda:{local}"
+
+
 def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 30, batches_per_epoch: int = 1000, device: str = "cuda",
         emb_path: Optional[str] = "../embeddings.npy", log=print) -> Classifier:
-    """The script body of main.py:516-685."""
+    """The script body of main.py:516-685 (on every rank of a data-parallel launch, see the module docstring)."""
+    rank, world = _dist()
+    if world > 1:
+        # numpy's global generator drives the split, the epoch shuffles and random_chrom: one seed for all ranks
+        seed = torch.tensor([int(np.random.randint(1 << 31)) if rank == 0 else 0], dtype=torch.int64, device=device)
+        torch.distributed.broadcast(seed, 0)
+        np.random.seed(int(seed.item()))
+        torch.manual_seed(int(seed.item()))          # identical initial weights before the Trainer's broadcast, too
     d = int(config["embed_dim"])
     size_list = [int(v) for v in config["k-mer_size"]]
     min_size, max_size = min(size_list), max(size_list)
@@ -242,7 +304,8 @@ def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 3
     else:
         ne = Wrap_Embedding(N + 1, d, padding_idx=0)
     model = Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True, bottle_neck=d, attribute_dict=attr).to(device)
-    save_embeddings(model, N, emb_path)                                           # main.py:625
+    if rank == 0:
+        save_embeddings(model, N, emb_path)                                       # main.py:625
 
     sess = Session(model, node2chrom, chrom_range.astype(np.int32), min_size, max_size, min_dis)
     # phase 1: alpha 0, beta 1, empty dict (negatives == positives)             main.py:637-643
@@ -254,8 +317,10 @@ def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 3
     sess.new_optimizer()
     train(sess, (train_data, train_w), (test_data, test_w), epochs2, 1.0, 0.001, temp_dir, N, batches_per_epoch=batches_per_epoch,
           emb_path=emb_path, log=log)
-    save_embeddings(model, N, emb_path)                                           # main.py:684
-    torch.save(model, os.path.join(temp_dir, "model2load"))                      # main.py:685
+    if rank == 0:
+        save_embeddings(model, N, emb_path)                                       # main.py:684
+        torch.save(model, os.path.join(temp_dir, "model2load"))                  # main.py:685
+    _barrier()
     return model
 
 
@@ -267,7 +332,10 @@ def main(argv=None):
     ap.add_argument("--epochs2", type=int, default=30)
     ap.add_argument("--batches-per-epoch", type=int, default=1000)
     a = ap.parse_args(argv)
-    run(U.get_config(a.config), a.front_end, a.epochs1, a.epochs2, a.batches_per_epoch)
+    rank, world, device = init_distributed()
+    run(U.get_config(a.config), a.front_end, a.epochs1, a.epochs2, a.batches_per_epoch, device=device)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -158,8 +158,9 @@ def g2_eval(M, name, num, d, mode, seed):
     print("G2", name, {k: v.shape for k, v in out.items() if k.startswith("logits")})
 
 
-def g3_train(M, name, num, d, mode, seed, alpha, beta, tag, n_steps=10, full=True):
-    """G3/G4: dropout-free training steps with the reference model + torch.optim.AdamW (main.py:630)."""
+def g3_train(M, name, num, d, mode, seed, alpha, beta, tag, n_steps=10, full=True, rows=None):
+    """G3/G4: dropout-free training steps with the reference model + torch.optim.AdamW (main.py:630).
+    ``rows`` = (rows per k of the mixed-k steps, rows of the k = 3 steps); default (6, 24)."""
     clf, attr, feats, inter_z, sd = build_ref(M, num, d, mode, seed)
     C, N = len(num), int(np.sum(num))
     set_dropout(clf, 0.0)
@@ -181,7 +182,8 @@ def g3_train(M, name, num, d, mode, seed, alpha, beta, tag, n_steps=10, full=Tru
         out["chroms"] = np.asarray(chroms, dtype=np.int64)
         brng = np.random.default_rng(seed + 3)
         for step in range(n_steps):
-            x, y, w = synth.make_batch(brng, N, [2, 3, 4, 5] if step % 2 == 0 else [3], 6 if step % 2 == 0 else 24)
+            r_mixed, r_k3 = rows or (6, 24)
+            x, y, w = synth.make_batch(brng, N, [2, 3, 4, 5] if step % 2 == 0 else [3], r_mixed if step % 2 == 0 else r_k3)
             out[f"x{step}"], out[f"y{step}"], out[f"w{step}"] = x, y, w
             pred, recon = clf(torch.from_numpy(x), return_recon=True)        # main.py:54
             bce = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.from_numpy(y), weight=torch.from_numpy(w))
@@ -580,6 +582,11 @@ def main():
         g3_train(M, f"tiny_{mode}", synth.LAYOUTS["tiny"], 16, mode, 31, 1.0, 0.001, "phase2")  # main.py:672-673
     g3_train(M, "hg38_table_d64", synth.LAYOUTS["hg38_1mb"], 64, "table", 41, 1.0, 0.001, "phase2", n_steps=3, full=False)
     g3_train(M, "hg38_adj_d64", synth.LAYOUTS["hg38_1mb"], 64, "adj", 42, 1.0, 0.001, "phase2", n_steps=3, full=False)
+    # FULL d = 64 fixtures (every gradient, parameters after 1 and 10 AdamW steps) on layouts small enough to commit: the shapes
+    # the fused d = 64 kernels run -- C1's 512 bins (n_attr = 5) and a 23-chromosome layout (n_attr = 24: the K = 32 attribute GEMM)
+    g3_train(M, "c1_table_d64", synth.LAYOUTS["c1"], 64, "table", 43, 1.0, 0.001, "phase2", n_steps=10, full=True, rows=(48, 160))
+    g3_train(M, "c23_table_d64", synth.LAYOUTS["c23"], 64, "table", 44, 1.0, 0.001, "phase2", n_steps=10, full=True, rows=(48, 160))
+    g3_train(M, "c23_adj_d64", synth.LAYOUTS["c23"], 64, "adj", 45, 1.0, 0.001, "phase2", n_steps=10, full=True, rows=(48, 160))
     sampler_stats(M, U)
     g6_inference(M, U)
     g7_kmers(M, U)

@@ -102,3 +102,74 @@ def test_shards_are_equal_and_disjoint():
     e = np.arange(40).reshape(20, 2)
     ee, ww = shard_edges(e, np.arange(20, dtype=np.float32), 1, 4)
     assert np.array_equal(ee[:, 0] // 2, ww.astype(int)) and len(ee) == 5
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    """Row-sparse exchange of the table gradient over gloo: every rank contributes its per-token
+    (node id, gradient row) list -- here: the oracle's d loss / d(gathered row) per token of its shard -- padded to a fixed
+    capacity with id-0 entries; after parallel.exchange_table_rows every rank holds all lists in rank order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from matcha_amd.parallel import exchange_table_rows
+    torch.set_num_threads(2)
+    num, d = synth.LAYOUTS["tiny"], 16
+    P, fe, _ = oracle_state(num, d, "table", 9, requires_grad=True)
+    x, y, w = synth.make_batch(np.random.default_rng(1), int(np.sum(num)), [2, 3, 5], 16)
+    idx = shard_rows(len(x), rank, world)
+    xs, ys, ws = (torch.from_numpy(a[idx]) for a in (x, y, w))
+    # per-token gradient rows: differentiate w.r.t. a per-token copy of the gathered rows
+    W = P["node_embedding.weight"]
+    tok = xs.reshape(-1)
+    rows_in = W.detach()[tok].clone().requires_grad_(True)
+    P2 = dict(P)
+
+    class _Fe:                                     # front end that hands out rows_in for this batch
+        mode, bounds, n_chrom, n_nodes = "table", fe.bounds, fe.n_chrom, fe.n_nodes
+    import oracle.hypersagnn as OH
+    orig = OH.node_embeddings
+    OH.node_embeddings = lambda P_, fe_, xf, rc=None, am=None: (rows_in * (xf != 0).unsqueeze(-1), torch.zeros(1))
+    try:
+        loss, *_ = O.total_loss(P2, fe, xs, ys, ws, 1.0, 0.0)
+        g_rows, = torch.autograd.grad(loss, [rows_in])
+    finally:
+        OH.node_embeddings = orig
+    cap = xs.numel() + 1                            # B*L + 1, the library's list capacity
+    ids = torch.zeros(cap, dtype=torch.int32)
+    rows = torch.full((cap, d), float("nan"))       # unused entries hold garbage: they must never be read
+    real = tok != 0
+    n_real = int(real.sum())
+    ids[:n_real] = tok[real].to(torch.int32)
+    rows[:n_real] = g_rows[real]
+    ids_all, rows_all = exchange_table_rows(ids, rows)
+    assert ids_all.shape == (world * cap,) and rows_all.shape == (world * cap, d)
+    assert torch.equal(ids_all[rank * cap:(rank + 1) * cap], ids)
+    # local reduce (what matcha_scatter_rows does on the device): entries with id 0 are skipped
+    dense = torch.zeros(W.shape[0], d, dtype=torch.float64)
+    use = ids_all != 0
+    dense.index_add_(0, ids_all[use].long(), rows_all[use].double())
+    if rank == 0:
+        torch.save({"dense": (dense / world).float()}, os.path.join(out_dir, "sparse.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sparse_table_exchange_equals_global_batch_gradient(tmp_path):
+    port = _free_port()
+    mp.spawn(_sparse_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(os.path.join(tmp_path, "sparse.pt"), weights_only=False)["dense"]
+    num, d = synth.LAYOUTS["tiny"], 16
+    P, fe, _ = oracle_state(num, d, "table", 9, requires_grad=True)
+    x, y, w = synth.make_batch(np.random.default_rng(1), int(np.sum(num)), [2, 3, 5], 16)
+    _, _, _, _, grads = O.loss_and_grads(P, fe, torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w), 1.0, 0.0)
+    ref = grads["node_embedding.weight"]
+    assert float(ref.abs().max()) > 0
+    assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    assert float(got[0].abs().max()) == 0.0
+
+
+def test_sparse_exchange_decision():
+    from matcha_amd.parallel import sparse_exchange_pays
+    assert not sparse_exchange_pays(3067, 64, 65536 * 5 + 1, 8)          # hg38 1 Mb: the table is smaller than one rank's list
+    assert sparse_exchange_pays(1_000_000, 256, 16384 * 8 + 1, 8)        # BASELINE configs[4]
+    assert not sparse_exchange_pays(1_000_000, 256, 16384 * 8 + 1, 1)

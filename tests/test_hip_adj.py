@@ -61,67 +61,10 @@ def test_reference_pickle_loads_and_runs_adj():
 
 
 def _train_g3_adj(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused):
-    g = gold(f"g3_{name}_{tag}.npz")
-    num = synth.LAYOUTS[layout]
-    clf, sd = hip_model(num, d, "adj", seed)
-    for m in clf.modules():
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-    N = int(np.sum(num))
-    clf.eval()
-    with torch.no_grad():
-        emb0 = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
-    np.testing.assert_allclose(emb0 if full else emb0[::16], g["emb_before"], rtol=0, atol=2e-6)
-    clf.train()
-    if use_fused:
-        from matcha_amd.engine import Trainer
-        tr = Trainer(clf, lr=1e-3)
-    else:
-        opt = torch.optim.AdamW(list(clf.parameters()), lr=1e-3, amsgrad=False)
-    none_ref = set(g["grad_none"].tolist()) - {"attribute_dict_embedding.weight"}
-    np.random.seed(1234)                                  # autograd path draws random_chrom like the reference
-    for step in range(n_steps):
-        x, y, w = (torch.from_numpy(g[f"{n}{step}"]).cuda() for n in "xyw")
-        if use_fused:
-            bce, recon, logits = tr.step(x, y, w, alpha=alpha, beta=beta, random_chrom=int(g["chroms"][step]))
-            logits = logits.view(-1, 1)
-        else:
-            logits, recon = clf(x, return_recon=True)
-            bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, y, weight=w)
-            loss = bce * alpha + recon * beta
-            opt.zero_grad()
-            loss.backward()
-            if step == 0:
-                grads = {n: p.grad for n, p in clf.named_parameters()}
-                assert {n for n, v in grads.items() if v is None} - {"attribute_dict_embedding.weight"} == none_ref
-                for n, v in grads.items():
-                    if v is None or n == GAUGE:
-                        continue
-                    if full:
-                        ref = g["grad0/" + n]
-                        assert np.abs(v.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
-                    else:
-                        gn = float(g["gradnorm0/" + n])
-                        assert abs(float(v.double().norm()) - gn) <= TOL * max(gn, 1e-3), n
-            opt.step()
-        assert rel_err(logits.detach().cpu().numpy(), g[f"logits{step}"]) < TOL, step
-        assert abs(float(bce) - float(g[f"bce{step}"])) < TOL * max(1.0, abs(float(g[f"bce{step}"])))
-        assert abs(float(recon.reshape(-1)[0]) - float(g[f"recon{step}"][0])) < TOL * max(1.0, abs(float(g[f"recon{step}"][0]))), step
-        if step in (0, n_steps - 1):
-            params = dict(clf.named_parameters())
-            for key in g.files:
-                if key.startswith(f"param{step}/"):
-                    n = key.split("/", 1)[1]
-                    if n == GAUGE:
-                        continue
-                    ref = g[key]
-                    assert np.abs(params[n].detach().cpu().numpy() - ref).max() <= 2 * TOL * max(np.abs(ref).max(), 1e-3), (step, n)
-    clf.eval()
-    with torch.no_grad():
-        emb1 = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
-    ref = g["emb_after"]
-    mine = emb1 if full else emb1[::16]
-    assert np.abs(mine - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    """G3 on the adj front end: the shared driver of tests/test_hip_model.py (gradients of step 0 read from the Trainer's flat
+    buffer before AdamW, parameters after the first and the last step, embeddings before / after)."""
+    from tests.test_hip_model import _train_g3
+    _train_g3(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused, mode="adj")
 
 
 @pytest.mark.parametrize("use_fused", [False, True])

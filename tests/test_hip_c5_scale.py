@@ -1,0 +1,165 @@
+"""BASELINE.json configs[4] ("C5": 1 M nodes, hyperedges with k in {2..8}, embed_dim 256, table front end) as a runnable
+workload on one MI355X: the device-side edge generator + int32 CSR shards (matcha_amd/synth.py), the exact hash set at 10 M
+hyperedges (the reference sizes its Bloom filters for this many, utils.py:75-97), the negative sampler at k = 8 against that
+set (main.py:361-459 invariants), and training steps on the 1 M x 256 table.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from matcha_amd import synth
+from matcha_amd.sampler import HyperedgeSet, NegativeSampler
+
+pytestmark = pytest.mark.gpu
+
+N_NODES = 1_000_000
+N_EDGES = 10_000_000
+KS = (2, 3, 4, 5, 6, 7, 8)
+_cache = {}
+
+
+def _edges():
+    if "e" not in _cache:
+        _cache["e"] = synth.make_edges_device(N_NODES, N_EDGES, ks=KS, seed=5, device="cuda")
+    return _cache["e"]
+
+
+def _row_hash(rows):
+    """63-bit polynomial hash of zero-padded int64 rows (torch wrap-around arithmetic) -- the ground truth's index."""
+    h = torch.full((rows.shape[0],), 1469598103934665603, dtype=torch.long, device=rows.device)
+    for c in range(rows.shape[1]):
+        h = (h ^ rows[:, c]) * 1099511628211
+        h = h ^ (h >> 29)
+    return h & 0x7FFFFFFFFFFFFFFF
+
+
+def test_c5_generator_and_csr_shards():
+    e = _edges()
+    assert e.shape == (N_EDGES, 8) and e.dtype == torch.long
+    k = (e != 0).sum(1)
+    cnt = torch.bincount(k, minlength=9)
+    assert int(cnt[:2].sum()) == 0 and float((cnt[2:].float() / N_EDGES - 1 / 7).abs().max()) < 2e-3     # k uniform in {2..8}
+    big = torch.where(e == 0, torch.full_like(e, 1 << 40), e)
+    assert bool(((big[:, 1:] > big[:, :-1]) | (big[:, 1:] == (1 << 40))).all())                            # ascending, distinct, pads last
+    assert int(e.max()) <= N_NODES and int(e[e != 0].min()) >= 1
+    deg = torch.bincount(e[e != 0], minlength=N_NODES + 1)[1:].float()                                      # uniform node usage
+    assert abs(float(deg.mean()) - 5.0 * N_EDGES / N_NODES) < 0.01 * float(deg.mean()) and float(deg.std()) < 1.3 * float(deg.mean()) ** 0.5
+    # int32 CSR shards of two ranks: disjoint, complete, and they expand back to the padded rows
+    for r in range(2):
+        off, ids = synth.edges_to_csr(e, r, 2)
+        assert ids.dtype == torch.int32 and off.dtype == torch.long and int(off[-1]) == ids.numel()
+        sel = torch.randint(0, off.numel() - 1, (4096,), device="cuda")
+        assert torch.equal(synth.csr_to_padded(off, ids, 8, sel), e[r::2][sel])
+
+
+def test_c5_hashset_membership_exact_on_samples():
+    e = _edges()
+    hs = HyperedgeSet(e)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    sel = torch.randint(0, N_EDGES, (200_000,), generator=g, device="cuda")
+    assert bool(hs.contains(e[sel]).all())                                    # every inserted row is found
+    # perturbed rows: replace one node by a random one and re-sort; ground truth through a sorted 63-bit row hash + row compare
+    cand = e[sel].clone()
+    k = (cand != 0).sum(1)
+    pos = (torch.rand(len(cand), generator=g, device="cuda") * k).long()
+    cand[torch.arange(len(cand), device="cuda"), pos] = torch.randint(1, N_NODES + 1, (len(cand),), generator=g, device="cuda")
+    cand = torch.where(cand == 0, torch.full_like(cand, 1 << 40), cand).sort(1).values
+    cand = torch.where(cand == (1 << 40), torch.zeros_like(cand), cand)
+    he = _row_hash(e)
+    order = torch.argsort(he)
+    hs_sorted = he[order]
+    hc = _row_hash(cand)
+    at = torch.searchsorted(hs_sorted, hc).clamp(max=N_EDGES - 1)
+    hit = hs_sorted[at] == hc
+    truth = hit & (e[order[at]] == cand).all(1)
+    assert int((hit & ~truth).sum()) == 0                                      # no 63-bit collision muddies the ground truth
+    got = hs.contains(cand)
+    assert torch.equal(got, truth)
+    assert int(truth.sum()) < 200 and int((~truth).sum()) > 190_000            # almost every perturbed row is new
+    # k-prefixes of wider rows are different hyperedges
+    wide = e[sel][(e[sel] != 0).sum(1) >= 4][:10000].clone()
+    wide[:, 3:] = 0
+    hw = _row_hash(wide)
+    at = torch.searchsorted(hs_sorted, hw).clamp(max=N_EDGES - 1)
+    truth_w = (hs_sorted[at] == hw) & (e[order[at]] == wide).all(1)
+    assert torch.equal(hs.contains(wide), truth_w)
+
+
+def test_c5_negative_sampler_invariants_k8():
+    e = _edges()
+    num = synth.LAYOUTS["c5"]
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    hs = HyperedgeSet(e)
+    smp = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=2, seed=77)
+    pos = e[torch.randperm(N_EDGES, device="cuda")[:20000]]
+    neg = smp.sample(pos)
+    assert smp.check_status() == 0                                             # no exhausted rows, every node has a chromosome
+    assert neg.shape == (60000, 8)
+    P = pos.repeat_interleave(3, dim=0)
+    kn, kp = (neg != 0).sum(1), (P != 0).sum(1)
+    assert torch.equal(kn, kp)                                                 # same k as the positive
+    big = torch.where(neg == 0, torch.full_like(neg, 1 << 40), neg)
+    gaps = big[:, 1:] - big[:, :-1]
+    real_gap = (neg[:, 1:] != 0)
+    assert bool((gaps[real_gap] > 2).all())                                    # ascending, distinct, adjacent gaps > min_dis
+    assert bool(((neg == 0) == (P == 0)).all())                                # pads stay pads
+    n2c_t = torch.from_numpy(n2c).cuda()
+    assert torch.equal(n2c_t[neg].sort(1).values, n2c_t[P].sort(1).values)     # every replaced node stays in its chromosome
+    assert not bool(hs.contains(neg).any())                                    # not a known hyperedge
+    # 1 .. k nodes differ from the positive; the count of k = 8 rows is the place where a truncation to k <= 5 would show
+    same = (neg.unsqueeze(2) == P.unsqueeze(1)) & (neg.unsqueeze(2) != 0)
+    diff = kn - same.any(2).sum(1)
+    assert int(diff.min()) >= 1 and bool((diff <= kn).all())
+    k8 = kn == 8
+    assert int(k8.sum()) > 5000 and float(diff[k8].float().mean()) > 3.0       # Binomial(8, 1/2) | != 0 has mean 4.02
+    # bit-exact against the oracle restatement on a slice (python loops: small)
+    from oracle import sampler as OS
+    sub = pos[:40].cpu().numpy()
+    smp2 = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=2, seed=5)
+    got = smp2.sample(pos[:40]).cpu().numpy()
+
+    class _Known:                                                              # membership through the device set itself (10 M tuples do not fit a python set cheaply)
+        def __contains__(self, t):
+            row = torch.zeros(1, 8, dtype=torch.long)
+            row[0, :len(t)] = torch.tensor(t)
+            return bool(hs.contains(row.cuda())[0])
+    ref = OS.sample_negatives(sub, _Known(), n2c, cr, 3, 2, seed=6)
+    assert np.array_equal(got, ref)
+
+
+def test_c5_training_steps_on_the_1m_x_256_table():
+    """Four optimisation steps of the C5 shape (1 M x 256 table, L = 8, 4 096 rows per step): finite losses that go down on a
+    fixed batch, only the gathered rows of the table move by more than weight decay, status word clean."""
+    import Modules as M
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["c5"]
+    e = _edges()
+    d = 256
+    attr = np.zeros((N_NODES + 1, len(num) + 1), dtype=np.float32)
+    n2c = synth.node2chrom(num)
+    attr[np.arange(1, N_NODES + 1), n2c[1:]] = 1.0
+    attr[1:, len(num)] = (np.arange(N_NODES) % num[0]) / np.float32(num[0])
+    torch.manual_seed(0)
+    clf = M.Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=M.Wrap_Embedding(N_NODES + 1, d, padding_idx=0), diag_mask=True,
+                       bottle_neck=d, attribute_dict=attr).cuda()
+    clf.train()
+    tr = Trainer(clf, base_seed=3)
+    hs = HyperedgeSet(e)
+    smp = NegativeSampler(hs, n2c, synth.chrom_range(num), neg_num=3, min_dis=0, seed=9)
+    pos = e[:1024]
+    x = torch.cat([pos, smp.sample(pos)])
+    y = torch.cat([torch.ones(1024, device="cuda"), torch.zeros(3072, device="cuda")])
+    w = torch.ones(4096, device="cuda")
+    t0 = clf.node_embedding.weight.detach().clone()
+    losses = []
+    for _ in range(4):
+        bce, _, logits = tr.step(x, y, w, alpha=1.0, beta=0.001)
+        losses.append(float(bce))
+    tr.check_status()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    moved = (clf.node_embedding.weight.detach() - t0).abs().amax(1)
+    seen = torch.zeros(N_NODES + 1, dtype=torch.bool, device="cuda")
+    seen[x.reshape(-1)] = True
+    seen[0] = False
+    assert float(moved[seen].min()) > 1e-3                                      # Adam moves a touched row by ~lr per step
+    assert float(moved[~seen].max()) < 1e-3 * 4 * 1e-2 * float(t0.abs().max()) + 1e-7   # the others only decay (lr * wd per step)

@@ -82,3 +82,112 @@ def test_two_rank_trainer_equals_single_rank_on_global_batch(tmp_path, mode, d):
         # further apart than a small fraction of the 2 * lr the two steps may move a weight
         assert float(torch.quantile(diff, 0.999)) <= 2e-5 * scale, (n, float(torch.quantile(diff, 0.999)))
         assert float(diff.max()) <= 1e-4 * scale, (n, float(diff.max()))
+
+
+def _sparse_worker(rank, world, port, out_dir, exchange, d):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from matcha_amd.engine import Trainer
+    from matcha_amd.parallel import shard_rows
+    from tests.test_hip_model import hip_model
+    num = synth.LAYOUTS["c1"]
+    clf, _ = hip_model(num, d, "table", 50)
+    clf.eval()
+    tr = Trainer(clf, lr=1e-3, table_exchange=exchange)
+    rng = np.random.default_rng(8)
+    N = int(np.sum(num))
+    for step in range(6):
+        x, y, w = synth.make_batch(rng, N, [2, 3, 4, 5], 64)                   # 256 rows, the same global batch on both ranks
+        idx = shard_rows(len(x), rank, world)
+        xs, ys, ws = (torch.from_numpy(a[idx]).cuda() for a in (x, y.reshape(-1), w.reshape(-1)))
+        tr.step(xs, ys, ws, alpha=1.0, beta=0.0)
+        assert tr._sparse == (exchange == "sparse")
+    torch.cuda.synchronize()
+    tr.check_status()
+    if rank == 0:
+        torch.save({n: p.detach().cpu() for n, p in clf.named_parameters()}, os.path.join(out_dir, f"dp_{exchange}.pt"))
+    # both ranks must hold the same parameters bit for bit (same gradient, same AdamW)
+    flat = clf._runtime().flat.detach().cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_two_rank_sparse_table_exchange_equals_dense_and_single_rank(tmp_path, d):
+    """all-gather of per-token (id, row) lists + deterministic local sum (Trainer table_exchange="sparse")
+    against the flat all-reduce ("dense") and against the single-rank run on the global batch, six AdamW steps; two runs of the
+    sparse path are bitwise equal (the dense path's table comes out of a sum whose order gloo fixes as well)."""
+    from matcha_amd.engine import Trainer
+    from tests.test_hip_model import GAUGE, hip_model
+    runs = {}
+    for tag, exchange in (("sparse", "sparse"), ("sparse2", "sparse"), ("dense", "dense")):
+        out = tmp_path / tag
+        out.mkdir()
+        mp.spawn(_sparse_worker, args=(2, _free_port(), str(out), exchange, d), nprocs=2, join=True)
+        runs[tag] = torch.load(os.path.join(out, f"dp_{exchange}.pt"), weights_only=False)
+    for n in runs["sparse"]:
+        assert torch.equal(runs["sparse"][n], runs["sparse2"][n]), n              # bitwise reproducible, table included
+    num = synth.LAYOUTS["c1"]
+    N = int(np.sum(num))
+    clf, _ = hip_model(num, d, "table", 50)
+    clf.eval()
+    tr = Trainer(clf, lr=1e-3)
+    rng = np.random.default_rng(8)
+    for step in range(6):
+        x, y, w = synth.make_batch(rng, N, [2, 3, 4, 5], 64)
+        tr.step(torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(), torch.from_numpy(w.reshape(-1)).cuda(), alpha=1.0, beta=0.0)
+    torch.cuda.synchronize()
+    for n, p in clf.named_parameters():
+        if n == GAUGE:
+            continue
+        a = p.detach().cpu()
+        for tag in ("sparse", "dense"):
+            b = runs[tag][n]
+            diff, scale = (a - b).abs().reshape(-1), max(1.0, float(a.abs().max()))
+            assert float(torch.quantile(diff[:1 << 20], 0.999)) <= 2e-5 * scale, (tag, n)
+            assert float(diff.max()) <= 6e-4 * scale, (tag, n, float(diff.max()))   # six steps of at most lr each where |g| ~ eps
+
+
+def _run_worker(rank, world, port, tmp, front_end):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MATCHA_DIST_BACKEND="gloo", MATCHA_LOCAL_DEVICE="0")
+    import json
+    from matcha_amd import train as T
+    r, w_, device = T.init_distributed()
+    assert (r, w_) == (rank, world)
+    np.random.seed(100 + rank)                                   # ranks start from DIFFERENT host RNG states: run() must align them
+    torch.manual_seed(200 + rank)
+    cfg = json.load(open(os.path.join(tmp, "config.JSON")))
+    logs = []
+    model = T.run(cfg, front_end=front_end, epochs1=1, epochs2=2, batches_per_epoch=3, device=device,
+                  emb_path=os.path.join(tmp, "embeddings.npy"), log=logs.append)
+    flat = model._runtime().flat.detach().cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])                         # replicas stayed in lockstep through both phases
+    if rank == 0:
+        assert any("Training" in l for l in logs)
+        json.dump({"n_logs": len(logs)}, open(os.path.join(tmp, "rank0.json"), "w"))
+    else:
+        assert not logs                                          # only rank 0 reports
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("front_end", ["table", "adj"])
+def test_train_run_data_parallel_two_ranks(tmp_path, front_end):
+    """matcha_amd.train.run (main.py:516-685's flow) under a two-rank launch: shared numpy stream (split, shuffles, random_chrom),
+    strided shards of each global batch, rank-0-only file writes, replicas bitwise identical at the end."""
+    from tests.test_train_driver import _write_temp_dir
+    cfg, num = _write_temp_dir(str(tmp_path), m=600)
+    mp.spawn(_run_worker, args=(2, _free_port(), str(tmp_path), front_end), nprocs=2, join=True)
+    N = int(np.sum(num))
+    emb = np.load(os.path.join(tmp_path, "embeddings.npy"))
+    assert emb.shape == (N, 16) and np.isfinite(emb).all()
+    assert os.path.exists(os.path.join(cfg["temp_dir"], "model.chkpt")) and os.path.exists(os.path.join(cfg["temp_dir"], "model2load"))
+    assert os.path.exists(os.path.join(tmp_path, "rank0.json"))

@@ -225,3 +225,71 @@ def test_embed_and_ln3(d):
     for i in range(3):
         ref = torch.nn.functional.layer_norm(X, (d,), gb[2 * i], gb[2 * i + 1], 1e-5)
         assert (outs[i].cpu() - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
+
+
+def _oracle_lib():
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libmatcha_oracle.so")
+    assert os.path.exists(path), "build it with __graft_entry__.build() (make -C oracle/c)"
+    return C.CDLL(path)
+
+
+@pytest.mark.parametrize("B,L,ks,bad", [(1, 1, [1], False), (7, 3, [0, 1, 3], False), (4096, 5, [2, 3, 4, 5], False), (65536, 5, [2, 3, 4, 5], False),
+                                        (20000, 8, [0, 2, 8], True), (3000, 8, [8], False), (5000, 2, [0], False)])
+def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad):
+    """The execution plan is integer / index work: the five plan kernels must equal the plain-C restatement
+    (oracle/c/ragged_plan.c) bit for bit -- CSR offsets, compact token lists, per-token keys, tile list -- including rows that
+    are all padding, pads in the middle of a row, and node ids outside [0, N] (flagged, read as 0)."""
+    import ctypes as C
+    lib = _lib.load()
+    ora = _oracle_lib()
+    rng = np.random.default_rng(B + L)
+    N = 1000
+    x = np.zeros((B, L), dtype=np.int64)
+    kk = rng.choice(ks, size=B)
+    kk = np.minimum(kk, L)
+    col = np.argsort(rng.random((B, L)), axis=1)                       # random slots: pads may sit anywhere in the row
+    vals = rng.integers(1, N + 1, size=(B, L))
+    mask = np.arange(L)[None, :] < kk[:, None]
+    np.put_along_axis(x, col, np.where(mask, vals, 0), axis=1)
+    if bad:
+        x[5, np.nonzero(x[5])[0][:1]] = N + 5
+        x[17, np.nonzero(x[17])[0][:1]] = -2
+    T = B * L
+    xt = torch.from_numpy(x).cuda()
+    ws = torch.zeros(lib.matcha_ragged_plan_bytes(B, L), dtype=torch.uint8, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    view = _lib.RaggedView()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.matcha_ragged_plan(_lib.ptr(xt), B, L, N, _lib.ptr(status), _lib.ptr(ws), ws.numel(), C.byref(view), st), "matcha_ragged_plan")
+    torch.cuda.synchronize()
+    base = ws.data_ptr()
+
+    def grab(p, n, dt):
+        nbytes = n * torch.empty(0, dtype=dt).element_size()
+        return ws[p - base:p - base + nbytes].view(dt).cpu().numpy()
+    cap = int(view.tiles_cap)
+    got = dict(row_off=grab(view.row_off, B + 1, torch.int32), tok_slot=grab(view.tok_slot, T + 1, torch.int32),
+               tok_id=grab(view.tok_id, T + 1, torch.int64), tok_key=grab(view.tok_key, T + 1, torch.int32),
+               tok_pos=grab(view.tok_pos, T + 1, torch.int32), count=grab(view.count, 3, torch.int32),
+               tile_meta=grab(view.tile_meta, cap * 4, torch.int32))
+    ref = dict(row_off=np.zeros(B + 1, np.int32), tok_slot=np.zeros(T + 1, np.int32), tok_id=np.zeros(T + 1, np.int64),
+               tok_key=np.zeros(T + 1, np.int32), tok_pos=np.zeros(T + 1, np.int32), count=np.zeros(3, np.int32),
+               tile_meta=np.zeros(cap * 4, np.int32))
+    ref_status = np.zeros(1, np.int32)
+    ora.matcha_oracle_ragged_plan.restype = C.c_int64
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    nt = ora.matcha_oracle_ragged_plan(p(x), C.c_int64(B), C.c_int32(L), C.c_int64(N), p(ref["row_off"]), p(ref["tok_slot"]), p(ref["tok_id"]),
+                                       p(ref["tok_key"]), p(ref["tok_pos"]), p(ref["count"]), p(ref["tile_meta"]), C.c_int64(cap), p(ref_status))
+    assert nt >= 1
+    Tr = int(ref["count"][1])
+    assert np.array_equal(got["count"], ref["count"]) and np.array_equal(got["row_off"], ref["row_off"])
+    for k_ in ("tok_slot", "tok_id", "tok_pos"):
+        assert np.array_equal(got[k_][:Tr + 1], ref[k_][:Tr + 1]), k_            # entries past the shared padding token are scratch
+    assert np.array_equal(got["tok_key"], ref["tok_key"])                        # zero in every unused entry
+    assert np.array_equal(got["tile_meta"], ref["tile_meta"])
+    assert int(status[0].item()) == int(ref_status[0]) == (1 if bad else 0)
+    # the tiles partition the hyperedges into runs of whole hyperedges with <= 63 tokens
+    tm = ref["tile_meta"].reshape(-1, 4)[:nt]
+    assert tm[:, 1].max() <= 63 and tm[:, 3].sum() == B and tm[:, 1].sum() == Tr

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from matcha_amd import synth
+from matcha_amd import synth, _lib
 from oracle import hypersagnn as O
 from tests.helpers import oracle_state, rel_err
 from tests.test_hip_model import GAUGE, TOL, hip_model
@@ -124,15 +124,19 @@ def test_full_size_train_step_is_reproducible():
 
 
 class _env:
-    """Set an environment switch of libmatcha_hip for the duration of a with-block (the library re-reads it per call)."""
+    """Flip one of the library's A/B switches for a block (matcha_set_option; the environment variable of the same name is
+    only the initial value, read once when the library loads)."""
+
     def __init__(self, name):
-        self.name = name
+        self.name = name[len("MATCHA_"):].lower()
 
     def __enter__(self):
-        os.environ[self.name] = "1"
+        from matcha_amd import _lib
+        self.old = _lib.set_option(self.name, 1)
 
     def __exit__(self, *a):
-        os.environ.pop(self.name, None)
+        from matcha_amd import _lib
+        _lib.set_option(self.name, self.old)
 
 
 def _mixed_batch(N, ks, per, rng):
@@ -184,13 +188,13 @@ def test_fused_backward_matches_layerwise(mode, ks):
         np.random.seed(8)
         clf.zero_grad()
         if layerwise:
-            os.environ["MATCHA_DISABLE_FUSED"] = "1"
+            _lib.set_option("disable_fused", 1)
         try:
             lg, rc = clf(x, return_recon=True)
             (torch.nn.functional.binary_cross_entropy_with_logits(lg, y) + 0.05 * rc.sum()).backward()
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("MATCHA_DISABLE_FUSED", None)
+            _lib.set_option("disable_fused", 0)
         res.append((lg.detach().clone(), {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.grad is not None}))
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
     assert res[0][1].keys() == res[1][1].keys()
@@ -216,13 +220,13 @@ def test_fused_kernels_with_empty_rows():
     for layerwise in (True, False):
         clf.zero_grad()
         if layerwise:
-            os.environ["MATCHA_DISABLE_FUSED"] = "1"
+            _lib.set_option("disable_fused", 1)
         try:
             lg = clf(x)
             torch.nn.functional.binary_cross_entropy_with_logits(lg, y).backward()
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("MATCHA_DISABLE_FUSED", None)
+            _lib.set_option("disable_fused", 0)
         res.append((lg.detach().clone(), {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.grad is not None}))
     assert float(res[1][0][40:240].abs().max()) == 0.0
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
@@ -250,12 +254,12 @@ def test_loss_in_forward_matches_separate_tail_backward(mode):
         clf.train(True)
         tr = Trainer(clf, base_seed=77)
         if separate:
-            os.environ["MATCHA_DISABLE_LOSS_IN_FORWARD"] = "1"
+            _lib.set_option("disable_loss_in_forward", 1)
         try:
             tr.forward_backward(x, y, w, alpha=0.7, beta=0.01, random_chrom=3)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("MATCHA_DISABLE_LOSS_IN_FORWARD", None)
+            _lib.set_option("disable_loss_in_forward", 0)
         res.append((tr.gflat.clone(), tr.losses.clone(), {n: (p.data_ptr() - tr.rt.flat.data_ptr()) // 4 for n, p in clf.named_parameters()
                                                           if p.data_ptr() >= tr.rt.flat.data_ptr() and p.data_ptr() < tr.rt.flat.data_ptr() + tr.rt.n_flat * 4},
                     {n: p.numel() for n, p in clf.named_parameters()}))
@@ -321,13 +325,13 @@ def test_tiny_batches_fused_matches_layerwise(rows):
     for layerwise in (True, False):
         clf.zero_grad()
         if layerwise:
-            os.environ["MATCHA_DISABLE_FUSED"] = "1"
+            _lib.set_option("disable_fused", 1)
         try:
             lg = clf(x)
             torch.nn.functional.binary_cross_entropy_with_logits(lg, y).backward()
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("MATCHA_DISABLE_FUSED", None)
+            _lib.set_option("disable_fused", 0)
         res.append((lg.detach().clone(), {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.grad is not None}))
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
     for n, a in res[0][1].items():
@@ -355,12 +359,12 @@ def test_fused_front_end_matches_separate_kernels(mode):
         clf.train(True)
         tr = Trainer(clf, base_seed=5)
         if separate:
-            os.environ["MATCHA_DISABLE_FUSED_FRONT"] = "1"
+            _lib.set_option("disable_fused_front", 1)
         try:
             logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=2)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("MATCHA_DISABLE_FUSED_FRONT", None)
+            _lib.set_option("disable_fused_front", 0)
         res.append((logits.clone(), tr.gflat.clone()))
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
     g0, g1 = res[0][1], res[1][1]
@@ -396,12 +400,12 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
         clf.train(True)
         tr = Trainer(clf, base_seed=8)
         if recompute:
-            os.environ["MATCHA_DISABLE_QKV_SAVE"] = "1"
+            _lib.set_option("disable_qkv_save", 1)
         try:
             logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("MATCHA_DISABLE_QKV_SAVE", None)
+            _lib.set_option("disable_qkv_save", 0)
         res.append((logits.clone(), tr.gflat.clone()))
     assert torch.equal(res[0][0], res[1][0])                 # the forward pass computes the same thing either way
     g0, g1 = res[0][1], res[1][1]
@@ -458,3 +462,55 @@ def test_forward_only_workspace_is_compact_and_equivalent(mode):
     rc_ = rt.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L, None, None,
                                 _lib.ptr(logits), _lib.ptr(losses), _lib.ptr(ws), small, rt.stream())
     assert rc_ != 0 and b"workspace" in rt.lib.matcha_last_error()
+
+
+@pytest.mark.parametrize("mode,layout,rows_per_k", [("table", "hg38_1mb", 1024), ("adj", "c23", 1024)])
+def test_trainer_fused_step_vs_oracle_4096_rows_dropout(mode, layout, rows_per_k):
+    """The bench's kernel configuration (Trainer: loss inside the fused forward, saved-Q/K/V fused backward, fused front end)
+    against the oracle ELEMENT BY ELEMENT on 4 096 mixed-k rows with dropout ON: the kernels' masks are the counter RNG of
+    oracle/rng.py, so the oracle with the same injected masks must reproduce logits, loss and every gradient (main.py:164-183)."""
+    from matcha_amd.engine import Trainer
+    from oracle import rng as R
+    from tests.test_hip_model import _trainer_grads
+    num = synth.LAYOUTS[layout]
+    N, d = int(np.sum(num)), 64
+    clf, _ = hip_model(num, d, mode, 17)
+    P, fe, _ = oracle_state(num, d, mode, 17, requires_grad=True)
+    clf.train()
+    rng = np.random.default_rng(11)
+    xs = [np.pad(synth.make_edges_fast(rng, N, k, rows_per_k), ((0, 0), (0, 5 - k))) for k in (2, 3, 4, 5)]
+    x = np.concatenate(xs)
+    x = x[rng.permutation(len(x))]
+    y = (rng.random((len(x), 1)) < 0.25).astype(np.float32)
+    w = np.where(y > 0, rng.uniform(0.5, 4.0, size=y.shape), 1.0).astype(np.float32)
+    xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
+    base_seed, chrom, alpha, beta = 4242, 3, 1.0, 0.05
+    tr = Trainer(clf, base_seed=base_seed)
+    logits = tr.forward_backward(xt.cuda(), yt.cuda().reshape(-1), wt.cuda().reshape(-1), alpha, beta, chrom)
+    torch.cuda.synchronize()
+    seed = base_seed + 1                       # Trainer advances the device seed before every step
+    T = x.size
+    masks = {"fc1": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_FC1, O.P_DROP_FC1, T, d)),
+             "pff": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_PFF, O.P_DROP_PFF, T, d))}
+    if mode == "adj":
+        masks["adj"] = torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_ADJ, O.P_DROP_ADJ, T, max(num)))
+    _, bce, recon, ref_logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, alpha, beta, random_chrom=chrom, masks=masks)
+    got = logits.cpu().numpy().reshape(-1)
+    ref = ref_logits.numpy().reshape(-1)
+    assert np.abs(got - ref).max() <= TOL * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * (1.0 + np.abs(ref)).max()            # element-wise, not only norm-wise
+    assert abs(float(tr.losses[0]) - float(bce)) <= TOL * max(1.0, abs(float(bce)))
+    assert abs(float(tr.losses[1]) - float(recon[0])) <= TOL * max(1.0, abs(float(recon[0])))
+    mine = _trainer_grads(tr, clf)
+    n_checked = 0
+    for n, gref in grads.items():
+        if gref is None:
+            assert mine[n] is None, n
+            continue
+        if n == GAUGE:
+            continue
+        assert mine[n] is not None, n
+        r = gref.numpy()
+        assert np.abs(mine[n].cpu().numpy() - r).max() <= TOL * max(np.abs(r).max(), 1e-3), n
+        n_checked += 1
+    assert n_checked >= 28
