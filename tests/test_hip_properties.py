@@ -513,4 +513,4 @@ def test_trainer_fused_step_vs_oracle_4096_rows_dropout(mode, layout, rows_per_k
         r = gref.numpy()
         assert np.abs(mine[n].cpu().numpy() - r).max() <= TOL * max(np.abs(r).max(), 1e-3), n
         n_checked += 1
-    assert n_checked >= 28
+    assert n_checked >= 26, n_checked          # table front end: 28 live tensors minus the gauge direction
