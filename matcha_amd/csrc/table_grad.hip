@@ -9,9 +9,10 @@
 // Entries with id 0 (padding / unused list slots) sort behind every real id and are skipped.
 //
 // Two sorters.  Up to 32 767 nodes (every hg38 layout: 3 067 bins at 1 Mb, 30 344 at 100 kb) the id IS the digit of a single
-// hand-written counting-sort pass: one wavefront per tile of 4 096 list entries keeps one counter per node in LDS, finds the
-// lanes that hold the same id with `bits` wave ballots (no per-lane loop), and writes each entry to  start[id] + (entries of the
-// id in earlier tiles) + (earlier entries of this tile)  -- a stable sort in 4 launches of a few microseconds each, after which
+// hand-written counting-sort pass: per tile of 4 096 list entries a histogram (LDS atomics), column / id scans, then up to four
+// wavefronts per tile keep one counter per node in LDS, find the lanes that hold the same id with `bits` wave ballots (no
+// per-lane loop), and write each entry to  start[id] + (entries of the id in earlier tiles) + (earlier entries of this tile)
+// -- a stable sort in 4 launches, after which
 // one WAVEFRONT per node adds its run with 16 rows in flight.  rocPRIM's generic radix sort took 12 launches (115 us) for the
 // 327 681 entries of the bench batch and the one-group-per-position sum 78 us; this path: see DESIGN.md §4.2.  Larger tables
 // (BASELINE config 5: 1 M nodes, runs of length ~1) keep rocPRIM's device radix sort + the one-group-per-position sum.
@@ -96,21 +97,62 @@ __global__ __launch_bounds__(256) void tg_segsum_kernel(const uint32_t* __restri
 constexpr int kCsTile = 4096;          // list entries per wavefront
 constexpr int kCsMaxNodes = 32767;     // counters of one wavefront: (n_nodes + 1) ints of LDS <= 128 KB
 
-// PLACE = false: hist[blk][id] = entries of id in tile blk.  PLACE = true: src[position] = entry index, position =
-// start[id] + base[blk][id] + rank inside the tile (ranks follow list order: the sort is stable).
-template <bool PLACE>
-__global__ __launch_bounds__(64) void tg_count_kernel(const int32_t* __restrict__ ids, int64_t n, int n_nodes, int bits, int stride,
-                                                      int32_t* __restrict__ hist, const int32_t* __restrict__ base,
-                                                      const int32_t* __restrict__ start, uint32_t* __restrict__ src) {
+// hist[blk][id] = entries of id in tile blk.  Counting needs no order: LDS integer atomics, 256 threads per tile.
+__global__ __launch_bounds__(256) void tg_hist_kernel(const int32_t* __restrict__ ids, int64_t n, int n_nodes, int stride, int32_t* __restrict__ hist) {
   extern __shared__ int cnt[];
-  const int lane = threadIdx.x;
   const int64_t blk = blockIdx.x;
-  for (int i = lane; i < stride; i += 64) cnt[i] = PLACE ? start[i] + base[blk * stride + i] : 0;
+  for (int i = threadIdx.x; i < stride; i += 256) cnt[i] = 0;
   __syncthreads();
-  const uint64_t lt = (1ull << lane) - 1ull;
   const int64_t t0 = blk * kCsTile;
+#pragma unroll 4
+  for (int it = threadIdx.x; it < kCsTile; it += 256) {
+    const int64_t t = t0 + it;
+    const int32_t id = t < n ? ids[t] : 0;
+    if (id >= 1 && id <= n_nodes) atomicAdd(&cnt[id], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < stride; i += 256) hist[blk * stride + i] = cnt[i];
+}
+
+// src[position] = entry index, position = start[id] + base[blk][id] + (entries of the id earlier in the tile): a STABLE
+// placement (ranks follow list order).  W wavefronts per tile, wave w owns the w-th part of the tile and its own LDS counters:
+//   1. every wave counts its part (LDS atomics on its own counters -- counts are order-free);
+//   2. counters become bases: start + base[blk] + the counts of the waves before;
+//   3. every wave ranks its part 64 entries at a time: the lanes that hold the same id find each other with `bits` wave
+//      ballots, rank = number of lower lanes among them, the lowest one advances the counter.
+template <int W>
+__global__ __launch_bounds__(64 * W) void tg_place_kernel(const int32_t* __restrict__ ids, int64_t n, int n_nodes, int bits, int stride,
+                                                          const int32_t* __restrict__ base, const int32_t* __restrict__ start,
+                                                          uint32_t* __restrict__ src) {
+  extern __shared__ int lds_cnt[];
+  constexpr int kPart = kCsTile / W;                                     // entries per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t blk = blockIdx.x;
+  int* cnt = lds_cnt + wave * stride;
+  const int64_t t0 = blk * kCsTile + (int64_t)wave * kPart;
+  if (W > 1) {
+    for (int i = lane; i < stride; i += 64) cnt[i] = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): this wave's own zeroes have landed (in-order LDS, one wave)
+#pragma unroll 4
+    for (int it = lane; it < kPart; it += 64) {
+      const int64_t t = t0 + it;
+      const int32_t id = t < n ? ids[t] : 0;
+      if (id >= 1 && id <= n_nodes) atomicAdd(&cnt[id], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < stride; i += 64 * W) {                 // exclusive prefix over the waves, plus the global bases
+      int run = start[i] + base[blk * stride + i];
+#pragma unroll
+      for (int w = 0; w < W; ++w) { const int c = lds_cnt[w * stride + i]; lds_cnt[w * stride + i] = run; run += c; }
+    }
+    __syncthreads();
+  } else {
+    for (int i = lane; i < stride; i += 64) cnt[i] = start[i] + base[blk * stride + i];
+    __syncthreads();
+  }
+  const uint64_t lt = (1ull << lane) - 1ull;
   constexpr int kBatch = 16;                                             // ids of 16 wave-steps are loaded before the first is ranked:
-  for (int it0 = 0; it0 < kCsTile; it0 += 64 * kBatch) {                 // one global-memory round trip per 1 024 entries, not per 64
+  for (int it0 = 0; it0 < kPart; it0 += 64 * kBatch) {                   // one global-memory round trip per 1 024 entries, not per 64
     int32_t idb[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
@@ -131,14 +173,10 @@ __global__ __launch_bounds__(64) void tg_count_kernel(const int32_t* __restrict_
       if (key != 0) {
         const int rank = __popcll(peers & lt);
         const int old = cnt[key];                                        // every peer reads the counter before the leader moves it
-        if (PLACE) src[old + rank] = (uint32_t)t;
+        src[old + rank] = (uint32_t)t;
         if (rank == 0) cnt[key] = old + __popcll(peers);                 // leaders hold distinct ids: no conflict
       }
     }
-  }
-  if (!PLACE) {
-    __syncthreads();
-    for (int i = lane; i < stride; i += 64) hist[blk * stride + i] = cnt[i];
   }
 }
 
@@ -302,18 +340,21 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
   ProfScope ps(MATCHA_PROF_EMBED_SCATTER, (double)n * (4.0 + 8.0 * d), st);
   if (n_nodes <= kCsMaxNodes) {
     const size_t lds = (size_t)w.stride * sizeof(int);
-    if (lds > 64 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tg_count_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tg_count_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    hipLaunchKernelGGL((tg_count_kernel<false>), dim3(w.nblk), dim3(64), lds, st, ids, n, n_nodes, bits, w.stride, w.hist, nullptr, nullptr, nullptr);
-    MATCHA_CHECK_LAUNCH("tg_count_kernel<hist>");
+    const int waves = 4 * lds <= 150 * 1024 ? 4 : (2 * lds <= 150 * 1024 ? 2 : 1);     // LDS counters per wavefront: (n_nodes + 1) ints
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tg_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tg_place_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tg_place_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tg_place_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(tg_hist_kernel, dim3(w.nblk), dim3(256), lds, st, ids, n, n_nodes, w.stride, w.hist);
+    MATCHA_CHECK_LAUNCH("tg_hist_kernel");
     hipLaunchKernelGGL(tg_colscan_kernel, dim3((unsigned)cdiv(w.stride, 256)), dim3(256), 0, st, w.hist, w.nblk, w.stride, w.totals);
     MATCHA_CHECK_LAUNCH("tg_colscan_kernel");
     hipLaunchKernelGGL(tg_idscan_kernel, dim3(1), dim3(1024), 0, st, w.totals, w.stride, w.start);
     MATCHA_CHECK_LAUNCH("tg_idscan_kernel");
-    hipLaunchKernelGGL((tg_count_kernel<true>), dim3(w.nblk), dim3(64), lds, st, ids, n, n_nodes, bits, w.stride, nullptr, w.hist, w.start, w.src);
-    MATCHA_CHECK_LAUNCH("tg_count_kernel<place>");
+    if (waves == 4) hipLaunchKernelGGL((tg_place_kernel<4>), dim3(w.nblk), dim3(256), 4 * lds, st, ids, n, n_nodes, bits, w.stride, w.hist, w.start, w.src);
+    else if (waves == 2) hipLaunchKernelGGL((tg_place_kernel<2>), dim3(w.nblk), dim3(128), 2 * lds, st, ids, n, n_nodes, bits, w.stride, w.hist, w.start, w.src);
+    else hipLaunchKernelGGL((tg_place_kernel<1>), dim3(w.nblk), dim3(64), lds, st, ids, n, n_nodes, bits, w.stride, w.hist, w.start, w.src);
+    MATCHA_CHECK_LAUNCH("tg_place_kernel");
     const dim3 grid((unsigned)cdiv(n_nodes, 4));
     if (d <= 64) hipLaunchKernelGGL((tg_runsum_kernel<1>), grid, dim3(256), 0, st, w.start, w.src, n_nodes, d, rows, dtable);
     else if (d <= 128) hipLaunchKernelGGL((tg_runsum_kernel<2>), grid, dim3(256), 0, st, w.start, w.src, n_nodes, d, rows, dtable);

@@ -31,10 +31,11 @@ def _csr(clusters: Sequence[Sequence[int]]):
 
 
 def generate_kmers(clusters: Sequence[Sequence[int]], size: int, min_dis: int, max_size: int, min_freq_cutoff: int, n_nodes: int = 0,
-                   device="cuda") -> Tuple[np.ndarray, np.ndarray]:
+                   device="cuda", max_combos_per_launch: int = 0) -> Tuple[np.ndarray, np.ndarray]:
     """(kmers int64 [M, size], freq int64 [M]) for one k-mer size (generate_kmers.py:8-69, :86-96).  ``clusters``: sorted
-    unique node-id lists (process.py:66-77).  Launches are split so that each counts fewer than 2^32 candidate subsets;
-    partial results of different launches are merged on the host (a k-mer may occur in several launches)."""
+    unique node-id lists (process.py:66-77).  Launches are split so that each counts fewer than 2^32 candidate subsets AND
+    fits half of the free device memory (``max_combos_per_launch`` lowers the bound further: tests); partial results of
+    different launches are merged on the device (a k-mer may occur in several launches)."""
     if max_size > MAX_CLUSTER_LEN:
         raise _lib.MatchaHipError(f"max_cluster_size {max_size} exceeds the device kernel's limit {MAX_CLUSTER_LEN}")
     lib = _lib.load()
@@ -49,13 +50,22 @@ def generate_kmers(clusters: Sequence[Sequence[int]], size: int, min_dis: int, m
     off_d = torch.from_numpy(offsets).to(dev)
     parts = []
     start = 0
-    while start < len(per):                                             # greedy split into launches of < 2^32 - 1 candidates
+    # A launch holds every candidate subset at once (keys, their sorted copy, run lengths, the unpacked rows): bound the
+    # candidates per launch by the FREE device memory as well as by the 2^32 - 2 index limit, so that a realistic data set
+    # (millions of clusters of up to 25 bins: 1e10 candidates at k = 5) splits further instead of running out of memory
+    probe = 1 << 20
+    per_cand = lib.matcha_kmer_workspace_bytes(probe, size, n_nodes) / probe + 8.0 * size + 8.0
+    free_bytes = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 1 << 34
+    launch_cap = int(min(MAX_COMBOS, max(1 << 16, 0.5 * free_bytes / max(per_cand, 1.0))))
+    if max_combos_per_launch:
+        launch_cap = min(launch_cap, int(max_combos_per_launch))
+    while start < len(per):                                             # greedy split into launches of <= launch_cap candidates
         run, end = 0, start
-        while end < len(per) and run + per[end] <= MAX_COMBOS:
+        while end < len(per) and run + per[end] <= launch_cap:
             run += int(per[end])
             end += 1
         if end == start:
-            raise _lib.MatchaHipError("one cluster alone has more than 2^32 candidate k-subsets")
+            raise _lib.MatchaHipError(f"one cluster alone has {int(per[start])} candidate k-subsets: more than a launch can hold ({launch_cap})")
         if run > 0:
             comb = np.zeros(end - start + 1, dtype=np.int64)
             np.cumsum(per[start:end], out=comb[1:])
@@ -75,22 +85,24 @@ def generate_kmers(clusters: Sequence[Sequence[int]], size: int, min_dis: int, m
                                                 n_nodes, min_dis, min_freq_cutoff if single else 1, _lib.ptr(out_k), _lib.ptr(out_f), cap,
                                                 _lib.ptr(n_out), _lib.ptr(ws), ws_bytes, st), "matcha_kmer_generate")
             m = int(n_out.item())
-            parts.append((out_k[:m].cpu().numpy(), out_f[:m].cpu().numpy(), single))
+            parts.append((out_k[:m].clone(), out_f[:m].clone(), single))     # compact copies; the launch's big buffers are freed
+            del ws, out_k, out_f
         start = end
     if len(parts) == 1 and parts[0][2]:
-        return parts[0][0], parts[0][1]
-    # several launches: merge equal rows (sorted inputs), then threshold
-    rows = np.concatenate([p[0] for p in parts])
-    freq = np.concatenate([p[1] for p in parts])
-    order = np.lexsort(rows.T[::-1])
+        return parts[0][0].cpu().numpy(), parts[0][1].cpu().numpy()
+    # several launches: merge equal rows ON THE DEVICE (each part is sorted and duplicate-free; the same k-mer may occur in
+    # several parts), then threshold: lexicographic order by stable sorts from the last column to the first
+    rows = torch.cat([p[0] for p in parts])
+    freq = torch.cat([p[1] for p in parts])
+    del parts
+    order = torch.arange(len(rows), device=rows.device)
+    for c in range(size - 1, -1, -1):
+        order = order[torch.sort(rows[order, c], stable=True).indices]
     rows, freq = rows[order], freq[order]
-    head = np.ones(len(rows), dtype=bool)
-    head[1:] = (rows[1:] != rows[:-1]).any(axis=1)
-    idx = np.flatnonzero(head)
-    freq = np.add.reduceat(freq, idx)
-    rows = rows[idx]
-    keep = freq >= min_freq_cutoff
-    return rows[keep], freq[keep]
+    uniq, inv = torch.unique_consecutive(rows, dim=0, return_inverse=True)
+    tot = torch.zeros(len(uniq), dtype=freq.dtype, device=freq.device).index_add_(0, inv, freq)
+    keep = tot >= min_freq_cutoff
+    return uniq[keep].cpu().numpy(), tot[keep].cpu().numpy()
 
 
 def main(argv=None):

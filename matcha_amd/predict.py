@@ -96,9 +96,20 @@ def pairwise_probabilities(model, chrom_range, chrom_id: int, min_dis: int, batc
     dev = model.layer_norm1.weight.device
     pairs = generate_pair_wise(chrom_range, chrom_id, min_dis, dev)
     out = torch.empty(len(pairs), dtype=torch.float32, device=dev)
-    with torch.no_grad():
-        for s in range(0, len(pairs), batch_rows):
-            out[s:s + batch_rows] = torch.sigmoid(model(pairs[s:s + batch_rows].contiguous()).reshape(-1))
+    # back-to-back forwards: the per-call read-back of the device status word (one synchronisation each) is switched off and the
+    # word is checked ONCE after the sweep (ids outside the model's tables are flagged on the device either way)
+    check_each = getattr(model, "check_ids", None)
+    if check_each is not None:
+        model.check_ids = False
+    try:
+        with torch.no_grad():
+            for s in range(0, len(pairs), batch_rows):
+                out[s:s + batch_rows] = torch.sigmoid(model(pairs[s:s + batch_rows].contiguous()).reshape(-1))
+        if check_each is not None:
+            model.check_status()            # IndexError if chrom_range does not belong to this model (ids beyond its tables)
+    finally:
+        if check_each is not None:
+            model.check_ids = check_each
     return pairs, out
 
 

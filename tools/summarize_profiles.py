@@ -45,6 +45,10 @@ def cls(n):
         return "front_fwd"
     if "front_bwd_kernel" in n:
         return "front_bwd"
+    if "tg_" in n:
+        return "embed_scatter"
+    if "gather_rows" in n:
+        return "gather_rows"
     for k in ("attn_fwd", "attn_bwd", "embed_fwd", "embed_scatter", "ln3_fwd", "ln3_bwd", "head_fwd", "head_bwd", "adamw_kernel", "neg_sample", "adj_encode"):
         if k in n:
             return k.replace("_kernel", "")
@@ -66,8 +70,15 @@ for i in ids:
         a[2] += wr.get(i, (None, 0))[1] * 1024
 out = {c: {"launches_per_step": v[0], "hbm_read_bytes_per_launch": v[1] / v[0], "hbm_write_bytes_per_launch": v[2] / v[0],
            "hbm_bytes_per_launch": (v[1] + v[2]) / v[0]} for c, v in agg.items()}
+import hashlib
+import os
+h = hashlib.sha256()
+for fsrc in sorted(glob.glob(os.path.join("matcha_amd", "csrc", "*.h*"))):
+    h.update(open(fsrc, "rb").read())
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of bench.py --steps 2 --warmup 1, 65536 rows/step); "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; bytes per launch averaged over the launches of the class in one step",
+           "csrc_sha16": h.hexdigest()[:16],          # bench.py quotes these figures only for the kernel sources they were measured on
+           "workload": ["hg38_1mb", 64, "table", 65536],
            "classes": out}, open(f"profiles/{rnd}_pmc_traffic.json", "w"), indent=1)
 for c, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"]):
     print(f"{c:14s} x{v['launches_per_step']:2d}  {v['hbm_bytes_per_launch']/1e6:9.1f} MB/launch")
