@@ -344,7 +344,9 @@ int launch_gemm_rm_direct(bool b_kn, const GemmArgs& g, hipStream_t st) {
 size_t gemm_tn_ws_bytes(int64_t M, int64_t N, int64_t R) {
   int tm, tn, P; int64_t rpb;
   tn_partition(M, N, R, &tm, &tn, &P, &rpb);
-  return align_up((size_t)P * (size_t)(M * N + M) * sizeof(float), 256);
+  const size_t a = align_up((size_t)P * (size_t)(M * N + M) * sizeof(float), 256);
+  const size_t b = gemm_tn_wide_ws_bytes(M, N, R);           // 0 when the shape is not eligible for the 128 x 128 kernel
+  return a > b ? a : b;
 }
 
 // C[M,N] (+)= A[R,M]^T . B[R,N];  colsum[M] (+)= sum_r A[r,:]
@@ -352,6 +354,14 @@ int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int6
                    int64_t lda, int64_t ldb, const int64_t* b_gather, bool accumulate, void* ws, size_t ws_bytes,
                    hipStream_t st, const int32_t* r_dev, const float* out_scale_dev, float out_scale) {
   if (M <= 0 || N <= 0) return MATCHA_OK;
+  if (gemm_tn_wide_eligible(M, N, R, lda, ldb, A, B, b_gather)) {
+    int Pw; int64_t stride;
+    {
+      ProfScope ps(MATCHA_PROF_GEMM_TN, 2.0 * (double)M * (double)N * (double)R, st);
+      MATCHA_TRY(launch_gemm_tn_wide(A, B, M, N, R, lda, ldb, colsum != nullptr, ws, ws_bytes, r_dev, &Pw, &stride, st));
+    }
+    return launch_slab_reduce((const float*)ws, C, M * N, colsum, stride, Pw, accumulate, st, out_scale_dev, out_scale);
+  }
   int tm, tn, P; int64_t rpb;
   tn_partition(M, N, R > 0 ? R : 1, &tm, &tn, &P, &rpb);
   const size_t need = (size_t)P * (size_t)(M * N + M) * sizeof(float);

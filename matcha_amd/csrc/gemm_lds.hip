@@ -283,6 +283,7 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
   if (!b_kn) vec = vec && (g.ldb >= g.K);
   if (b_kn) vec = vec && (g.N % 4 == 0);
   const bool indirect = g.m_dev || g.a_row_map || g.c_row_map || g.seg;
+  if (vec && gemm_wide_eligible(b_kn, g)) return launch_gemm_wide(b_kn, g, st);     // embed_dim >= 128: 128 x 128 tiles (gemm_wide.hip)
   if (!vec) {
     if (indirect) { set_error("gemm: row maps / grouped mode need 16-byte aligned operands"); return MATCHA_EINVAL; }
     return launch_gemm_rm_direct(b_kn, g, st);

@@ -66,6 +66,14 @@ int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int6
 int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st,
                        const float* scale_dev = nullptr, float scale = 1.f);
 
+// gemm_wide.hip: 128 x 128 workgroup tiles for embed_dim >= 128 (returns / eligibility: see the file header)
+bool gemm_wide_eligible(bool b_kn, const GemmArgs& g);
+int launch_gemm_wide(bool b_kn, const GemmArgs& g, hipStream_t st);
+bool gemm_tn_wide_eligible(int64_t M, int64_t N, int64_t R, int64_t lda, int64_t ldb, const float* A, const float* B, const int64_t* b_gather);
+size_t gemm_tn_wide_ws_bytes(int64_t M, int64_t N, int64_t R);
+int launch_gemm_tn_wide(const float* A, const float* B, int64_t M, int64_t N, int64_t R, int64_t lda, int64_t ldb, bool colsum, void* ws,
+                        size_t ws_bytes, const int32_t* r_dev, int* P_out, int64_t* slab_stride_out, hipStream_t st);
+
 // token_kernels.hip
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev = nullptr);
@@ -82,6 +90,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save, disable_sorted_scatter;
+  int disable_wide_gemm;
   int debug_nan, fused_dbg, fwd_lds_pad;
 };
 Options& options();

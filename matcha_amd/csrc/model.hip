@@ -80,12 +80,13 @@ struct Workspace {
 //   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
 //   disable_sorted_scatter   table gradient through float atomics instead of table_grad.hip's sort + segmented sum
+//   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
 struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
     {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_sorted_scatter", &Options::disable_sorted_scatter},
-    {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
+    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
     Options v;

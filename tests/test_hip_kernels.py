@@ -31,7 +31,9 @@ def _gemm(op, A, B, M, N, K, epi=None, colsum=None, gather=None, C_init=None):
     return out
 
 
-SHAPES = [(128, 64, 64), (1000, 64, 64), (37, 16, 16), (515, 512, 64), (515, 64, 512), (300, 128, 128), (70, 24, 20), (130, 96, 250)]
+SHAPES = [(128, 64, 64), (1000, 64, 64), (37, 16, 16), (515, 512, 64), (515, 64, 512), (300, 128, 128), (70, 24, 20), (130, 96, 250),
+          # the 128 x 128-tile kernels of gemm_wide.hip (N % 128 == 0, K % 32 == 0, K >= 64): embed_dim 128 / 256 layer shapes
+          (1000, 1024, 128), (515, 128, 1024), (257, 256, 256), (1, 128, 64), (2049, 2048, 256), (129, 256, 2048)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -57,7 +59,8 @@ def test_gemm_unaligned_rows():
     assert (out - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("R_,M,N", [(1000, 64, 64), (5000, 512, 64), (777, 64, 512), (333, 16, 16), (4096, 64, 24), (50, 128, 128)])
+@pytest.mark.parametrize("R_,M,N", [(1000, 64, 64), (5000, 512, 64), (777, 64, 512), (333, 16, 16), (4096, 64, 24), (50, 128, 128),
+                                    (5000, 1024, 128), (777, 128, 1024), (33, 256, 256), (1, 128, 128), (20000, 2048, 256)])
 def test_gemm_tn(R_, M, N):
     g = torch.Generator().manual_seed(R_ + M + N)
     dY, X = torch.randn(R_, M, generator=g), torch.randn(R_, N, generator=g)
@@ -118,6 +121,41 @@ def test_gemm_epilogues():
     ref2 = (A.double() @ W.double().t()).float() * mask * (1 - (aux * 0.7) ** 2)
     out2 = _gemm(_lib.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K, epi=epi2).cpu()
     assert (out2 - ref2).abs().max() <= 2e-5 * max(1.0, ref2.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1000, 1024, 128), (130, 128, 1024)])
+def test_gemm_wide_tiles_equal_narrow_tiles_and_epilogues(M, N, K):
+    """gemm_wide.hip against the 64-wide kernels it replaces at embed_dim >= 128 (option disable_wide_gemm) with the epilogues
+    the model uses, dropout masks bit-identical (counter RNG on (row, column)); TN including the column sums."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ids = torch.randint(0, 3, (M,), generator=g)
+    seed = torch.tensor([987654321], dtype=torch.int64)
+    keep = [bias.to(DEV), res.to(DEV), ids.to(DEV), seed.to(DEV)]
+    outs = {}
+    for wide in (True, False):
+        with _lib.option("disable_wide_gemm", 0 if wide else 1):
+            epi = _lib.GemmEpilogue()
+            epi.flags = _lib.EPI_BIAS | _lib.EPI_ROWMASK | _lib.EPI_DROPOUT           # fc1's epilogue (Modules.py:572)
+            epi.bias, epi.row_ids, epi.seed = keep[0].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr()
+            epi.stream_id, epi.p_drop, epi.aux_scale = R.STREAM_DROP_FC1, 0.3, 1.0
+            a = _gemm(_lib.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K, epi=epi).cpu()
+            epi2 = _lib.GemmEpilogue()
+            epi2.flags = _lib.EPI_RESIDUAL | _lib.EPI_ROWMASK                          # pff_n1 conv0 backward
+            epi2.residual, epi2.row_ids = keep[1].data_ptr(), keep[2].data_ptr()
+            b = _gemm(_lib.GEMM_NN, A.to(DEV), W.t().contiguous().to(DEV), M, N, K, epi=epi2).cpu()
+            col = torch.zeros(K, device=DEV)
+            dY = (A @ torch.ones(K, N) * 0.01 + res).contiguous()                      # [M, N] "upstream gradient"
+            c = _gemm(_lib.GEMM_TN, A.to(DEV), dY.to(DEV), K, N, M, colsum=col).cpu()  # A^T . dY : [K, N], column sums of A
+            outs[wide] = (a, b, c, col.cpu())
+    ref = (A.double() @ W.double().t()).float()
+    mask = torch.from_numpy(R.dropout_mask(int(seed[0]), R.STREAM_DROP_FC1, 0.3, M, N))
+    want = (ref + bias) * mask * (ids != 0).float()[:, None]
+    assert (outs[True][0] - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(outs[True][0] == 0, outs[False][0] == 0)                          # same dropout pattern
+    for x, y in zip(outs[True], outs[False]):
+        assert (x - y).abs().max() <= 3e-5 * max(1.0, float(y.abs().max()))
 
 
 def _attn_ref(Q, K, V, B, L, d):
