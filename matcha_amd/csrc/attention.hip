@@ -388,6 +388,7 @@ int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_
   dim3 grid((unsigned)attn_blocks(B));
   // algorithmic bytes (upper bound, all L slots real): read Q,K,V, write O (+P)
   ProfScope ps(MATCHA_PROF_ATTN_FWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 4.0 + (double)B * MATCHA_N_HEAD * L * L), st);
+  if (attn_wide_eligible(d)) return launch_attn_fwd_wide(Q, K, V, row_off, B, L, d, inv_temp, O, P, attn_blocks(B), st);
   switch (chunk_of(d)) {
     case 8: ATTN_FWD_L(8, Q, K, V, row_off, B, L, d, inv_temp, O, P); break;
     case 4: ATTN_FWD_L(4, Q, K, V, row_off, B, L, d, inv_temp, O, P); break;
@@ -420,6 +421,9 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
     // algorithmic bytes (upper bound): read Q,K,V,dO (+P), write dQ,dK,dV
     ProfScope ps(MATCHA_PROF_ATTN_BWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 7.0 + (double)B * MATCHA_N_HEAD * L * L), st);
     const int per_lane = d / 8;
+    if (attn_wide_eligible(d)) {
+      MATCHA_TRY(launch_attn_bwd_wide(Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, nblk, st));
+    } else
     switch (chunk_of(d)) {
       case 8:
         if (per_lane == 8) { ATTN_BWD_L(8, 1, Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab); }

@@ -148,5 +148,11 @@ int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_
 int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
                     int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st);
 size_t attn_bwd_slab_bytes(int64_t B, int d);
+// attention_wide.hip: the same attention for embed_dim >= 128 with one operand set live at a time (no spills at L = 8, d = 256)
+bool attn_wide_eligible(int d);
+int launch_attn_fwd_wide(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float inv_temp, float* O,
+                         float* P, int nblk, hipStream_t st);
+int launch_attn_bwd_wide(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
+                         int d, float inv_temp, float* dQ, float* dK, float* dV, float* slab, int nblk, hipStream_t st);
 
 }  // namespace matcha

@@ -25,7 +25,7 @@ for name, N, d, T in (("C2 (3 067 nodes, L2-resident)", 3067, 64, 1 << 20), ("C5
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
-        _lib.check(lib.matcha_node_embeddings(C.byref(shp), C.byref(par), C.byref(fro), _lib.ptr(ids), T, _lib.ptr(rows), None, 0, st), "gather")
+        _lib.check(lib.matcha_node_embeddings(C.byref(shp), C.byref(par), C.byref(fro), _lib.ptr(ids), T, _lib.ptr(rows), None, 0, None, st), "gather")
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
