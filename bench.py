@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU)")
     ap.add_argument("--table-exchange", choices=["auto", "dense", "sparse"], default="auto")
+    ap.add_argument("--deterministic", action="store_true", help="sorted (bitwise reproducible) embedding backward instead of float atomics")
     return ap.parse_args()
 
 
@@ -128,7 +129,7 @@ class Dist:
 
 
 def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof="auto", graph=False, edges_per_k=100000, edges=0,
-                 table_exchange="auto", model_only=True):
+                 table_exchange="auto", model_only=True, deterministic=False):
     """Build the workload on the device, run `warmup` untimed + `steps` timed steps, return the measurements."""
     from matcha_amd.engine import Trainer
     from matcha_amd.sampler import HyperedgeSet, NegativeSampler
@@ -173,7 +174,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
 
     clf = make_model(front_end, dim, num, device)
     clf.train()                                                           # dropout ON, as in the reference's training step
-    trainer = Trainer(clf, lr=1e-3, base_seed=99, table_exchange=table_exchange)
+    trainer = Trainer(clf, lr=1e-3, base_seed=99, table_exchange=table_exchange, deterministic=deterministic)
     trainer.force_collectives = dist.launched and world == 1       # 1-rank torchrun: still go through RCCL
 
     x = torch.zeros((B, L), dtype=torch.long, device=device)
@@ -364,7 +365,7 @@ def main():
 
     m = run_workload(dist, layout=args.layout, dim=args.dim, ks=ks, rows=args.rows, front_end=args.front_end, steps=args.steps,
                      warmup=args.warmup, prof=args.prof, graph=args.graph, edges_per_k=args.edges_per_k, edges=args.edges,
-                     table_exchange=args.table_exchange)
+                     table_exchange=args.table_exchange, deterministic=args.deterministic)
     B, P, L, N = m["B"], m["P"], m["L"], m["N"]
     elapsed = m["elapsed"]
     result = {
@@ -379,7 +380,8 @@ def main():
                                f"front end={args.front_end}, neg_num=3, dropout on, AdamW lr=1e-3, {m['known_edges']} known hyperedges",
                    "rows_per_gpu_per_step": B, "positives_per_gpu_per_step": P, "global_rows_per_step": B * world,
                    "parallelism": f"dp{world}", "hipgraph": bool(args.graph),
-                   "table_gradient_exchange": "row-sparse all-gather" if m["sparse_exchange"] else ("flat all-reduce" if world > 1 else "none")},
+                   "table_gradient_exchange": "row-sparse all-gather" if m["sparse_exchange"] else ("flat all-reduce" if world > 1 else "none"),
+                   "embedding_backward": "sorted, one writer per row (bitwise reproducible)" if args.deterministic else "float atomics"},
         "positives_per_s": round(P * world * args.steps / elapsed, 1),
         "last_bce": round(m["losses"][0], 5),
         "model_step_only": None if m["model_only_ms"] is None else {"ms_per_step": round(m["model_only_ms"], 4),
@@ -393,7 +395,8 @@ def main():
         result["roofline_gather"] = gather_roofline(dist.device)
         if default_run:
             extras = {}
-            for key, kw in (("adj_front_end_configs2", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="adj")),
+            for key, kw in (("deterministic_embedding_backward", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="table", deterministic=True)),
+                            ("adj_front_end_configs2", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="adj")),
                             ("reference_batch_384_rows", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="table")),
                             ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table")),
                             ("configs4_c5_1M_nodes_d256", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=16384, front_end="table",

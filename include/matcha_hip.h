@@ -75,7 +75,7 @@ int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
  * environment per call.  Names: "disable_fused" (layer-by-layer kernels at every embed_dim), "disable_fused_train" (fused
  * kernels only for forwards that will not be differentiated), "disable_fused_front" (front end as separate kernels),
  * "disable_loss_in_forward", "disable_qkv_save" (the fused backward recomputes Q/K/V instead of reloading saved tiles),
- * "disable_sorted_scatter" (table gradient through float atomics instead of the sort + segmented sum), "disable_wide_gemm"
+ * "disable_wide_gemm"
  * (embed_dim >= 128: 64-wide GEMM tiles instead of the 128 x 128 ones), "debug_nan",
  * "fused_dbg", "fwd_lds_pad".  Returns MATCHA_EINVAL for an unknown name; matcha_get_option returns -1 for one.
  * Process-global: flip them only while no call is in flight. */
@@ -170,9 +170,14 @@ typedef struct matcha_step_opts {
                                 matcha_backward must then be called with the SAME opts and dlogits == NULL.  0: the
                                 backward pass starts from the saved activations (required for an arbitrary dlogits)   */
   int32_t* status;           /* optional DEVICE int32[4] status word (see above); NULL = not reported                   */
-  int32_t sparse_table_grad; /* table mode, matcha_backward: 1 = do NOT add the table gradient into grads->table; leave it as
-                                (unique node ids, summed gradient rows) in the workspace for matcha_table_grad_rows (the
+  int32_t sparse_table_grad; /* table mode, matcha_backward: 1 = do NOT add the table gradient into grads->table; leave it as a
+                                per-token (node id, gradient row) list in the workspace for matcha_table_grad_rows (the
                                 row-sparse data-parallel exchange); 0 = dense grads->table as usual      */
+  int32_t deterministic;     /* table mode, matcha_backward: 1 = the embedding backward sorts the tokens by node id and adds each
+                                node's rows in token order with ONE writer per table row (csrc/table_grad.hip: bitwise
+                                reproducible, ~60 us per 65 536-row step at hg38 1 Mb sizes); 0 = float atomics from the
+                                front-end backward kernel (order of additions varies from run to run, like
+                                torch.nn.Embedding's CUDA backward; nothing else in the step is order-dependent)            */
 } matcha_step_opts;
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */

@@ -79,13 +79,12 @@ struct Workspace {
 //   disable_loss_in_forward  the tail's backward as separate kernels even when opts->loss_in_forward is set
 //   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
-//   disable_sorted_scatter   table gradient through float atomics instead of table_grad.hip's sort + segmented sum
 //   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
 struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
-    {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_sorted_scatter", &Options::disable_sorted_scatter},
+    {"disable_qkv_save", &Options::disable_qkv_save},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
@@ -110,7 +109,6 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
   return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && !options().disable_loss_in_forward;
 }
 static bool save_qkv() { return !options().disable_qkv_save; }
-static bool sorted_scatter() { return !options().disable_sorted_scatter; }
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
 // x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
@@ -173,11 +171,11 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
 }
 
 // Table mode, after the backward pass left one gradient row per compact token in w.dX0 (ids in w.rg.tok_key): add them into the
-// dense table gradient deterministically (table_grad.hip) -- unless the caller asked for the row-sparse form
+// dense table gradient deterministically (table_grad.hip; opts.deterministic) -- unless the caller asked for the row-sparse form
 // (opts.sparse_table_grad: the list stays in the workspace for matcha_table_grad_rows / the data-parallel exchange).
 static int table_gradient(const matcha_shape& s, const matcha_step_opts& o, const Workspace& w, int64_t Tn, matcha_tensors& g, hipStream_t st) {
   if (o.sparse_table_grad) return MATCHA_OK;
-  if (!sorted_scatter()) return MATCHA_OK;                // the front-end kernel already added the rows with float atomics
+  if (!o.deterministic) return MATCHA_OK;                 // the front-end kernel already added the rows with float atomics
   return launch_table_grad(w.rg.tok_key, w.dX0, Tn, s.d, s.n_nodes, g.table, w.tg_ws, w.tg_ws_bytes, st);
 }
 
@@ -337,11 +335,14 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     const bool lif = loss_in_forward(s, *opts, y, w_bce);            // the tail's backward runs in this kernel: nothing saved
     const bool save = !opts->forward_only && !lif;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
+    // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
+    // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
+    float* lg_out = (logits && !save) ? logits : w.logits;
     MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
-                                w.logits, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
+                                lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                 lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, (!opts->forward_only && save_qkv()) ? w.qkv : nullptr));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
-    if (logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
     }
     return MATCHA_OK;
@@ -505,7 +506,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
-      const bool rows_out = s.mode == 1 || sorted_scatter() || opts->sparse_table_grad;     // dX0 rows instead of float atomics
+      const bool rows_out = s.mode == 1 || opts->deterministic || opts->sparse_table_grad;     // dX0 rows instead of float atomics
       MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
                                   rows_out ? w.dX0 : nullptr, rows_out ? nullptr : g_.table, w.front_ws, g_, st));
       if (s.mode == 0) {
@@ -552,7 +553,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   // node embedding
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
-    if (sorted_scatter() || opts->sparse_table_grad) MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));
+    if (opts->deterministic || opts->sparse_table_grad) MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));
     else MATCHA_TRY(launch_embed_scatter(ids, Tn, d, w.dX0, g_.table, st, cnt));
     if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
   } else {

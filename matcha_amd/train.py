@@ -110,20 +110,21 @@ class Session:
     """Everything one training run needs on the device: model, fused trainer, positive set, negative sampler."""
 
     def __init__(self, model: Classifier, node2chrom: np.ndarray, chrom_range: np.ndarray, min_size: int, max_size: int, min_dis: int,
-                 seed: int = 0):
+                 seed: int = 0, deterministic: bool = False):
+        self.deterministic = deterministic
         self.model = model
         self.dev = model.layer_norm1.weight.device
         self.min_size, self.max_size, self.min_dis = min_size, max_size, min_dis
         self.node2chrom, self.chrom_range = node2chrom, chrom_range
         self.n_chrom = len(chrom_range)
         self.rank, self.world = _dist()
-        self.trainer = Trainer(model, lr=1e-3, base_seed=seed)                    # AdamW(lr=1e-3), main.py:630
+        self.trainer = Trainer(model, lr=1e-3, base_seed=seed, deterministic=deterministic)      # AdamW(lr=1e-3), main.py:630
         self.set_known(None)
         self.rng = np.random.default_rng(seed)
 
     def new_optimizer(self):
         """main.py:671 builds a fresh AdamW (moments and step counts reset) for phase 2."""
-        self.trainer = Trainer(self.model, lr=1e-3, base_seed=int(self.rng.integers(1 << 30)))
+        self.trainer = Trainer(self.model, lr=1e-3, base_seed=int(self.rng.integers(1 << 30)), deterministic=self.deterministic)
 
     def set_known(self, edges: Optional[np.ndarray]):
         """The 'dict' negatives are checked against (main.py:589 empty sets in phase 1; build_hash at :664)."""
@@ -266,7 +267,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, str]:
 
 
 def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 30, batches_per_epoch: int = 1000, device: str = "cuda",
-        emb_path: Optional[str] = "../embeddings.npy", log=print) -> Classifier:
+        emb_path: Optional[str] = "../embeddings.npy", log=print, deterministic: bool = False) -> Classifier:
     """The script body of main.py:516-685 (on every rank of a data-parallel launch, see the module docstring)."""
     rank, world = _dist()
     if world > 1:
@@ -307,7 +308,7 @@ def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 3
     if rank == 0:
         save_embeddings(model, N, emb_path)                                       # main.py:625
 
-    sess = Session(model, node2chrom, chrom_range.astype(np.int32), min_size, max_size, min_dis)
+    sess = Session(model, node2chrom, chrom_range.astype(np.int32), min_size, max_size, min_dis, deterministic=deterministic)
     # phase 1: alpha 0, beta 1, empty dict (negatives == positives)             main.py:637-643
     train(sess, (train_data, train_w), (test_data, test_w), epochs1, 0.0, 1.0, temp_dir, N, batches_per_epoch=batches_per_epoch,
           emb_path=emb_path, log=log)
@@ -331,9 +332,10 @@ def main(argv=None):
     ap.add_argument("--epochs1", type=int, default=3)
     ap.add_argument("--epochs2", type=int, default=30)
     ap.add_argument("--batches-per-epoch", type=int, default=1000)
+    ap.add_argument("--deterministic", action="store_true", help="table front end: sorted embedding backward (bitwise reproducible table)")
     a = ap.parse_args(argv)
     rank, world, device = init_distributed()
-    run(U.get_config(a.config), a.front_end, a.epochs1, a.epochs2, a.batches_per_epoch, device=device)
+    run(U.get_config(a.config), a.front_end, a.epochs1, a.epochs2, a.batches_per_epoch, device=device, deterministic=a.deterministic)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -96,9 +96,11 @@ def test_full_size_properties_table():
     assert float(g[~seen].abs().max()) == 0.0 and float(g[seen][1:].abs().max()) > 0.0
 
 
-def test_full_size_train_step_is_reproducible():
-    """Two Trainers from identical weights fed the same batch produce the same loss and (up to the embedding
-    scatter's atomic ordering) the same parameters; everything except the table is bitwise equal."""
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_full_size_train_step_is_reproducible(deterministic):
+    """Two Trainers from identical weights fed the same batch produce the same loss and the same parameters: with
+    Trainer(deterministic=True) EVERYTHING is bitwise equal, the table included (sorted embedding backward, csrc/table_grad.hip);
+    with the default float-atomic scatter the table agrees up to the order of its additions and the rest is bitwise equal."""
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS["hg38_1mb"]
     N = int(np.sum(num))
@@ -110,14 +112,15 @@ def test_full_size_train_step_is_reproducible():
     for _ in range(2):
         clf, _ = hip_model(num, 64, "table", 3)
         clf.train()
-        tr = Trainer(clf, base_seed=5)
-        bce, _, _ = tr.step(x, y, w)
+        tr = Trainer(clf, base_seed=5, deterministic=deterministic)
+        for _ in range(3 if deterministic else 1):      # with atomics the table differs in the last bits after one step, and everything after it then does
+            bce, _, _ = tr.step(x, y, w)
         torch.cuda.synchronize()
         outs.append((float(bce), {n: p.detach().clone() for n, p in clf.named_parameters()}))
     assert outs[0][0] == outs[1][0]
     for n in outs[0][1]:
         a, b = outs[0][1][n], outs[1][1][n]
-        if n == "node_embedding.weight":
+        if n == "node_embedding.weight" and not deterministic:
             assert torch.allclose(a, b, rtol=0, atol=1e-6)
         else:
             assert torch.equal(a, b), n

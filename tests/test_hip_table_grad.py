@@ -50,9 +50,9 @@ def test_scatter_rows_matches_index_add_and_is_reproducible(n_nodes, d, n):
 
 @pytest.mark.parametrize("d,layout", [(64, "hg38_1mb"), (128, "c1")])
 def test_sorted_table_gradient_equals_atomic_scatter_and_is_bitwise_reproducible(d, layout):
-    """The Trainer's table gradient with the sort + segmented sum (default) against the float-atomic scatter it replaces
-    (option disable_sorted_scatter), fused (d = 64) and layer-wise (d = 128) paths; two runs of the default path are bitwise equal
-    INCLUDING the table (round 1 had to exempt it)."""
+    """The Trainer's table gradient with the sort + segmented sum (Trainer(deterministic=True)) against the float-atomic scatter
+    (the default), fused (d = 64) and layer-wise (d = 128) paths; two runs of the deterministic path are bitwise equal INCLUDING
+    the table (round 1 had to exempt it)."""
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS[layout]
     N = int(np.sum(num))
@@ -63,13 +63,12 @@ def test_sorted_table_gradient_equals_atomic_scatter_and_is_bitwise_reproducible
     w = torch.ones(len(x), device="cuda")
     grads = []
     for sorted_ in (True, True, False):
-        with _lib.option("disable_sorted_scatter", 0 if sorted_ else 1):
-            clf, _ = hip_model(num, d, "table", 3)
-            clf.train()
-            tr = Trainer(clf, base_seed=5)
-            tr.forward_backward(x, y, w, 1.0, 0.001, 0)
-            torch.cuda.synchronize()
-            grads.append(tr.gflat.clone())
+        clf, _ = hip_model(num, d, "table", 3)
+        clf.train()
+        tr = Trainer(clf, base_seed=5, deterministic=sorted_)
+        tr.forward_backward(x, y, w, 1.0, 0.001, 0)
+        torch.cuda.synchronize()
+        grads.append(tr.gflat.clone())
     assert torch.equal(grads[0], grads[1])                                      # bitwise, table included
     nt = (N + 1) * d
     a, b = grads[0][:nt], grads[2][:nt]
