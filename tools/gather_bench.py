@@ -6,7 +6,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matcha_amd import _lib
 
 lib = _lib.load()
