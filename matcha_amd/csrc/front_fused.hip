@@ -124,10 +124,7 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
       for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         Ds[row * kLd + col] = acc[reg];
-        const int64_t t = t_base + row;
-        if (g.dX0) {
-          if (t < T) g.dX0[t * 64 + col] = acc[reg];
-        } else {
+        if (!g.dX0) {
           const int id = ids_s[row];
           if (id != 0) atomicAdd(g.dtable + (int64_t)id * 64 + col, acc[reg]);      // embedding backward (padding_idx = 0 skipped)
         }
@@ -142,6 +139,16 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
       aWn = __builtin_amdgcn_mfma_f32_32x32x2f32(gz, X0s[t * kLd + 32 * wc + r], aWn, 0, 0, 0);
     }
     __syncthreads();                              // dX0 tile complete
+    if (g.dX0) {
+      // gradient rows for the adj front end / the sorted table gradient: whole 256-byte rows from the LDS tile (16 lanes x 16 B)
+      // instead of 16 four-byte stores per lane in the accumulator layout
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = srow + 16 * i;
+        const int64_t t = t_base + row;
+        if (t < T) *reinterpret_cast<float4*>(g.dX0 + t * 64 + sc4) = *reinterpret_cast<const float4*>(&Ds[row * kLd + sc4]);
+      }
+    }
     // ---- dWa[n][a] += sum_t dX0[t][n] attr[t][a]  (a < 32: the waves with wc = 0);  d ba = column sums of dX0 ----
     if (wc == 0) {
 #pragma unroll 8
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
   float* Es = lds + kTile;                        // node rows, then x0 in place
   float* Was = lds + 2 * kTile;                   // attribute_nn.weight [64][kLdA] (columns >= n_attr zero), resident
   float* As = Was + 64 * kLdA;                    // attribute rows [64][kLdA]
+  float* Xs = As + 64 * kLdA;                     // X tile on its way out
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
@@ -237,10 +245,16 @@ __global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
         const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         const float v = acc[reg] + bav + Es[row * kLd + col];
         Es[row * kLd + col] = v;                                      // in place: this lane owns the element
-        if (t_base + row < T) g.x0[(t_base + row) * 64 + col] = v;
       }
     }
     __syncthreads();
+    // x0 and (below) X leave as whole 256-byte rows read back from their LDS tiles -- 16 lanes x 16 bytes -- not as 16 four-byte
+    // stores per lane in the accumulator layout: this kernel only moves bytes, and store ISSUE was what bounded it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      if (t_base + row < T) *reinterpret_cast<float4*>(g.x0 + (t_base + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&Es[row * kLd + sc4]);
+    }
     // ---- X = tanh(x0 . Wn^T + bn) ----
     {
       f32x16 acc = {0};
@@ -256,8 +270,14 @@ __global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (t_base + row < T) g.X[(t_base + row) * 64 + col] = fast_tanh(acc[reg] + bnv);
+        Xs[row * kLd + col] = fast_tanh(acc[reg] + bnv);
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 16 * i;
+      if (t_base + row < T) *reinterpret_cast<float4*>(g.X + (t_base + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&Xs[row * kLd + sc4]);
     }
   }
 }
@@ -313,7 +333,7 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   int grid = front_grid();
   const int64_t max_tiles = cdiv(tcap, 64);
   if (grid > max_tiles) grid = (int)max_tiles;
-  const size_t lds = ((size_t)2 * kTile + 2 * 64 * kLdA) * sizeof(float);
+  const size_t lds = ((size_t)3 * kTile + 2 * 64 * kLdA) * sizeof(float);
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
   ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + 512.0), st);
   hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);

@@ -559,9 +559,12 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       cs1 += gh;
       aw = __builtin_amdgcn_mfma_f32_32x32x2f32(gh, H1s[t * kLdT + 32 * wc + r], aw, 0, 0, 0);
     }
-    const int col = 32 * wc + r;
+    // the slab is private scratch: it keeps the ACCUMULATOR layout ([wave][lane][16 registers] = four 16-byte stores per lane,
+    // 4 KB contiguous per wave) and tail_slab_reduce_kernel un-permutes once; written row-major this was 16 four-byte stores per
+    // lane and matrix, and store issue is what such an epilogue costs (gemm_wide.hip measured it)
+    f32x4* ts4 = reinterpret_cast<f32x4*>(tsl) + (wave * 64 + lane) * 4;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) tsl[(32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + col] = aw[reg];
+    for (int gq = 0; gq < 4; ++gq) ts4[gq] = (f32x4){aw[4 * gq], aw[4 * gq + 1], aw[4 * gq + 2], aw[4 * gq + 3]};
   }
   {
     f32x16 acc = {0};
@@ -599,9 +602,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       cs0 += gz;
       aw = __builtin_amdgcn_mfma_f32_32x32x2f32(gz, Ys[t * kLdT + 32 * wc + r], aw, 0, 0, 0);
     }
-    const int col = 32 * wc + r;
+    f32x4* ts4 = reinterpret_cast<f32x4*>(tsl + 4096) + (wave * 64 + lane) * 4;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) tsl[4096 + (32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + col] = aw[reg];
+    for (int gq = 0; gq < 4; ++gq) ts4[gq] = (f32x4){aw[4 * gq], aw[4 * gq + 1], aw[4 * gq + 2], aw[4 * gq + 3]};
   }
   {
     f32x16 acc = {0};
@@ -620,17 +623,25 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
       if (row <= n_real) {
         float v = 0.f;                                 // the padding token's row is masked (Modules.py:614)
-        const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
         if (row < n_real) {
           v = acc[reg] + H2s[row * kLdT + col];        // residual: H2 = conv1(H1) + Y
           if (drop1) v = ((keep1 >> reg) & 1u) ? v * ks1 : 0.f;
         }
-        g.ddyn0[tok * 64 + col] = v;
+        H2s[row * kLdT + col] = v;                     // in place: in this phase only the owning lane reads H2s[row][col]
       }
     }
   }
   // ---- parameter-vector partials of this tile: rows of the 16 staging groups, then the two column sums ----
   __syncthreads();                                     // all reads of the tiles are done: Qs is scratch now
+  // d dyn leaves as whole 256-byte rows (16 lanes x 16 bytes) instead of 16 four-byte stores per lane in the accumulator layout
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = srow + 16 * i;
+    if (row <= n_real) {
+      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
+      *reinterpret_cast<float4*>(g.ddyn0 + tok * 64 + sc4) = *reinterpret_cast<const float4*>(&H2s[row * kLdT + sc4]);
+    }
+  }
   float* red = Qs;                                     // [16][7][64]
   *reinterpret_cast<float4*>(&red[(srow * 7 + 0) * 64 + sc4]) = aGp; *reinterpret_cast<float4*>(&red[(srow * 7 + 1) * 64 + sc4]) = aBp;
   *reinterpret_cast<float4*>(&red[(srow * 7 + 2) * 64 + sc4]) = aG1; *reinterpret_cast<float4*>(&red[(srow * 7 + 3) * 64 + sc4]) = aB1;
@@ -688,8 +699,12 @@ __global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) s += part[t][o];
-    if (i < 4096) a.dst[0][i] += s;
-    else if (i < 8192) a.dst[1][i - 4096] += s;
+    if (i < 8192) {
+      // the two weight-gradient matrices arrive in the MFMA accumulator layout [wave][lane][register] (fused_fwd_kernel)
+      const int e = i & 4095, wv = e >> 10, ln = (e >> 4) & 63, reg = e & 15;
+      const int row = 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), col = 32 * (wv >> 1) + (ln & 31);
+      a.dst[i >> 12][row * 64 + col] += s;
+    }
     else { const int v = (i - kTailVec) >> 6, j = (i - kTailVec) & 63; a.dst[2 + v][j] += s; }
   }
 }

@@ -47,11 +47,17 @@ def _worker(rank, world, port, out_dir, mode, d):
     x, y, w = _batch(num)
     idx = shard_rows(len(x), rank, world)
     xs, ys, ws = (torch.from_numpy(a[idx]).cuda() for a in (x, y, w))
-    for _ in range(2):
-        tr.step(xs, ys, ws, alpha=1.0, beta=0.3, random_chrom=1)
+    # step 0 taken apart so that the EXCHANGED gradient can be compared (parameters after AdamW amplify rounding noise near eps)
+    tr.forward_backward(xs, ys, ws, 1.0, 0.3, 1)
+    tr.all_reduce()
+    torch.cuda.synchronize()
+    g0 = (tr.gflat / world).cpu()
+    t0 = tr.touched.cpu()
+    tr.optimizer_step()
+    tr.step(xs, ys, ws, alpha=1.0, beta=0.3, random_chrom=1)
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({n: p.detach().cpu() for n, p in clf.named_parameters()}, os.path.join(out_dir, "dp.pt"))
+        torch.save({"params": {n: p.detach().cpu() for n, p in clf.named_parameters()}, "g0": g0, "touched": t0}, os.path.join(out_dir, "dp.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,13 +75,23 @@ def test_two_rank_trainer_equals_single_rank_on_global_batch(tmp_path, mode, d):
     tr = Trainer(clf, lr=1e-3)
     x, y, w = _batch(num)
     xt, yt, wt = (torch.from_numpy(a).cuda() for a in (x, y, w))
-    for _ in range(2):
-        tr.step(xt, yt, wt, alpha=1.0, beta=0.3, random_chrom=1)
+    tr.forward_backward(xt, yt, wt, 1.0, 0.3, 1)
     torch.cuda.synchronize()
+    g_ref, t_ref = tr.gflat.cpu(), tr.touched.cpu()
+    tr.optimizer_step()
+    tr.step(xt, yt, wt, alpha=1.0, beta=0.3, random_chrom=1)
+    torch.cuda.synchronize()
+    # the exchanged gradient (sum over the two ranks / 2) == the single-rank gradient on the global batch, tensor by tensor, and
+    # "grad is None" (the touched flags) is decided on the global batch
+    assert torch.equal(got["touched"], t_ref)
+    rt = tr.rt
+    for p_, o in zip(rt.live, rt.seg_off_list[:-1]):
+        ref = g_ref[o:o + p_.numel()]
+        assert float((got["g0"][o:o + p_.numel()] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6), o
     for n, p in clf.named_parameters():
         if n == GAUGE:
             continue
-        a, b = p.detach().cpu(), got[n]
+        a, b = p.detach().cpu(), got["params"][n]
         diff, scale = (a - b).abs().reshape(-1), max(1.0, float(a.abs().max()))
         # the two runs sum the same fp32 terms in a different order; AdamW's g / (|g| + eps) turns that rounding noise into a
         # visible fraction of lr only where |g| is itself near eps: all but a handful of elements agree to 2e-5, none moves
@@ -102,12 +118,21 @@ def _sparse_worker(rank, world, port, out_dir, exchange, d):
         x, y, w = synth.make_batch(rng, N, [2, 3, 4, 5], 64)                   # 256 rows, the same global batch on both ranks
         idx = shard_rows(len(x), rank, world)
         xs, ys, ws = (torch.from_numpy(a[idx]).cuda() for a in (x, y.reshape(-1), w.reshape(-1)))
-        tr.step(xs, ys, ws, alpha=1.0, beta=0.0)
+        if step == 0:
+            # the step taken apart: the exchanged gradient (sum over ranks, scaled by 1/world in AdamW) is what must equal the
+            # single-rank gradient on the global batch; parameters after AdamW amplify rounding noise wherever |g| ~ eps
+            tr.forward_backward(xs, ys, ws, 1.0, 0.0, 0)
+            tr.all_reduce()
+            torch.cuda.synchronize()
+            g0 = (tr.gflat / world).cpu()
+            tr.optimizer_step()
+        else:
+            tr.step(xs, ys, ws, alpha=1.0, beta=0.0)
         assert tr._sparse == (exchange == "sparse")
     torch.cuda.synchronize()
     tr.check_status()
     if rank == 0:
-        torch.save({n: p.detach().cpu() for n, p in clf.named_parameters()}, os.path.join(out_dir, f"dp_{exchange}.pt"))
+        torch.save({"params": {n: p.detach().cpu() for n, p in clf.named_parameters()}, "g0": g0}, os.path.join(out_dir, f"dp_{exchange}.pt"))
     # both ranks must hold the same parameters bit for bit (same gradient, same AdamW)
     flat = clf._runtime().flat.detach().cpu()
     both = [torch.zeros_like(flat) for _ in range(world)]
@@ -130,8 +155,9 @@ def test_two_rank_sparse_table_exchange_equals_dense_and_single_rank(tmp_path, d
         out.mkdir()
         mp.spawn(_sparse_worker, args=(2, _free_port(), str(out), exchange, d), nprocs=2, join=True)
         runs[tag] = torch.load(os.path.join(out, f"dp_{exchange}.pt"), weights_only=False)
-    for n in runs["sparse"]:
-        assert torch.equal(runs["sparse"][n], runs["sparse2"][n]), n              # bitwise reproducible, table included
+    for n in runs["sparse"]["params"]:
+        assert torch.equal(runs["sparse"]["params"][n], runs["sparse2"]["params"][n]), n      # bitwise reproducible, table included
+    assert torch.equal(runs["sparse"]["g0"], runs["sparse2"]["g0"])
     num = synth.LAYOUTS["c1"]
     N = int(np.sum(num))
     clf, _ = hip_model(num, d, "table", 50)
@@ -140,17 +166,33 @@ def test_two_rank_sparse_table_exchange_equals_dense_and_single_rank(tmp_path, d
     rng = np.random.default_rng(8)
     for step in range(6):
         x, y, w = synth.make_batch(rng, N, [2, 3, 4, 5], 64)
-        tr.step(torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(), torch.from_numpy(w.reshape(-1)).cuda(), alpha=1.0, beta=0.0)
+        xt, yt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(), torch.from_numpy(w.reshape(-1)).cuda()
+        if step == 0:
+            tr.forward_backward(xt, yt, wt, 1.0, 0.0, 0)
+            torch.cuda.synchronize()
+            g_ref = tr.gflat.cpu()
+            tr.optimizer_step()
+        else:
+            tr.step(xt, yt, wt, alpha=1.0, beta=0.0)
     torch.cuda.synchronize()
+    # (1) the exchanged gradient of step 0 == the single-rank gradient on the global batch, tensor by tensor
+    rt = tr.rt
+    for p_, o in zip(rt.live, rt.seg_off_list[:-1]):
+        ref = g_ref[o:o + p_.numel()]
+        for tag in ("sparse", "dense"):
+            got = runs[tag]["g0"][o:o + p_.numel()]
+            assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6), (tag, o)
+    # (2) parameters after six AdamW steps: all but a fraction of a percent of the elements agree closely; where |g| is within a few
+    #     orders of eps the rounding noise of the two summation orders moves an element by up to lr per step in either direction
     for n, p in clf.named_parameters():
         if n == GAUGE:
             continue
         a = p.detach().cpu()
         for tag in ("sparse", "dense"):
-            b = runs[tag][n]
+            b = runs[tag]["params"][n]
             diff, scale = (a - b).abs().reshape(-1), max(1.0, float(a.abs().max()))
-            assert float(torch.quantile(diff[:1 << 20], 0.999)) <= 2e-5 * scale, (tag, n)
-            assert float(diff.max()) <= 6e-4 * scale, (tag, n, float(diff.max()))   # six steps of at most lr each where |g| ~ eps
+            assert float(torch.quantile(diff[:1 << 20], 0.99)) <= 2e-5 * scale, (tag, n)
+            assert float(diff.max()) <= 2 * 1e-3 * 6 + 1e-5 * scale, (tag, n, float(diff.max()))
 
 
 def _run_worker(rank, world, port, tmp, front_end):
