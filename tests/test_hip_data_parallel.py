@@ -87,7 +87,8 @@ def test_two_rank_trainer_equals_single_rank_on_global_batch(tmp_path, mode, d):
     rt = tr.rt
     for p_, o in zip(rt.live, rt.seg_off_list[:-1]):
         ref = g_ref[o:o + p_.numel()]
-        assert float((got["g0"][o:o + p_.numel()] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6), o
+        # (absolute floor: one tensor's true gradient is zero -- the gauge direction, DESIGN.md §2 -- and holds rounding noise ~1e-9)
+        assert float((got["g0"][o:o + p_.numel()] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 2e-8, o
     for n, p in clf.named_parameters():
         if n == GAUGE:
             continue
@@ -181,7 +182,7 @@ def test_two_rank_sparse_table_exchange_equals_dense_and_single_rank(tmp_path, d
         ref = g_ref[o:o + p_.numel()]
         for tag in ("sparse", "dense"):
             got = runs[tag]["g0"][o:o + p_.numel()]
-            assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6), (tag, o)
+            assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 2e-8, (tag, o)
     # (2) parameters after six AdamW steps: all but a fraction of a percent of the elements agree closely; where |g| is within a few
     #     orders of eps the rounding noise of the two summation orders moves an element by up to lr per step in either direction
     for n, p in clf.named_parameters():
