@@ -184,7 +184,7 @@ typedef struct matcha_step_opts {
 size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L);
 /* Scratch (bytes) that is enough for matcha_forward with opts->forward_only = 1 (inference: predict(), the pairwise sweep,
  * save_embeddings).  At embed_dim 64 only the ragged plan, two [tokens, d] buffers and the front end's buffers exist
- * (~1 KB per token instead of ~27 KB); for other shapes it equals matcha_workspace_bytes. */
+ * (~1 KB per token instead of ~20 KB); for other shapes it equals matcha_workspace_bytes. */
 size_t matcha_workspace_bytes_forward(const matcha_shape* shp, int64_t B, int32_t L);
 
 /* Classifier.forward(x, return_recon=True) (Modules.py:278-318) + the weighted BCE of main.py:56.
@@ -204,7 +204,9 @@ int matcha_forward(const matcha_shape* shp, const matcha_tensors* params, const 
  * Gradients are ACCUMULATED into `grads` (same layout as params; caller zeroes them -- the fused AdamW
  * does).  `touched` (device int32 [2+2C], may be NULL) receives 1 for each tensor group that received a
  * gradient this step: [0] always 1, [1] table, [2+i] adj encoder of chromosome i, [2+C+i] recon head i --
- * these are the tensors whose grad is not None in the reference (SURVEY.md §7 "AdamW semantics"). */
+ * these are the tensors whose grad is not None in the reference (SURVEY.md §7 "AdamW semantics").
+ * The call CONSUMES the activations its forward left in `ws` (gradients overwrite them): one backward per forward,
+ * as loss.backward() without retain_graph. */
 int matcha_backward(const matcha_shape* shp, const matcha_tensors* params, const matcha_frozen* frozen,
                     const matcha_step_opts* opts, const int64_t* x, int64_t B, int32_t L,
                     const float* y, const float* w, const float* dlogits, const float* drecon,

@@ -418,7 +418,7 @@ class _ClassifierFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rt: _Runtime, opts: "_lib.StepOpts", seed_t, *live):
         B, L = x.shape
-        ws = rt.workspace(B, L, forward_only=bool(opts.forward_only))      # inference: ~1 KB per token instead of ~27 KB
+        ws = rt.workspace(B, L, forward_only=bool(opts.forward_only))      # inference: ~1 KB per token instead of ~20 KB
         logits = torch.empty(B, dtype=torch.float32, device=rt.device)
         losses = torch.zeros(3, dtype=torch.float32, device=rt.device)
         opts.status = rt.status.data_ptr()
@@ -432,6 +432,9 @@ class _ClassifierFn(torch.autograd.Function):
     def backward(ctx, dlogits, drecon):
         rt, opts, x = ctx.rt, ctx.opts, ctx.x
         B, L = x.shape
+        if ctx.ws is None:      # matcha_backward overwrites the saved activations with their gradients (include/matcha_hip.h)
+            raise RuntimeError("matcha_amd: second backward through the same forward (retain_graph=True is not supported: "
+                               "the backward pass consumes the forward's workspace, as torch frees its saved tensors)")
         gflat = torch.zeros(rt.n_flat, dtype=torch.float32, device=rt.device)
         grads = rt.tensors_for(gflat)
         touched = torch.zeros(rt.n_touched, dtype=torch.int32, device=rt.device)
@@ -440,6 +443,7 @@ class _ClassifierFn(torch.autograd.Function):
         _lib.check(rt.lib.matcha_backward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                           None, None, _lib.ptr(dl), _lib.ptr(dr), C.byref(grads), _lib.ptr(touched), _lib.ptr(ctx.ws),
                                           ctx.ws.numel(), rt.stream()), "matcha_backward")
+        ctx.ws = None
         outs = []
         tl = touched.tolist() if rt.mode == 1 else None      # adj: which per-chromosome tensors have grad None
         for p, o, g in zip(rt.live, rt.seg_off_list[:-1], rt.seg_group_list):

@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 //   dQ_i = sum_j dS_ij K_j + n_pad dSp_i K_pad ;  dK_j = sum_i dS_ij Q_i ;  dK_pad += n_pad * sum_i dSp_i Q_i
 // slab[blk] = {dK_pad [8d], dV_pad [8d]} summed over the block's hyperedges (waves in fixed order).
 template <int CH, int kMaxL, int NCHUNK>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* Q, const float* K, const float* V,
                                                        const float* __restrict__ P, const float* __restrict__ dO,
                                                        const int32_t* __restrict__ row_off, int64_t B, int L, int d, float inv_temp,
-                                                       float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+                                                       float* dQ, float* dK, float* dV,
                                                        float* __restrict__ slab) {
   extern __shared__ float red[];                 // [2][8d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -156,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const float* __re
 // backward: formulas in attention.hip (attn_bwd_kernel).  slab[blk] = {dK_pad [8d], dV_pad [8d]} of the block's hyperedges
 // (waves added in a fixed order).
 template <int kMaxL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+__global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, const float* K, const float* V,
                                                             const float* __restrict__ P, const float* __restrict__ dO,
                                                             const int32_t* __restrict__ row_off, int64_t B, int L, int d, float inv_temp,
-                                                            float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+                                                            float* dQ, float* dK, float* dV,
                                                             float* __restrict__ slab) {
   extern __shared__ float lds[];                 // [4 waves][2][8d] padding-token partial sums | [4 waves][8 heads][kMaxL * kMaxL] probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   // ---- parameter-vector partials of this tile: rows of the 16 staging groups, then the two column sums ----
-  __syncthreads();                                     // all reads of the tiles are done: Qs is scratch now
+  __syncthreads();                                     // all reads of the tiles are done: Bs / dZs are scratch now
   // d dyn leaves as whole 256-byte rows (16 lanes x 16 bytes) instead of 16 four-byte stores per lane in the accumulator layout
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -642,12 +642,14 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       *reinterpret_cast<float4*>(g.ddyn0 + tok * 64 + sc4) = *reinterpret_cast<const float4*>(&H2s[row * kLdT + sc4]);
     }
   }
-  float* red = Qs;                                     // [16][7][64]
+  // [16][7][64] + the column sums: 7312 floats laid over the weight tile and the front of the dZ tile (tiles 0, 1 -- both dead
+  // after the barrier above).  NOT over tile 2: the rows of H2s are still being copied out by slower waves in this phase.
+  float* red = Bs;
   *reinterpret_cast<float4*>(&red[(srow * 7 + 0) * 64 + sc4]) = aGp; *reinterpret_cast<float4*>(&red[(srow * 7 + 1) * 64 + sc4]) = aBp;
   *reinterpret_cast<float4*>(&red[(srow * 7 + 2) * 64 + sc4]) = aG1; *reinterpret_cast<float4*>(&red[(srow * 7 + 3) * 64 + sc4]) = aB1;
   *reinterpret_cast<float4*>(&red[(srow * 7 + 4) * 64 + sc4]) = aG2; *reinterpret_cast<float4*>(&red[(srow * 7 + 5) * 64 + sc4]) = aB2;
   *reinterpret_cast<float4*>(&red[(srow * 7 + 6) * 64 + sc4]) = aWc;
-  float* redc = Qs + 16 * 7 * 64;                      // [2][64] column sums, [16] bc partials
+  float* redc = red + 16 * 7 * 64;                     // [2][64] column sums, [16] bc partials
   cs1 += __shfl_xor(cs1, 32, 64);
   cs0 += __shfl_xor(cs0, 32, 64);
   if (wc == 0 && h == 0) { redc[32 * wr + r] = cs1; redc[64 + 32 * wr + r] = cs0; }

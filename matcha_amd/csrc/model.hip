@@ -136,8 +136,14 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.row_loss = take_always(B); w.logits = take_always(B);
   w.node = take_always(s.mode == 1 ? Tn * d : 0);
   w.dH2 = take(Tn * d); w.dXs = take(Tn * d); w.dZ1 = take(Tn * d); w.ddyn0 = take(Tn * d);
-  w.dO = take(Tn * hd); w.dQ = take(Tn * hd); w.dK = take(Tn * hd); w.dV = take(Tn * hd);
-  w.dqin = take(Tn * d); w.dkin = take(Tn * d); w.dvin = take(Tn * d);
+  // The attention block's gradients REPLACE the activations they are computed from (layer-by-layer path; the 8d-wide tensors are
+  // 32 of the ~80 d floats a token cost): dO overwrites O once the fc1 weight gradient has read it; attn_bwd reads every V chunk
+  // of a hyperedge before it writes its first dV chunk, and per chunk loads all K rows before it stores dQ and all Q rows before
+  // it stores dK -- so dV lives in V, dQ in K's buffer and dK in Q's (attention.hip / attention_wide.hip keep that order);
+  // dqin / dkin / dvin overwrite qin / kin / vin after the projection weight gradients have read them.  With embed_dim 64 the
+  // fused kernels use dO as the 8 per-head d x_hat slabs and never touch Q/K/V/O, so there the alias is harmless too.
+  w.dO = w.O; w.dQ = w.K; w.dK = w.Q; w.dV = w.V;
+  w.dqin = w.qin; w.dkin = w.kin; w.dvin = w.vin;
   w.dZ0 = take(Tn * d); w.dX0 = take(Tn * d);
   size_t sb = colsum_slab_bytes(Tn, 6, (int)d);
   size_t sb2 = colsum_slab_bytes(B, 7, (int)d);

@@ -319,3 +319,17 @@ def test_adamw_fused_vs_torch():
     for i, p in enumerate(params):
         ref = p.detach()
         assert (got[offs[i]:offs[i] + sizes[i]] - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())), i
+
+
+def test_second_backward_through_one_forward_is_refused():
+    """matcha_backward overwrites the saved activations with their gradients (include/matcha_hip.h): like torch without
+    retain_graph, a second backward through the same forward must fail loudly, not return garbage."""
+    num = synth.LAYOUTS["tiny"]
+    clf, _ = hip_model(num, 128, "table", 4)
+    clf.train()
+    x, y, _ = synth.make_batch(np.random.default_rng(0), int(np.sum(num)), [2, 3], 8)
+    lg = clf(torch.from_numpy(x))
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.from_numpy(y).cuda())
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()

@@ -109,21 +109,22 @@ def test_full_size_train_step_is_reproducible(deterministic):
     y = (torch.rand(len(x), device="cuda") < 0.25).float()
     w = torch.ones(len(x), device="cuda")
     outs = []
-    for _ in range(2):
+    for _ in range(4):                                   # an intra-kernel race shows up in a fraction of the runs only: take several
         clf, _ = hip_model(num, 64, "table", 3)
         clf.train()
         tr = Trainer(clf, base_seed=5, deterministic=deterministic)
-        for _ in range(3 if deterministic else 1):      # with atomics the table differs in the last bits after one step, and everything after it then does
+        for _ in range(6 if deterministic else 1):      # with atomics the table differs in the last bits after one step, and everything after it then does
             bce, _, _ = tr.step(x, y, w)
         torch.cuda.synchronize()
         outs.append((float(bce), {n: p.detach().clone() for n, p in clf.named_parameters()}))
-    assert outs[0][0] == outs[1][0]
-    for n in outs[0][1]:
-        a, b = outs[0][1][n], outs[1][1][n]
-        if n == "node_embedding.weight" and not deterministic:
-            assert torch.allclose(a, b, rtol=0, atol=1e-6)
-        else:
-            assert torch.equal(a, b), n
+    for other in outs[1:]:
+        assert outs[0][0] == other[0]
+        for n in outs[0][1]:
+            a, b = outs[0][1][n], other[1][n]
+            if n == "node_embedding.weight" and not deterministic:
+                assert torch.allclose(a, b, rtol=0, atol=1e-6)
+            else:
+                assert torch.equal(a, b), n
 
 
 class _env:
