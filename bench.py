@@ -317,7 +317,11 @@ def gather_roofline(device):
     out = []
     for name, N, d, T, resident in (("1M x 64 (244 MiB table: Infinity-Cache sized)", 1 << 20, 64, 1 << 24, "mall"),
                                     ("16M x 64 (4 GiB table)", 1 << 24, 64, 1 << 24, "hbm"),
-                                    ("C5 1M x 256 (1 GiB table)", 1 << 20, 256, 1 << 22, "hbm")):
+                                    ("C5 1M x 256 (1 GiB table)", 1 << 20, 256, 1 << 22, "hbm"),
+                                    # the same two HBM-resident tables at the launch size a training step has (its token count): the
+                                    # gathered rows (80 / 128 MiB) then stay in the 256 MiB Infinity Cache instead of streaming out
+                                    ("16M x 64 (4 GiB table), one step's tokens per launch (65536 x 5)", 1 << 24, 64, 65536 * 5, "hbm"),
+                                    ("C5 1M x 256 (1 GiB table), one C5 step's tokens per launch (16384 x 8)", 1 << 20, 256, 16384 * 8, "hbm")):
         table = torch.randn(N + 1, d, device=device)
         ids = torch.randint(1, N + 1, (T,), device=device, dtype=torch.int64)
         rows = torch.empty(T, d, device=device)

@@ -318,6 +318,110 @@ __device__ __forceinline__ void attn_col_fb(const float* __restrict__ Qs, const 
   }
 }
 
+// Streaming variants for the eight-wave kernel (256 registers per lane): one key / value row live at a time plus the next one in
+// flight, fenced so that the scheduler does not hoist all ML rows of a pass (its default: 40 - 80 registers of operands).  With two
+// wavefronts per SIMD the other wave covers the LDS latency this gives up.  The forward pass's probabilities are required (have_p).
+// FB_PIN(addr, x): an empty asm that takes the LDS offset of the NEXT row and the eight registers of the running sum as in/out operands:
+// the load of row j + 1 cannot be issued before the arithmetic on row j - 1 has produced x, so exactly one row is in use and one
+// in flight.  (sched_barrier alone does not do it: instruction selection has already placed the unchained LDS loads of all rows
+// ahead of the arithmetic when the machine scheduler sees the fence.)
+#define FB_PIN(addr, x) asm volatile("" : "+v"(addr), "+v"((x).a), "+v"((x).b), "+v"((x).c), "+v"((x).d))
+template <int ML>
+__device__ __forceinline__ void attn_row8(const float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs,
+                                          const float* __restrict__ Fs, const float* __restrict__ kpad, const float* __restrict__ vpad,
+                                          const float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0, int k, int n_pad, int sub,
+                                          float inv_temp, V8& o, V8& gq, V8& accK, V8& accV) {
+  const float padf = (float)n_pad;
+  const bool hp = n_pad > 0;
+  float p[ML], ds[ML], pp, dsp;
+  {
+    const float4 pa = *reinterpret_cast<const float4*>(&Ps[li * 8]), pb = *reinterpret_cast<const float4*>(&Ps[li * 8 + 4]);
+    const float w[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+    for (int j = 0; j < ML; ++j) p[j] = (j < k) ? w[j] : 0.f;
+    pp = hp ? w[7] : 0.f;
+  }
+  const float ppf = padf * pp;
+  const int ro0 = li0 * kLd + 8 * sub;                   // key / value row j (clamped to the hyperedge): ro0 + min(j, k - 1) rows
+  {
+    const V8 go = ld8(&Fs[li * kLd + 8 * sub]);
+    const V8 vp = ld8(vpad + 8 * sub);
+    o = scale8(ppf, vp);
+    dsp = group_sum8_dpp(dot8(go, vp));
+    float sig = ppf * dsp;
+    V8 vn = ld8(&Vs[ro0]);
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      const V8 v = vn;
+      if (j + 1 < ML) {
+        int a = ro0 + (j + 1 < k ? j + 1 : 0) * kLd;
+        FB_PIN(a, o);
+        vn = ld8(&Vs[a]);
+      }
+      axpy8(o, p[j], v);
+      const float d = group_sum8_dpp(dot8(go, v));
+      ds[j] = d;
+      sig += p[j] * d;
+    }
+#pragma unroll
+    for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
+    dsp = pp * (dsp - sig) * inv_temp;
+    axpy8(accV, ppf, go);
+  }
+  const float dspf = padf * dsp;
+  {
+    const V8 kp = ld8(kpad + 8 * sub);
+    gq = scale8(dspf, kp);
+    int a0 = ro0;
+    FB_PIN(a0, o);                                     // the K pass starts after the V pass is done with its rows
+    V8 kn = ld8(&Ks[a0]);
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      const V8 kk = kn;
+      if (j + 1 < ML) {
+        int a = ro0 + (j + 1 < k ? j + 1 : 0) * kLd;
+        FB_PIN(a, gq);
+        kn = ld8(&Ks[a]);
+      }
+      axpy8(gq, ds[j], kk);
+    }
+  }
+  {
+    int a = li * kLd + 8 * sub;
+    FB_PIN(a, gq);
+    const V8 q = ld8(&Qs[a]);
+    axpy8(accK, dspf, q);
+  }
+  if (sub == 1) {                                          // row i of dS for the column phase (P is in Ps already)
+    float* dst = dSs + li * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(ds[0], ds[1 % ML], ML > 2 ? ds[2 % ML] : 0.f, ML > 3 ? ds[3 % ML] : 0.f);
+    if (ML > 4) *reinterpret_cast<float4*>(dst + 4) = make_float4(ds[4 % ML], ML > 5 ? ds[5 % ML] : 0.f, ML > 6 ? ds[6 % ML] : 0.f, ML > 7 ? ds[7 % ML] : 0.f);
+  }
+}
+
+template <int ML>
+__device__ __forceinline__ void attn_col8(const float* __restrict__ Qs, const float* __restrict__ Fs, const float* __restrict__ Ps,
+                                          const float* __restrict__ dSs, int li, int li0, int k, int sub, V8& gk, V8& gv) {
+  const int jj = li - li0;
+  gk = zero8();
+  gv = zero8();
+  const int ro0 = li0 * kLd + 8 * sub;
+  V8 qn = ld8(&Qs[ro0]), gn = ld8(&Fs[ro0]);
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    const V8 q = qn, go = gn;
+    const int ri = li0 + (i < k ? i : 0);
+    const float pij = (i < k) ? Ps[ri * 8 + jj] : 0.f, dsij = (i < k) ? dSs[ri * 8 + jj] : 0.f;
+    if (i + 1 < ML) {
+      int a = ro0 + (i + 1 < k ? i + 1 : 0) * kLd;
+      FB_PIN(a, gk);
+      qn = ld8(&Qs[a]); gn = ld8(&Fs[a]);
+    }
+    axpy8(gv, pij, go);
+    axpy8(gk, dsij, q);
+  }
+}
+
 // -DFB_TIMING: per-phase wall-clock (100 MHz) of workgroup 0, printed at the end -- development builds only
 #ifdef FB_TIMING
 #define FB_T(i) do { const long long now__ = wall_clock64(); tph[i] += now__ - tlast; tlast = now__; } while (0)
@@ -692,6 +796,361 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
 }
 
+// ---- the same walk with EIGHT wavefronts: two per SIMD -------------------------------------------------------------------
+// fused_bwd_kernel runs one wavefront per SIMD (157 KB of LDS, > 256 registers per lane), so nothing hides its LDS / global
+// latency and barrier skew: 6.9 us of MFMA + 2.9 us of VALU issue per (tile, head) take 13.9 us.  Here the SAME tiles in LDS are
+// worked on by 512 threads: wave (quad, hf) with quad = the old (wr, wc) output quadrant; waves w and w + 4 share a SIMD.
+//   token-side products (dO, d x_hat): v_mfma_f32_16x16x4_f32, wave (quad, hf) owns feature columns 32 wc + 16 hf .. + 16 of its
+//     quadrant's 32 token rows (two 16 x 16 tiles) -- half the MFMAs per wave, an 8-register accumulator
+//   weight gradients: v_mfma_f32_32x32x2_f32 as before, the 64-token contraction split by hf (tokens 32 hf .. 32 hf + 31); each half
+//     keeps its own four accumulators for the whole walk and writes its own slab (fb_unfold_kernel sums 2 x nchunks slabs)
+//   attention: one token per 8-lane group in ONE pass (64 groups), half the live state per lane
+// Requires the Q/K/V images of the training forward (no recompute path).
+#ifndef FB8_ABL
+#define FB8_ABL 0
+#endif
+#define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+template <int ML>
+__global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wq = lds;
+  float* Xs = lds + 3 * kTile;        // x_hat (rows >= n_real are zero)
+  float* Ds = lds + 4 * kTile;        // dDyn  (rows >= n_real are zero)
+  float* Qs = lds + 5 * kTile;        // Q -> dQ
+  float* Ks = lds + 6 * kTile;        // K -> dK
+  float* Vs = lds + 7 * kTile;        // V -> dV
+  float* Fs = lds + 8 * kTile;        // dO -> O
+  float* sm = lds + 9 * kTile;
+  int* tinfo = reinterpret_cast<int*>(sm);
+  float* cb = sm + 64;
+  float* kpad = cb + 192;
+  float* vpad = kpad + 64;
+  float* xpad = vpad + 64;
+  float* Ps = xpad + 64;
+  float* dSs = Ps + 512;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = wave & 3, hf = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;              // 32x32x2 fragments (weight gradients)
+  const int wr = quad & 1, wc = quad >> 1;
+  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x4 fragments (token-side products)
+  const int fb = 32 * wc + 16 * hf;                    // this wave's 16 feature columns there
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;     // staging: 32 rows x 16 lanes (float4)
+  const int sub = lane & 7;
+
+  int head, chunk;
+  if ((g.nchunks & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    head = j & 7;
+    chunk = (j >> 3) * 8 + xcd;
+  } else {
+    head = blockIdx.x & 7;
+    chunk = blockIdx.x >> 3;
+  }
+  const int tr = g.count[1];
+  int ntr = g.count[2];
+  if (ntr > g.ntiles) ntr = g.ntiles;
+  const int per = (ntr + g.nchunks - 1) / g.nchunks;
+  const int tile_lo = chunk * per;
+  const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
+  const float inv_temp = 0.125f;
+
+  // ---- resident weights ----
+  const int64_t wofs = (int64_t)head * 64 * 64;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const float* src = (m == 0 ? g.wq : (m == 1 ? g.wk : g.wv)) + wofs;
+    const float4 t0 = *reinterpret_cast<const float4*>(src + (int64_t)srow * 64 + sc4);
+    const float4 t1 = *reinterpret_cast<const float4*>(src + (int64_t)(srow + 32) * 64 + sc4);
+    *reinterpret_cast<float4*>(&Wq[m * kTile + srow * kLd + sc4]) = t0;
+    *reinterpret_cast<float4*>(&Wq[m * kTile + (srow + 32) * kLd + sc4]) = t1;
+  }
+  if (tid < 192) cb[tid] = (tid < 64 ? g.cq : (tid < 128 ? g.ck : g.cv))[head * 64 + (tid & 63)];
+  if (tid < 16) {
+    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
+    float m, rs;
+    ln_row16(xv, m, rs);
+    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int n = tid & 63;
+    const float* W = Wq + (tid < 64 ? 1 : 2) * kTile;
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += xpad[k] * W[n * kLd + k];
+    (tid < 64 ? kpad : vpad)[n] = s + cb[64 + (tid >> 6) * 64 + n];
+  }
+
+  // weight-gradient accumulators: rows n = 32 wr + 16 mt + 4 kq + reg, column k = fb + c16 of dW'q, dW'k, dW'v, dWfc1 (two 16 x 16 tiles each)
+  f32x4 aq0 = {0.f, 0.f, 0.f, 0.f}, aq1 = aq0, ak0 = aq0, ak1 = aq0, av0 = aq0, av1 = aq0, af0 = aq0, af1 = aq0;
+  V8 accK = zero8(), accV = zero8();
+  f2 csq2 = {0.f, 0.f}, csk2 = csq2, csv2 = csq2, csd2 = csq2;      // column sums of dQ, dK, dV, dDyn over this lane's tokens, columns 32 wr + c16 and + 16
+
+  const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
+  const int4 mzero = make_int4(0, 0, 0, 0);
+  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
+  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
+  float4 xn0, xn1, dn0, dn1;
+  int tpn = 0;
+#define FB8_ROW_GLOAD(I, M)                                                                              \
+  do {                                                                                                   \
+    const int row__ = srow + 32 * (I);                                                                   \
+    const int64_t tok__ = (M).x + (row__ < (M).y ? row__ : ((M).y > 0 ? (M).y - 1 : 0));                 \
+    xn##I = *reinterpret_cast<const float4*>(g.X + tok__ * 64 + sc4);                                    \
+    dn##I = *reinterpret_cast<const float4*>(g.dDyn + tok__ * 64 + sc4);                                 \
+  } while (0)
+#define FB8_ROWS_GLOAD(M)                                                                                \
+  do {                                                                                                   \
+    FB8_ROW_GLOAD(0, M); FB8_ROW_GLOAD(1, M);                                                            \
+    if (tid < 64) tpn = g.tok_pos[(M).x + (tid < (M).y ? tid : ((M).y > 0 ? (M).y - 1 : 0))];           \
+  } while (0)
+#define FB8_ROW_STAGE(I)                                                                                 \
+  do {                                                                                                   \
+    const int row__ = srow + 32 * (I);                                                                   \
+    const float msk__ = row__ < n_real ? 1.f : 0.f;                                                      \
+    const float4 xv__ = xn##I, dv__ = dn##I;                                                             \
+    const float mean__ = group_sum16_dpp((xv__.x + xv__.y) + (xv__.z + xv__.w)) * (1.f / 64.f);          \
+    const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
+    const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
+    const float rs__ = msk__ * __builtin_amdgcn_rsqf(q__ * (1.f / 64.f) + kEpsLn);                       \
+    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
+    const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
+    *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
+  } while (0)
+  // Q, K, V register images of the forward pass (fused_fwd.hip, proj_store_T: [quadrant][gq][lane] float4): this wave takes the
+  // two feature groups gq = 2 hf, 2 hf + 1 of its quadrant
+  f32x4 qi0, qi1, ki0, ki1, vi0, vi1, pn = {0.f, 0.f, 0.f, 0.f};
+  const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
+#define FB8_QKV_GLOAD(TILE)                                                                              \
+  do {                                                                                                   \
+    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.qkv + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * kImgRec);  \
+    const f32x4* b__ = r__ + img_lane;                                                                   \
+    if (tid < 128) pn = __builtin_nontemporal_load(r__ + 3072 + tid);                                    \
+    qi0 = __builtin_nontemporal_load(b__); qi1 = __builtin_nontemporal_load(b__ + 64);                   \
+    ki0 = __builtin_nontemporal_load(b__ + 1024); ki1 = __builtin_nontemporal_load(b__ + 1088);          \
+    vi0 = __builtin_nontemporal_load(b__ + 2048); vi1 = __builtin_nontemporal_load(b__ + 2112);          \
+  } while (0)
+#define FB8_IMG_STAGE(TS, R0, R1)                                                                        \
+  do {                                                                                                   \
+    f32x4* d__ = reinterpret_cast<f32x4*>(&(TS)[(32 * wr + r) * kLd + 32 * wc + 4 * h]);                 \
+    d__[4 * hf] = R0; d__[4 * hf + 2] = R1;                                                              \
+  } while (0)
+  // A fragments (16 feature rows x 64 k) of the head's fc1 block for dO^T = Wfc1[:, head block]^T . dDyn^T, held for the whole walk
+  // (measured: re-reading them per tile from L2, at the top of the tile or as a prefetch during the weight-gradient GEMMs, is 2 - 6 % slower)
+  float fcb[16];
+#define FB8_FC_GLOAD(P)                                                                                  \
+  do {                                                                                                   \
+    _Pragma("unroll") for (int c__ = 0; c__ < 4; ++c__)                                                  \
+      _Pragma("unroll") for (int x__ = 0; x__ < 4; ++x__) fcb[4 * c__ + x__] = (P)[(16 * c__ + x__) * 512]; \
+  } while (0)
+  FB8_ROWS_GLOAD(mc);
+  if (tile_lo < tile_hi) FB8_QKV_GLOAD(tile_lo);
+  FB8_FC_GLOAD(g.fc1_w + (int64_t)(4 * kq) * 512 + head * 64 + fb + c16);
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
+    const int t0 = mc.x, n_real = mc.y;
+    if (n_real <= 0) {
+      FB8_ROWS_GLOAD(mn);
+      if (tile + 1 < tile_hi) FB8_QKV_GLOAD(tile + 1);
+      mc = mn; mn = mnn;
+      continue;
+    }
+    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
+    // Every per-lane index below is re-derived from an opaque copy of the thread id: left to itself the compiler hoists some fifty
+    // loop-invariant LDS / global addresses out of the tile loop and then spills them (256 registers per lane here).
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
+    const int quad = wave & 3, hf = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = quad & 1, wc = quad >> 1;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int fb = 32 * wc + 16 * hf;
+    const int srow = tid_ >> 4, sc4 = (tid_ & 15) * 4;
+    const int sub = lane & 7;
+    const float* fcp = g.fc1_w + (int64_t)(4 * kq) * 512 + head * 64 + fb + c16;
+    const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
+    FB8_ROW_STAGE(0); FB8_ROW_STAGE(1);
+    if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
+    FB8_IMG_STAGE(Qs, qi0, qi1);
+    FB8_IMG_STAGE(Ks, ki0, ki1);
+    FB8_IMG_STAGE(Vs, vi0, vi1);
+    if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
+    __syncthreads();
+    // ---- dO^T = Wfc1[:, head block]^T . dDyn^T: lane (c16, kq) ends with token 32 wr + c16 (+ 16) and features fb + 4 kq + {0..3} ----
+    {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const float* dp = Ds + (32 * wr + c16) * kLd + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 b0 = *reinterpret_cast<const float4*>(dp + 16 * c), b1 = *reinterpret_cast<const float4*>(dp + 16 * kLd + 16 * c);
+        acc0 = MFMA16(fcb[4 * c + 0], b0.x, acc0); acc1 = MFMA16(fcb[4 * c + 0], b1.x, acc1);
+        acc0 = MFMA16(fcb[4 * c + 1], b0.y, acc0); acc1 = MFMA16(fcb[4 * c + 1], b1.y, acc1);
+        acc0 = MFMA16(fcb[4 * c + 2], b0.z, acc0); acc1 = MFMA16(fcb[4 * c + 2], b1.z, acc1);
+        acc0 = MFMA16(fcb[4 * c + 3], b0.w, acc0); acc1 = MFMA16(fcb[4 * c + 3], b1.w, acc1);
+      }
+      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + c16) * kLd + fb + 4 * kq]) = acc0;
+      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]) = acc1;
+    }
+    __syncthreads();
+    // ---- attention forward + backward: 8 lanes per token, all 64 tokens in one pass ----
+    {
+      V8 o0, q0, k0, v0;
+      const int la = wave * 8 + (lane >> 3);
+      const bool acta = la < n_real && !(FB8_ABL & 1);
+      int ia = 0;
+      if (acta) { ia = tinfo[la]; attn_row8<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      if (acta) attn_col8<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
+      __syncthreads();
+      if (acta) {
+        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0); st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
+      } else {
+        ZR8(&Qs[la * kLd + 8 * sub]); ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
+      }
+    }
+    __syncthreads();
+    FB8_ROWS_GLOAD(mn);                               // next tile's rows: in flight during the GEMMs below
+    if (!(FB8_ABL & 8))
+    // ---- this head's share of d x_hat^T = W'q^T dQ^T + W'k^T dK^T + W'v^T dV^T: 12 steps of 16 contraction indices ----
+    {
+      f32x4 dx0 = {0.f, 0.f, 0.f, 0.f}, dx1 = dx0;
+      const float* arow = Qs + (32 * wr + c16) * kLd + 4 * kq;
+      const float* wcol = Wq + (4 * kq) * kLd + fb + c16;
+      float4 a00, a01, a10, a11;
+      float w00, w01, w02, w03, w10, w11, w12, w13;
+#define FB8_DX_LOAD(A0, A1, W, S)                                                                        \
+  do {                                                                                                   \
+    constexpr int m__ = (S) / 4, c__ = (S) % 4;                                                          \
+    const float* ap__ = arow + m__ * kTile + 16 * c__;                                                   \
+    const float* wp__ = wcol + m__ * kTile + (16 * c__) * kLd;                                           \
+    A0 = *reinterpret_cast<const float4*>(ap__); A1 = *reinterpret_cast<const float4*>(ap__ + 16 * kLd); \
+    W##0 = wp__[0]; W##1 = wp__[kLd]; W##2 = wp__[2 * kLd]; W##3 = wp__[3 * kLd];                        \
+  } while (0)
+#define FB8_DX_MMA(A0, A1, W)                                                                            \
+  do {                                                                                                   \
+    dx0 = MFMA16(W##0, A0.x, dx0); dx1 = MFMA16(W##0, A1.x, dx1);                                        \
+    dx0 = MFMA16(W##1, A0.y, dx0); dx1 = MFMA16(W##1, A1.y, dx1);                                        \
+    dx0 = MFMA16(W##2, A0.z, dx0); dx1 = MFMA16(W##2, A1.z, dx1);                                        \
+    dx0 = MFMA16(W##3, A0.w, dx0); dx1 = MFMA16(W##3, A1.w, dx1);                                        \
+  } while (0)
+#define FB8_DX_PAIR(S)                                                                                   \
+  do {                                                                                                   \
+    FB8_DX_LOAD(a10, a11, w1, (S) + 1);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FB8_DX_MMA(a00, a01, w0);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if ((S) + 2 < 12) FB8_DX_LOAD(a00, a01, w0, ((S) + 2 < 12 ? (S) + 2 : 0));                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FB8_DX_MMA(a10, a11, w1);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+      FB8_DX_LOAD(a00, a01, w0, 0);
+      FB8_DX_PAIR(0); FB8_DX_PAIR(2); FB8_DX_PAIR(4); FB8_DX_PAIR(6); FB8_DX_PAIR(8); FB8_DX_PAIR(10);
+      float* out = g.dxh + ((int64_t)head * g.tcap + t0 + 32 * wr + c16) * 64 + fb + 4 * kq;
+      if (32 * wr + c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
+      if (32 * wr + 16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
+    }
+    if (tile + 1 < tile_hi) FB8_QKV_GLOAD(tile + 1);     // next tile's Q, K, V: in flight during the weight-gradient GEMMs
+    // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k], 16 steps of 4 tokens; lane group kq takes token 16 c + 4 kq + x in
+    //      step (c, x) (rows 4 apart = 16 banks apart: the two lane groups of a half-wave do not collide) ----
+    if (!(FB8_ABL & 4)) {
+      const float* pq = Qs + (4 * kq) * kLd + 32 * wr + c16;      // Qs, Ks, Vs are consecutive tiles; columns n and n + 16 as one ds_read2
+      const float* pd = Ds + (4 * kq) * kLd + 32 * wr + c16;
+      const float* px = Xs + (4 * kq) * kLd + fb + c16;
+      const float* po = Fs + (4 * kq) * kLd + fb + c16;
+      f2 qa, ka, va, da, qb, kb, vb, db;
+      float xa, oa, xb, ob;
+#define FB8_TN_LOAD(S, ST)                                                                               \
+  do {                                                                                                   \
+    constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
+    q##S = (f2){pq[o__], pq[o__ + 16]}; k##S = (f2){pq[kTile + o__], pq[kTile + o__ + 16]};              \
+    v##S = (f2){pq[2 * kTile + o__], pq[2 * kTile + o__ + 16]}; d##S = (f2){pd[o__], pd[o__ + 16]};      \
+    x##S = px[o__]; o##S = po[o__];                                                                      \
+  } while (0)
+#define FB8_TN_MMA(S)                                                                                    \
+  do {                                                                                                   \
+    csq2 += q##S; csk2 += k##S; csv2 += v##S; csd2 += d##S;                                              \
+    aq0 = MFMA16(q##S.x, x##S, aq0); aq1 = MFMA16(q##S.y, x##S, aq1);                                    \
+    ak0 = MFMA16(k##S.x, x##S, ak0); ak1 = MFMA16(k##S.y, x##S, ak1);                                    \
+    av0 = MFMA16(v##S.x, x##S, av0); av1 = MFMA16(v##S.y, x##S, av1);                                    \
+    af0 = MFMA16(d##S.x, o##S, af0); af1 = MFMA16(d##S.y, o##S, af1);                                    \
+  } while (0)
+#define FB8_TN_PAIR(ST)                                                                                  \
+  do {                                                                                                   \
+    FB8_TN_LOAD(b, (ST) + 1);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FB8_TN_MMA(a);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if ((ST) + 2 < 16) FB8_TN_LOAD(a, ((ST) + 2 < 16 ? (ST) + 2 : 0));                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FB8_TN_MMA(b);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+      FB8_TN_LOAD(a, 0);
+      FB8_TN_PAIR(0); FB8_TN_PAIR(2); FB8_TN_PAIR(4); FB8_TN_PAIR(6); FB8_TN_PAIR(8); FB8_TN_PAIR(10); FB8_TN_PAIR(12); FB8_TN_PAIR(14);
+    }
+    mc = mn; mn = mnn;
+  }
+
+  // ---- workgroup slab ----
+  __syncthreads();
+  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
+  {
+    const int col = fb + c16;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = 32 * wr + 4 * kq + reg;
+      slab[0 * 4096 + row * 64 + col] = aq0[reg]; slab[0 * 4096 + (row + 16) * 64 + col] = aq1[reg];
+      slab[1 * 4096 + row * 64 + col] = ak0[reg]; slab[1 * 4096 + (row + 16) * 64 + col] = ak1[reg];
+      slab[2 * 4096 + row * 64 + col] = av0[reg]; slab[2 * 4096 + (row + 16) * 64 + col] = av1[reg];
+      slab[3 * 4096 + row * 64 + col] = af0[reg]; slab[3 * 4096 + (row + 16) * 64 + col] = af1[reg];
+    }
+  }
+  // column sums: lane (c16, kq) covered tokens 16 c + 4 kq + x for columns 32 wr + c16 (.x) and + 16 (.y); the four lane groups are
+  // added in a fixed xor order; the waves with fb != 0 hold duplicates
+  float* red = Xs;                      // [3][64]: dcq dck dcv
+  float* red2 = Ds;                     // [64] fc1 bias gradient
+  {
+    f2 cs[4] = {csq2, csk2, csv2, csd2};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float a = cs[m].x, b = cs[m].y;
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (fb == 0 && kq == 0) {
+        float* dst = m < 3 ? red + m * 64 : red2;
+        dst[32 * wr + c16] = a; dst[32 * wr + 16 + c16] = b;
+      }
+    }
+  }
+  // dK_pad / dV_pad: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 8 waves in order
+  float* redp = Xs + 3 * 64;            // [8][2][64]
+  const float accp[16] = {accK.a.x, accK.a.y, accK.b.x, accK.b.y, accK.c.x, accK.c.y, accK.d.x, accK.d.y,
+                          accV.a.x, accV.a.y, accV.b.x, accV.b.y, accV.c.x, accV.c.y, accV.d.x, accV.d.y};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float v = accp[i];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 8) redp[(wave * 2 + (i >> 3)) * 64 + 8 * lane + (i & 7)] = v;
+  }
+  __syncthreads();
+  if (tid < 192) slab[kVecOff + tid] = red[tid];
+  if (tid < 128) {
+    const int vec = tid >> 6, f = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += redp[(w * 2 + vec) * 64 + f];
+    slab[kVecOff + 192 + tid] = t;
+  }
+  if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
+}
+
 // ---- slab reduction + un-folding of the LayerNorm affines -------------------------------------------------------
 struct UnfoldArgs {
   const float* wslab; int nchunks;
@@ -852,7 +1311,9 @@ size_t fused_bwd_ws_floats(int64_t B, int L) {
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv) {
   const int64_t tcap = B * L + 1;
-  const int nchunks = chunks_for(rg.ntiles);
+  // eight wavefronts per workgroup (fused_bwd8_kernel) when the forward pass left its Q/K/V tiles
+  const bool eight = qkv != nullptr && !options().disable_bwd8;
+  int nchunks = chunks_for(rg.ntiles);
   float* wslab = ws;
   float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
   float* dxpad = part + 32 * 3 * 3 * 64;
@@ -867,23 +1328,35 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     const size_t lds = ((size_t)9 * kTile + 64 + 192 + 3 * 64 + 2 * 512) * sizeof(float);
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
+      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(eight ? 512 : 256), lds, st, g);
     };
     // algorithmic flops: 8 heads x 8 GEMMs (dO, dWfc1, 3 dW', 3 d x_hat terms) of 2*64*64 per token; the Q/K/V recompute is not counted
     ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
-    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
-      case 2: launch(fused_bwd_kernel<2>); break;
-      case 3: launch(fused_bwd_kernel<3>); break;
-      case 4: launch(fused_bwd_kernel<4>); break;
-      case 5: launch(fused_bwd_kernel<5>); break;
-      case 6: launch(fused_bwd_kernel<6>); break;
-      default: launch(fused_bwd_kernel<8>); break;
+    if (eight) {
+      switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+        case 2: launch(fused_bwd8_kernel<2>); break;
+        case 3: launch(fused_bwd8_kernel<3>); break;
+        case 4: launch(fused_bwd8_kernel<4>); break;
+        case 5: launch(fused_bwd8_kernel<5>); break;
+        case 6: launch(fused_bwd8_kernel<6>); break;
+        default: launch(fused_bwd8_kernel<8>); break;
+      }
+    } else {
+      switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+        case 2: launch(fused_bwd_kernel<2>); break;
+        case 3: launch(fused_bwd_kernel<3>); break;
+        case 4: launch(fused_bwd_kernel<4>); break;
+        case 5: launch(fused_bwd_kernel<5>); break;
+        case 6: launch(fused_bwd_kernel<6>); break;
+        default: launch(fused_bwd_kernel<8>); break;
+      }
     }
     MATCHA_CHECK_LAUNCH("fused_bwd_kernel");
   }
+  const int nslabs = nchunks;
   {
     UnfoldArgs a;
-    a.wslab = wslab; a.nchunks = nchunks; a.X = X; a.count = rg.count;
+    a.wslab = wslab; a.nchunks = nslabs; a.X = X; a.count = rg.count;
     a.W[0] = p.w_q; a.W[1] = p.w_k; a.W[2] = p.w_v;
     a.g[0] = p.ln_q_g; a.g[1] = p.ln_k_g; a.g[2] = p.ln_v_g;
     a.b[0] = p.ln_q_b; a.b[1] = p.ln_k_b; a.b[2] = p.ln_v_b;
@@ -892,7 +1365,7 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     hipLaunchKernelGGL(fb_unfold_kernel, dim3(4, 4, MATCHA_N_HEAD), dim3(256), 0, st, a);
     MATCHA_CHECK_LAUNCH("fb_unfold_kernel");
     Unfold2Args b;
-    b.part = part; b.wslab = wslab; b.nchunks = nchunks;
+    b.part = part; b.wslab = wslab; b.nchunks = nslabs;
     b.dg[0] = grads.ln_q_g; b.dg[1] = grads.ln_k_g; b.dg[2] = grads.ln_v_g;
     b.db[0] = grads.ln_q_b; b.db[1] = grads.ln_k_b; b.db[2] = grads.ln_v_b;
     b.dfc1_b = grads.fc1_b; b.dxpad = dxpad;

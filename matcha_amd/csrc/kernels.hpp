@@ -90,7 +90,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
-  int disable_wide_gemm;
+  int disable_wide_gemm, disable_bwd8;
   int debug_nan, fused_dbg, fwd_lds_pad;
 };
 Options& options();

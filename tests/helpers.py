@@ -40,3 +40,13 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def logit_err(a, b, floor=0.05):
+    """ELEMENT-wise relative error of a batch of logits: each |a_i - b_i| against max(|b_i|, floor * max|b|), so a small logit next
+    to one large logit is still held to the tolerance (rel_err alone is norm-wise: max|delta| / max|ref|).  The floor is there
+    because a logit is a sum of terms of the batch's typical magnitude: below it the absolute error is the meaningful one."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    den = np.maximum(np.abs(b), floor * (np.abs(b).max() + 1e-30))
+    return float((np.abs(a - b) / den).max())

@@ -12,7 +12,7 @@ import torch
 from matcha_amd import synth, _lib
 from oracle import hypersagnn as O
 from oracle import rng as R
-from tests.helpers import GOLD, gold, oracle_state, rel_err, front_end
+from tests.helpers import GOLD, gold, oracle_state, logit_err, rel_err, front_end
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4     # north_star: <= 1e-4 rel fp32
@@ -61,11 +61,11 @@ def test_g2_eval_logits_table(name, layout, d, seed):
             x = torch.from_numpy(g[f"x_k{k}"])
             lg = clf(x).cpu().numpy()
             assert lg.shape == (len(x), 1)
-            assert rel_err(lg, g[f"logits_k{k}"]) < TOL, k
+            assert logit_err(lg, g[f"logits_k{k}"]) < TOL, k
             lg5 = clf(torch.nn.functional.pad(x, (0, 5 - k))).cpu().numpy()
-            assert rel_err(lg5, g[f"logits_k{k}_L5"]) < TOL, k     # pad slots are attended (fact 7)
+            assert logit_err(lg5, g[f"logits_k{k}_L5"]) < TOL, k     # pad slots are attended (fact 7)
         lg, rc = clf(torch.from_numpy(g["x_mixed"]), return_recon=True)
-        assert rel_err(lg.cpu().numpy(), g["logits_mixed"]) < TOL
+        assert logit_err(lg.cpu().numpy(), g["logits_mixed"]) < TOL
         assert float(rc.cpu()[0]) == 0.0
 
 
@@ -78,7 +78,7 @@ def test_reference_pickle_loads_and_runs_table():
     clf.eval()
     with torch.no_grad():
         lg = clf(torch.from_numpy(out["x"]))
-    assert rel_err(lg.cpu().numpy(), out["logits"]) < TOL
+    assert logit_err(lg.cpu().numpy(), out["logits"]) < TOL
     assert clf.layer_norm1.weight.device.type == "cuda"       # denoise_contact.py:101 reads this
     # round trip through our own torch.save / torch.load
     buf = io.BytesIO()
@@ -167,7 +167,7 @@ def _train_g3(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused,
             if step == 0:
                 _check_grads(g, {n: p.grad for n, p in clf.named_parameters()}, none_ref, full)
             opt.step()
-        assert rel_err(logits.detach().cpu().numpy(), g[f"logits{step}"]) < TOL, step
+        assert logit_err(logits.detach().cpu().numpy(), g[f"logits{step}"]) < TOL, step
         assert abs(float(bce) - float(g[f"bce{step}"])) < TOL * max(1.0, abs(float(g[f"bce{step}"])))
         assert abs(float(recon.reshape(-1)[0]) - float(g[f"recon{step}"][0])) < TOL * max(1.0, abs(float(g[f"recon{step}"][0]))), step
         if step in (0, n_steps - 1):
@@ -243,7 +243,7 @@ def test_backward_matches_oracle_other_dims(d, layout):
     lg = clf(xt)
     l2 = torch.nn.functional.binary_cross_entropy_with_logits(lg, yt.cuda(), weight=wt.cuda())
     l2.backward()
-    assert rel_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
+    assert logit_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
     for n, p in clf.named_parameters():
         if grads.get(n) is None or n == GAUGE:
             assert p.grad is None or n == GAUGE or not p.requires_grad
@@ -271,7 +271,7 @@ def test_training_dropout_masks_match_oracle_rng():
              "pff": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_PFF, O.P_DROP_PFF, T, d))}
     with torch.no_grad():
         ref, _ = O.classifier_forward(P, fe, xt, masks=masks)
-    assert rel_err(lg, ref.numpy()) < TOL
+    assert logit_err(lg, ref.numpy()) < TOL
     # and the masks have the right rate
     assert abs(float((masks["fc1"] == 0).float().mean()) - 0.3) < 0.05
     assert abs(float((masks["pff"] == 0).float().mean()) - 0.4) < 0.05

@@ -10,7 +10,7 @@ import torch
 
 from matcha_amd import synth, _lib
 from oracle import hypersagnn as O
-from tests.helpers import oracle_state, rel_err
+from tests.helpers import oracle_state, logit_err, rel_err
 from tests.test_hip_model import GAUGE, TOL, hip_model
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def test_forward_backward_vs_oracle_wide(mode, d, layout, ks):
     loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, yt.cuda(), weight=wt.cuda()) + 0.01 * rc
     loss.backward()
     _, _, recon, logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, 1.0, 0.01, random_chrom=chrom)
-    assert rel_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
+    assert logit_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
     assert abs(float(rc.detach().cpu()[0]) - float(recon[0])) <= TOL * max(1.0, abs(float(recon[0])))
     for n, p in clf.named_parameters():
         if grads.get(n) is None or n == GAUGE:

@@ -15,7 +15,9 @@ HBM_PEAK = 8.0e12
 print("| table | d | rows per launch | us | read GB/s (4d+8) | % of 8 TB/s read | read+write GB/s |")
 print("|---|---:|---:|---:|---:|---:|---:|")
 for name, N, d, T in (("C2 (3 067 nodes, L2-resident)", 3067, 64, 1 << 20), ("C5-like 1 M nodes", 1 << 20, 64, 1 << 24),
-                      ("16 M nodes (4 GB, beyond the 256 MB cache)", 1 << 24, 64, 1 << 24), ("C5 1 M nodes", 1 << 20, 256, 1 << 22)):
+                      ("16 M nodes (4 GB, beyond the 256 MB cache)", 1 << 24, 64, 1 << 24), ("C5 1 M nodes", 1 << 20, 256, 1 << 22),
+                      ("16 M nodes, one training step's tokens per launch", 1 << 24, 64, 65536 * 5),
+                      ("C5 1 M nodes, one C5 step's tokens per launch", 1 << 20, 256, 16384 * 8)):
     table = torch.randn(N + 1, d, device="cuda")
     ids = torch.randint(1, N + 1, (T,), device="cuda", dtype=torch.int64)
     rows = torch.empty(T, d, device="cuda")

@@ -142,9 +142,10 @@ if grows and glob.glob(f"gpurun_out/{tag}_gather_fetch/*/*_counter_collection.cs
                 out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
         return sorted(out)
     fe2, wr2 = load2("gather_fetch", "FETCH_SIZE"), load2("gather_write", "WRITE_SIZE")
-    # tools/gather_bench.py launches 13 gathers per table (3 warm-up + 10 timed), four tables in this order
+    # tools/gather_bench.py launches 13 gathers per table (3 warm-up + 10 timed), six cases in this order
     cases = [("C2: 3 067 nodes x 64 (L2-resident)", 64, 1 << 20), ("1 M nodes x 64 (244 MiB)", 64, 1 << 24), ("16 M nodes x 64 (4 GiB)", 64, 1 << 24),
-             ("C5: 1 M nodes x 256 (1 GiB)", 256, 1 << 22)]
+             ("C5: 1 M nodes x 256 (1 GiB)", 256, 1 << 22), ("16 M nodes x 64 (4 GiB), step-sized launch", 64, 65536 * 5),
+             ("C5: 1 M nodes x 256 (1 GiB), step-sized launch", 256, 16384 * 8)]
     tr = glob.glob(f"gpurun_out/{tag}_gather_stats/*/*_kernel_trace.csv")
     durs = []
     if tr:
