@@ -309,7 +309,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
 
 def gather_roofline(device):
     """The embedding-row gather alone (Wrap_Embedding.forward / get_node_embeddings, Modules.py:33-34, :252-259) through the C ABI
-    with uniform random ids; gather_rows_kernel timed live with HIP events on its stream.  ALGORITHMIC bytes per row = 4 d + 8 read
+    with uniform random ids; gather_rows_kernel timed live with HIP events on its stream (back-to-back launches, one event pair).  ALGORITHMIC bytes per row = 4 d + 8 read
     (SURVEY.md §8 d4); the rows are also written (4 d) because this surface materialises them, so the kernel as a whole is bound by
     the ~6.3 TB/s read + write copy ceiling: `frac` (read bytes against the 8 TB/s read roof) tops out near 0.39 for an
     HBM-resident table, and `copy_frac` says how close the kernel is to THAT ceiling."""
@@ -335,14 +335,17 @@ def gather_roofline(device):
         for _ in range(3):
             run()
         torch.cuda.synchronize(device)
-        lib.matcha_profile_select(_lib.PROF["gather_rows"])
-        for _ in range(10):
+        # one HIP event pair around `reps` back-to-back launches on the stream they are launched on (torch's current stream here): a
+        # per-launch event pair costs ~3 us, which is 10 % of a 30 us step-sized launch
+        reps = 10 if T >= (1 << 22) else 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
             run()
-        ms, n, wk = C.c_double(), C.c_int64(), C.c_double()
-        _lib.check(lib.matcha_profile_read(C.byref(ms), C.byref(n), C.byref(wk)))
-        lib.matcha_profile_select(0)
+        e1.record()
+        torch.cuda.synchronize(device)
         assert torch.equal(rows[:4096], table[ids[:4096]])
-        t = ms.value * 1e-3 / n.value
+        t = e0.elapsed_time(e1) * 1e-3 / reps
         read = T * (4.0 * d + 8.0)
         out.append(dict(table=name, d=d, rows_per_launch=T, resident=resident, bound="hbm", kernel="gather_rows", avg_launch_ms=round(t * 1e3, 4),
                         achieved=round(read / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(read / t / 1e9 / HBM_PEAK_GBS, 4),

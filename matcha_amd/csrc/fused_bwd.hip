@@ -349,14 +349,15 @@ __device__ __forceinline__ void attn_row8(const float* __restrict__ Qs, const fl
     o = scale8(ppf, vp);
     dsp = group_sum8_dpp(dot8(go, vp));
     float sig = ppf * dsp;
-    V8 vn = ld8(&Vs[ro0]);
+    V8 vn = ld8(&Vs[ro0]), vn2 = ld8(&Vs[ro0 + (1 < k ? 1 : 0) * kLd]);      // two rows in flight
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
       const V8 v = vn;
-      if (j + 1 < ML) {
-        int a = ro0 + (j + 1 < k ? j + 1 : 0) * kLd;
+      vn = vn2;
+      if (j + 2 < ML) {
+        int a = ro0 + (j + 2 < k ? j + 2 : 0) * kLd;
         FB_PIN(a, o);
-        vn = ld8(&Vs[a]);
+        vn2 = ld8(&Vs[a]);
       }
       axpy8(o, p[j], v);
       const float d = group_sum8_dpp(dot8(go, v));
@@ -374,14 +375,15 @@ __device__ __forceinline__ void attn_row8(const float* __restrict__ Qs, const fl
     gq = scale8(dspf, kp);
     int a0 = ro0;
     FB_PIN(a0, o);                                     // the K pass starts after the V pass is done with its rows
-    V8 kn = ld8(&Ks[a0]);
+    V8 kn = ld8(&Ks[a0]), kn2 = ld8(&Ks[a0 + (1 < k ? 1 : 0) * kLd]);
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
       const V8 kk = kn;
-      if (j + 1 < ML) {
-        int a = ro0 + (j + 1 < k ? j + 1 : 0) * kLd;
+      kn = kn2;
+      if (j + 2 < ML) {
+        int a = ro0 + (j + 2 < k ? j + 2 : 0) * kLd;
         FB_PIN(a, gq);
-        kn = ld8(&Ks[a]);
+        kn2 = ld8(&Ks[a]);
       }
       axpy8(gq, ds[j], kk);
     }
@@ -814,6 +816,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
 template <int ML>
 __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef FB_TIMING
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+#endif
   float* Wq = lds;
   float* Xs = lds + 3 * kTile;        // x_hat (rows >= n_real are zero)
   float* Ds = lds + 4 * kTile;        // dDyn  (rows >= n_real are zero)
@@ -885,7 +891,7 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
   // weight-gradient accumulators: rows n = 32 wr + 16 mt + 4 kq + reg, column k = fb + c16 of dW'q, dW'k, dW'v, dWfc1 (two 16 x 16 tiles each)
   f32x4 aq0 = {0.f, 0.f, 0.f, 0.f}, aq1 = aq0, ak0 = aq0, ak1 = aq0, av0 = aq0, av1 = aq0, af0 = aq0, af1 = aq0;
   V8 accK = zero8(), accV = zero8();
-  f2 csq2 = {0.f, 0.f}, csk2 = csq2, csv2 = csq2, csd2 = csq2;      // column sums of dQ, dK, dV, dDyn over this lane's tokens, columns 32 wr + c16 and + 16
+  f2 cs2 = {0.f, 0.f};              // column sums (bias gradients) of ONE of {dDyn, dQ, dK, dV} -- tile 4 + u, u = 2 wc + hf -- columns 32 wr + c16 and + 16
 
   const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
   const int4 mzero = make_int4(0, 0, 0, 0);
@@ -958,6 +964,7 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       continue;
     }
     __syncthreads();                                  // previous tile's GEMMs are done with every working tile
+    FB_T(7);
     // Every per-lane index below is re-derived from an opaque copy of the thread id: left to itself the compiler hoists some fifty
     // loop-invariant LDS / global addresses out of the tile loop and then spills them (256 registers per lane here).
     int tid_ = tid;
@@ -979,6 +986,7 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
     FB8_IMG_STAGE(Vs, vi0, vi1);
     if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
     __syncthreads();
+    FB_T(0);
     // ---- dO^T = Wfc1[:, head block]^T . dDyn^T: lane (c16, kq) ends with token 32 wr + c16 (+ 16) and features fb + 4 kq + {0..3} ----
     {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -995,6 +1003,7 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       *reinterpret_cast<f32x4*>(&Fs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]) = acc1;
     }
     __syncthreads();
+    FB_T(1);
     // ---- attention forward + backward: 8 lanes per token, all 64 tokens in one pass ----
     {
       V8 o0, q0, k0, v0;
@@ -1004,8 +1013,10 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       if (acta) { ia = tinfo[la]; attn_row8<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      FB_T(2);
       if (acta) attn_col8<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
       __syncthreads();
+      FB_T(3);
       if (acta) {
         st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0); st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
       } else {
@@ -1013,6 +1024,7 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       }
     }
     __syncthreads();
+    FB_T(4);
     FB8_ROWS_GLOAD(mn);                               // next tile's rows: in flight during the GEMMs below
     if (!(FB8_ABL & 8))
     // ---- this head's share of d x_hat^T = W'q^T dQ^T + W'k^T dK^T + W'v^T dV^T: 12 steps of 16 contraction indices ----
@@ -1054,6 +1066,7 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       if (32 * wr + c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
       if (32 * wr + 16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
     }
+    FB_T(5);
     if (tile + 1 < tile_hi) FB8_QKV_GLOAD(tile + 1);     // next tile's Q, K, V: in flight during the weight-gradient GEMMs
     // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k], 16 steps of 4 tokens; lane group kq takes token 16 c + 4 kq + x in
     //      step (c, x) (rows 4 apart = 16 banks apart: the two lane groups of a half-wave do not collide) ----
@@ -1062,18 +1075,20 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       const float* pd = Ds + (4 * kq) * kLd + 32 * wr + c16;
       const float* px = Xs + (4 * kq) * kLd + fb + c16;
       const float* po = Fs + (4 * kq) * kLd + fb + c16;
-      f2 qa, ka, va, da, qb, kb, vb, db;
+      const float* pc = pd + (2 * wc + hf) * kTile;             // this wave's share of the column sums: its own extra operand read (the four
+                                                                // waves of a row half split the four matrices instead of all summing all four)
+      f2 qa, ka, va, da, qb, kb, vb, db, ca, cb;
       float xa, oa, xb, ob;
 #define FB8_TN_LOAD(S, ST)                                                                               \
   do {                                                                                                   \
     constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
     q##S = (f2){pq[o__], pq[o__ + 16]}; k##S = (f2){pq[kTile + o__], pq[kTile + o__ + 16]};              \
     v##S = (f2){pq[2 * kTile + o__], pq[2 * kTile + o__ + 16]}; d##S = (f2){pd[o__], pd[o__ + 16]};      \
-    x##S = px[o__]; o##S = po[o__];                                                                      \
+    x##S = px[o__]; o##S = po[o__]; c##S = (f2){pc[o__], pc[o__ + 16]};                                  \
   } while (0)
 #define FB8_TN_MMA(S)                                                                                    \
   do {                                                                                                   \
-    csq2 += q##S; csk2 += k##S; csv2 += v##S; csd2 += d##S;                                              \
+    cs2 += c##S;                                                                                         \
     aq0 = MFMA16(q##S.x, x##S, aq0); aq1 = MFMA16(q##S.y, x##S, aq1);                                    \
     ak0 = MFMA16(k##S.x, x##S, ak0); ak1 = MFMA16(k##S.y, x##S, ak1);                                    \
     av0 = MFMA16(v##S.x, x##S, av0); av1 = MFMA16(v##S.y, x##S, av1);                                    \
@@ -1093,11 +1108,17 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       FB8_TN_LOAD(a, 0);
       FB8_TN_PAIR(0); FB8_TN_PAIR(2); FB8_TN_PAIR(4); FB8_TN_PAIR(6); FB8_TN_PAIR(8); FB8_TN_PAIR(10); FB8_TN_PAIR(12); FB8_TN_PAIR(14);
     }
+    FB_T(6);
     mc = mn; mn = mnn;
   }
 
   // ---- workgroup slab ----
   __syncthreads();
+#ifdef FB_TIMING
+  if (blockIdx.x == 0 && (tid == 0 || tid == 256))
+    printf("fused_bwd8 wg0 wave %d us: stage %.1f dO %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (tiles %d)\n", tid >> 6,
+           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
+#endif
   float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
   {
     const int col = fb + c16;
@@ -1110,21 +1131,18 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       slab[3 * 4096 + row * 64 + col] = af0[reg]; slab[3 * 4096 + (row + 16) * 64 + col] = af1[reg];
     }
   }
-  // column sums: lane (c16, kq) covered tokens 16 c + 4 kq + x for columns 32 wr + c16 (.x) and + 16 (.y); the four lane groups are
-  // added in a fixed xor order; the waves with fb != 0 hold duplicates
+  // column sums: lane (c16, kq) covered tokens 16 c + 4 kq + x of matrix u = 2 wc + hf for columns 32 wr + c16 (.x) and + 16 (.y); the four
+  // lane groups are added in a fixed xor order
   float* red = Xs;                      // [3][64]: dcq dck dcv
-  float* red2 = Ds;                     // [64] fc1 bias gradient
+  float* red2 = Ds;                     // [64] fc1 bias gradient (column sums of dDyn)
   {
-    f2 cs[4] = {csq2, csk2, csv2, csd2};
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      float a = cs[m].x, b = cs[m].y;
-      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-      if (fb == 0 && kq == 0) {
-        float* dst = m < 3 ? red + m * 64 : red2;
-        dst[32 * wr + c16] = a; dst[32 * wr + 16 + c16] = b;
-      }
+    float a = cs2.x, b = cs2.y;
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+    const int u = 2 * wc + hf;
+    if (kq == 0) {
+      float* dst = u == 0 ? red2 : red + (u - 1) * 64;
+      dst[32 * wr + c16] = a; dst[32 * wr + 16 + c16] = b;
     }
   }
   // dK_pad / dV_pad: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 8 waves in order
