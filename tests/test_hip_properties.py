@@ -386,11 +386,12 @@ def test_fused_front_end_matches_separate_kernels(mode):
 
 
 @pytest.mark.parametrize("mode", ["table", "adj"])
-@pytest.mark.parametrize("ks", [[2, 3, 4, 5], [8, 3], [2]])
+@pytest.mark.parametrize("ks", [[2, 3, 4, 5], [8, 3], [2], [3], [2, 4], [6, 3]])
 def test_saved_tiles_backward_matches_recompute(mode, ks):
-    """d = 64 training step: the fused backward fed by the Q/K/V tiles and attention probabilities the training forward saved
-    against the same kernel recomputing them (MATCHA_DISABLE_QKV_SAVE): same weights, same dropout seed, same batch.  The
-    workspace keeps its size in both cases (the switch only changes which path runs), so one Trainer per case."""
+    """d = 64 training step, three backward kernels on the same weights, dropout seed and batch: (0) the four-wave kernel recomputing
+    Q/K/V and the softmax (disable_qkv_save), (1) the eight-wave kernel fed by the tiles and probabilities the training forward
+    saved (the default, fused_bwd8_kernel), (2) the four-wave kernel fed by the same saved tiles (disable_bwd8).  Batch widths
+    L = 2, 3, 4, 5, 6, 8 cover every template instance.  The workspace keeps its size in all cases, so one Trainer per case."""
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS["hg38_1mb"]
     N = int(np.sum(num))
@@ -399,20 +400,21 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
     y = (torch.rand(len(x), device="cuda") < 0.3).float()
     w = torch.rand(len(x), device="cuda") + 0.5
     res = []
-    for recompute in (True, False):
+    for option in ("disable_qkv_save", None, "disable_bwd8"):
         clf, _ = hip_model(num, 64, mode, 41)
         clf.train(True)
         tr = Trainer(clf, base_seed=8)
-        if recompute:
-            _lib.set_option("disable_qkv_save", 1)
+        if option:
+            _lib.set_option(option, 1)
         try:
             logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
             torch.cuda.synchronize()
         finally:
-            _lib.set_option("disable_qkv_save", 0)
+            if option:
+                _lib.set_option(option, 0)
         res.append((logits.clone(), tr.gflat.clone()))
-    assert torch.equal(res[0][0], res[1][0])                 # the forward pass computes the same thing either way
-    g0, g1 = res[0][1], res[1][1]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[1][0], res[2][0])      # the forward pass computes the same thing either way
+    g0 = res[0][1]
     assert float(g0.abs().max()) > 0
     clf, _ = hip_model(num, 64, mode, 41)
     rt = clf._runtime()
@@ -420,9 +422,11 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
         o = (p.data_ptr() - rt.flat.data_ptr()) // 4
         if n == GAUGE or o < 0 or o >= rt.n_flat:
             continue
-        a, b = g0[o:o + p.numel()], g1[o:o + p.numel()]
+        a = g0[o:o + p.numel()]
         scale = max(float(a.abs().max()), 1e-6)
-        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+        for which in (1, 2):
+            b = res[which][1][o:o + p.numel()]
+            assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
 
 
 @pytest.mark.parametrize("mode", ["table", "adj"])
