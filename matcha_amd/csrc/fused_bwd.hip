@@ -1014,13 +1014,20 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       FB_T(2);
-      if (acta) attn_col8<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
+      // dK / dV replace K / V right away: the column phase reads only Q and dO rows of other tokens (K and V were last read in the
+      // row phase, before the barrier above); dQ and O wait for the barrier below
+      if (acta) {
+        attn_col8<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
+        st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
+      } else {                                        // rows past the tile's tokens: zero, the weight-gradient GEMMs run over all 64 rows
+        ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
+      }
       __syncthreads();
       FB_T(3);
       if (acta) {
-        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0); st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
+        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0);
       } else {
-        ZR8(&Qs[la * kLd + 8 * sub]); ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
+        ZR8(&Qs[la * kLd + 8 * sub]);
       }
     }
     __syncthreads();
