@@ -61,8 +61,10 @@ static void check_carve(const matcha_shape& s, int64_t B, int L, bool compact) {
   // regions in carve order (null = size 0 in this layout)
   const void* order[] = {w.rg.row_off, w.rg.tok_slot, w.rg.tok_id, w.rg.count, w.rg.blk_sum, w.rg.tok_pos, w.rg.tok_key, w.rg.tile_meta,
                          w.rg.sb_tiles, w.rg.sb_cnt, w.rg.sb_first, w.x0, w.X, w.qin, w.kin, w.vin, w.stats, w.Q, w.K, w.V, w.P, w.O, w.Y, w.H1,
-                         w.H2, w.row_loss, w.logits, w.node, w.dH2, w.dXs, w.dZ1, w.ddyn0, w.dO, w.dQ, w.dK, w.dV, w.dqin, w.dkin, w.dvin, w.dZ0,
+                         w.H2, w.row_loss, w.logits, w.node, w.dH2, w.dXs, w.dZ1, w.ddyn0, w.dZ0,
                          w.dX0, w.slab, w.gemm_ws, w.adj_ws, w.folded, w.fb_ws, w.tslab, w.qkv, w.front_ws, w.tg_ws};
+  // the attention block's gradients live in the buffers of the activations they replace (model.hip::carve)
+  CHECK(w.dO == w.O && w.dQ == w.K && w.dK == w.Q && w.dV == w.V && w.dqin == w.qin && w.dkin == w.kin && w.dvin == w.vin);
   const int n = (int)(sizeof(order) / sizeof(order[0]));
   const char* prev = base;
   for (int i = 0; i < n; ++i) {
