@@ -276,6 +276,13 @@ __device__ __forceinline__ float4 ln_apply(const float4& v, float mean, float rs
 template <int ML>
 __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef FF_TIMING
+  long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+#define FF_T(i) do { const long long now__ = wall_clock64(); tph[i] += now__ - tlast; tlast = now__; } while (0)
+#else
+#define FF_T(i) do { } while (0)
+#endif
   float* Bs = lds;                    // current weight tile
   float* Qs = lds + 1 * kTileF;       // Q, then O (per head); later H1
   float* Ks = lds + 2 * kTileF;       // K; later H2
@@ -352,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       afr[c] = make_float4((afr[c].x - mean) * rstd, (afr[c].y - mean) * rstd, (afr[c].z - mean) * rstd, (afr[c].w - mean) * rstd);
   }
 
+  FF_T(0);
   f32x16 dyn = {0};
   for (int hd = 0; hd < MATCHA_N_HEAD; ++hd) {
     const int64_t wofs = (int64_t)hd * 64 * 64;
@@ -363,16 +371,20 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     TILE_GLOAD(wA, g.wv + wofs, 64);
     TILE_GLOAD(wB, g.fc1_w + (int64_t)hd * 64, 512);    // fc1_w[n][hd*64 + k]: the head's column block as an [n][k] tile
     __syncthreads();
+    FF_T(1);
     float* img = g.qkv ? g.qkv + ((int64_t)blockIdx.x * MATCHA_N_HEAD + hd) * kImgRec : nullptr;
     proj_store_T(Qs, afr, Bs, cbias + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img);
     proj_store_T(Ks, afr, Vs, cbias + 512 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img ? img + 4096 : nullptr);
     // ---- V ----
     __syncthreads();                                   // both weight tiles consumed
+    FF_T(2);
     TILE_LSTORE(Bs, wA);
     TILE_GLOAD(wA, last ? g.p0w : g.wq + wofs + 64 * 64, 64);
     __syncthreads();
+    FF_T(3);
     proj_store_T(Vs, afr, Bs, cbias + 1024 + hd * 64, wr, wc, r, h, (g.dbg & 2) != 0, img ? img + 8192 : nullptr);
     __syncthreads();                                   // Q, K, V tiles complete; Bs free
+    FF_T(4);
     TILE_LSTORE(Bs, wB);                               // fc1 block (read after the next barrier)
     TILE_GLOAD(wB, last ? g.p1w : g.wk + wofs + 64 * 64, 64);
     // ---- attention: 8 lanes per query token, two passes of 32 tokens ----
@@ -383,10 +395,13 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       if (lb < n_real) { const int ti = tinfo[lb]; attn_row_fwd<ML>(Qs, Ks, Vs, lb, ti & 255, ti >> 8, g.L - (ti >> 8), n_real, lane & 7, inv_temp, pimg); }
     }
     __syncthreads();
+    FF_T(5);
     // ---- dyn += O_h . Wfc1[:, head block]^T ----
     if (!(g.dbg & 2)) dyn = quad_gemm_ldsA(dyn, Qs, Bs, wr, wc, r, h);
+    FF_T(6);
   }
   __syncthreads();                                     // last fc1 GEMM done: Bs, Qs, Ks, Vs free
+  FF_T(7);
 
   // ---- Y = mask * dropout(dyn + b) -> Vs (+ global) ----
   uint32_t keep1 = 0, keep2 = 0;                        // this lane's 16 keep bits of the two dropout masks (reused by the backward part)
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       for (int i = 0; i < k; ++i) douts[li0 + i] = dout;
     }
   }
+  FF_T(8);
   if (!g.ddyn0) return;
 
   // =========== backward of the tail and of pff_n1 (Modules.py:290-311, :353-376), everything still in LDS ===========
@@ -667,6 +683,12 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     for (int q = 0; q < 16; ++q) t += redc[128 + q];
     tsl[kTailVec + 9 * 64] = t;
   }
+  FF_T(9);
+#ifdef FF_TIMING
+  if (blockIdx.x == 1000 && tid == 0)
+    printf("fused_fwd wg1000 us: setup %.1f | 8 heads: stageQK %.1f gemmQK %.1f stageV %.1f gemmV %.1f attn %.1f fc1 %.1f | drain %.1f tail-fwd %.1f tail-bwd %.1f\n",
+           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tph[8] * 0.01, tph[9] * 0.01);
+#endif
 }
 
 // Sum the per-tile slabs of the training forward in a fixed order and accumulate into the gradient tensors.
