@@ -522,3 +522,47 @@ def test_trainer_fused_step_vs_oracle_4096_rows_dropout(mode, layout, rows_per_k
         assert np.abs(mine[n].cpu().numpy() - r).max() <= TOL * max(np.abs(r).max(), 1e-3), n
         n_checked += 1
     assert n_checked >= 26, n_checked          # table front end: 28 live tensors minus the gauge direction
+
+
+def test_captured_step_replays_like_eager_steps():
+    """Trainer.capture(): two eager warm-up steps + N replays of the captured hipGraph leave the same parameters as N + 2 eager
+    steps on the same (static) batch -- bitwise with the deterministic embedding backward; the dropout seed lives in device memory
+    and is advanced by the graph itself, so every replay draws new masks exactly like an eager step."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(12)
+    x = _mixed_batch(N, [2, 3, 4, 5], 512, rng)
+    y = (torch.rand(len(x), device="cuda") < 0.25).float()
+    w = torch.ones(len(x), device="cuda")
+    res = []
+    for graph in (False, True):
+        clf, _ = hip_model(num, 64, "table", 6)
+        clf.train()
+        tr = Trainer(clf, base_seed=3, deterministic=True)
+        if graph:
+            replay = tr.capture(x, y, w, alpha=1.0, beta=0.0)       # runs two eager steps, then records the third
+            for _ in range(3):
+                bce, _, _ = replay()
+        else:
+            for _ in range(5):
+                bce, _, _ = tr.step(x, y, w, alpha=1.0, beta=0.0)
+        torch.cuda.synchronize()
+        res.append((float(bce), {n: p.detach().clone() for n, p in clf.named_parameters()}))
+    assert res[0][0] == res[1][0]
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_capture_refuses_to_freeze_the_reconstruction_chromosome():
+    """adj front end with beta != 0: random_chrom is a host-side launch parameter, so a graph would train one recon head forever."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["c1"]
+    clf, _ = hip_model(num, 64, "adj", 6)
+    clf.train()
+    tr = Trainer(clf)
+    x = _mixed_batch(int(np.sum(num)), [2, 3], 16, np.random.default_rng(0))
+    y = torch.zeros(len(x), device="cuda")
+    w = torch.ones(len(x), device="cuda")
+    with pytest.raises(RuntimeError, match="random_chrom"):
+        tr.capture(x, y, w, alpha=1.0, beta=0.001, random_chrom=1)
