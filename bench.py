@@ -120,6 +120,11 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # torch.distributed.run / torchrun
+        # plumbing tests on a one-GPU box: MATCHA_DIST_BACKEND=gloo MATCHA_LOCAL_DEVICE=0 runs every rank on device 0 (as
+        # matcha_amd.train.init_distributed does); the driver's runs use neither: one rank per GPU over RCCL
+        self.backend = os.environ.get("MATCHA_DIST_BACKEND", "nccl")
+        if "MATCHA_LOCAL_DEVICE" in os.environ:
+            self.local_rank = int(os.environ["MATCHA_LOCAL_DEVICE"])
         self.device = torch.device("cuda", self.local_rank)
 
     def barrier(self):
@@ -366,7 +371,10 @@ def main():
     torch.cuda.set_device(dist.local_rank)
     if dist.world > 1 or dist.launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dist.device)
+        if dist.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dist.device)
+        else:
+            torch.distributed.init_process_group(dist.backend)
     world, rank = dist.world, dist.rank
     ks = [int(v) for v in args.ks.split(",")]
 

@@ -234,3 +234,27 @@ def test_train_run_data_parallel_two_ranks(tmp_path, front_end):
     assert emb.shape == (N, 16) and np.isfinite(emb).all()
     assert os.path.exists(os.path.join(cfg["temp_dir"], "model.chkpt")) and os.path.exists(os.path.join(cfg["temp_dir"], "model2load"))
     assert os.path.exists(os.path.join(tmp_path, "rank0.json"))
+
+
+def test_bench_multi_rank_path_two_ranks_on_one_gpu(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one JSON line from rank 0), here with two
+    ranks sharing device 0 over gloo: sharding of the positives, the barrier-bracketed timed region, the max over ranks, the
+    per-step gradient all-reduce and rank 0's record."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MATCHA_DIST_BACKEND="gloo", MATCHA_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--rows", "8192", "--edges-per-k", "20000"]
+    run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    assert rec["config"]["global_rows_per_step"] == 2 * rec["config"]["rows_per_gpu_per_step"] == 16384
+    assert rec["config"]["parallelism"] == "dp2" and rec["config"]["table_gradient_exchange"] == "flat all-reduce"
+    assert abs(rec["value"] - 16384 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-3 * rec["value"]
+    assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None          # rank 0 at N = 1 only
+    assert rec["roofline"] is not None and 0.0 < rec["last_bce"] < 5.0
