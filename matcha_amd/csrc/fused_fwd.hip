@@ -312,6 +312,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   uint32_t* hrow1 = reinterpret_cast<uint32_t*>(tinfo + 64);       // [64] lowbias32(slot ^ key) for the fc1 dropout stream
   uint32_t* hrow2 = hrow1 + 64;                                    // [64] ... for the pff dropout stream
   float* cbias = lds + 4 * kTileF + 272;                          // [3][512]
+  // the tail's parameter vectors, the three bias vectors of fc1 / conv0 / conv1 and the tile's labels and weights: fetched here once
+  // (their latency hides behind the head loop) instead of as global loads at the head of each of the tail's short phases
+  float* tpar = cbias + 3 * 512;                                  // [12][64]: gp bp g1 b1 g2 b2 wc | fc1_b p0b p1b | y w
   const bool lroff = n_h <= 78;                                   // more only when many all-padding rows share the window
   if (lroff)
     for (int i = tid; i <= n_h; i += 256) roff[i] = g.row_off[b0 + i] - t0;
@@ -330,6 +333,14 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     hrow2[tid] = lowbias32(slot ^ rng_key(*g.seed, kStreamDropPff));
   }
   for (int i = tid; i < 3 * 512; i += 256) cbias[i] = (i < 512) ? g.cq[i] : (i < 1024 ? g.ck[i - 512] : g.cv[i - 1024]);
+  for (int i = tid; i < 10 * 64; i += 256) {
+    const int v = i >> 6, j = i & 63;
+    const float* src = v == 0 ? g.hp.gp : v == 1 ? g.hp.bp : v == 2 ? g.hp.g1 : v == 3 ? g.hp.b1 : v == 4 ? g.hp.g2 : v == 5 ? g.hp.b2
+                     : v == 6 ? g.hp.wc : v == 7 ? g.fc1_b : v == 8 ? g.p0b : g.p1b;
+    tpar[i] = src[j];
+  }
+  const bool lyw = g.row_loss && n_h <= 64;                       // labels / weights of the tile's hyperedges (training forward)
+  if (lyw && tid < n_h) { tpar[10 * 64 + tid] = g.y[b0 + tid]; tpar[11 * 64 + tid] = g.w[b0 + tid]; }
 
   // ---- x_hat fragments straight from global memory: lane (r, h) holds k = 8c + 4h .. +3 of row 32 wr + r; the other
   //      half of the row lives in lane r + 32, so the LayerNorm statistics need one cross-half shuffle ----
@@ -403,6 +414,16 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   __syncthreads();                                     // last fc1 GEMM done: Bs, Qs, Ks, Vs free
   FF_T(7);
 
+  // the static branch's rows of X (LN2 in the tail): fetched now, in flight during the two pff GEMMs, instead of a dependent global
+  // load per row in the middle of the tail's chain of short phases
+  float4 xs0, xs1, xs2, xs3;
+#define FF_XS_GLOAD(I)                                                                                   \
+  do {                                                                                                   \
+    const int row__ = srow + 16 * (I);                                                                   \
+    const int64_t tok__ = row__ < n_real ? (int64_t)(t0 + row__) : (int64_t)tok_pad;                     \
+    xs##I = *reinterpret_cast<const float4*>(g.X + tok__ * 64 + sc4);                                    \
+  } while (0)
+  FF_XS_GLOAD(0); FF_XS_GLOAD(1); FF_XS_GLOAD(2); FF_XS_GLOAD(3);
   // ---- Y = mask * dropout(dyn + b) -> Vs (+ global) ----
   uint32_t keep1 = 0, keep2 = 0;                        // this lane's 16 keep bits of the two dropout masks (reused by the backward part)
   float* Ys = Vs;
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   TILE_LSTORE(Bs, wA);                                 // conv0 weight (fetched during the last head)
   {
     const int col = 32 * wc + r;
-    const float bv = g.fc1_b[col];
+    const float bv = tpar[7 * 64 + col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     f32x16 acc = {0};
     acc = quad_gemm_ldsA(acc, Ys, Bs, wr, wc, r, h);
     const int col = 32 * wc + r;
-    const float bv = g.p0b[col];
+    const float bv = tpar[8 * 64 + col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -459,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     f32x16 acc = {0};
     acc = quad_gemm_ldsA(acc, H1s, Bs, wr, wc, r, h);
     const int col = 32 * wc + r;
-    const float bv = g.p1b[col];
+    const float bv = tpar[9 * 64 + col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -474,10 +495,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   float* outs = cbias;                                  // [64] per-token outputs (the folded biases are dead after the head loop)
   float* douts = cbias + 64;                            // [64] per-token gradient of them (training step)
   {
-    const float4 Gp = *reinterpret_cast<const float4*>(g.hp.gp + sc4), Bp = *reinterpret_cast<const float4*>(g.hp.bp + sc4);
-    const float4 G1 = *reinterpret_cast<const float4*>(g.hp.g1 + sc4), B1 = *reinterpret_cast<const float4*>(g.hp.b1 + sc4);
-    const float4 G2 = *reinterpret_cast<const float4*>(g.hp.g2 + sc4), B2 = *reinterpret_cast<const float4*>(g.hp.b2 + sc4);
-    const float4 Wc = *reinterpret_cast<const float4*>(g.hp.wc + sc4);
+    const float4 Gp = *reinterpret_cast<const float4*>(tpar + 0 * 64 + sc4), Bp = *reinterpret_cast<const float4*>(tpar + 1 * 64 + sc4);
+    const float4 G1 = *reinterpret_cast<const float4*>(tpar + 2 * 64 + sc4), B1 = *reinterpret_cast<const float4*>(tpar + 3 * 64 + sc4);
+    const float4 G2 = *reinterpret_cast<const float4*>(tpar + 4 * 64 + sc4), B2 = *reinterpret_cast<const float4*>(tpar + 5 * 64 + sc4);
+    const float4 Wc = *reinterpret_cast<const float4*>(tpar + 6 * 64 + sc4);
     const float bc = g.hp.bc[0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -488,8 +509,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       const float4 u = ln_apply(hv, m, rs, Gp, Bp);
       ln_row16(u, m, rs);
       const float4 dn = ln_apply(u, m, rs, G1, B1);
-      const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
-      const float4 xv = *reinterpret_cast<const float4*>(g.X + tok * 64 + sc4);     // static branch: LN2 of the raw X row
+      const float4 xv = i == 0 ? xs0 : (i == 1 ? xs1 : (i == 2 ? xs2 : xs3));          // static branch: LN2 of the raw X row
       ln_row16(xv, m, rs);
       const float4 sn = ln_apply(xv, m, rs, G2, B2);
       const float a = dn.x - sn.x, b = dn.y - sn.y, c = dn.z - sn.z, e = dn.w - sn.w;
@@ -507,9 +527,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     for (int i = 0; i < k; ++i) tot += outs[li0 + i];
     const float z = tot / ((float)k + 1e-15f);
     g.logits[b] = z;
-    if (g.row_loss) g.row_loss[b] = g.w[b] * (fmaxf(z, 0.f) - z * g.y[b] + log1pf(expf(-fabsf(z))));
+    const float yb = g.row_loss ? (lyw ? tpar[10 * 64 + e] : g.y[b]) : 0.f, wb = g.row_loss ? (lyw ? tpar[11 * 64 + e] : g.w[b]) : 0.f;
+    if (g.row_loss) g.row_loss[b] = wb * (fmaxf(z, 0.f) - z * yb + log1pf(expf(-fabsf(z))));
     if (g.ddyn0) {                                     // main.py:56 backward: d bce / d z = w (sigmoid(z) - y) / B  (x alpha, main.py:166)
-      const float dz = g.alpha_over_B * g.w[b] * (1.f / (1.f + expf(-z)) - g.y[b]);
+      const float dz = g.alpha_over_B * wb * (1.f / (1.f + expf(-z)) - yb);
       const float dout = dz / ((float)k + 1e-15f);
       for (int i = 0; i < k; ++i) douts[li0 + i] = dout;
     }
@@ -524,10 +545,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   float4 aGp = make_float4(0.f, 0.f, 0.f, 0.f), aBp = aGp, aG1 = aGp, aB1 = aGp, aG2 = aGp, aB2 = aGp, aWc = aGp;
   float abc = 0.f;
   {
-    const float4 Gp = *reinterpret_cast<const float4*>(g.hp.gp + sc4), Bp = *reinterpret_cast<const float4*>(g.hp.bp + sc4);
-    const float4 G1 = *reinterpret_cast<const float4*>(g.hp.g1 + sc4), B1 = *reinterpret_cast<const float4*>(g.hp.b1 + sc4);
-    const float4 G2 = *reinterpret_cast<const float4*>(g.hp.g2 + sc4), B2 = *reinterpret_cast<const float4*>(g.hp.b2 + sc4);
-    const float4 Wc = *reinterpret_cast<const float4*>(g.hp.wc + sc4);
+    const float4 Gp = *reinterpret_cast<const float4*>(tpar + 0 * 64 + sc4), Bp = *reinterpret_cast<const float4*>(tpar + 1 * 64 + sc4);
+    const float4 G1 = *reinterpret_cast<const float4*>(tpar + 2 * 64 + sc4), B1 = *reinterpret_cast<const float4*>(tpar + 3 * 64 + sc4);
+    const float4 G2 = *reinterpret_cast<const float4*>(tpar + 4 * 64 + sc4), B2 = *reinterpret_cast<const float4*>(tpar + 5 * 64 + sc4);
+    const float4 Wc = *reinterpret_cast<const float4*>(tpar + 6 * 64 + sc4);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -541,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       ln_row16(u, m, ru);
       const float4 uh = ln_apply(u, m, ru, one4, zero4);
       const int64_t tok = row < n_real ? (int64_t)(t0 + row) : (int64_t)tok_pad;
-      const float4 xv = *reinterpret_cast<const float4*>(g.X + tok * 64 + sc4);
+      const float4 xv = i == 0 ? xs0 : (i == 1 ? xs1 : (i == 2 ? xs2 : xs3));          // the rows fetched before the pff GEMMs
       ln_row16(xv, m, rx);
       const float4 xh = ln_apply(xv, m, rx, one4, zero4);
       const float4 df = make_float4((uh.x * G1.x + B1.x) - (xh.x * G2.x + B2.x), (uh.y * G1.y + B1.y) - (xh.y * G2.y + B2.y),
@@ -777,7 +798,7 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   g.dbg = options().fused_dbg;
   const int ntiles = rg.ntiles;
-  size_t lds = ((size_t)4 * kTileF + 272 + 3 * 512) * sizeof(float);
+  size_t lds = ((size_t)4 * kTileF + 272 + 3 * 512 + 12 * 64) * sizeof(float);
   lds += (size_t)options().fwd_lds_pad;      // occupancy experiment: 1 workgroup per CU
   auto launch = [&](auto kfn) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
