@@ -277,7 +277,7 @@ template <int ML>
 __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef FF_TIMING
-  long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tph[24] = {0};
   long long tlast = wall_clock64();
 #define FF_T(i) do { const long long now__ = wall_clock64(); tph[i] += now__ - tlast; tlast = now__; } while (0)
 #else
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
+  FF_T(10);
   // ---- H1 = dropout(tanh(Y W0^T + b0)) -> Qs ----
   {
     f32x16 acc = {0};
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
+  FF_T(11);
   TILE_LSTORE(Bs, wB);                                 // conv1 weight
   __syncthreads();
   // ---- H2 = H1 W1^T + b1 + Y -> Ks ----
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
+  FF_T(12);
   // ---- tail per token (16 lanes per row): out_t = sum_j (LN1(LN_pff(H2)) - LN2(X))_j^2 wc_j + bc ----
   float* outs = cbias;                                  // [64] per-token outputs (the folded biases are dead after the head loop)
   float* douts = cbias + 64;                            // [64] per-token gradient of them (training step)
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
+  FF_T(13);
   // ---- per-hyperedge masked mean -> logit (+ BCE term) ----
   for (int e = tid; e < n_h; e += 256) {
     const int64_t b = b0 + e;
@@ -541,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   // =========== backward of the tail and of pff_n1 (Modules.py:290-311, :353-376), everything still in LDS ===========
   TILE_GLOAD(wA, g.p0w, 64);                           // conv0 weight for the last phase; Bs still holds conv1's
   __syncthreads();                                     // douts complete
+  FF_T(14);
   float* tsl = g.tslab + (int64_t)blockIdx.x * kTailSlab;
   float4 aGp = make_float4(0.f, 0.f, 0.f, 0.f), aBp = aGp, aG1 = aGp, aB1 = aGp, aG2 = aGp, aB2 = aGp, aWc = aGp;
   float abc = 0.f;
@@ -584,6 +589,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
+  FF_T(15);
   // ---- conv1: dW1[n][k] += sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2;  dZ1 = (dH2 W1) * dropmask * tanh' ----
   float* dZs = H1s;
   float cs1 = 0.f, cs0 = 0.f;
@@ -615,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * kLdT], acc, 0, 0, 0);
     }
     __syncthreads();                                   // every wave is done reading H1 (weight gradient) and W1
+    FF_T(16);
     const int col = 32 * wc + r;
     const float unscale = drop2 ? 1.f - g.p_pff : 1.f;
 #pragma unroll
@@ -629,6 +636,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
     TILE_LSTORE(Bs, wA);                               // conv0 weight
   }
   __syncthreads();
+  FF_T(17);
   // ---- conv0: dW0[n][k] += sum_t dZ1[t][n] Y[t][k];  d b0 = column sums of dZ1;  d dyn = (dZ1 W0 + dH2) * dropmask * rowmask ----
   {
     f32x16 aw = {0};
@@ -670,6 +678,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   }
   // ---- parameter-vector partials of this tile: rows of the 16 staging groups, then the two column sums ----
   __syncthreads();                                     // all reads of the tiles are done: Bs / dZs are scratch now
+  FF_T(18);
   // d dyn leaves as whole 256-byte rows (16 lanes x 16 bytes) instead of 16 four-byte stores per lane in the accumulator layout
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -692,6 +701,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   if (wc == 0 && h == 0) { redc[32 * wr + r] = cs1; redc[64 + 32 * wr + r] = cs0; }
   if ((tid & 15) == 0) redc[128 + srow] = abc;
   __syncthreads();
+  FF_T(19);
   for (int i = tid; i < 7 * 64; i += 256) {
     float t = 0.f;
 #pragma unroll
@@ -709,6 +719,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
   if (blockIdx.x == 1000 && tid == 0)
     printf("fused_fwd wg1000 us: setup %.1f | 8 heads: stageQK %.1f gemmQK %.1f stageV %.1f gemmV %.1f attn %.1f fc1 %.1f | drain %.1f tail-fwd %.1f tail-bwd %.1f\n",
            tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tph[8] * 0.01, tph[9] * 0.01);
+  if (blockIdx.x == 1000 && tid == 0)
+    printf("   tail fwd: Y %.1f H1 %.1f H2 %.1f ln %.1f (logit -> tph8 %.1f) | tail bwd: sync %.1f ln-bwd %.1f conv1-dW %.1f sync %.1f dZ1 %.1f conv0 %.1f rest %.1f\n",
+           tph[10] * 0.01, tph[11] * 0.01, tph[12] * 0.01, tph[13] * 0.01, tph[8] * 0.01, tph[14] * 0.01, tph[15] * 0.01, tph[16] * 0.01, tph[17] * 0.01, tph[18] * 0.01, tph[19] * 0.01, tph[9] * 0.01);
 #endif
 }
 
