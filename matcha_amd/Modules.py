@@ -445,7 +445,11 @@ class _ClassifierFn(torch.autograd.Function):
                                           ctx.ws.numel(), rt.stream()), "matcha_backward")
         ctx.ws = None
         outs = []
-        tl = touched.tolist() if rt.mode == 1 else None      # adj: which per-chromosome tensors have grad None
+        # adj front end: the reference leaves .grad None for the encoders / recon heads of chromosomes that did not occur in the batch,
+        # and torch.optim.AdamW skips such tensors (no weight decay, no moment decay): reproducing that through autograd needs the
+        # flags on the host, i.e. one synchronisation per backward of THIS path (loss.backward() with torch optimisers).  The
+        # training path proper (engine.Trainer) keeps the flags on the device and never synchronises.
+        tl = touched.tolist() if rt.mode == 1 else None
         for p, o, g in zip(rt.live, rt.seg_off_list[:-1], rt.seg_group_list):
             if tl is not None and g >= 2 and tl[g] == 0:
                 outs.append(None)
