@@ -223,6 +223,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
     # which kernel class is dominant?  measure every class over two steps each (outside the timed region)
     prof_cls = prof
     class_ms = {}
+    class_work = {}
     if prof_cls == "auto" and not graph:
         for name, cid in _lib.PROF.items():
             lib.matcha_profile_select(cid)
@@ -232,6 +233,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             _lib.check(lib.matcha_profile_read(C.byref(ms), C.byref(n), C.byref(wk)))
             if n.value:
                 class_ms[name] = ms.value / 2.0
+                class_work[name] = (wk.value / n.value, n.value / 2.0)       # work per launch (launch bound B*L + 1 rows), launches per step
         lib.matcha_profile_select(0)
         prof_cls = max(class_ms, key=class_ms.get) if class_ms else "none"
     if graph:
@@ -303,7 +305,22 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
     trainer.check_status()
     exhausted = sampler.check_status()
     losses = trainer.losses.cpu().tolist()
-    out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, roof=roof, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
+    # every MFMA- / HBM-bound kernel class against its roofline, from the same two-step measurement that picked the dominant one
+    # (work scaled from the launch bound to the real tokens like `roofline`; the sampler's and AdamW's work is exact)
+    fill_all = (float((x != 0).sum().item()) + 1.0) / (B * L + 1.0)
+    roof_all = {}
+    for name, ms_step in class_ms.items():
+        wpl, lps = class_work[name]
+        work = wpl * lps * (1.0 if name in ("adamw", "neg_sample") else fill_all)
+        if ms_step <= 0 or work <= 0:
+            continue
+        if name in GEMM_CLASSES:
+            ach = work / (ms_step * 1e-3) / 1e12
+            roof_all[name] = dict(bound="mfma", ms_per_step=round(ms_step, 4), achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
+        else:
+            ach = work / (ms_step * 1e-3) / 1e9
+            roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+    out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, roof=roof, roof_all=roof_all, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
                pool=pool, wts=None if pool is None else wts, num=num, known_edges=workload_edges, sparse_exchange=bool(trainer._sparse),
                exhausted_negatives=exhausted)
     del trainer, clf, sampler, hset, pool_all
@@ -403,6 +420,7 @@ def main():
                                                                      "hyperedges_per_s": round(B * world / (m["model_only_ms"] * 1e-3), 1)},
         "roofline": m["roof"],
         "kernel_class_ms_per_step": {k: round(v, 4) for k, v in sorted(m["class_ms"].items(), key=lambda kv: -kv[1])},
+        "roofline_by_kernel_class": m["roof_all"],
         "csrc_sha16": csrc_sha16(),
     }
     default_run = (args.layout, args.dim, args.front_end, args.rows, args.ks) == ("hg38_1mb", 64, "table", 65536, "2,3,4,5")
