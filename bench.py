@@ -322,7 +322,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
     out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, roof=roof, roof_all=roof_all, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
                pool=pool, wts=None if pool is None else wts, num=num, known_edges=workload_edges, sparse_exchange=bool(trainer._sparse),
-               exhausted_negatives=exhausted)
+               exhausted_negatives=exhausted, comm_bytes=dict(trainer.comm_bytes), overlap=bool(trainer._side is not None and trainer._overlap()))
     del trainer, clf, sampler, hset, pool_all
     gc.collect()
     torch.cuda.empty_cache()
@@ -378,11 +378,36 @@ def gather_roofline(device):
     return out
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed.run launch: start the N ranks ourselves -- one process per GPU
+    over RCCL, exactly the command the driver would have used -- as a CHILD process, before anything in this process has touched
+    the GPU (no HIP call, no torch.cuda.is_available(); counting devices does not initialise it), and hand its exit code back.
+    Rank 0's JSON line reaches stdout through the inherited descriptor.  Never falls back to one rank."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to report a {args.gpus}-GPU line", file=sys.stderr)
+        return 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     dist = Dist()
-    if args.gpus != dist.world and dist.world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {dist.world}")
+    if args.gpus != dist.world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {dist.world} (launch with `python bench.py --gpus N`, or with "
+                         f"torch.distributed.run --nproc-per-node N bench.py --gpus N)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(dist.local_rank)
@@ -412,8 +437,11 @@ def main():
                                f"front end={args.front_end}, neg_num=3, dropout on, AdamW lr=1e-3, {m['known_edges']} known hyperedges",
                    "rows_per_gpu_per_step": B, "positives_per_gpu_per_step": P, "global_rows_per_step": B * world,
                    "parallelism": f"dp{world}", "hipgraph": bool(args.graph),
-                   "table_gradient_exchange": "row-sparse all-gather" if m["sparse_exchange"] else ("flat all-reduce" if world > 1 else "none"),
-                   "embedding_backward": "sorted, one writer per row (bitwise reproducible)" if args.deterministic else "float atomics"},
+                   "table_gradient_exchange": "row-sparse all-gather" if m["sparse_exchange"] else ("flat all-reduce" if (world > 1 or dist.launched) else "none"),
+                   "embedding_backward": "sorted, one writer per row (bitwise reproducible)" if args.deterministic else "float atomics",
+                   # bytes each collective of one step moves per rank (payload; a ring all-reduce sends and receives 2 (N-1)/N of it,
+                   # the all-gather receives what is listed), and whether the encoder part overlaps the front-end backward
+                   "collective_payload_bytes_per_step": m["comm_bytes"], "exchange_overlapped": m["overlap"]},
         "positives_per_s": round(P * world * args.steps / elapsed, 1),
         "last_bce": round(m["losses"][0], 5),
         "model_step_only": None if m["model_only_ms"] is None else {"ms_per_step": round(m["model_only_ms"], 4),

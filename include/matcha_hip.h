@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MATCHA_ABI_VERSION 4
+#define MATCHA_ABI_VERSION 5
 
 #define MATCHA_OK 0
 #define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
@@ -178,6 +178,11 @@ typedef struct matcha_step_opts {
                                 reproducible, ~60 us per 65 536-row step at hg38 1 Mb sizes); 0 = float atomics from the
                                 front-end backward kernel (order of additions varies from run to run, like
                                 torch.nn.Embedding's CUDA backward; nothing else in the step is order-dependent)            */
+  void* encoder_done_event;  /* optional hipEvent_t (NULL = off): matcha_backward records it on `stream` as soon as the gradients
+                                of every parameter from ln_q_g to cls_b (the encoder, pff_n1 and the classifier tail -- the
+                                contiguous tail of a flat gradient buffer laid out in matcha_tensors order) are final, i.e.
+                                before the front-end backward and the embedding scatter run: a data-parallel caller starts the
+                                all-reduce of that part on a second stream and overlaps it with the rest of the backward      */
 } matcha_step_opts;
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */

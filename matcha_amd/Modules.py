@@ -497,6 +497,11 @@ class Classifier(nn.Module):
     def check_status(self):
         self._runtime().check_status("Classifier")
 
+    def deferred_id_check(self):
+        """Context manager for bulk callers: ``with model.deferred_id_check(): ...many forwards...`` enqueues the calls without
+        the per-call status read-back and raises the reference's IndexError once, at the end of the block."""
+        return _DeferredIdCheck(self)
+
     # ---- runtime plumbing ---------------------------------------------------------------------------
     def __getstate__(self):
         st = self.__dict__.copy()
@@ -591,7 +596,7 @@ class Classifier(nn.Module):
         ws = rt.workspace(B, L)
         dyn = torch.empty(B, L, rt.d, dtype=torch.float32, device=rt.device)
         sta = torch.empty_like(dyn)
-        praw = torch.zeros(B, _lib.N_HEAD, L, L, dtype=torch.float32, device=rt.device)
+        praw = torch.empty(B, _lib.N_HEAD, L, L, dtype=torch.float32, device=rt.device)      # filled by a copy of the workspace's P
         losses = torch.zeros(3, dtype=torch.float32, device=rt.device)
         _lib.check(rt.lib.matcha_get_embedding(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                                _lib.ptr(dyn), _lib.ptr(sta), _lib.ptr(praw), _lib.ptr(losses), _lib.ptr(ws), ws.numel(),
@@ -607,11 +612,34 @@ class Classifier(nn.Module):
         row = torch.where(real, torch.cumsum(real.long(), 1) - 1, torch.zeros_like(col))          # compact row of a real query slot
         p = praw.gather(3, col.view(B, 1, 1, L).expand(B, _lib.N_HEAD, L, L))                     # columns in slot order
         p = p.gather(2, row.view(B, 1, L, 1).expand(B, _lib.N_HEAD, L, L))                        # rows in slot order
-        p = p * real.view(B, 1, L, 1).to(p.dtype)
+        # rows / columns at or beyond k are never written by the attention kernel (uninitialised workspace bytes, possibly NaN):
+        # select, do not multiply
+        p = torch.where(real.view(B, 1, L, 1), p, torch.zeros((), dtype=p.dtype, device=p.device))
         attn = p.permute(1, 0, 2, 3).reshape(_lib.N_HEAD * B, L, L)
         if return_recon:
             return dyn, sta, attn, losses[1:2]
         return dyn, sta, attn
+
+
+class _DeferredIdCheck:
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        m = self.model
+        self.had, self.prev = "check_ids" in m.__dict__, m.check_ids
+        m.__dict__["check_ids"] = False
+        return m
+
+    def __exit__(self, exc_type, exc, tb):
+        m = self.model
+        if self.had:
+            m.__dict__["check_ids"] = self.prev
+        else:
+            m.__dict__.pop("check_ids", None)
+        if exc_type is None and self.prev:
+            m.check_status()
+        return False
 
 
 class DataGenerator:

@@ -47,7 +47,7 @@ class StepOpts(C.Structure):
     _fields_ = [("training", C.c_int32), ("random_chrom", C.c_int32), ("p_drop_adj", C.c_float),
                 ("p_drop_fc1", C.c_float), ("p_drop_pff", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
                 ("seed", _fp), ("forward_only", C.c_int32), ("loss_in_forward", C.c_int32), ("status", _fp),
-                ("sparse_table_grad", C.c_int32), ("deterministic", C.c_int32)]
+                ("sparse_table_grad", C.c_int32), ("deterministic", C.c_int32), ("encoder_done_event", _fp)]
 
 
 class RaggedView(C.Structure):
@@ -108,7 +108,7 @@ SIGNATURES = {
     "matcha_zscore_rows": (C.c_int, [_fp, _I64, _I64, _fp]),
 }
 
-ABI_VERSION = 4             # MATCHA_ABI_VERSION of include/matcha_hip.h
+ABI_VERSION = 5             # MATCHA_ABI_VERSION of include/matcha_hip.h
 
 _lib = None
 

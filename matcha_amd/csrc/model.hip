@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "kernels.hpp"
 
 namespace matcha {
@@ -110,6 +113,22 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
   return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && !options().disable_loss_in_forward;
 }
 static bool save_qkv() { return !options().disable_qkv_save; }
+// Whether the forward that last ran on a workspace left its Q/K/V tiles there.  matcha_backward keys off THIS record, not off the
+// option: flipping disable_qkv_save between a forward and its backward (two separate calls on the autograd path) would otherwise
+// make the eight-wave backward consume tiles nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so
+// it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
+static std::mutex g_qkv_mu;
+static std::unordered_map<const void*, bool> g_qkv_saved;
+static void note_qkv_saved(const void* ws, bool saved) {
+  std::lock_guard<std::mutex> lk(g_qkv_mu);
+  if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
+  g_qkv_saved[ws] = saved;
+}
+static bool qkv_saved(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_qkv_mu);
+  auto it = g_qkv_saved.find(ws);
+  return it != g_qkv_saved.end() && it->second;
+}
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
 // x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
@@ -184,6 +203,14 @@ static int table_gradient(const matcha_shape& s, const matcha_step_opts& o, cons
   if (o.sparse_table_grad) return MATCHA_OK;
   if (!o.deterministic) return MATCHA_OK;                 // the front-end kernel already added the rows with float atomics
   return launch_table_grad(w.rg.tok_key, w.dX0, Tn, s.d, s.n_nodes, g.table, w.tg_ws, w.tg_ws_bytes, st);
+}
+
+// opts->encoder_done_event: every gradient from ln_q_g to cls_b is final at this point of the stream (include/matcha_hip.h)
+static int encoder_done(const matcha_step_opts& o, hipStream_t st) {
+  if (o.encoder_done_event && hipEventRecord((hipEvent_t)o.encoder_done_event, st) != hipSuccess) {
+    set_error("matcha_backward: recording encoder_done_event failed"); return MATCHA_EHIP;
+  }
+  return MATCHA_OK;
 }
 
 static int check_shape(const matcha_shape* s, int64_t B, int32_t L) {
@@ -342,12 +369,14 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     const bool lif = loss_in_forward(s, *opts, y, w_bce);            // the tail's backward runs in this kernel: nothing saved
     const bool save = !opts->forward_only && !lif;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
+    const bool keep_qkv = !opts->forward_only && save_qkv();
+    note_qkv_saved(ws, keep_qkv);
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
     MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                 lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, (!opts->forward_only && save_qkv()) ? w.qkv : nullptr));
+                                lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -509,7 +538,8 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
     const bool front = front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
-    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, save_qkv() ? w.qkv : nullptr));
+    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
+    MATCHA_TRY(encoder_done(*opts, st));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
@@ -547,6 +577,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   // LayerNorm x3 backward + static-branch gradient + tanh'
   MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, Tn, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
                             g_.ln_q_b, g_.ln_k_g, g_.ln_k_b, g_.ln_v_g, g_.ln_v_b, st, cnt));
+  MATCHA_TRY(encoder_done(*opts, st));
   }
   // next_w: dW += dZ0^T x0 ; db += colsum ; dX0 = dZ0 Wn
   MATCHA_TRY(launch_gemm_tn(w.dZ0, w.x0, g_.next_w, g_.next_b, d, d, Tn, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));

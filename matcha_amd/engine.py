@@ -75,6 +75,13 @@ class Trainer:
         # starts behind it
         self._n_table = (rt.field_off_after("table") if rt.mode == 0 else 0)
         self._sparse = False
+        # exchange options (A/B in tests): overlap the encoder part of the bucket with the front-end backward; exchange the
+        # row-sparse lists compacted to the real tokens
+        self.overlap_exchange = True
+        self.compact_exchange = True
+        self._side = None
+        self._enc_work = None
+        self.comm_bytes = {}              # bytes each collective of the last step moved per rank (bench.py reports them)
 
     # ---- buffers ------------------------------------------------------------------------------------
     def _buffers(self, B: int, L: int):
@@ -123,6 +130,11 @@ class Trainer:
         self._last_shape = (B, L)
         opts = self._opts(alpha, beta, random_chrom)
         st = rt.stream()
+        self.comm_bytes = {}
+        self._begin_exchange(x)
+        overlap = self._overlap()
+        if overlap:
+            opts.encoder_done_event = self._enc_event.cuda_event
         self.seed.add_(1)                                   # new dropout masks every step (graph-replay safe)
         _lib.check(self.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                            _lib.ptr(y), _lib.ptr(w), _lib.ptr(logits), _lib.ptr(self.losses), _lib.ptr(ws), ws.numel(),
@@ -134,34 +146,110 @@ class Trainer:
         _lib.check(self.lib.matcha_backward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                             _lib.ptr(y), _lib.ptr(w), None, _lib.ptr(drecon) if drecon is not None else None,
                                             C.byref(self.grads), _lib.ptr(self.touched), _lib.ptr(ws), ws.numel(), st), "matcha_backward")
+        if overlap:
+            self._start_encoder_allreduce()
         return logits
 
+    # ---- data-parallel exchange ----------------------------------------------------------------------
+    def _exchange_setup(self):
+        """Side stream + event of the overlapped exchange (table front end): the encoder part of the flat bucket (everything from
+        ln_q_g on, the contiguous tail) is all-reduced on ``_side`` as soon as matcha_backward records ``_enc_event``, while the
+        front-end backward, the embedding scatter / table-gradient sort still run on the main stream."""
+        if getattr(self, "_side", None) is None:
+            dev = self.rt.device
+            self._side = torch.cuda.Stream(dev)
+            self._enc_event = torch.cuda.Event()
+            self._enc_event.record(torch.cuda.current_stream(dev))       # creates the hipEvent_t behind the handle
+            self._cnt_event = torch.cuda.Event()
+            self._enc_work = None
+            self._cnt_host = torch.zeros(self.world, dtype=torch.int32).pin_memory()
+            self._n_enc_off = self.rt.field_off["ln_q_g"]
+
+    def _overlap(self) -> bool:
+        """Overlapped two-part bucket: table front end only (there the touched flags are constant, so nothing rides behind the
+        gradients), and not while a hipGraph is being captured."""
+        return (self.overlap_exchange and self.rt.mode == 0 and (self.world > 1 or self.force_collectives)
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _begin_exchange(self, x):
+        """Called before matcha_forward.  Row-sparse exchange: start the all-gather of the ranks' real-token counts on the side
+        stream (tokens = non-zero slots of x: the plan's Tr, known long before the backward finishes), so that the lists can be
+        exchanged COMPACTED to max_r(Tr_r) + 1 entries instead of the fixed capacity B*L + 1 -- the padding fraction (38 % at k in
+        {2..8}, L = 8) never crosses xGMI -- without stalling the host: by the time the backward is enqueued the 4-byte counts
+        are in pinned memory."""
+        if not (self.world > 1 or self.force_collectives):
+            return
+        self._exchange_setup()
+        if self._sparse and self.compact_exchange:
+            main = torch.cuda.current_stream(self.rt.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                cnt = (x != 0).sum().to(torch.int32).view(1)
+                if self.world > 1:
+                    cnt_all = torch.empty(self.world, dtype=torch.int32, device=self.rt.device)
+                    torch.distributed.all_gather_into_tensor(cnt_all, cnt, group=self.pg)
+                else:
+                    cnt_all = cnt
+                self._cnt_host.copy_(cnt_all, non_blocking=True)
+                self._cnt_event.record(self._side)
+            x.record_stream(self._side)
+
+    def _start_encoder_allreduce(self):
+        """Right after matcha_backward was enqueued: all-reduce gflat[ln_q_g:] on the side stream behind the encoder_done event."""
+        rt = self.rt
+        self._side.wait_event(self._enc_event)
+        with torch.cuda.stream(self._side):
+            part = self.gflat[self._n_enc_off:rt.n_flat]
+            self._enc_work = torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.comm_bytes["encoder_allreduce"] = 4 * (rt.n_flat - self._n_enc_off)
+
     def all_reduce(self):
-        """One RCCL all-reduce per step over [gradients | touched flags] (matcha_amd/parallel.py::allreduce_bucket).  With the
-        row-sparse table exchange the bucket starts BEHIND the table gradient, and the table's (id, row) lists are all-gathered
-        and summed locally in a fixed order instead (matcha_scatter_rows): every rank ends with the same dense table gradient."""
+        """Gradient exchange of one step (matcha_amd/parallel.py).  Dense: the flat bucket [gradients | touched flags] in ONE RCCL
+        all-reduce -- or, with the table front end, in two parts: the encoder tail already in flight on the side stream
+        (``_start_encoder_allreduce``) and [table | attribute_nn | next_w] here.  Row-sparse: the bucket starts BEHIND the table
+        gradient, and the table's (id, row) lists are all-gathered (compacted to the largest real-token count of any rank) and
+        summed locally in a fixed order (matcha_scatter_rows): every rank ends with the same dense table gradient."""
         if not (self.world > 1 or self.force_collectives):
             return
         rt = self.rt
+        dev = rt.device
+        lo = self._n_table if self._sparse else 0
+        if self._enc_work is not None:
+            # table mode: both touched flags are set by every rank's backward -- nothing to exchange behind the gradients
+            front = self.gflat[lo:self._n_enc_off]
+            if front.numel():
+                torch.distributed.all_reduce(front, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self.comm_bytes["front_allreduce"] = 4 * front.numel()
+            self._enc_work.wait()                                          # main stream waits for the side stream's collective
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._enc_work = None
+        else:
+            allreduce_bucket(self.gbuf[lo:], rt.n_flat - lo, self.touched, self.pg, force=self.force_collectives)
+            self.comm_bytes["bucket_allreduce"] = 4 * (rt.n_flat - lo + self._n_touched)
         if not self._sparse:
-            allreduce_bucket(self.gbuf, rt.n_flat, self.touched, self.pg, force=self.force_collectives)
             return
-        allreduce_bucket(self.gbuf[self._n_table:], rt.n_flat - self._n_table, self.touched, self.pg, force=self.force_collectives)
         B, L = self._last_shape
         ws = self._ws[(B, L)]
         p_ids, p_rows, p_n, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
         _lib.check(self.lib.matcha_table_grad_rows(C.byref(rt.shape), B, L, _lib.ptr(ws), ws.numel(), C.byref(p_ids), C.byref(p_rows),
                                                    C.byref(p_n), C.byref(cap)), "matcha_table_grad_rows")
         cap, d, base = int(cap.value), rt.d, ws.data_ptr()
-        ids = ws[p_ids.value - base:p_ids.value - base + 4 * cap].view(torch.int32)
-        rows = ws[p_rows.value - base:p_rows.value - base + 4 * cap * d].view(torch.float32).view(cap, d)
-        ids_all, rows_all = exchange_table_rows(ids, rows, self.pg)
-        n = ids_all.numel()
-        key = (n, d)
-        if key not in self._xws:
-            self._xws[key] = torch.empty(self.lib.matcha_scatter_rows_workspace_bytes(n, d, rt.n_nodes), dtype=torch.uint8, device=rt.device)
-        xws = self._xws[key]
-        self._keep = (ids_all, rows_all)               # alive until the kernels that read them have run
+        n_send = cap
+        if self.compact_exchange:
+            self._cnt_event.synchronize()                                  # counts were gathered while forward + backward ran
+            n_send = min(cap, (int(self._cnt_host.max()) + 1 + 63) // 64 * 64)   # real tokens of the fullest rank + the padding token
+        ids = ws[p_ids.value - base:p_ids.value - base + 4 * n_send].view(torch.int32)
+        rows = ws[p_rows.value - base:p_rows.value - base + 4 * n_send * d].view(torch.float32).view(n_send, d)
+        key = (cap, d)
+        if key not in self._xws:          # receive buffers + sort scratch, sized once for the full capacity and reused every step
+            world = self.world
+            self._xws[key] = (torch.empty(world * cap, dtype=torch.int32, device=dev), torch.empty(world * cap * d, dtype=torch.float32, device=dev),
+                              torch.empty(self.lib.matcha_scatter_rows_workspace_bytes(world * cap, d, rt.n_nodes), dtype=torch.uint8, device=dev))
+        ids_buf, rows_buf, xws = self._xws[key]
+        n = self.world * n_send
+        ids_all, rows_all = exchange_table_rows(ids, rows, self.pg, out=(ids_buf[:n], rows_buf[:n * d].view(n, d)))
+        self.comm_bytes["table_rows_allgather"] = 4 * (self.world - 1) * n_send * (d + 1)
+        self.comm_bytes["table_rows_fill"] = n_send / cap
         _lib.check(self.lib.matcha_scatter_rows(_lib.ptr(ids_all), _lib.ptr(rows_all), n, d, rt.n_nodes, _lib.ptr(self.gflat), _lib.ptr(xws),
                                                 xws.numel(), rt.stream()), "matcha_scatter_rows")
 

@@ -70,14 +70,17 @@ def sparse_exchange_pays(n_nodes: int, d: int, cap: int, world: int) -> bool:
     return (world - 1) * cap * (d + 1) < 2 * (world - 1) / world * (n_nodes + 1) * d
 
 
-def exchange_table_rows(ids: torch.Tensor, rows: torch.Tensor, group=None):
-    """All-gather every rank's (node id, gradient row) list: ids int32 [cap] (0 = unused entry), rows float [cap, d] ->
-    (ids_all [world * cap], rows_all [world * cap, d]) in rank order on every rank.  Fixed-size lists, so no host
-    synchronisation is needed to size the collective; xGMI is point-to-point, and an all-gather sends each list once to each
-    peer (one hop), where a ring all-reduce of the dense table would forward 2 (world - 1) / world table copies."""
+def exchange_table_rows(ids: torch.Tensor, rows: torch.Tensor, group=None, out=None):
+    """All-gather every rank's (node id, gradient row) list: ids int32 [n] (0 = unused entry), rows float [n, d] ->
+    (ids_all [world * n], rows_all [world * n, d]) in rank order on every rank; ``out`` = preallocated (ids_all, rows_all) to
+    receive into (the Trainer reuses one pair across steps).  Every rank passes the same ``n`` (the Trainer agrees on
+    max_r(real tokens) + 1 beforehand, so the lists travel without their padding); xGMI is point-to-point, and an all-gather
+    sends each list once to each peer (one hop), where a ring all-reduce of the dense table would forward
+    2 (world - 1) / world table copies."""
     world = dist.get_world_size(group)
-    ids_all = ids.new_empty(world * ids.numel())
-    rows_all = rows.new_empty((world * rows.shape[0], rows.shape[1]))
+    if out is None:
+        out = (ids.new_empty(world * ids.numel()), rows.new_empty((world * rows.shape[0], rows.shape[1])))
+    ids_all, rows_all = out
     dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=group)
     dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=group)
     return ids_all, rows_all

@@ -14,7 +14,8 @@ Data parallel (the reference is single-process): launched with
 Everything drawn from numpy's global generator -- the 80/20 split, the epoch shuffles, ``random_chrom`` -- is identical on
 every rank (rank 0's seed is broadcast), each global batch of ``world * 96`` positives is cut strided by rank
 (parallel.shard_rows), each rank draws its own negatives, gradients are exchanged inside ``Trainer.step``, and only rank 0
-writes files.
+writes files.  Work that draws from numpy's global stream (``save_embeddings`` with the adj front end) therefore runs on EVERY
+rank -- only the file write is root-only -- so the streams never drift apart (tests/test_hip_data_parallel.py asserts it).
 """
 from __future__ import annotations
 
@@ -86,8 +87,9 @@ def save_embeddings(model: Classifier, n_nodes: int, path: Optional[str] = "../e
     model.eval()
     dev = model.layer_norm1.weight.device
     ids = torch.arange(1, n_nodes + 1, dtype=torch.long, device=dev).view(-1, 1)
-    out = [model.get_node_embeddings(ids[j:j + batch_size])[:, 0, :].cpu().numpy() for j in range(0, n_nodes, batch_size)]
-    emb = np.concatenate(out, axis=0)
+    with model.deferred_id_check():                     # one status read-back for the sweep instead of one per 4096 ids
+        out = [model.get_node_embeddings(ids[j:j + batch_size])[:, 0, :] for j in range(0, n_nodes, batch_size)]
+    emb = torch.cat(out, dim=0).cpu().numpy()
     if path is not None:
         np.save(path, emb)
     model.train(was)
@@ -100,10 +102,11 @@ def predict(model: Classifier, rows, batch_size: int = 100000) -> np.ndarray:
     model.eval()
     dev = model.layer_norm1.weight.device
     outs = []
-    for j in range(0, len(rows), batch_size):
-        x = U.pad_rows(rows[j:j + batch_size]).to(dev)
-        outs.append(model(x).cpu().numpy())
-    return np.concatenate(outs, axis=0)
+    with model.deferred_id_check():
+        for j in range(0, len(rows), batch_size):
+            x = U.pad_rows(rows[j:j + batch_size]).to(dev, non_blocking=True)
+            outs.append(model(x))
+    return np.concatenate([o.cpu().numpy() for o in outs], axis=0) if outs else np.zeros((0, 1), dtype=np.float32)
 
 
 class Session:
@@ -201,18 +204,19 @@ def eval_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, batch_size
     perm = torch.from_numpy(np.random.permutation(len(e))[:max_rows]).to(dev)   # rank-shared stream: every rank evaluates the same rows
     e, w = e[perm], w[perm]
     n_batch = len(e) // batch_size
-    bce_sum, rec_sum = 0.0, 0.0
+    bce_sum, rec_sum = torch.zeros((), device=dev), torch.zeros((), device=dev)
     preds, labels, sizes = [], [], []
-    for i in range(n_batch):
-        pos, pw = e[i * batch_size:(i + 1) * batch_size], w[i * batch_size:(i + 1) * batch_size]
-        x, y, ww, s = sess.make_batch(pos, pw)
-        logits, recon = model(x, return_recon=True)
-        bce = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y, weight=ww)
-        bce_sum += float(bce)
-        rec_sum += float(recon[0])
-        preds.append(torch.sigmoid(logits.view(-1)))
-        labels.append(y)
-        sizes.append(s)
+    with model.deferred_id_check():                     # nothing synchronises inside the loop; ids are checked once behind it
+        for i in range(n_batch):
+            pos, pw = e[i * batch_size:(i + 1) * batch_size], w[i * batch_size:(i + 1) * batch_size]
+            x, y, ww, s = sess.make_batch(pos, pw)
+            logits, recon = model(x, return_recon=True)
+            bce_sum += torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y, weight=ww)
+            rec_sum += recon[0]
+            preds.append(torch.sigmoid(logits.view(-1)))
+            labels.append(y)
+            sizes.append(s)
+    bce_sum, rec_sum = float(bce_sum), float(rec_sum)
     pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()
     auc, aupr = U.roc_auc_cuda(label, pred, size, sess.max_size)
     acc = U.accuracy(pred, label, size, sess.max_size)
@@ -231,8 +235,9 @@ def train(sess: Session, training_data, validation_data, epochs: int, alpha: flo
     # an "iteration" serves batches_per_epoch GLOBAL batches: world times the rows of the single-process run, same number of steps
     gen = DataGenerator(rows, weights, int(batch_size) * sess.world, batches_per_epoch, min_size=sess.min_size, max_size=sess.max_size)
     for epoch in range(epochs):
-        if root:
-            save_embeddings(sess.model, n_nodes, emb_path)
+        # every rank runs the sweep (the adj front end draws from numpy's rank-shared global stream once per chunk, Modules.py:192:
+        # a root-only call would leave rank 0's stream ahead of the others and the "global batch" would stop being one); root writes
+        save_embeddings(sess.model, n_nodes, emb_path if root else None)
         t0 = time.time()
         e_part, w_part = gen.next_iter()
         bce, rec, acc, auc, aupr = train_epoch(sess, e_part, w_part, alpha, beta, batch_size)
@@ -305,8 +310,7 @@ def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 3
     else:
         ne = Wrap_Embedding(N + 1, d, padding_idx=0)
     model = Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True, bottle_neck=d, attribute_dict=attr).to(device)
-    if rank == 0:
-        save_embeddings(model, N, emb_path)                                       # main.py:625
+    save_embeddings(model, N, emb_path if rank == 0 else None)                     # main.py:625 (every rank: keeps the numpy stream shared)
 
     sess = Session(model, node2chrom, chrom_range.astype(np.int32), min_size, max_size, min_dis, deterministic=deterministic)
     # phase 1: alpha 0, beta 1, empty dict (negatives == positives)             main.py:637-643
@@ -318,8 +322,8 @@ def run(config: dict, front_end: str = "adj", epochs1: int = 3, epochs2: int = 3
     sess.new_optimizer()
     train(sess, (train_data, train_w), (test_data, test_w), epochs2, 1.0, 0.001, temp_dir, N, batches_per_epoch=batches_per_epoch,
           emb_path=emb_path, log=log)
+    save_embeddings(model, N, emb_path if rank == 0 else None)                     # main.py:684
     if rank == 0:
-        save_embeddings(model, N, emb_path)                                       # main.py:684
         torch.save(model, os.path.join(temp_dir, "model2load"))                  # main.py:685
     _barrier()
     return model

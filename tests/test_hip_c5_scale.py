@@ -53,7 +53,10 @@ def test_c5_generator_and_csr_shards():
 
 def test_c5_hashset_membership_exact_on_samples():
     e = _edges()
-    hs = HyperedgeSet(e)
+    _membership_exact(e, HyperedgeSet(e), N_EDGES)
+
+
+def _membership_exact(e, hs, N_EDGES):
     g = torch.Generator(device="cuda")
     g.manual_seed(1)
     sel = torch.randint(0, N_EDGES, (200_000,), generator=g, device="cuda")
@@ -87,11 +90,14 @@ def test_c5_hashset_membership_exact_on_samples():
 
 def test_c5_negative_sampler_invariants_k8():
     e = _edges()
+    _sampler_invariants_k8(e, HyperedgeSet(e), N_EDGES)
+
+
+def _sampler_invariants_k8(e, hs, N_EDGES):
     num = synth.LAYOUTS["c5"]
     n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
-    hs = HyperedgeSet(e)
     smp = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=2, seed=77)
-    pos = e[torch.randperm(N_EDGES, device="cuda")[:30000]]
+    pos = e[torch.randint(0, N_EDGES, (30000,), device="cuda")]
     # the reference's positives come out of generate_kmers.py's min_distance filter (generate_kmers.py:24-32): every adjacent gap
     # exceeds min_dis.  A synthetic row that violates it between two nodes the sampler leaves unchanged can never be repaired
     # (the reference would loop forever, the kernel counts it as exhausted): keep the rows that satisfy the rule
@@ -140,10 +146,14 @@ def test_c5_negative_sampler_invariants_k8():
 def test_c5_training_steps_on_the_1m_x_256_table():
     """Four optimisation steps of the C5 shape (1 M x 256 table, L = 8, 4 096 rows per step): finite losses that go down on a
     fixed batch, only the gathered rows of the table move by more than weight decay, status word clean."""
+    e = _edges()
+    _training_steps(e, HyperedgeSet(e))
+
+
+def _training_steps(e, hs):
     import Modules as M
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS["c5"]
-    e = _edges()
     d = 256
     attr = np.zeros((N_NODES + 1, len(num) + 1), dtype=np.float32)
     n2c = synth.node2chrom(num)
@@ -154,7 +164,6 @@ def test_c5_training_steps_on_the_1m_x_256_table():
                        bottle_neck=d, attribute_dict=attr).cuda()
     clf.train()
     tr = Trainer(clf, base_seed=3)
-    hs = HyperedgeSet(e)
     smp = NegativeSampler(hs, n2c, synth.chrom_range(num), neg_num=3, min_dis=0, seed=9)
     pos = e[:1024]
     x = torch.cat([pos, smp.sample(pos)])
@@ -173,3 +182,40 @@ def test_c5_training_steps_on_the_1m_x_256_table():
     seen[0] = False
     assert float(moved[seen].min()) > 1e-3                                      # Adam moves a touched row by ~lr per step
     assert float(moved[~seen].max()) <= 1.01 * (1e-3 * 4 * 1e-2 * float(t0.abs().max())) + 1e-7   # the others only decay (lr * wd per step)
+
+
+def test_c5_full_known_set_100m_hyperedges():
+    """BASELINE.json configs[4] at its FULL size: 1 M nodes and 100 M known hyperedges of k in {2..8} (6.4 GB of int64 rows + a
+    2^28-slot table of int32 indices) -- the size where int32 slot indices, the probe sequence over a 1 GiB table and the
+    n * L int64 offsets actually matter.  Generator statistics, exact membership on a 200 K sample against the sorted-hash ground
+    truth (inserted, perturbed and prefix rows), the sampler's invariants at k = 8 (incl. bit-exact agreement with the oracle on
+    a slice, membership answered by the 100 M-entry set), and training steps on the 1 M x 256 table with negatives drawn against
+    the full set.  utils.py:75-97, main.py:361-459, Modules.py:29-34."""
+    _cache.clear()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip(f"needs ~40 GB of free HBM, {free >> 30} GB available")
+    n = 100_000_000
+    e = synth.make_edges_device(N_NODES, n, ks=KS, seed=5, device="cuda")
+    assert e.shape == (n, 8) and e.dtype == torch.long
+    k = (e != 0).sum(1)
+    cnt = torch.bincount(k, minlength=9)
+    assert int(cnt[:2].sum()) == 0 and float((cnt[2:].float() / n - 1 / 7).abs().max()) < 1e-3
+    assert int(e.max()) <= N_NODES and int(e[e != 0].min()) >= 1
+    del k, cnt
+    # the rows are distinct (the generator's contract for a "known set"): the sorted 63-bit row hashes have no equal neighbours
+    # beyond what 63-bit collisions explain
+    hs = HyperedgeSet(e)
+    _membership_exact(e, hs, n)
+    # rows near the END of the list: indices >= 2^26 are what a narrower index type or a 32-bit n * L product would lose
+    tail = e[n - 100_000:]
+    assert bool(hs.contains(tail).all())
+    bumped = tail.clone()
+    bumped[:, 0] = torch.where(bumped[:, 0] > 1, bumped[:, 0] - 1, bumped[:, 0])       # still ascending & distinct; almost surely unknown
+    changed = (bumped[:, 0] != tail[:, 0])
+    assert float(hs.contains(bumped)[changed].float().mean()) < 1e-3
+    _sampler_invariants_k8(e, hs, n)
+    _training_steps(e, hs)
+    del hs, e
+    torch.cuda.empty_cache()

@@ -196,6 +196,91 @@ def test_two_rank_sparse_table_exchange_equals_dense_and_single_rank(tmp_path, d
             assert float(diff.max()) <= 2 * 1e-3 * 6 + 1e-5 * scale, (tag, n, float(diff.max()))
 
 
+def _nccl_worker(rank, world, port, out_dir):
+    """ONE rank over the real RCCL backend (the test box has one GPU): every collective of both exchange forms runs through
+    torch.distributed's nccl backend on device buffers (all-reduce of the encoder tail on the side stream behind the
+    encoder_done event, all-reduce of the front part, all-gather of the 4-byte counts and of the compacted (id, row) lists) and,
+    with one rank, must be the identity: parameters bitwise equal to the step without collectives."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from matcha_amd.engine import Trainer
+    from tests.test_hip_model import hip_model
+    num = synth.LAYOUTS["c1"]
+    N = int(np.sum(num))
+    report = {}
+    for d, exchange, overlap, compact in ((64, "dense", True, True), (64, "dense", False, True), (64, "sparse", True, True),
+                                          (128, "sparse", True, True), (128, "sparse", False, False), (128, "dense", True, True)):
+        flats = []
+        for forced in (False, True):
+            clf, _ = hip_model(num, d, "table", 50)
+            clf.train()                                              # dropout on: the same (seed, slot) masks in both runs
+            tr = Trainer(clf, lr=1e-3, base_seed=5, table_exchange=exchange, deterministic=True)
+            tr.force_collectives = forced
+            tr.overlap_exchange, tr.compact_exchange = overlap, compact
+            rng = np.random.default_rng(8)
+            for step in range(4):
+                x, y, w = synth.make_batch(rng, N, [2, 3, 4, 5], 64)
+                tr.step(torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(), torch.from_numpy(w.reshape(-1)).cuda(), alpha=1.0, beta=0.0)
+            torch.cuda.synchronize()
+            tr.check_status()
+            flats.append(clf._runtime().flat.detach().cpu())
+            if forced:
+                assert tr._sparse == (exchange == "sparse")
+                cb = dict(tr.comm_bytes)
+                if exchange == "sparse":
+                    assert cb["table_rows_allgather"] == 0 and (cb["table_rows_fill"] < 0.9) == compact      # (world - 1) = 0 peers; mixed k: ~70 % fill
+                assert ("encoder_allreduce" in cb) == overlap and ("bucket_allreduce" in cb) == (not overlap)
+                report[f"{d}-{exchange}-{overlap}-{compact}"] = cb
+        assert torch.equal(flats[0], flats[1]), (d, exchange, overlap, compact)
+    import json
+    json.dump(report, open(os.path.join(out_dir, "nccl.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_both_exchange_forms_are_identity(tmp_path):
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "nccl.json"))
+
+
+def test_bench_refuses_to_report_more_gpus_than_it_ran(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself (one child torch.distributed.run before this process
+    touches the GPU); on a box with fewer GPUs it must exit non-zero and print NO record -- never an n_gpus: 1 line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert run.returncode != 0
+    assert not [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert "refusing" in run.stderr
+
+
+def test_bench_one_rank_launch_goes_through_rccl(tmp_path):
+    """The driver's N > 1 command line with N = 1 and the default backend: bench.py joins an nccl (= RCCL) process group and every
+    step runs its collectives; the record says which and how many bytes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("MATCHA_DIST_BACKEND", "MATCHA_LOCAL_DEVICE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for extra, form in (([], "flat all-reduce"), (["--table-exchange", "sparse"], "row-sparse all-gather")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+               "--rows", "8192", "--edges-per-k", "20000", "--no-extras", "--no-cpu-baseline"] + extra
+        run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+        assert run.returncode == 0, run.stderr[-2000:]
+        rec = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+        assert rec["n_gpus"] == 1 and rec["config"]["table_gradient_exchange"] == form
+        cb = rec["config"]["collective_payload_bytes_per_step"]
+        assert cb["encoder_allreduce"] > 0 and rec["config"]["exchange_overlapped"] is True
+        assert ("table_rows_allgather" in cb) == (form == "row-sparse all-gather")
+
+
 def _run_worker(rank, world, port, tmp, front_end):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MATCHA_DIST_BACKEND="gloo", MATCHA_LOCAL_DEVICE="0")
@@ -213,6 +298,12 @@ def _run_worker(rank, world, port, tmp, front_end):
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     assert torch.equal(both[0], both[1])                         # replicas stayed in lockstep through both phases
+    # numpy's global stream (epoch permutations, DataGenerator shuffles, random_chrom) is still shared after both phases: root-only
+    # work that draws from it (save_embeddings with the adj front end) would have pushed rank 0 ahead
+    nxt = torch.from_numpy(np.random.randint(0, 1 << 30, size=8))
+    seen = [torch.zeros_like(nxt) for _ in range(world)]
+    dist.all_gather(seen, nxt)
+    assert torch.equal(seen[0], seen[1]), "the ranks' numpy streams drifted apart"
     if rank == 0:
         assert any("Training" in l for l in logs)
         json.dump({"n_logs": len(logs)}, open(os.path.join(tmp, "rank0.json"), "w"))
