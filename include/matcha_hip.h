@@ -334,11 +334,14 @@ int matcha_gemm(int32_t op, const float* A, const float* B, float* C, int64_t M,
  * zero-padded x [B,L] (pad_sequence, main.py:435-437) compacted into a CSR token list + ONE shared padding token, and tiles of
  * whole hyperedges (<= 63 tokens) for the fused kernels.  matcha_forward builds it inside its workspace; this entry point
  * builds it alone so that it can be compared bit for bit with the C restatement oracle/c/ragged_plan.c.
- *   view->row_off  int32 [B+1]; tok_slot, tok_key, tok_pos int32 [B*L+1]; tok_id int64 [B*L+1]; count int32 [3] = {Tr+1, Tr,
- *   tiles}; tile_meta int32 [tiles_cap][4] = {first token, tokens, first hyperedge, hyperedges} -- device pointers into `ws`. */
+ *   view->row_off  int32 [B+1]; tok_slot, tok_key, tok_pos int32 [B*L+1]; tok_id int64 [B*L+1]; count int32 [4] = {Tr+1, Tr,
+ *   tiles, half tiles}; tile_meta int32 [tiles_cap][4] = {first token, tokens, first hyperedge, hyperedges}; half_meta: the same
+ *   stream cut into half tiles of <= 31 tokens (one wavefront each in the fused forward) -- device pointers into `ws`. */
 typedef struct matcha_ragged_view {
   const int32_t* row_off; const int32_t* tok_slot; const int64_t* tok_id; const int32_t* tok_key; const int32_t* tok_pos;
   const int32_t* count; const int32_t* tile_meta; int64_t tiles_cap;
+  const int32_t* half_meta; int64_t halves_cap;   /* half tiles: whole hyperedges, <= 31 tokens, same four fields; count[3] of them */
+  const int32_t* tok_tile;                        /* int32 [B*L+1]: (tile << 6) | row of each token inside tile_meta's tiling        */
 } matcha_ragged_view;
 size_t matcha_ragged_plan_bytes(int64_t B, int32_t L);
 int matcha_ragged_plan(const int64_t* x, int64_t B, int32_t L, int32_t n_nodes, int32_t* status, void* ws, size_t ws_bytes,

@@ -52,7 +52,7 @@ class StepOpts(C.Structure):
 
 class RaggedView(C.Structure):
     _fields_ = [("row_off", _fp), ("tok_slot", _fp), ("tok_id", _fp), ("tok_key", _fp), ("tok_pos", _fp), ("count", _fp),
-                ("tile_meta", _fp), ("tiles_cap", C.c_int64)]
+                ("tile_meta", _fp), ("tiles_cap", C.c_int64), ("half_meta", _fp), ("halves_cap", C.c_int64), ("tok_tile", _fp)]
 
 
 class GemmEpilogue(C.Structure):

@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
 
 // Sum the per-tile slabs of the training forward in a fixed order and accumulate into the gradient tensors.
 struct TailReduceArgs {
-  const float* tslab; const int32_t* count; int L; int ntiles_cap;
+  const float* tslab; const int32_t* count; int L; int ntiles_cap; int count_idx;
   float* dst[12];     // pff1_w, pff0_w, gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b, bc
 };
 // 32 slab elements per block (one per lane of a half-wave: 128-byte segments), 32 slab-row groups: 276 blocks, so that every CU
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a
   __shared__ float part[32][33];
   const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + o;                   // element of the slab
-  int nt = a.count[2];                                 // tiles planned by ragged.hip (every one of them wrote its slab)
+  int nt = a.count[a.count_idx];                       // tiles (or half tiles) planned by ragged.hip: every one of them wrote its slab
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;   // eight independent chains: the walk is latency-bound
   if (i < kTailSlab) {
@@ -786,9 +786,9 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
 size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
 size_t fused_qkv_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRec; }
 
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st) {
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves) {
   TailReduceArgs a;
-  a.tslab = tslab; a.count = rg.count; a.L = L; a.ntiles_cap = rg.ntiles;
+  a.tslab = tslab; a.count = rg.count; a.L = L; a.ntiles_cap = halves ? rg.nhalves : rg.ntiles; a.count_idx = halves ? 3 : 2;
   float* dst[12] = {g_.pff1_w, g_.pff0_w, g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.pff1_b, g_.pff0_b, g_.cls_b};
   for (int i = 0; i < 12; ++i) a.dst[i] = dst[i];
   hipLaunchKernelGGL(tail_slab_reduce_kernel, dim3((unsigned)cdiv(kTailSlab, 32)), dim3(1024), 0, st, a);

@@ -1,0 +1,691 @@
+// Wave-independent fused forward for embed_dim 64 (round 3; replaces the four-wave tile kernel of fused_fwd.hip on every path,
+// A/B: matcha_set_option("disable_fwd32", 1)).  Same mathematics (Modules.py:519-572, :353-376, :290-311; main.py:56), other
+// decomposition:
+//
+//   ONE WAVEFRONT = ONE WORKGROUP = one HALF TILE: <= 31 real tokens of whole hyperedges + the shared padding token as local row n
+//   (ragged.hip: half_meta).  Nothing is shared between wavefronts, so there is no workgroup barrier anywhere: the four-wave kernel
+//   spent a third of its time in 59 barrier phases per tile with two waves per SIMD to cover them.
+//
+//   Layout "FL": lane (r, h) owns token row r and the 32 features  f(e) = 32 wc + 8 g + 4 h + j,  e = 16 wc + 4 g + j  -- exactly what
+//   the 32x32x2 MFMA leaves in a lane when a projection is computed as the TRANSPOSED product  D[feature][token] = W . x^T, and exactly
+//   what the next product needs as its token-side operand.  Q, O, dyn, Y, H1, H2 and their gradients therefore never leave the
+//   registers; only K / V rows (read by the other tokens of a hyperedge) and the weight-gradient operands pass through the
+//   wave's two private LDS tiles (2 x 8.5 KB: eight wavefronts per CU, two per SIMD, limited by the 256 registers).
+//
+//   Weights are STREAMED FROM L2 in fragment-major order (fold_frag_kernel rewrites them once per step: one coalesced 1 KB load per
+//   wave and four MFMAs) through a rolling window of eight float4 per lane; tools/ubench/mfma_l2stream.hip measured 85 - 88 % of the
+//   matrix pipe's rate for that pattern with two decoupled waves per SIMD, without any LDS staging.
+//
+//   Attention: two lanes per query token (32 features each), every token of the half tile at once; the dot products' cross-lane part
+//   is ONE v_permlane32_swap instead of three DPP steps, softmax runs twice instead of eight times per token: ~270 VALU
+//   instructions per head and 32 tokens (four-wave kernel: ~600).
+//
+//   The Q / K / V rows and attention probabilities the fused backward reloads are written in ITS tile layout (fused_bwd.hip walks
+//   64-row tiles that cut the token stream elsewhere): tok_tile[t] = (tile << 6) | row says where each token's rows go.
+#include "kernels.hpp"
+
+namespace matcha {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kLdH = 68;                  // LDS row stride (floats)
+constexpr int kHT = 32 * kLdH;            // one half tile [32 rows][68]
+constexpr float kEps32 = 1e-5f;
+constexpr int kFragF4 = 1024;             // float4 per 64 x 64 matrix in fragment-major order: [wc][c][lane]
+constexpr int kNMat = 36;                 // 8 heads x {K, Q, V, fc1 block}, conv0, conv1, conv1^T, conv0^T -- in consumption order
+constexpr int kTailVec32 = 2 * 4096;      // same slab format as fused_fwd.hip (tail_slab_reduce_kernel reads both)
+constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
+
+struct FL { f32x16 lo, hi; };             // 32 features of one token row in layout FL (lo: wc = 0, hi: wc = 1)
+
+__device__ __forceinline__ float xhalf_sum(float v) {
+  // lanes (r, 0) and (r, 1) hold the two halves of a row sum: v_permlane32_swap broadcasts each half to both
+  const auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+}
+__device__ __forceinline__ float fl_sum(const FL& a) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { s0 += a.lo[e]; s1 += a.hi[e]; }
+  return s0 + s1;
+}
+__device__ __forceinline__ float fl_dot(const FL& a, const FL& b) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { s0 += a.lo[e] * b.lo[e]; s1 += a.hi[e] * b.hi[e]; }
+  return s0 + s1;
+}
+// (mean, rstd) of a 64-feature row held as FL over two lanes
+__device__ __forceinline__ void fl_stats(const FL& v, float& mean, float& rstd) {
+  mean = xhalf_sum(fl_sum(v)) * (1.f / 64.f);
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { const float a = v.lo[e] - mean, b = v.hi[e] - mean; q0 += a * a; q1 += b * b; }
+  rstd = __builtin_amdgcn_rsqf(xhalf_sum(q0 + q1) * (1.f / 64.f) + kEps32);
+}
+// row r of an LDS tile <-> FL registers (eight 16-byte accesses at columns 32 wc + 8 g + 4 h)
+__device__ __forceinline__ void fl_store(float* __restrict__ rowp, const FL& v) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *reinterpret_cast<f32x4*>(rowp + 8 * g) = (f32x4){v.lo[4 * g], v.lo[4 * g + 1], v.lo[4 * g + 2], v.lo[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(rowp + 32 + 8 * g) = (f32x4){v.hi[4 * g], v.hi[4 * g + 1], v.hi[4 * g + 2], v.hi[4 * g + 3]};
+  }
+}
+__device__ __forceinline__ FL fl_load(const float* __restrict__ rowp) {
+  FL v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 8 * g), b = *reinterpret_cast<const f32x4*>(rowp + 32 + 8 * g);
+    v.lo[4 * g] = a.x; v.lo[4 * g + 1] = a.y; v.lo[4 * g + 2] = a.z; v.lo[4 * g + 3] = a.w;
+    v.hi[4 * g] = b.x; v.hi[4 * g + 1] = b.y; v.hi[4 * g + 2] = b.z; v.hi[4 * g + 3] = b.w;
+  }
+  return v;
+}
+// q . k over this lane's 32 features (packed pairs), k read from an LDS row
+__device__ __forceinline__ float fl_dot_lds(const FL& q, const float* __restrict__ rowp) {
+  f2 s = {0.f, 0.f}, t = {0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 8 * g), b = *reinterpret_cast<const f32x4*>(rowp + 32 + 8 * g);
+    s = __builtin_elementwise_fma((f2){q.lo[4 * g], q.lo[4 * g + 1]}, (f2){a.x, a.y}, s);
+    t = __builtin_elementwise_fma((f2){q.lo[4 * g + 2], q.lo[4 * g + 3]}, (f2){a.z, a.w}, t);
+    s = __builtin_elementwise_fma((f2){q.hi[4 * g], q.hi[4 * g + 1]}, (f2){b.x, b.y}, s);
+    t = __builtin_elementwise_fma((f2){q.hi[4 * g + 2], q.hi[4 * g + 3]}, (f2){b.z, b.w}, t);
+  }
+  s += t;
+  return s.x + s.y;
+}
+// o += w * row
+__device__ __forceinline__ void fl_axpy_lds(FL& o, float w, const float* __restrict__ rowp) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 8 * g), b = *reinterpret_cast<const f32x4*>(rowp + 32 + 8 * g);
+    o.lo[4 * g] += w * a.x; o.lo[4 * g + 1] += w * a.y; o.lo[4 * g + 2] += w * a.z; o.lo[4 * g + 3] += w * a.w;
+    o.hi[4 * g] += w * b.x; o.hi[4 * g + 1] += w * b.y; o.hi[4 * g + 2] += w * b.z; o.hi[4 * g + 3] += w * b.w;
+  }
+}
+// v += vector (64 floats, global or LDS) at this lane's features
+__device__ __forceinline__ void fl_add_vec(FL& v, const float* __restrict__ vec_h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(vec_h + 8 * g), b = *reinterpret_cast<const f32x4*>(vec_h + 32 + 8 * g);
+    v.lo[4 * g] += a.x; v.lo[4 * g + 1] += a.y; v.lo[4 * g + 2] += a.z; v.lo[4 * g + 3] += a.w;
+    v.hi[4 * g] += b.x; v.hi[4 * g + 1] += b.y; v.hi[4 * g + 2] += b.z; v.hi[4 * g + 3] += b.w;
+  }
+}
+__device__ __forceinline__ FL fl_vec(const float* __restrict__ vec_h) {
+  FL v;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { v.lo[e] = 0.f; v.hi[e] = 0.f; }
+  fl_add_vec(v, vec_h);
+  return v;
+}
+// rows of a [T, 64] global tensor <-> FL (16-byte accesses; a row's 256 bytes are covered by the two lanes in 8 instructions)
+__device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, const FL& v) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *reinterpret_cast<f32x4*>(rowp_h + 8 * g) = (f32x4){v.lo[4 * g], v.lo[4 * g + 1], v.lo[4 * g + 2], v.lo[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(rowp_h + 32 + 8 * g) = (f32x4){v.hi[4 * g], v.hi[4 * g + 1], v.hi[4 * g + 2], v.hi[4 * g + 3]};
+  }
+}
+
+#define MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
+// One 64 x 64 matrix of the weight stream against a token-side operand in layout FL:  ACC(FL)[feature][token] += W . B^T.
+// The window W_[0..7] holds the matrix's first eight fragments on entry; every consumed slot is refilled with the fragment eight
+// ahead (PF: also across the end of the matrix into the next one), so eight 1 KB loads are always in flight.
+#define W32_STEP(ACCV, BV, C, PF)                                                                        \
+  do {                                                                                                   \
+    const f32x4 a__ = W_[C];                                                                             \
+    if (PF) W_[C] = wp[8 * 64];                                                                          \
+    wp += 64;                                                                                            \
+    ACCV = MFMA32(a__.x, BV[4 * ((C) & 3) + 0], ACCV);                                                   \
+    ACCV = MFMA32(a__.y, BV[4 * ((C) & 3) + 1], ACCV);                                                   \
+    ACCV = MFMA32(a__.z, BV[4 * ((C) & 3) + 2], ACCV);                                                   \
+    ACCV = MFMA32(a__.w, BV[4 * ((C) & 3) + 3], ACCV);                                                   \
+  } while (0)
+#define W32_BLOCK(ACCV, B, PF)                                                                           \
+  do {                                                                                                   \
+    W32_STEP(ACCV, B.lo, 0, PF); W32_STEP(ACCV, B.lo, 1, PF); W32_STEP(ACCV, B.lo, 2, PF); W32_STEP(ACCV, B.lo, 3, PF); \
+    W32_STEP(ACCV, B.hi, 4, PF); W32_STEP(ACCV, B.hi, 5, PF); W32_STEP(ACCV, B.hi, 6, PF); W32_STEP(ACCV, B.hi, 7, PF); \
+  } while (0)
+#define W32_CHAIN(ACC, B, PF_LAST)                                                                       \
+  do {                                                                                                   \
+    W32_BLOCK(ACC.lo, B, true);                                                                          \
+    W32_BLOCK(ACC.hi, B, PF_LAST);                                                                       \
+  } while (0)
+#define W32_PRIME()                                                                                      \
+  do {                                                                                                   \
+    _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) W_[i__] = wp[i__ * 64];                          \
+  } while (0)
+
+__device__ __forceinline__ FL fl_zero() {
+  FL v;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { v.lo[e] = 0.f; v.hi[e] = 0.f; }
+  return v;
+}
+
+}  // namespace
+
+// ---- fragment-major weights, rewritten once per step (after fold_ln_kernel) ----------------------------------------------
+struct FragArgs {
+  const float* wq; const float* wk; const float* wv;      // folded W' [512][64]
+  const float* fc1_w;                                     // [64][512]
+  const float* p0w; const float* p1w;                     // [64][64]
+  f32x4* out;                                             // [kNMat + 1][kFragF4] (one matrix of zero padding behind the stream)
+};
+// grid (kNMat + 1, 4) x 256: fragment (wc, c, lane) of matrix m = W[32 wc + r][8 c + 4 h .. + 3]
+__global__ __launch_bounds__(256) void fold_frag_kernel(FragArgs a) {
+  const int m = blockIdx.x, idx = blockIdx.y * 256 + threadIdx.x;
+  const int wc = idx >> 9, c = (idx >> 6) & 7, lane = idx & 63, r = lane & 31, h = lane >> 5;
+  const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (m < 32) {
+    const int hd = m >> 2, which = m & 3;               // K, Q, V, fc1 block
+    if (which < 3) {
+      const float* W = which == 0 ? a.wk : (which == 1 ? a.wq : a.wv);
+      v = *reinterpret_cast<const f32x4*>(W + ((int64_t)hd * 64 + n) * 64 + k0);
+    } else {
+      v = *reinterpret_cast<const f32x4*>(a.fc1_w + (int64_t)n * 512 + hd * 64 + k0);
+    }
+  } else if (m == 32) {
+    v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
+  } else if (m == 33) {
+    v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
+  } else if (m == 34) {                                  // conv1^T: A[i][contraction n'] = W1[n'][i]
+    v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
+  } else if (m == 35) {
+    v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
+  }
+  a.out[(int64_t)m * kFragF4 + idx] = v;
+}
+
+struct Fwd32Args {
+  const float* X;
+  const int32_t* row_off; const int32_t* tok_slot; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos; const int32_t* tok_tile;
+  int L;
+  const f32x4* wfrag;
+  const float* cq; const float* ck; const float* cv;      // folded projection biases [512]
+  const float* fc1_b; const float* p0b; const float* p1b;
+  HeadParams hp;
+  const float* y; const float* w;
+  float* Y; float* H1; float* H2;
+  float* logits; float* row_loss;
+  const uint64_t* seed;
+  float p_fc1, p_pff;
+  float* ddyn0; float* dXs; float* tslab; float alpha_over_B;
+  float* qkv;
+};
+
+template <int ML>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_fwd32_kernel(Fwd32Args g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* T1 = lds;                       // K, then V (per head); tail: product tiles, dH2, Y
+  float* T2 = lds + kHT;                 // the tail's parameter vectors until the weight-gradient GEMMs; then H1, dZ1
+  float* outs = lds + 2 * kHT;           // [32] per-token classifier outputs
+  float* douts = outs + 32;              // [32] their gradients
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+
+  const int4 meta = reinterpret_cast<const int4*>(g.half_meta)[blockIdx.x];
+  const int t0 = meta.x, n = meta.y, b0 = meta.z, n_h = meta.w;       // n <= 31 tokens, local row n = the shared padding token
+  if (n_h <= 0) return;
+  const int tok_pad = g.count[1];
+  const float inv_temp = 0.125f;
+  const bool real = r < n;
+  const int64_t tok = real ? (int64_t)(t0 + r) : (int64_t)tok_pad;    // rows past the padding token compute on its copy (finite, unused)
+
+  // ---- weight stream: prime the window with the first matrix (head 0's K) ----
+  const f32x4* wp = g.wfrag + lane;
+  f32x4 W_[8];
+  W32_PRIME();
+
+  // ---- x_hat in layout FL straight from global memory ----
+  FL xh;
+  {
+    const float* xp = g.X + tok * 64 + 4 * h;
+    xh = fl_load(xp);
+  }
+  // per-token metadata
+  int pos = 0, k = 0, tt = 0;
+  if (real) {
+    const int tp = g.tok_pos[tok];
+    pos = tp & 255; k = tp >> 8;
+    tt = g.tok_tile[tok];
+  }
+  const int li0 = r - pos;
+  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
+  uint32_t thr1 = 0, thr2 = 0, hrow1 = 0, hrow2 = 0;
+  float ks1 = 1.f, ks2 = 1.f;
+  if (drop1 || drop2) {
+    const uint32_t slot = (uint32_t)g.tok_slot[tok];
+    const uint64_t seed = *g.seed;
+    hrow1 = lowbias32(slot ^ rng_key(seed, kStreamDropFc1));
+    hrow2 = lowbias32(slot ^ rng_key(seed, kStreamDropPff));
+    if (drop1) { thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
+    if (drop2) { thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
+  }
+  // hyperedges of this half tile: lane e < n_h holds hyperedge b0 + e (the first 64; more only with many all-padding rows)
+  int he_lo = 0, he_k = 0;
+  float he_y = 0.f, he_w = 0.f;
+  if (lane < n_h) {
+    he_lo = g.row_off[b0 + lane];
+    he_k = g.row_off[b0 + lane + 1] - he_lo;
+    he_lo -= t0;
+    if (g.row_loss) { he_y = g.y[b0 + lane]; he_w = g.w[b0 + lane]; }
+  }
+  // T2 (exactly 2176 floats) until the weight-gradient GEMMs: the tail's vectors [10][64] = gp bp g1 b1 g2 b2 wc | fc1_b p0b p1b, then
+  // the folded projection biases cq, ck, cv [3][512] -- read back as the accumulators' initial values (no bias adds)
+  for (int i4 = lane; i4 < 544; i4 += 64) {
+    const float* src;
+    if (i4 < 160) {
+      const int v = i4 >> 4;
+      src = (v == 0 ? g.hp.gp : v == 1 ? g.hp.bp : v == 2 ? g.hp.g1 : v == 3 ? g.hp.b1 : v == 4 ? g.hp.g2 : v == 5 ? g.hp.b2
+           : v == 6 ? g.hp.wc : v == 7 ? g.fc1_b : v == 8 ? g.p0b : g.p1b) + 4 * (i4 & 15);
+    } else {
+      const int ii = i4 - 160;
+      src = ((ii >> 7) == 0 ? g.cq : (ii >> 7) == 1 ? g.ck : g.cv) + 4 * (ii & 127);
+    }
+    *reinterpret_cast<f32x4*>(T2 + 4 * i4) = *reinterpret_cast<const f32x4*>(src);
+  }
+  float rx;
+  {
+    float mean;
+    fl_stats(xh, mean, rx);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { xh.lo[e] = (xh.lo[e] - mean) * rx; xh.hi[e] = (xh.hi[e] - mean) * rx; }
+  }
+  // where this token's rows go in the backward kernel's tile images: float4 index ((2 wr' + wc) * 4 + g) * 64 + 32 h + r'
+  float* img_tok = nullptr;
+  float* pimg_tok = nullptr;
+  if (g.qkv && real) {
+    const int tile = tt >> 6, rho = tt & 63;
+    float* base = g.qkv + (int64_t)tile * MATCHA_N_HEAD * kImgRec;
+    img_tok = base + ((rho >> 5) * 8 * 64 + 32 * h + (rho & 31)) * 4;
+    pimg_tok = base + 3 * 4096 + rho * 8;
+  }
+#define F32_IMG_STORE(ACC, HD, M)                                                                        \
+  do {                                                                                                   \
+    if (img_tok) {                                                                                       \
+      f32x4* d__ = reinterpret_cast<f32x4*>(img_tok + (int64_t)(HD) * kImgRec + (M) * 4096);             \
+      _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
+        __builtin_nontemporal_store((f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]}, d__ + g__ * 64); \
+        __builtin_nontemporal_store((f32x4){ACC.hi[4 * g__], ACC.hi[4 * g__ + 1], ACC.hi[4 * g__ + 2], ACC.hi[4 * g__ + 3]}, d__ + (4 + g__) * 64); \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+
+  const int n_pad = g.L - k;
+  const float padf = (float)n_pad;
+  const bool hpad = n_pad > 0;
+  int ro[ML];                                         // LDS offset of key / value row j of this token's hyperedge (slots j >= k: clamped)
+#pragma unroll
+  for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLdH + 4 * h;
+  const int ro_pad = n * kLdH + 4 * h;
+  float* myrow = T1 + r * kLdH + 4 * h;
+
+  FL dyn = fl_zero();
+  __syncthreads();                                    // T2's vectors and biases are visible
+  const float* cbq = T2 + 640 + 4 * h;                // + which * 512 + hd * 64
+  FL acck = fl_vec(cbq + 512);                        // head 0's K accumulator starts from its bias
+  for (int hd = 0; hd < MATCHA_N_HEAD; ++hd) {
+    // the NEXT product's bias is read from LDS before the current chain of MFMAs starts, so no chain waits for its initial value
+    FL q = fl_vec(cbq + hd * 64);
+    // ---- K = W'k . x_hat^T + ck -> T1 ----
+    W32_CHAIN(acck, xh, true);
+    __syncthreads();                                  // (single wave: orders the LDS traffic) previous head's V reads are done
+    fl_store(myrow, acck);
+    F32_IMG_STORE(acck, hd, 1);
+    FL accv = fl_vec(cbq + 1024 + hd * 64);
+    // ---- Q (stays in registers) ----
+    W32_CHAIN(q, xh, true);
+    F32_IMG_STORE(q, hd, 0);
+    __syncthreads();                                  // K rows visible
+    // ---- scores + softmax: every token of the half tile at once, two lanes per token ----
+    float p[ML], pp;
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      float a = xhalf_sum(fl_dot_lds(q, T1 + ro[j])) * inv_temp;
+      a = (j == pos) ? -1e32f : a;                    // masked diagonal (Modules.py:443-445)
+      p[j] = a;
+      mx = (j < k) ? fmaxf(mx, a) : mx;
+    }
+    pp = xhalf_sum(fl_dot_lds(q, T1 + ro_pad)) * inv_temp;
+    mx = hpad ? fmaxf(mx, pp) : mx;
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
+      den += p[j];
+    }
+    pp = hpad ? __expf(pp - mx) : 0.f;
+    den += padf * pp;
+    const float inv = __builtin_amdgcn_rcpf(den);
+    if (pimg_tok && h == 0) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[j] = j < ML ? p[j < ML ? j : 0] * inv : 0.f;
+      if (hpad) wv[7] = pp * inv;
+      f32x4* dst = reinterpret_cast<f32x4*>(pimg_tok + (int64_t)hd * kImgRec);
+      __builtin_nontemporal_store((f32x4){wv[0], wv[1], wv[2], wv[3]}, dst);
+      __builtin_nontemporal_store((f32x4){wv[4], wv[5], wv[6], wv[7]}, dst + 1);
+    }
+    acck = fl_vec(cbq + 512 + (hd + 1 < MATCHA_N_HEAD ? hd + 1 : hd) * 64);      // next head's K bias
+    // ---- V = W'v . x_hat^T + cv -> T1 (K is dead) ----
+    W32_CHAIN(accv, xh, true);
+    __syncthreads();                                  // every lane's K reads are done
+    fl_store(myrow, accv);
+    F32_IMG_STORE(accv, hd, 2);
+    __syncthreads();
+    // ---- O = P V (in registers, layout FL) ----
+    FL o = fl_zero();
+    fl_axpy_lds(o, padf * pp * inv, T1 + ro_pad);
+#pragma unroll
+    for (int j = 0; j < ML; ++j) fl_axpy_lds(o, p[j] * inv, T1 + ro[j]);
+    // ---- dyn += Wfc1[:, head block] . O^T ----
+    W32_CHAIN(dyn, o, true);
+  }
+
+  // =========================== tail: pff_n1, LayerNorms, classifier (all in registers) ===========================
+  const float* tpar = T2 + 4 * h;                     // this lane's feature offset inside a 64-float vector
+  uint32_t keep1 = 0xFFFFFFFFu, keep2 = 0xFFFFFFFFu;
+  FL y;
+  {
+    fl_add_vec(dyn, tpar + 7 * 64);                   // + fc1 bias
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int f = 32 * (e >> 4) + 8 * ((e >> 2) & 3) + (e & 3);     // + 4 h
+      float v = e < 16 ? dyn.lo[e] : dyn.hi[e - 16];
+      if (drop1) {
+        const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow1) >= thr1;
+        keep1 = kp ? keep1 : (keep1 & ~(1u << e));
+        v = kp ? v * ks1 : 0.f;
+      }
+      v = real ? v : 0.f;                             // the padding token's row is masked (Modules.py:614)
+      if (e < 16) y.lo[e] = v; else y.hi[e - 16] = v;
+    }
+    if (g.Y && r <= n) fl_store_global(g.Y + tok * 64 + 4 * h, y);
+  }
+  FL h1 = fl_zero();
+  W32_CHAIN(h1, y, true);                             // conv0
+  {
+    fl_add_vec(h1, tpar + 8 * 64);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int f = 32 * (e >> 4) + 8 * ((e >> 2) & 3) + (e & 3);
+      float v = fast_tanh(e < 16 ? h1.lo[e] : h1.hi[e - 16]);
+      if (drop2) {
+        const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow2) >= thr2;
+        keep2 = kp ? keep2 : (keep2 & ~(1u << e));
+        v = kp ? v * ks2 : 0.f;
+      }
+      if (e < 16) h1.lo[e] = v; else h1.hi[e - 16] = v;
+    }
+    if (g.H1 && r <= n) fl_store_global(g.H1 + tok * 64 + 4 * h, h1);
+  }
+  FL h2 = y;                                          // residual as the accumulator's initial value
+  W32_CHAIN(h2, h1, false);                           // conv1 (the window is re-primed before the backward GEMMs)
+  fl_add_vec(h2, tpar + 9 * 64);
+  if (g.H2 && r <= n) fl_store_global(g.H2 + tok * 64 + 4 * h, h2);
+
+  // ---- out_t = sum_f (LN1(LN_pff(H2)) - LN2(X))_f^2 wc_f + bc ----
+  float mh, rh, mu, ru;
+  fl_stats(h2, mh, rh);
+  FL u;                                               // LN_pff output (before layer_norm1)
+  {
+    const FL Gp = fl_vec(tpar + 0 * 64), Bp = fl_vec(tpar + 1 * 64);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { u.lo[e] = (h2.lo[e] - mh) * rh * Gp.lo[e] + Bp.lo[e]; u.hi[e] = (h2.hi[e] - mh) * rh * Gp.hi[e] + Bp.hi[e]; }
+  }
+  fl_stats(u, mu, ru);
+  FL df;                                              // dynamic - static
+  {
+    const FL G1 = fl_vec(tpar + 2 * 64), B1 = fl_vec(tpar + 3 * 64);
+    const FL G2 = fl_vec(tpar + 4 * 64), B2 = fl_vec(tpar + 5 * 64);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      df.lo[e] = ((u.lo[e] - mu) * ru * G1.lo[e] + B1.lo[e]) - (xh.lo[e] * G2.lo[e] + B2.lo[e]);
+      df.hi[e] = ((u.hi[e] - mu) * ru * G1.hi[e] + B1.hi[e]) - (xh.hi[e] * G2.hi[e] + B2.hi[e]);
+    }
+  }
+  {
+    const FL Wc = fl_vec(tpar + 6 * 64);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0 += df.lo[e] * df.lo[e] * Wc.lo[e]; s1 += df.hi[e] * df.hi[e] * Wc.hi[e]; }
+    const float o = xhalf_sum(s0 + s1) + g.hp.bc[0];
+    if (h == 0) outs[r] = real ? o : 0.f;
+  }
+  __syncthreads();
+  // ---- per-hyperedge masked mean -> logit (+ BCE term, + its gradient) ----
+  for (int e = lane; e < n_h; e += 64) {
+    const int64_t b = b0 + e;
+    int lo = he_lo, kk = he_k;
+    float yb = he_y, wb = he_w;
+    if (e >= 64) {                                    // beyond the prefetched 64 (many all-padding rows in one half tile)
+      lo = g.row_off[b] - t0; kk = g.row_off[b + 1] - g.row_off[b];
+      if (g.row_loss) { yb = g.y[b]; wb = g.w[b]; }
+    }
+    float tot = 0.f;
+    for (int i = 0; i < kk; ++i) tot += outs[lo + i];
+    const float z = tot / ((float)kk + 1e-15f);
+    g.logits[b] = z;
+    if (g.row_loss) g.row_loss[b] = wb * (fmaxf(z, 0.f) - z * yb + log1pf(expf(-fabsf(z))));
+    if (g.ddyn0) {                                    // main.py:56 backward: d bce / d z = w (sigmoid(z) - y) / B  (x alpha, main.py:166)
+      const float dz = g.alpha_over_B * wb * (1.f / (1.f + expf(-z)) - yb);
+      const float dout = dz / ((float)kk + 1e-15f);
+      for (int i = 0; i < kk; ++i) douts[lo + i] = dout;
+    }
+  }
+  if (!g.ddyn0) return;
+
+  // =========================== backward of the tail and of pff_n1 (Modules.py:290-311, :353-376) ===========================
+  __syncthreads();
+  const float dout = real ? douts[r] : 0.f;
+  float* tsl = g.tslab + (int64_t)blockIdx.x * kTailSlab32;
+  // cross-token sums of a per-token FL quantity: through T1 as [token][feature], one lane per feature column
+#define F32_COLSUM(V, SLOT)                                                                              \
+  do {                                                                                                   \
+    __syncthreads();                                                                                     \
+    fl_store(myrow, V);                                                                                  \
+    __syncthreads();                                                                                     \
+    float c0__ = 0.f, c1__ = 0.f, c2__ = 0.f, c3__ = 0.f;                                                \
+    _Pragma("unroll") for (int t__ = 0; t__ < 32; t__ += 4) {                                            \
+      c0__ += T1[t__ * kLdH + lane]; c1__ += T1[(t__ + 1) * kLdH + lane];                                \
+      c2__ += T1[(t__ + 2) * kLdH + lane]; c3__ += T1[(t__ + 3) * kLdH + lane];                          \
+    }                                                                                                    \
+    cs_last = (c0__ + c1__) + (c2__ + c3__);                                                             \
+    tsl[kTailVec32 + (SLOT) * 64 + lane] = cs_last;                                                      \
+  } while (0)
+  float cs_last = 0.f, db1 = 0.f;
+  FL dh2;
+  {
+    // d(dynamic) = 2 df wc dout;  d(static) = - d(dynamic)
+    FL ddn;
+    {
+      const FL Wc = fl_vec(tpar + 6 * 64);
+      FL aw;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        aw.lo[e] = df.lo[e] * df.lo[e] * dout; aw.hi[e] = df.hi[e] * df.hi[e] * dout;
+        ddn.lo[e] = 2.f * df.lo[e] * Wc.lo[e] * dout; ddn.hi[e] = 2.f * df.hi[e] * Wc.hi[e] * dout;
+      }
+      F32_COLSUM(aw, 6);                              // d wc
+    }
+    // layer_norm2 (static branch) -> gradient into X; its affine gradients
+    {
+      const FL G2 = fl_vec(tpar + 4 * 64);
+      FL t;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { t.lo[e] = -ddn.lo[e] * xh.lo[e]; t.hi[e] = -ddn.hi[e] * xh.hi[e]; }
+      F32_COLSUM(t, 4);                               // d g2
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { t.lo[e] = -ddn.lo[e] * G2.lo[e]; t.hi[e] = -ddn.hi[e] * G2.hi[e]; }      // d x_hat
+      const float a = xhalf_sum(fl_sum(t)) * (1.f / 64.f), b = xhalf_sum(fl_dot(t, xh)) * (1.f / 64.f);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { t.lo[e] = rx * (t.lo[e] - a - xh.lo[e] * b); t.hi[e] = rx * (t.hi[e] - a - xh.hi[e] * b); }
+      if (r <= n) fl_store_global(g.dXs + tok * 64 + 4 * h, t);      // the padding token's row is zero (dout = 0)
+    }
+    // layer_norm1 (dynamic branch)
+    FL uh;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { uh.lo[e] = (u.lo[e] - mu) * ru; uh.hi[e] = (u.hi[e] - mu) * ru; }
+    {
+      FL t;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { t.lo[e] = ddn.lo[e] * uh.lo[e]; t.hi[e] = ddn.hi[e] * uh.hi[e]; }
+      F32_COLSUM(t, 2);                               // d g1
+      F32_COLSUM(ddn, 3);                             // d b1   (d b2 = - d b1: written below)
+      db1 = cs_last;
+    }
+    FL du;
+    {
+      const FL G1 = fl_vec(tpar + 2 * 64);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { du.lo[e] = ddn.lo[e] * G1.lo[e]; du.hi[e] = ddn.hi[e] * G1.hi[e]; }
+      const float a = xhalf_sum(fl_sum(du)) * (1.f / 64.f), b = xhalf_sum(fl_dot(du, uh)) * (1.f / 64.f);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { du.lo[e] = ru * (du.lo[e] - a - uh.lo[e] * b); du.hi[e] = ru * (du.hi[e] - a - uh.hi[e] * b); }
+    }
+    // pff_n1.layer_norm
+    FL hh;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { hh.lo[e] = (h2.lo[e] - mh) * rh; hh.hi[e] = (h2.hi[e] - mh) * rh; }
+    {
+      FL t;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { t.lo[e] = du.lo[e] * hh.lo[e]; t.hi[e] = du.hi[e] * hh.hi[e]; }
+      F32_COLSUM(t, 0);                               // d gp
+      F32_COLSUM(du, 1);                              // d bp
+    }
+    {
+      const FL Gp = fl_vec(tpar + 0 * 64);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dh2.lo[e] = du.lo[e] * Gp.lo[e]; dh2.hi[e] = du.hi[e] * Gp.hi[e]; }
+      const float a = xhalf_sum(fl_sum(dh2)) * (1.f / 64.f), b = xhalf_sum(fl_dot(dh2, hh)) * (1.f / 64.f);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dh2.lo[e] = rh * (dh2.lo[e] - a - hh.lo[e] * b); dh2.hi[e] = rh * (dh2.hi[e] - a - hh.hi[e] * b); }
+    }
+  }
+  // d b2 = - d b1;  d bc = sum of dout over the tokens
+  {
+    tsl[kTailVec32 + 5 * 64 + lane] = -db1;
+    float sd = (h == 0) ? dout : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o, 64);
+    if (lane == 0) tsl[kTailVec32 + 9 * 64] = sd;
+  }
+  // the weight stream resumes at conv1^T (the window was not refilled across the end of conv1)
+  W32_PRIME();
+  // ---- conv1: dW1[n][k] = sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2 ----
+  __syncthreads();
+  fl_store(myrow, dh2);                               // T1 = dH2 [token][feature] (rows past the tokens are zero: dout = 0)
+  fl_store(T2 + r * kLdH + 4 * h, h1);                // T2 = H1 (the parameter vectors are dead)
+  __syncthreads();
+#define F32_TN(A_T, B_T, SLAB, CS_SLOT)                                                                  \
+  do {                                                                                                   \
+    float cs__[2];                                                                                       \
+    _Pragma("unroll") for (int wr__ = 0; wr__ < 2; ++wr__) {                                             \
+      f32x16 a0__ = {0}, a1__ = {0};                                                                     \
+      float s__ = 0.f;                                                                                   \
+      _Pragma("unroll 8") for (int m__ = 0; m__ < 16; ++m__) {                                           \
+        const int t__ = 2 * m__ + h;                                                                     \
+        const float ga__ = (A_T)[t__ * kLdH + 32 * wr__ + r];                                            \
+        s__ += ga__;                                                                                     \
+        a0__ = MFMA32(ga__, (B_T)[t__ * kLdH + r], a0__);                                                \
+        a1__ = MFMA32(ga__, (B_T)[t__ * kLdH + 32 + r], a1__);                                           \
+      }                                                                                                  \
+      cs__[wr__] = xhalf_sum(s__);                                                                       \
+      f32x4* s0__ = reinterpret_cast<f32x4*>(SLAB) + ((0 * 2 + wr__) * 64 + lane) * 4;                   \
+      f32x4* s1__ = reinterpret_cast<f32x4*>(SLAB) + ((1 * 2 + wr__) * 64 + lane) * 4;                   \
+      _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__) {                                              \
+        s0__[q__] = (f32x4){a0__[4 * q__], a0__[4 * q__ + 1], a0__[4 * q__ + 2], a0__[4 * q__ + 3]};     \
+        s1__[q__] = (f32x4){a1__[4 * q__], a1__[4 * q__ + 1], a1__[4 * q__ + 2], a1__[4 * q__ + 3]};     \
+      }                                                                                                  \
+    }                                                                                                    \
+    tsl[kTailVec32 + (CS_SLOT) * 64 + lane] = h == 0 ? cs__[0] : cs__[1];                                \
+  } while (0)
+  F32_TN(T1, T2, tsl, 7);
+  // ---- dZ1^T = W1^T . dH2^T, x dropout mask x tanh' ----
+  FL dz = fl_zero();
+  W32_CHAIN(dz, dh2, true);
+  {
+    const float unscale = drop2 ? 1.f - g.p_pff : 1.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float hval = (e < 16 ? h1.lo[e] : h1.hi[e - 16]) * unscale;       // tanh value (0 where dropped)
+      float v = e < 16 ? dz.lo[e] : dz.hi[e - 16];
+      if (drop2) v = ((keep2 >> e) & 1u) ? v * ks2 : 0.f;
+      v *= 1.f - hval * hval;
+      if (e < 16) dz.lo[e] = v; else dz.hi[e - 16] = v;
+    }
+  }
+  // ---- conv0: dW0[n][k] = sum_t dZ1[t][n] Y[t][k];  d b0 = column sums of dZ1 ----
+  __syncthreads();                                    // the column walks over dH2 and H1 are done
+  fl_store(T2 + r * kLdH + 4 * h, dz);
+  fl_store(myrow, y);
+  __syncthreads();
+  F32_TN(T2, T1, tsl + 4096, 8);
+  // ---- d dyn^T = (W0^T . dZ1^T + dH2^T) x dropout mask x row mask ----
+  FL dd = dh2;                                        // residual: H2 = conv1(H1) + Y
+  W32_CHAIN(dd, dz, false);
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    float v = e < 16 ? dd.lo[e] : dd.hi[e - 16];
+    if (drop1) v = ((keep1 >> e) & 1u) ? v * ks1 : 0.f;
+    v = real ? v : 0.f;
+    if (e < 16) dd.lo[e] = v; else dd.hi[e - 16] = v;
+  }
+  if (r <= n) fl_store_global(g.ddyn0 + tok * 64 + 4 * h, dd);     // the padding token's row: zeros (every half tile writes the same)
+}
+
+size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragF4 * 4; }
+size_t fused_tail_slab32_floats(int64_t B, int L) { return (size_t)(ragged_halves_cap(B, L) + 2) * kTailSlab32; }
+
+int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st) {
+  FragArgs a;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64;
+  a.wq = folded; a.wk = folded + wsz; a.wv = folded + 2 * wsz;
+  a.fc1_w = p.fc1_w; a.p0w = p.pff0_w; a.p1w = p.pff1_w;
+  a.out = reinterpret_cast<f32x4*>(frag);
+  hipLaunchKernelGGL(fold_frag_kernel, dim3(kNMat + 1, 4), dim3(256), 0, st, a);
+  MATCHA_CHECK_LAUNCH("fold_frag_kernel");
+  return MATCHA_OK;
+}
+
+int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
+                       const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
+                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv) {
+  Fwd32Args g;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
+  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.tok_tile = rg.tok_tile;
+  g.L = L;
+  g.wfrag = reinterpret_cast<const f32x4*>(frag);
+  g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
+  g.fc1_b = p.fc1_b; g.p0b = p.pff0_b; g.p1b = p.pff1_b;
+  g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
+  g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;
+  g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
+  g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B; g.qkv = qkv;
+  const size_t lds = ((size_t)2 * kHT + 64) * sizeof(float);
+  auto launch = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(rg.nhalves), dim3(64), lds, st, g); };
+  // algorithmic flops per token: 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
+  ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);
+  switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+    case 2: launch(fused_fwd32_kernel<2>); break;
+    case 3: launch(fused_fwd32_kernel<3>); break;
+    case 4: launch(fused_fwd32_kernel<4>); break;
+    case 5: launch(fused_fwd32_kernel<5>); break;
+    case 6: launch(fused_fwd32_kernel<6>); break;
+    default: launch(fused_fwd32_kernel<8>); break;
+  }
+  MATCHA_CHECK_LAUNCH("fused_fwd32_kernel");
+  return MATCHA_OK;
+}
+
+}  // namespace matcha

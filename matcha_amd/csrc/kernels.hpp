@@ -36,7 +36,7 @@ struct Ragged {
   int32_t* row_off;    // [B+1]
   int32_t* tok_slot;   // [T+1]
   int64_t* tok_id;     // [T+1]
-  int32_t* count;      // {Tr + 1, Tr, tiles}
+  int32_t* count;      // {Tr + 1, Tr, tiles, half tiles}
   int32_t* blk_sum;
   int nblk;
   int ntiles;          // capacity of tile_meta (upper bound of the tile count; the count itself is count[2])
@@ -47,9 +47,15 @@ struct Ragged {
   int32_t* sb_cnt;
   int32_t* sb_first;   // [nsb + 1] first hyperedge of each planning superblock (B where none starts)
   int nsb, sb_cap;
+  int32_t* half_meta;  // [nhalves + 2][4] half tiles (<= 31 tokens of whole hyperedges), same fields as tile_meta; count[3] of them
+  int32_t* tok_tile;   // [T+1] (tile << 6) | row of the token inside tile_meta's tiling
+  int32_t* sb_htiles;  // planning scratch of the half tiles
+  int32_t* sb_hcnt;
+  int nhalves, sb_hcap;
 };
 size_t ragged_bytes(int64_t B, int L);
 int ragged_tiles_cap(int64_t B, int L);
+int ragged_halves_cap(int64_t B, int L);
 void ragged_carve(int64_t B, int L, char* base, Ragged& r);
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st);
 
@@ -90,7 +96,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
-  int disable_wide_gemm, disable_bwd8;
+  int disable_wide_gemm, disable_bwd8, disable_fwd32;
   int debug_nan, fused_dbg, fwd_lds_pad;
 };
 Options& options();
@@ -119,7 +125,16 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
                      hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr);
 size_t fused_tail_slab_floats(int64_t B, int L);
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st);
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves = false);
+
+// fused_fwd32.hip (embed_dim 64): the same forward with ONE wavefront per half tile (<= 31 tokens), weights streamed from L2 in
+// MFMA-fragment order (launch_fold_frag rewrites them once per step, after launch_fold_ln), no workgroup barriers
+size_t fused_frag_floats();
+size_t fused_tail_slab32_floats(int64_t B, int L);
+int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st);
+int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
+                       const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
+                       hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr);
 
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)

@@ -66,6 +66,7 @@ struct Workspace {
   float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
   void* adj_ws;     size_t adj_ws_bytes;
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
+  float* frag;                            // the same weights + fc1 / pff_n1 blocks in MFMA-fragment order (fused_fwd32.hip streams them from L2)
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
   float* qkv;                             // training forward -> fused backward: Q, K, V tiles of every (tile, head), 384 KB per tile
@@ -82,13 +83,14 @@ struct Workspace {
 //   disable_loss_in_forward  the tail's backward as separate kernels even when opts->loss_in_forward is set
 //   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
+//   disable_fwd32            the four-wave tile forward (fused_fwd.hip) instead of the wave-independent one (fused_fwd32.hip)
 //   disable_bwd8             the fused backward with four wavefronts per workgroup (fused_bwd_kernel) instead of eight (fused_bwd8_kernel)
 //   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
 struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
-    {"disable_qkv_save", &Options::disable_qkv_save},
+    {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
@@ -118,17 +120,19 @@ static bool save_qkv() { return !options().disable_qkv_save; }
 // make the eight-wave backward consume tiles nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so
 // it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
 static std::mutex g_qkv_mu;
-static std::unordered_map<const void*, bool> g_qkv_saved;
-static void note_qkv_saved(const void* ws, bool saved) {
+static std::unordered_map<const void*, int> g_qkv_saved;     // bit 0: Q/K/V tiles saved; bit 1: the forward ran per HALF tile (fused_fwd32)
+static void note_qkv_saved(const void* ws, bool saved, bool halves) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
   if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
-  g_qkv_saved[ws] = saved;
+  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0);
 }
-static bool qkv_saved(const void* ws) {
+static int ws_state(const void* ws) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
   auto it = g_qkv_saved.find(ws);
-  return it != g_qkv_saved.end() && it->second;
+  return it != g_qkv_saved.end() ? it->second : 0;
 }
+static bool qkv_saved(const void* ws) { return (ws_state(ws) & 1) != 0; }
+static bool fwd_ran_halves(const void* ws) { return (ws_state(ws) & 2) != 0; }
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
 // x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
@@ -186,8 +190,9 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.adj_ws_bytes = (s.mode == 1) ? adj_workspace_bytes(s, Tn) : 0;
   w.adj_ws = take_always(w.adj_ws_bytes / sizeof(float));
   w.folded = take_always(s.d == 64 ? fused_fold_floats() : 0);
+  w.frag = take_always(s.d == 64 ? fused_frag_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
-  w.tslab = take(s.d == 64 ? fused_tail_slab_floats(B, L) : 0);
+  w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
   w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever MATCHA_DISABLE_QKV_SAVE says: the layout must not depend on a switch read per call
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
   w.tg_ws_bytes = (s.mode == 0 && !compact) ? table_grad_ws_bytes(Tn, s.n_nodes) : 0;
@@ -370,13 +375,21 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     const bool save = !opts->forward_only && !lif;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
     const bool keep_qkv = !opts->forward_only && save_qkv();
-    note_qkv_saved(ws, keep_qkv);
+    const bool fwd32 = !options().disable_fwd32;                     // wave-independent forward (one wavefront per half tile)
+    note_qkv_saved(ws, keep_qkv, fwd32);
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
-    MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
-                                lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
+    if (fwd32) {
+      MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st));
+      MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
+                                    lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
+                                    lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
+    } else {
+      MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
+                                  lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
+                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
+    }
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -511,7 +524,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
   if (lif) {
     // ddyn0 and dXs were produced by matcha_forward; only the per-tile parameter-gradient partials remain to be summed
-    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st));
+    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, fwd_ran_halves(ws)));
   } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};

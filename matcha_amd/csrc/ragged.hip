@@ -14,9 +14,13 @@
 //                   caller's status word and replaced by 0, so that no later kernel indexes out of bounds
 //   tok_key [T+1]   the same ids as int32 with 0 in every unused slot (the (id, gradient row) list of table_grad.hip and of
 //                   the row-sparse data-parallel exchange)
-//   count [3]       {Tr + 1, Tr, number of tiles}  -- device-side counts consumed by every kernel through m_dev / t_dev
+//   count [4]       {Tr + 1, Tr, number of tiles, number of half tiles}  -- device-side counts consumed by every kernel through m_dev / t_dev
 //   tok_pos [T+1]   position of the compact token inside its hyperedge | k << 8 (fused kernels: token -> hyperedge rows)
-//   tile_meta       tiles of whole hyperedges (<= 63 tokens) for the fused d = 64 kernels
+//   tile_meta       tiles of whole hyperedges (<= 63 tokens) for the fused d = 64 kernels (fused_bwd.hip walks these)
+//   half_meta       the same token stream packed into HALF tiles of whole hyperedges with <= 31 tokens (+ the shared padding token =
+//                   32 rows: one wavefront of the wave-independent fused forward, fused_fwd32.hip); count[3] = number of half tiles
+//   tok_tile [T+1]  compact token -> (tile << 6) | row inside that tile: where the forward's wavefront stores the token's Q / K / V
+//                   rows for the backward kernel, whose 64-row tiles cut the stream at other places than the half tiles
 #include "kernels.hpp"
 
 namespace matcha {
@@ -128,13 +132,20 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
 // tokens, ~32 tiles): one wavefront per superblock loads 64 row offsets at a time; a ballot finds the first hyperedge that
 // ends beyond the open tile, which closes it (about 4 closes per 64 hyperedges); only a superblock's last tile is partial.  A second kernel compacts the per-superblock lists.
 // tile_meta[w] = {first token t0, tokens, first hyperedge b0, hyperedges}; entries past the tile count are zero.
-constexpr int kTileTok = 63;
+constexpr int kFullTok = 63;
+constexpr int kHalfTok = 31;
 constexpr int kSuperTok = 63 * 32;
 
-__global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb,
-                                                       const int32_t* __restrict__ sb_first, int32_t* __restrict__ sb_tiles,
-                                                       int32_t* __restrict__ sb_cnt) {
+// blockIdx.y = 0: tiles of <= 63 tokens; 1: half tiles of <= 31 tokens (same superblocks, own lists)
+__global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb0, int cap_per_sb1,
+                                                       const int32_t* __restrict__ sb_first, int32_t* __restrict__ sb_tiles0,
+                                                       int32_t* __restrict__ sb_cnt0, int32_t* __restrict__ sb_tiles1, int32_t* __restrict__ sb_cnt1) {
   const int s = blockIdx.x, lane = threadIdx.x;
+  const bool half = blockIdx.y != 0;
+  const int kTileTok = half ? kHalfTok : kFullTok;
+  const int cap_per_sb = half ? cap_per_sb1 : cap_per_sb0;
+  int32_t* sb_tiles = half ? sb_tiles1 : sb_tiles0;
+  int32_t* sb_cnt = half ? sb_cnt1 : sb_cnt0;
   const int b_lo = sb_first[s];                        // marked by row_fill_kernel (B: nothing starts here)
   int b_hi = (int)B;
   for (int q = s + 1; q < nsb; ++q)                    // next superblock that has a first hyperedge (normally s + 1)
@@ -168,8 +179,16 @@ __global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict
 }
 
 // exclusive scan of the superblock tile counts (one block, 1024 counts per pass), compaction, zero fill; count[2] = tiles
-__global__ __launch_bounds__(1024) void tile_compact_kernel(const int32_t* __restrict__ sb_tiles, int32_t* __restrict__ sb_cnt, int nsb,
-                                                            int cap_per_sb, int ntiles_cap, int32_t* __restrict__ meta, int32_t* __restrict__ count) {
+struct CompactArgs {
+  const int32_t* sb_tiles[2]; int32_t* sb_cnt[2]; int cap_per_sb[2]; int ntiles_cap[2]; int32_t* meta[2];
+};
+// blockIdx.x = 0: tiles -> tile_meta, count[2];  1: half tiles -> half_meta, count[3]
+__global__ __launch_bounds__(1024) void tile_compact_kernel(CompactArgs a, int nsb, int32_t* __restrict__ count) {
+  const int which = blockIdx.x;
+  const int32_t* __restrict__ sb_tiles = a.sb_tiles[which];
+  int32_t* __restrict__ sb_cnt = a.sb_cnt[which];
+  const int cap_per_sb = a.cap_per_sb[which], ntiles_cap = a.ntiles_cap[which];
+  int32_t* __restrict__ meta = a.meta[which];
   __shared__ int buf[1024];
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(const int32_t* __res
     __syncthreads();
   }
   const int total = carry < ntiles_cap ? carry : ntiles_cap;
-  if (threadIdx.x == 0) count[2] = total;
+  if (threadIdx.x == 0) count[2 + which] = total;
   __syncthreads();                                     // sb_cnt (now offsets) written by this block: visible after the barrier
   const int4* src = reinterpret_cast<const int4*>(sb_tiles);
   int4* dst = reinterpret_cast<int4*>(meta);
@@ -203,11 +222,20 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(const int32_t* __res
   for (int i = total + threadIdx.x; i < ntiles_cap + 2; i += 1024) dst[i] = make_int4(0, 0, 0, 0);
 }
 
+// tok_tile[t] = (tile << 6) | row for every token of every planned tile (one 64-thread block per tile slot; slots past the count are zero)
+__global__ __launch_bounds__(64) void tok_tile_kernel(const int32_t* __restrict__ meta, int32_t* __restrict__ tok_tile) {
+  const int4 m = reinterpret_cast<const int4*>(meta)[blockIdx.x];
+  if ((int)threadIdx.x < m.y) tok_tile[m.x + threadIdx.x] = (int32_t)((blockIdx.x << 6) | threadIdx.x);
+}
+
 static inline int super_blocks(int64_t T) { return (int)cdiv(T + 1, kSuperTok); }
 static inline int super_cap(int L) { return (int)cdiv(kSuperTok + L, 64 - L) + 2; }
 static inline int tiles_cap(int64_t T, int L) { return (int)cdiv(T + 1, 64 - L) + super_blocks(T); }   // every tile but a superblock's last holds > 63 - L tokens
+static inline int super_hcap(int L) { return (int)cdiv(kSuperTok + L, 32 - L) + 2; }
+static inline int halves_cap(int64_t T, int L) { return (int)cdiv(T + 1, 32 - L) + super_blocks(T); }  // ... > 31 - L tokens
 
 int ragged_tiles_cap(int64_t B, int L) { return tiles_cap(B * L, L); }
+int ragged_halves_cap(int64_t B, int L) { return halves_cap(B * L, L); }
 
 size_t ragged_bytes(int64_t B, int L) {
   const int64_t T = B * L;
@@ -223,6 +251,10 @@ size_t ragged_bytes(int64_t B, int L) {
   n += align_up((size_t)super_blocks(T) * super_cap(L) * 16, 256);           // sb_tiles
   n += align_up((size_t)super_blocks(T) * 4, 256);                           // sb_cnt
   n += align_up((size_t)(super_blocks(T) + 1) * 4, 256);                     // sb_first
+  n += align_up((size_t)(halves_cap(T, L) + 2) * 16, 256);                   // half_meta
+  n += align_up((size_t)super_blocks(T) * super_hcap(L) * 16, 256);          // sb_htiles
+  n += align_up((size_t)super_blocks(T) * 4, 256);                           // sb_hcnt
+  n += align_up((size_t)(T + 1) * 4, 256);                                   // tok_tile
   return n;
 }
 
@@ -245,6 +277,12 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.sb_tiles = (int32_t*)take((size_t)r.nsb * r.sb_cap * 16);
   r.sb_cnt = (int32_t*)take((size_t)r.nsb * 4);
   r.sb_first = (int32_t*)take((size_t)(r.nsb + 1) * 4);
+  r.nhalves = halves_cap(T, L);
+  r.sb_hcap = super_hcap(L);
+  r.half_meta = (int32_t*)take((size_t)(r.nhalves + 2) * 16);
+  r.sb_htiles = (int32_t*)take((size_t)r.nsb * r.sb_hcap * 16);
+  r.sb_hcnt = (int32_t*)take((size_t)r.nsb * 4);
+  r.tok_tile = (int32_t*)take((size_t)(T + 1) * 4);
 }
 
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st) {
@@ -256,10 +294,16 @@ int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int3
   hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos, r.sb_first, kSuperTok,
                      r.tok_key, n_nodes, status);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_first, r.sb_tiles, r.sb_cnt);
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb, 2), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_hcap, r.sb_first, r.sb_tiles, r.sb_cnt,
+                     r.sb_htiles, r.sb_hcnt);
   MATCHA_CHECK_LAUNCH("tile_pack_kernel");
-  hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, st, r.sb_tiles, r.sb_cnt, r.nsb, r.sb_cap, r.ntiles, r.tile_meta, r.count);
+  CompactArgs ca;
+  ca.sb_tiles[0] = r.sb_tiles; ca.sb_cnt[0] = r.sb_cnt; ca.cap_per_sb[0] = r.sb_cap; ca.ntiles_cap[0] = r.ntiles; ca.meta[0] = r.tile_meta;
+  ca.sb_tiles[1] = r.sb_htiles; ca.sb_cnt[1] = r.sb_hcnt; ca.cap_per_sb[1] = r.sb_hcap; ca.ntiles_cap[1] = r.nhalves; ca.meta[1] = r.half_meta;
+  hipLaunchKernelGGL(tile_compact_kernel, dim3(2), dim3(1024), 0, st, ca, r.nsb, r.count);
   MATCHA_CHECK_LAUNCH("tile_compact_kernel");
+  hipLaunchKernelGGL(tok_tile_kernel, dim3(r.ntiles), dim3(64), 0, st, r.tile_meta, r.tok_tile);
+  MATCHA_CHECK_LAUNCH("tok_tile_kernel");
   return MATCHA_OK;
 }
 
@@ -283,5 +327,6 @@ extern "C" int matcha_ragged_plan(const int64_t* x, int64_t B, int32_t L, int32_
   ragged_carve(B, L, (char*)ws, r);
   view->row_off = r.row_off; view->tok_slot = r.tok_slot; view->tok_id = r.tok_id; view->tok_key = r.tok_key; view->tok_pos = r.tok_pos;
   view->count = r.count; view->tile_meta = r.tile_meta; view->tiles_cap = r.ntiles;
+  view->half_meta = r.half_meta; view->halves_cap = r.nhalves; view->tok_tile = r.tok_tile;
   return launch_ragged_plan(x, B, L, n_nodes, status, r, (hipStream_t)stream);
 }

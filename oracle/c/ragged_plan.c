@@ -76,3 +76,41 @@ int64_t matcha_oracle_ragged_plan(const int64_t* x, int64_t B, int32_t L, int64_
   count[2] = (int32_t)nt;
   return nt;
 }
+
+/* The half tiles and the token -> (tile, row) map of the wave-independent fused forward (matcha_amd/csrc/fused_fwd32.hip):
+ *   half_meta [halves_cap][4]  the same greedy packing inside the same superblocks with at most HALF_TOK = 31 tokens per half tile
+ *                              (+ the shared padding token = 32 rows, one wavefront); zeros past the count
+ *   tok_tile [T+1]             (tile << 6) | row for every token of tile_meta's tiles (entries of no tile are left untouched)
+ * row_off / tile_meta / n_tiles are the outputs of matcha_oracle_ragged_plan.  Returns the number of half tiles (= count[3]),
+ * or -1 if halves_cap is too small. */
+#define HALF_TOK 31
+
+int64_t matcha_oracle_ragged_halves(const int32_t* row_off, int64_t B, const int32_t* tile_meta, int64_t n_tiles, int32_t* half_meta,
+                                    int64_t halves_cap, int32_t* tok_tile) {
+  memset(half_meta, 0, (size_t)halves_cap * 4 * sizeof(int32_t));
+  int64_t nh = 0;
+  int64_t b = 0;
+  while (b < B) {
+    int64_t b_hi = b + 1;
+    while (b_hi < B && row_off[b_hi] / SUPER_TOK == row_off[b_hi - 1] / SUPER_TOK) ++b_hi;
+    int64_t tile_b0 = b;
+    int32_t tile_tok0 = row_off[b];
+    for (int64_t i = b; i < b_hi; ++i) {
+      while (row_off[i + 1] - tile_tok0 > HALF_TOK) {
+        if (nh >= halves_cap) return -1;
+        half_meta[4 * nh + 0] = tile_tok0; half_meta[4 * nh + 1] = row_off[i] - tile_tok0;
+        half_meta[4 * nh + 2] = (int32_t)tile_b0; half_meta[4 * nh + 3] = (int32_t)(i - tile_b0);
+        ++nh;
+        tile_b0 = i; tile_tok0 = row_off[i];
+      }
+    }
+    if (nh >= halves_cap) return -1;
+    half_meta[4 * nh + 0] = tile_tok0; half_meta[4 * nh + 1] = row_off[b_hi] - tile_tok0;
+    half_meta[4 * nh + 2] = (int32_t)tile_b0; half_meta[4 * nh + 3] = (int32_t)(b_hi - tile_b0);
+    ++nh;
+    b = b_hi;
+  }
+  for (int64_t w = 0; w < n_tiles; ++w)
+    for (int32_t i = 0; i < tile_meta[4 * w + 1]; ++i) tok_tile[tile_meta[4 * w] + i] = (int32_t)((w << 6) | i);
+  return nh;
+}

@@ -20,6 +20,8 @@
 
 #include "../../matcha_amd/csrc/model.hip"
 
+extern "C" int64_t matcha_oracle_ragged_halves(const int32_t* row_off, int64_t B, const int32_t* tile_meta, int64_t n_tiles, int32_t* half_meta,
+                                               int64_t halves_cap, int32_t* tok_tile);
 extern "C" int64_t matcha_oracle_ragged_plan(const int64_t* x, int64_t B, int32_t L, int64_t n_nodes, int32_t* row_off, int32_t* tok_slot,
                                              int64_t* tok_id, int32_t* tok_key, int32_t* tok_pos, int32_t* count, int32_t* tile_meta,
                                              int64_t tiles_cap, int32_t* status);
@@ -230,6 +232,22 @@ static void fuzz_plan_oracle() {
       CHECK(key[t] == (int32_t)id[t] && (id[t] == x[slot[t]] || (id[t] == 0 && (x[slot[t]] < 0 || x[slot[t]] > N))));
     }
     for (int64_t t = Tr; t <= T; ++t) CHECK(key[t] == 0);
+    // half tiles (<= 31 tokens: one wavefront of the fused forward) + the token -> (tile, row) map
+    const int64_t hcap = (T + 1 + (32 - L) - 1) / (32 - L) + (T + 1 + 63 * 32 - 1) / (63 * 32) + 2;       // ragged.hip: halves_cap
+    std::vector<int32_t> half(hcap * 4), tt(T + 1, -1);
+    const int64_t nh = matcha_oracle_ragged_halves(row_off.data(), B, meta.data(), nt, half.data(), hcap, tt.data());
+    CHECK(nh >= nt && nh <= hcap);
+    tok = 0; hy = 0;
+    for (int64_t t = 0; t < nh; ++t) {
+      CHECK(half[4 * t] == tok && half[4 * t + 2] == hy && half[4 * t + 1] <= 31 && half[4 * t + 3] >= 1);
+      CHECK(row_off[half[4 * t + 2] + half[4 * t + 3]] == half[4 * t] + half[4 * t + 1]);
+      tok += half[4 * t + 1]; hy += half[4 * t + 3];
+    }
+    CHECK(tok == Tr && hy == B);
+    for (int64_t t = 0; t < Tr; ++t) {
+      const int64_t w = tt[t] >> 6, row = tt[t] & 63;
+      CHECK(tt[t] >= 0 && w < nt && meta[4 * w] + row == t && row < meta[4 * w + 1]);
+    }
   }
 }
 

@@ -343,6 +343,10 @@ def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad):
                tok_id=grab(view.tok_id, T + 1, torch.int64), tok_key=grab(view.tok_key, T + 1, torch.int32),
                tok_pos=grab(view.tok_pos, T + 1, torch.int32), count=grab(view.count, 3, torch.int32),
                tile_meta=grab(view.tile_meta, cap * 4, torch.int32))
+    hcap = int(view.halves_cap)
+    got_half = grab(view.half_meta, hcap * 4, torch.int32)
+    got_tt = grab(view.tok_tile, T + 1, torch.int32)
+    got_nh = int(grab(view.count, 4, torch.int32)[3])
     ref = dict(row_off=np.zeros(B + 1, np.int32), tok_slot=np.zeros(T + 1, np.int32), tok_id=np.zeros(T + 1, np.int64),
                tok_key=np.zeros(T + 1, np.int32), tok_pos=np.zeros(T + 1, np.int32), count=np.zeros(3, np.int32),
                tile_meta=np.zeros(cap * 4, np.int32))
@@ -362,3 +366,13 @@ def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad):
     # the tiles partition the hyperedges into runs of whole hyperedges with <= 63 tokens
     tm = ref["tile_meta"].reshape(-1, 4)[:nt]
     assert tm[:, 1].max() <= 63 and tm[:, 3].sum() == B and tm[:, 1].sum() == Tr
+    # half tiles (<= 31 tokens, one wavefront of the fused forward each) and the token -> (tile, row) map
+    ref_half, ref_tt = np.zeros(hcap * 4, np.int32), np.zeros(T + 1, np.int32)
+    ora.matcha_oracle_ragged_halves.restype = C.c_int64
+    nh = ora.matcha_oracle_ragged_halves(p(ref["row_off"]), C.c_int64(B), p(ref["tile_meta"]), C.c_int64(nt), p(ref_half), C.c_int64(hcap), p(ref_tt))
+    assert nh >= 1 and nh == got_nh
+    assert np.array_equal(got_half, ref_half)
+    assert np.array_equal(got_tt[:Tr], ref_tt[:Tr])
+    hm = ref_half.reshape(-1, 4)[:nh]
+    assert hm[:, 1].max() <= 31 and hm[:, 3].sum() == B and hm[:, 1].sum() == Tr
+    assert np.array_equal(hm[1:, 0], hm[:-1, 0] + hm[:-1, 1]) and np.array_equal(hm[1:, 2], hm[:-1, 2] + hm[:-1, 3])     # contiguous cover
