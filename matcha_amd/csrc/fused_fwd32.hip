@@ -43,9 +43,12 @@ constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
 struct FL { f32x16 lo, hi; };             // 32 features of one token row in layout FL (lo: wc = 0, hi: wc = 1)
 
 __device__ __forceinline__ float xhalf_sum(float v) {
-  // lanes (r, 0) and (r, 1) hold the two halves of a row sum: v_permlane32_swap broadcasts each half to both
-  const auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  // lanes (r, 0) and (r, 1) hold the two halves of a row sum.  v_permlane32_swap a, b exchanges a[32:63] with b[0:31]: with a = b = v
+  // it leaves a = {lo, lo}, b = {hi, hi}.  Inline asm: __builtin_amdgcn_permlane32_swap of this toolchain returns the FIRST result in
+  // both elements (tools/debug/permlane_test.hip), i.e. only the lower half's broadcast.
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
 }
 __device__ __forceinline__ float fl_sum(const FL& a) {
   float s0 = 0.f, s1 = 0.f;
