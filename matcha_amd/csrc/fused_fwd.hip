@@ -725,47 +725,62 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs g) {
 #endif
 }
 
-// Sum the per-tile slabs of the training forward in a fixed order and accumulate into the gradient tensors.
+// Sum the per-tile slabs of the training forward in a fixed order and accumulate into the gradient tensors: a pure stream (133 MB per
+// 65 536-row step with the four-wave forward, twice that with one slab per half tile), so what matters is bytes in flight.  Pass 1:
+// block (column block of 64 float4, split s of the tile range) -- eight wavefronts, each reading whole 1 KB rows of its tiles with
+// four independent chains (64 KB in flight per CU; the one-pass kernel with 4-byte loads ran at 3.2 TB/s) -> partial[s].  Pass 2:
+// the kTailSplits partials of every element in split order, un-permuted into the gradient tensors.
+constexpr int kTailSplits = 8;
+constexpr int kTailF4 = kTailSlab / 4;                       // 2208 float4 per slab
+constexpr int kTailColBlocks = (kTailF4 + 63) / 64;          // 35
 struct TailReduceArgs {
   const float* tslab; const int32_t* count; int L; int ntiles_cap; int count_idx;
+  float* partial;     // [kTailSplits][kTailSlab]
   float* dst[12];     // pff1_w, pff0_w, gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b, bc
 };
-// 32 slab elements per block (one per lane of a half-wave: 128-byte segments), 32 slab-row groups: 276 blocks, so that every CU
-// takes part in what is a pure 133 MB stream (64 elements per block left 118 of the 256 CUs idle: 40 us instead of ~25)
-__global__ __launch_bounds__(1024) void tail_slab_reduce_kernel(TailReduceArgs a) {
-  __shared__ float part[32][33];
-  const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + o;                   // element of the slab
+__global__ __launch_bounds__(512) void tail_slab_reduce_kernel(TailReduceArgs a) {
+  __shared__ float4 part[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 64 + lane, sp = blockIdx.y;
   int nt = a.count[a.count_idx];                       // tiles (or half tiles) planned by ragged.hip: every one of them wrote its slab
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;   // eight independent chains: the walk is latency-bound
-  if (i < kTailSlab) {
-    int b = q;
-    for (; b + 224 < nt; b += 256) {
-      s0 += a.tslab[(int64_t)b * kTailSlab + i];
-      s1 += a.tslab[(int64_t)(b + 32) * kTailSlab + i];
-      s2 += a.tslab[(int64_t)(b + 64) * kTailSlab + i];
-      s3 += a.tslab[(int64_t)(b + 96) * kTailSlab + i];
-      s4 += a.tslab[(int64_t)(b + 128) * kTailSlab + i];
-      s5 += a.tslab[(int64_t)(b + 160) * kTailSlab + i];
-      s6 += a.tslab[(int64_t)(b + 192) * kTailSlab + i];
-      s7 += a.tslab[(int64_t)(b + 224) * kTailSlab + i];
+  const int lo = (int)((int64_t)nt * sp / kTailSplits), hi = (int)((int64_t)nt * (sp + 1) / kTailSplits);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (c4 < kTailF4) {
+    const float4* base = reinterpret_cast<const float4*>(a.tslab) + c4;
+    int t = lo + wave;
+    for (; t + 24 < hi; t += 32) {
+      const float4 v0 = base[(int64_t)t * kTailF4], v1 = base[(int64_t)(t + 8) * kTailF4], v2 = base[(int64_t)(t + 16) * kTailF4], v3 = base[(int64_t)(t + 24) * kTailF4];
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+      s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+      s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
     }
-    for (; b < nt; b += 32) s0 += a.tslab[(int64_t)b * kTailSlab + i];
+    for (; t < hi; t += 8) { const float4 v = base[(int64_t)t * kTailF4]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
   }
-  part[q][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+  part[wave][lane] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
   __syncthreads();
-  if (q == 0 && i <= kTailVec + 9 * 64) {
-    float s = 0.f;
+  if (wave == 0 && c4 < kTailF4) {
+    float4 s = part[0][lane];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) s += part[t][o];
-    if (i < 8192) {
-      // the two weight-gradient matrices arrive in the MFMA accumulator layout [wave][lane][register] (fused_fwd_kernel)
-      const int e = i & 4095, wv = e >> 10, ln = (e >> 4) & 63, reg = e & 15;
-      const int row = 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), col = 32 * (wv >> 1) + (ln & 31);
-      a.dst[i >> 12][row * 64 + col] += s;
-    }
-    else { const int v = (i - kTailVec) >> 6, j = (i - kTailVec) & 63; a.dst[2 + v][j] += s; }
+    for (int w = 1; w < 8; ++w) { const float4 v = part[w][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    reinterpret_cast<float4*>(a.partial)[sp * kTailF4 + c4] = s;
+  }
+}
+__global__ __launch_bounds__(256) void tail_slab_finish_kernel(TailReduceArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > kTailVec + 9 * 64) return;
+  float s = 0.f;
+#pragma unroll
+  for (int sp = 0; sp < kTailSplits; ++sp) s += a.partial[sp * kTailSlab + i];
+  if (i < 8192) {
+    // the two weight-gradient matrices arrive in the MFMA accumulator layout [wave][lane][register] (fused_fwd_kernel)
+    const int e = i & 4095, wv = e >> 10, ln = (e >> 4) & 63, reg = e & 15;
+    const int row = 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), col = 32 * (wv >> 1) + (ln & 31);
+    a.dst[i >> 12][row * 64 + col] += s;
+  } else {
+    const int v = (i - kTailVec) >> 6, j = (i - kTailVec) & 63;
+    a.dst[2 + v][j] += s;
   }
 }
 
@@ -784,15 +799,19 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
 }
 
 size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
+size_t fused_tail_partial_floats() { return (size_t)kTailSplits * kTailSlab; }
 size_t fused_qkv_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRec; }
 
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves) {
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves, float* partial) {
   TailReduceArgs a;
   a.tslab = tslab; a.count = rg.count; a.L = L; a.ntiles_cap = halves ? rg.nhalves : rg.ntiles; a.count_idx = halves ? 3 : 2;
+  a.partial = partial;
   float* dst[12] = {g_.pff1_w, g_.pff0_w, g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.pff1_b, g_.pff0_b, g_.cls_b};
   for (int i = 0; i < 12; ++i) a.dst[i] = dst[i];
-  hipLaunchKernelGGL(tail_slab_reduce_kernel, dim3((unsigned)cdiv(kTailSlab, 32)), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(tail_slab_reduce_kernel, dim3(kTailColBlocks, kTailSplits), dim3(512), 0, st, a);
   MATCHA_CHECK_LAUNCH("tail_slab_reduce_kernel");
+  hipLaunchKernelGGL(tail_slab_finish_kernel, dim3((unsigned)cdiv(kTailSlab, 256)), dim3(256), 0, st, a);
+  MATCHA_CHECK_LAUNCH("tail_slab_finish_kernel");
   return MATCHA_OK;
 }
 

@@ -24,6 +24,10 @@
 //   64-row tiles that cut the token stream elsewhere): tok_tile[t] = (tile << 6) | row says where each token's rows go.
 #include "kernels.hpp"
 
+#ifndef F32_ABL
+#define F32_ABL 0                     // timing ablations (tools/debug/abl_fwd32.sh): 1 no attention, 2 no image stores, 4 no tail backward, 8 no tail
+#endif
+
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,8 +39,8 @@ namespace {
 constexpr int kLdH = 68;                  // LDS row stride (floats)
 constexpr int kHT = 32 * kLdH;            // one half tile [32 rows][68]
 constexpr float kEps32 = 1e-5f;
-constexpr int kFragF4 = 1024;             // float4 per 64 x 64 matrix in fragment-major order: [wc][c][lane]
-constexpr int kNMat = 36;                 // 8 heads x {K, Q, V, fc1 block}, conv0, conv1, conv1^T, conv0^T -- in consumption order
+constexpr int kFragF4 = 18 * 64;           // float4 per 64 x 64 matrix in fragment-major order: [wc][c = 0..7 | bias][lane]
+constexpr int kNMat = 36;                 // 8 heads x {K, Q, V, fc1 block}, conv0, conv1, conv1^T, conv0^T -- in consumption order (fold_frag_kernel)
 constexpr int kTailVec32 = 2 * 4096;      // same slab format as fused_fwd.hip (tail_slab_reduce_kernel reads both)
 constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
 
@@ -138,32 +142,51 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
 
 #define MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
-// One 64 x 64 matrix of the weight stream against a token-side operand in layout FL:  ACC(FL)[feature][token] += W . B^T.
-// The window W_[0..7] holds the matrix's first eight fragments on entry; every consumed slot is refilled with the fragment eight
-// ahead (PF: also across the end of the matrix into the next one), so eight 1 KB loads are always in flight.
-#define W32_STEP(ACCV, BV, C, PF)                                                                        \
+// ---- the weight stream ---------------------------------------------------------------------------------------------------
+// One 64 x 64 matrix = 18 fragments of one float4 per lane: for wc = 0, 1 the eight k-groups c (W[32 wc + r][8 c + 4 h .. + 3]) and a
+// BIAS fragment (.x = bias[32 wc + r] in the lower half-wave, zero elsewhere) that enters the accumulator as one more MFMA against
+// the constant 1 -- the bias costs 2 of 66 MFMAs, no register, no LDS traffic, no wait.  A product in layout FL is 18 STEPS; the
+// window W_[0..8] holds the nine fragments of the current block and every consumed slot is refilled with the fragment nine ahead
+// (one block = 33 MFMAs = 0.9 us of lead), pinned there by a scheduling barrier: left alone the scheduler sinks each refill next to
+// its use and the window's depth becomes 1.
+#define W32_MMA(ACC, B, S)                                                                               \
   do {                                                                                                   \
-    const f32x4 a__ = W_[C];                                                                             \
-    if (PF) W_[C] = wp[8 * 64];                                                                          \
+    constexpr int c__ = (S) % 9;                                                                         \
+    if constexpr (c__ == 8) {                                                                            \
+      if constexpr ((S) < 9) ACC.lo = MFMA32(W_[8].x, 1.f, ACC.lo); else ACC.hi = MFMA32(W_[8].x, 1.f, ACC.hi); \
+    } else {                                                                                             \
+      constexpr int e__ = 4 * (c__ & 3);                                                                 \
+      const float b0__ = c__ < 4 ? B.lo[e__] : B.hi[e__], b1__ = c__ < 4 ? B.lo[e__ + 1] : B.hi[e__ + 1]; \
+      const float b2__ = c__ < 4 ? B.lo[e__ + 2] : B.hi[e__ + 2], b3__ = c__ < 4 ? B.lo[e__ + 3] : B.hi[e__ + 3]; \
+      if constexpr ((S) < 9) {                                                                           \
+        ACC.lo = MFMA32(W_[c__].x, b0__, ACC.lo); ACC.lo = MFMA32(W_[c__].y, b1__, ACC.lo);              \
+        ACC.lo = MFMA32(W_[c__].z, b2__, ACC.lo); ACC.lo = MFMA32(W_[c__].w, b3__, ACC.lo);              \
+      } else {                                                                                           \
+        ACC.hi = MFMA32(W_[c__].x, b0__, ACC.hi); ACC.hi = MFMA32(W_[c__].y, b1__, ACC.hi);              \
+        ACC.hi = MFMA32(W_[c__].z, b2__, ACC.hi); ACC.hi = MFMA32(W_[c__].w, b3__, ACC.hi);              \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#define W32_REFILL(S, PF)                                                                                \
+  do {                                                                                                   \
+    if (PF) W_[(S) % 9] = wp[9 * 64];                                                                    \
     wp += 64;                                                                                            \
-    ACCV = MFMA32(a__.x, BV[4 * ((C) & 3) + 0], ACCV);                                                   \
-    ACCV = MFMA32(a__.y, BV[4 * ((C) & 3) + 1], ACCV);                                                   \
-    ACCV = MFMA32(a__.z, BV[4 * ((C) & 3) + 2], ACCV);                                                   \
-    ACCV = MFMA32(a__.w, BV[4 * ((C) & 3) + 3], ACCV);                                                   \
+    asm volatile("" ::: "memory");         /* instruction selection clusters every LDS read of the block at its top otherwise */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
   } while (0)
-#define W32_BLOCK(ACCV, B, PF)                                                                           \
-  do {                                                                                                   \
-    W32_STEP(ACCV, B.lo, 0, PF); W32_STEP(ACCV, B.lo, 1, PF); W32_STEP(ACCV, B.lo, 2, PF); W32_STEP(ACCV, B.lo, 3, PF); \
-    W32_STEP(ACCV, B.hi, 4, PF); W32_STEP(ACCV, B.hi, 5, PF); W32_STEP(ACCV, B.hi, 6, PF); W32_STEP(ACCV, B.hi, 7, PF); \
-  } while (0)
+#define W32_STEP(ACC, B, S) do { W32_MMA(ACC, B, S); W32_REFILL(S, true); } while (0)
+// a whole product without anything interleaved; PF_LAST = false stops refilling in the second block (the window is primed again later)
 #define W32_CHAIN(ACC, B, PF_LAST)                                                                       \
   do {                                                                                                   \
-    W32_BLOCK(ACC.lo, B, true);                                                                          \
-    W32_BLOCK(ACC.hi, B, PF_LAST);                                                                       \
+    W32_STEP(ACC, B, 0); W32_STEP(ACC, B, 1); W32_STEP(ACC, B, 2); W32_STEP(ACC, B, 3); W32_STEP(ACC, B, 4);                 \
+    W32_STEP(ACC, B, 5); W32_STEP(ACC, B, 6); W32_STEP(ACC, B, 7); W32_STEP(ACC, B, 8);                                      \
+    W32_MMA(ACC, B, 9); W32_REFILL(9, PF_LAST); W32_MMA(ACC, B, 10); W32_REFILL(10, PF_LAST); W32_MMA(ACC, B, 11); W32_REFILL(11, PF_LAST); \
+    W32_MMA(ACC, B, 12); W32_REFILL(12, PF_LAST); W32_MMA(ACC, B, 13); W32_REFILL(13, PF_LAST); W32_MMA(ACC, B, 14); W32_REFILL(14, PF_LAST); \
+    W32_MMA(ACC, B, 15); W32_REFILL(15, PF_LAST); W32_MMA(ACC, B, 16); W32_REFILL(16, PF_LAST); W32_MMA(ACC, B, 17); W32_REFILL(17, PF_LAST); \
   } while (0)
 #define W32_PRIME()                                                                                      \
   do {                                                                                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) W_[i__] = wp[i__ * 64];                          \
+    _Pragma("unroll") for (int i__ = 0; i__ < 9; ++i__) W_[i__] = wp[i__ * 64];                          \
   } while (0)
 
 __device__ __forceinline__ FL fl_zero() {
@@ -178,32 +201,44 @@ __device__ __forceinline__ FL fl_zero() {
 // ---- fragment-major weights, rewritten once per step (after fold_ln_kernel) ----------------------------------------------
 struct FragArgs {
   const float* wq; const float* wk; const float* wv;      // folded W' [512][64]
-  const float* fc1_w;                                     // [64][512]
-  const float* p0w; const float* p1w;                     // [64][64]
+  const float* cq; const float* ck; const float* cv;      // folded biases [512]
+  const float* fc1_w; const float* fc1_b;                 // [64][512], [64]
+  const float* p0w; const float* p0b; const float* p1w; const float* p1b;   // [64][64], [64]
   f32x4* out;                                             // [kNMat + 1][kFragF4] (one matrix of zero padding behind the stream)
 };
-// grid (kNMat + 1, 4) x 256: fragment (wc, c, lane) of matrix m = W[32 wc + r][8 c + 4 h .. + 3]
-__global__ __launch_bounds__(256) void fold_frag_kernel(FragArgs a) {
-  const int m = blockIdx.x, idx = blockIdx.y * 256 + threadIdx.x;
-  const int wc = idx >> 9, c = (idx >> 6) & 7, lane = idx & 63, r = lane & 31, h = lane >> 5;
+// Stream order = consumption order of fused_fwd32_kernel: K0 Q0 | V_h K_{h+1} Q_{h+1} F_h (h = 0..6) | V7 F7 | conv0 conv1 conv1^T conv0^T.
+// grid (kNMat + 1, 9) x 128: fragment (wc, c, lane) of matrix m
+__global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
+  const int m = blockIdx.x, idx = blockIdx.y * 128 + threadIdx.x;       // 0 .. 1151
+  const int wc = idx / 576, c = (idx % 576) >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
   const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
+  int type = -1, hd = 0;                                 // 0 K, 1 Q, 2 V, 3 fc1 block, 4 conv0, 5 conv1, 6 conv1^T, 7 conv0^T
+  if (m == 0) { type = 0; } else if (m == 1) { type = 1; }
+  else if (m < 30) { const int t = (m - 2) & 3; hd = (m - 2) >> 2; type = t == 0 ? 2 : (t == 1 ? 0 : (t == 2 ? 1 : 3)); if (t == 1 || t == 2) ++hd; }
+  else if (m == 30) { type = 2; hd = 7; } else if (m == 31) { type = 3; hd = 7; }
+  else if (m < 36) type = m - 28;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (m < 32) {
-    const int hd = m >> 2, which = m & 3;               // K, Q, V, fc1 block
-    if (which < 3) {
-      const float* W = which == 0 ? a.wk : (which == 1 ? a.wq : a.wv);
+  if (c < 8) {
+    if (type >= 0 && type < 3) {
+      const float* W = type == 0 ? a.wk : (type == 1 ? a.wq : a.wv);
       v = *reinterpret_cast<const f32x4*>(W + ((int64_t)hd * 64 + n) * 64 + k0);
-    } else {
+    } else if (type == 3) {
       v = *reinterpret_cast<const f32x4*>(a.fc1_w + (int64_t)n * 512 + hd * 64 + k0);
+    } else if (type == 4) {
+      v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
+    } else if (type == 5) {
+      v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
+    } else if (type == 6) {                              // conv1^T: A[i][contraction n'] = W1[n'][i]
+      v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
+    } else if (type == 7) {
+      v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
     }
-  } else if (m == 32) {
-    v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
-  } else if (m == 33) {
-    v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
-  } else if (m == 34) {                                  // conv1^T: A[i][contraction n'] = W1[n'][i]
-    v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
-  } else if (m == 35) {
-    v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
+  } else if (h == 0) {                                   // bias fragment: lane (r, 0) supplies A[i = r][k = 0]; B is the constant 1
+    float bv = 0.f;
+    if (type == 0) bv = a.ck[hd * 64 + n]; else if (type == 1) bv = a.cq[hd * 64 + n]; else if (type == 2) bv = a.cv[hd * 64 + n];
+    else if (type == 3) bv = hd == 0 ? a.fc1_b[n] : 0.f;   // the fc1 bias enters dyn once
+    else if (type == 4) bv = a.p0b[n]; else if (type == 5) bv = a.p1b[n];
+    v.x = bv;
   }
   a.out[(int64_t)m * kFragF4 + idx] = v;
 }
@@ -213,8 +248,6 @@ struct Fwd32Args {
   const int32_t* row_off; const int32_t* tok_slot; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos; const int32_t* tok_tile;
   int L;
   const f32x4* wfrag;
-  const float* cq; const float* ck; const float* cv;      // folded projection biases [512]
-  const float* fc1_b; const float* p0b; const float* p1b;
   HeadParams hp;
   const float* y; const float* w;
   float* Y; float* H1; float* H2;
@@ -228,8 +261,15 @@ struct Fwd32Args {
 template <int ML>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_fwd32_kernel(Fwd32Args g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* T1 = lds;                       // K, then V (per head); tail: product tiles, dH2, Y
-  float* T2 = lds + kHT;                 // the tail's parameter vectors until the weight-gradient GEMMs; then H1, dZ1
+#ifdef FF_TIMING
+  long long tph[16] = {0};
+  long long tlast = wall_clock64();
+#define FF_T(i) do { const long long now__ = wall_clock64(); tph[i] += now__ - tlast; tlast = now__; } while (0)
+#else
+#define FF_T(i) do { } while (0)
+#endif
+  float* TK = lds;                       // K rows of the current head; tail: product tiles, dH2, Y
+  float* TV = lds + kHT;                 // V rows; tail: the parameter vectors until the weight-gradient GEMMs, then H1, dZ1
   float* outs = lds + 2 * kHT;           // [32] per-token classifier outputs
   float* douts = outs + 32;              // [32] their gradients
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -242,18 +282,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const bool real = r < n;
   const int64_t tok = real ? (int64_t)(t0 + r) : (int64_t)tok_pad;    // rows past the padding token compute on its copy (finite, unused)
 
-  // ---- weight stream: prime the window with the first matrix (head 0's K) ----
+  // ---- weight stream: prime the window with the first block of head 0's K ----
   const f32x4* wp = g.wfrag + lane;
-  f32x4 W_[8];
+  f32x4 W_[9];
   W32_PRIME();
 
   // ---- x_hat in layout FL straight from global memory ----
-  FL xh;
-  {
-    const float* xp = g.X + tok * 64 + 4 * h;
-    xh = fl_load(xp);
-  }
-  // per-token metadata
+  FL xh = fl_load(g.X + tok * 64 + 4 * h);
   int pos = 0, k = 0, tt = 0;
   if (real) {
     const int tp = g.tok_pos[tok];
@@ -261,9 +296,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     tt = g.tok_tile[tok];
   }
   const int li0 = r - pos;
-  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
+  // dropout: keep <=> lowbias32(col ^ lowbias32(slot ^ key)) >= threshold (threshold 0 = keep everything: no branches below)
   uint32_t thr1 = 0, thr2 = 0, hrow1 = 0, hrow2 = 0;
   float ks1 = 1.f, ks2 = 1.f;
+  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
   if (drop1 || drop2) {
     const uint32_t slot = (uint32_t)g.tok_slot[tok];
     const uint64_t seed = *g.seed;
@@ -280,20 +316,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     he_k = g.row_off[b0 + lane + 1] - he_lo;
     he_lo -= t0;
     if (g.row_loss) { he_y = g.y[b0 + lane]; he_w = g.w[b0 + lane]; }
-  }
-  // T2 (exactly 2176 floats) until the weight-gradient GEMMs: the tail's vectors [10][64] = gp bp g1 b1 g2 b2 wc | fc1_b p0b p1b, then
-  // the folded projection biases cq, ck, cv [3][512] -- read back as the accumulators' initial values (no bias adds)
-  for (int i4 = lane; i4 < 544; i4 += 64) {
-    const float* src;
-    if (i4 < 160) {
-      const int v = i4 >> 4;
-      src = (v == 0 ? g.hp.gp : v == 1 ? g.hp.bp : v == 2 ? g.hp.g1 : v == 3 ? g.hp.b1 : v == 4 ? g.hp.g2 : v == 5 ? g.hp.b2
-           : v == 6 ? g.hp.wc : v == 7 ? g.fc1_b : v == 8 ? g.p0b : g.p1b) + 4 * (i4 & 15);
-    } else {
-      const int ii = i4 - 160;
-      src = ((ii >> 7) == 0 ? g.cq : (ii >> 7) == 1 ? g.ck : g.cv) + 4 * (ii & 127);
-    }
-    *reinterpret_cast<f32x4*>(T2 + 4 * i4) = *reinterpret_cast<const f32x4*>(src);
   }
   float rx;
   {
@@ -313,11 +335,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 #define F32_IMG_STORE(ACC, HD, M)                                                                        \
   do {                                                                                                   \
-    if (img_tok) {                                                                                       \
+    if (img_tok && !(F32_ABL & 2)) {                                                                     \
       f32x4* d__ = reinterpret_cast<f32x4*>(img_tok + (int64_t)(HD) * kImgRec + (M) * 4096);             \
       _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
+        if (F32_ABL & 16) {                                                                              \
+          d__[g__ * 64] = (f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]};   \
+          d__[(4 + g__) * 64] = (f32x4){ACC.hi[4 * g__], ACC.hi[4 * g__ + 1], ACC.hi[4 * g__ + 2], ACC.hi[4 * g__ + 3]}; \
+        } else {                                                                                         \
         __builtin_nontemporal_store((f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]}, d__ + g__ * 64); \
         __builtin_nontemporal_store((f32x4){ACC.hi[4 * g__], ACC.hi[4 * g__ + 1], ACC.hi[4 * g__ + 2], ACC.hi[4 * g__ + 3]}, d__ + (4 + g__) * 64); \
+        }                                                                                                \
       }                                                                                                  \
     }                                                                                                    \
   } while (0)
@@ -325,117 +352,199 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int n_pad = g.L - k;
   const float padf = (float)n_pad;
   const bool hpad = n_pad > 0;
-  int ro[ML];                                         // LDS offset of key / value row j of this token's hyperedge (slots j >= k: clamped)
+  int ro[ML + 1];                                     // LDS offset of key / value row j of this token's hyperedge (slots j >= k: clamped); [ML] = the padding token's row
 #pragma unroll
   for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLdH + 4 * h;
-  const int ro_pad = n * kLdH + 4 * h;
-  float* myrow = T1 + r * kLdH + 4 * h;
+  ro[ML] = n * kLdH + 4 * h;
+  float* krow = TK + r * kLdH + 4 * h;
+  float* vrow = TV + r * kLdH + 4 * h;
 
+  // Attention of one head is cut into PIECES of one half key / value row (4 LDS reads + 8 packed FMAs) that ride between the steps of a
+  // product that does not depend on them: the scores of head h between the MFMAs of V_h, P V of head h between those of K_{h+1}.
+  // Instruction selection places pure arithmetic wherever it likes inside the basic block -- it sank every piece's FMAs to the end of
+  // the stage and spilled the rows they wait for; an empty asm that takes the piece's results as in/out operands pins them to the step.
+#define F32_PIN1(V) asm volatile("" : "+v"(V))
+  float p[ML + 1];                                    // scores, then probabilities x 1 / denominator ([ML]: all padding slots together)
+  float sc_part = 0.f;
+#define F32_SC_PIECE(S)                                                                                  \
+  do {                                                                                                   \
+    constexpr int j__ = (S) >> 1, hf__ = (S) & 1;                                                        \
+    if constexpr (j__ <= ML) {                                                                           \
+      const float* rp__ = TK + ro[j__] + 32 * hf__;                                                      \
+      f2 s__ = {0.f, 0.f}, t__ = {0.f, 0.f};                                                             \
+      _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
+        const f32x4 a__ = *reinterpret_cast<const f32x4*>(rp__ + 8 * g__);                               \
+        const f32x16& qq__ = hf__ ? q.hi : q.lo;                                                         \
+        s__ = __builtin_elementwise_fma((f2){qq__[4 * g__], qq__[4 * g__ + 1]}, (f2){a__.x, a__.y}, s__); \
+        t__ = __builtin_elementwise_fma((f2){qq__[4 * g__ + 2], qq__[4 * g__ + 3]}, (f2){a__.z, a__.w}, t__); \
+      }                                                                                                  \
+      s__ += t__;                                                                                        \
+      if constexpr (hf__ == 0) { sc_part = s__.x + s__.y; F32_PIN1(sc_part); }                            \
+      else {                                                                                             \
+        float a__ = xhalf_sum(sc_part + (s__.x + s__.y)) * inv_temp;                                     \
+        if constexpr (j__ < ML) a__ = (j__ == pos) ? -1e32f : a__;     /* masked diagonal (Modules.py:443-445) */ \
+        p[j__] = a__;                                                                                    \
+        F32_PIN1(p[j__]);                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+    if constexpr ((S) == 2 * (ML + 1)) {                                                                 \
+      float mx__ = -3.4e38f;                                                                             \
+      _Pragma("unroll") for (int i__ = 0; i__ < ML; ++i__) mx__ = (i__ < k) ? fmaxf(mx__, p[i__]) : mx__; \
+      mx__ = hpad ? fmaxf(mx__, p[ML]) : mx__;                                                           \
+      float den__ = 0.f;                                                                                 \
+      _Pragma("unroll") for (int i__ = 0; i__ < ML; ++i__) { p[i__] = (i__ < k) ? __expf(p[i__] - mx__) : 0.f; den__ += p[i__]; } \
+      p[ML] = hpad ? __expf(p[ML] - mx__) : 0.f;                                                         \
+      den__ += padf * p[ML];                                                                             \
+      const float inv__ = __builtin_amdgcn_rcpf(den__);                                                  \
+      _Pragma("unroll") for (int i__ = 0; i__ <= ML; ++i__) { p[i__] *= inv__; F32_PIN1(p[i__]); }       \
+    }                                                                                                    \
+    if constexpr ((S) == 2 * (ML + 1) + 1) {                                                             \
+      /* training: row i of P for the backward pass -- slots 0..k-1 the real keys, slot 7 the per-slot padding probability */ \
+      if (pimg_tok && h == 0) {                                                                          \
+        float wv__[8];                                                                                   \
+        _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) wv__[i__] = i__ < ML ? p[i__ < ML ? i__ : 0] : 0.f; \
+        if (hpad) wv__[7] = p[ML];                                                                       \
+        f32x4* dst__ = reinterpret_cast<f32x4*>(pimg_tok + (int64_t)hd * kImgRec);                       \
+        __builtin_nontemporal_store((f32x4){wv__[0], wv__[1], wv__[2], wv__[3]}, dst__);                 \
+        __builtin_nontemporal_store((f32x4){wv__[4], wv__[5], wv__[6], wv__[7]}, dst__ + 1);             \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#define F32_PV_PIECE(S)                                                                                  \
+  do {                                                                                                   \
+    constexpr int j__ = (S) >> 1, hf__ = (S) & 1;                                                        \
+    if constexpr (j__ <= ML) {                                                                           \
+      const float* rp__ = TV + ro[j__] + 32 * hf__;                                                      \
+      const float w__ = j__ < ML ? p[j__] : padf * p[ML];                                                \
+      const f2 w2__ = {w__, w__};                                                                        \
+      f32x16& oo__ = hf__ ? o.hi : o.lo;                                                                 \
+      _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
+        const f32x4 a__ = *reinterpret_cast<const f32x4*>(rp__ + 8 * g__);                               \
+        const f2 u0__ = __builtin_elementwise_fma(w2__, (f2){a__.x, a__.y}, (f2){oo__[4 * g__], oo__[4 * g__ + 1]});     \
+        const f2 u1__ = __builtin_elementwise_fma(w2__, (f2){a__.z, a__.w}, (f2){oo__[4 * g__ + 2], oo__[4 * g__ + 3]}); \
+        oo__[4 * g__] = u0__.x; oo__[4 * g__ + 1] = u0__.y; oo__[4 * g__ + 2] = u1__.x; oo__[4 * g__ + 3] = u1__.y;      \
+      }                                                                                                  \
+      asm volatile("" : "+v"(oo__));                                                                     \
+    }                                                                                                    \
+  } while (0)
+#define F32_STAGE18(MAC)                                                                                 \
+  do {                                                                                                   \
+    MAC(0); MAC(1); MAC(2); MAC(3); MAC(4); MAC(5); MAC(6); MAC(7); MAC(8);                              \
+    MAC(9); MAC(10); MAC(11); MAC(12); MAC(13); MAC(14); MAC(15); MAC(16); MAC(17);                      \
+  } while (0)
+
+  FF_T(0);
   FL dyn = fl_zero();
-  __syncthreads();                                    // T2's vectors and biases are visible
-  const float* cbq = T2 + 640 + 4 * h;                // + which * 512 + hd * 64
-  FL acck = fl_vec(cbq + 512);                        // head 0's K accumulator starts from its bias
-  for (int hd = 0; hd < MATCHA_N_HEAD; ++hd) {
-    // the NEXT product's bias is read from LDS before the current chain of MFMAs starts, so no chain waits for its initial value
-    FL q = fl_vec(cbq + hd * 64);
-    // ---- K = W'k . x_hat^T + ck -> T1 ----
-    W32_CHAIN(acck, xh, true);
-    __syncthreads();                                  // (single wave: orders the LDS traffic) previous head's V reads are done
-    fl_store(myrow, acck);
-    F32_IMG_STORE(acck, hd, 1);
-    FL accv = fl_vec(cbq + 1024 + hd * 64);
-    // ---- Q (stays in registers) ----
+  FL q = fl_zero(), o;
+  {
+    // ---- prologue: K_0 -> TK, Q_0 ----
+    FL acc = fl_zero();
+    W32_CHAIN(acc, xh, true);
+    fl_store(krow, acc);
+    F32_IMG_STORE(acc, 0, 1);
     W32_CHAIN(q, xh, true);
-    F32_IMG_STORE(q, hd, 0);
-    __syncthreads();                                  // K rows visible
-    // ---- scores + softmax: every token of the half tile at once, two lanes per token ----
-    float p[ML], pp;
-    float mx = -3.4e38f;
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-      float a = xhalf_sum(fl_dot_lds(q, T1 + ro[j])) * inv_temp;
-      a = (j == pos) ? -1e32f : a;                    // masked diagonal (Modules.py:443-445)
-      p[j] = a;
-      mx = (j < k) ? fmaxf(mx, a) : mx;
-    }
-    pp = xhalf_sum(fl_dot_lds(q, T1 + ro_pad)) * inv_temp;
-    mx = hpad ? fmaxf(mx, pp) : mx;
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-      p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
-      den += p[j];
-    }
-    pp = hpad ? __expf(pp - mx) : 0.f;
-    den += padf * pp;
-    const float inv = __builtin_amdgcn_rcpf(den);
-    if (pimg_tok && h == 0) {
-      float wv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wv[j] = j < ML ? p[j < ML ? j : 0] * inv : 0.f;
-      if (hpad) wv[7] = pp * inv;
-      f32x4* dst = reinterpret_cast<f32x4*>(pimg_tok + (int64_t)hd * kImgRec);
-      __builtin_nontemporal_store((f32x4){wv[0], wv[1], wv[2], wv[3]}, dst);
-      __builtin_nontemporal_store((f32x4){wv[4], wv[5], wv[6], wv[7]}, dst + 1);
-    }
-    acck = fl_vec(cbq + 512 + (hd + 1 < MATCHA_N_HEAD ? hd + 1 : hd) * 64);      // next head's K bias
-    // ---- V = W'v . x_hat^T + cv -> T1 (K is dead) ----
-    W32_CHAIN(accv, xh, true);
-    __syncthreads();                                  // every lane's K reads are done
-    fl_store(myrow, accv);
-    F32_IMG_STORE(accv, hd, 2);
-    __syncthreads();
-    // ---- O = P V (in registers, layout FL) ----
-    FL o = fl_zero();
-    fl_axpy_lds(o, padf * pp * inv, T1 + ro_pad);
-#pragma unroll
-    for (int j = 0; j < ML; ++j) fl_axpy_lds(o, p[j] * inv, T1 + ro[j]);
-    // ---- dyn += Wfc1[:, head block] . O^T ----
-    W32_CHAIN(dyn, o, true);
+    F32_IMG_STORE(q, 0, 0);
+    __syncthreads();                                  // (single wave: a compiler fence) K rows visible
   }
+  FF_T(1);
+#if F32_ABL & 1
+#define F32_A_STEP(S) do { W32_MMA(acc, xh, S); W32_REFILL(S, true); } while (0)
+#define F32_B_STEP(S) do { W32_MMA(acc, xh, S); W32_REFILL(S, true); } while (0)
+#define F32_B_ONLY(S) do { o = q; } while (0)
+#else
+#define F32_A_STEP(S) do { W32_MMA(acc, xh, S); F32_SC_PIECE(S); W32_REFILL(S, true); } while (0)
+#define F32_B_STEP(S) do { W32_MMA(acc, xh, S); F32_PV_PIECE(S); W32_REFILL(S, true); } while (0)
+#define F32_B_ONLY(S) do { F32_PV_PIECE(S); } while (0)
+#endif
+  // stage A: V_hd = W'v . x_hat^T + cv, the scores and the softmax of head hd between its MFMAs
+#define F32_STAGE_A()                                                                                    \
+  do {                                                                                                   \
+    FL acc = fl_zero();                                                                                  \
+    F32_STAGE18(F32_A_STEP);                                                                             \
+    if (!(F32_ABL & 1)) { F32_SC_PIECE(18); F32_SC_PIECE(19); }   /* ML = 8: the softmax does not fit between the 18 steps */ \
+    fl_store(vrow, acc);                                                                                 \
+    F32_IMG_STORE(acc, hd, 2);                                                                           \
+    __syncthreads();                                /* V rows visible */                                 \
+  } while (0)
+  int hd = 0;
+  for (; hd + 1 < MATCHA_N_HEAD; ++hd) {
+    F32_STAGE_A();
+    FF_T(2);
+    // ---- stage B: K_{hd+1}, O_hd = P V between its MFMAs ----
+    o = fl_zero();
+    {
+      FL acc = fl_zero();
+      F32_STAGE18(F32_B_STEP);
+      fl_store(krow, acc);                            // the scores of head hd are done with TK
+      F32_IMG_STORE(acc, hd + 1, 1);
+    }
+    FF_T(3);
+    // ---- stage C: Q_{hd+1} ----
+    q = fl_zero();
+    W32_CHAIN(q, xh, true);
+    F32_IMG_STORE(q, hd + 1, 0);
+    __syncthreads();                                  // K rows visible
+    FF_T(4);
+    // ---- stage D: dyn += Wfc1[:, head block] . O^T (+ the fc1 bias with head 0's block) ----
+    W32_CHAIN(dyn, o, true);
+    FF_T(5);
+  }
+  // the last head: no next K / Q to hide P V behind (written after the loop, not as an else-branch inside it: the compiler hoists the
+  // LDS reads common to both branches above the branch and then spills them)
+  F32_STAGE_A();
+  FF_T(2);
+  o = fl_zero();
+  F32_STAGE18(F32_B_ONLY);
+  FF_T(3);
+  W32_CHAIN(dyn, o, true);
+  FF_T(5);
 
   // =========================== tail: pff_n1, LayerNorms, classifier (all in registers) ===========================
+  if (F32_ABL & 8) { if (dyn.lo[0] == 12345.f) g.logits[0] = dyn.hi[3]; return; }
+  // the tail's seven parameter vectors -> TV [7][64]: gp bp g1 b1 g2 b2 wc  (the biases of fc1 / conv0 / conv1 come with the weight stream)
+  __syncthreads();                                    // the last head's P V reads of TV are done
+  for (int i4 = lane; i4 < 112; i4 += 64) {
+    const int v = i4 >> 4;
+    const float* src = (v == 0 ? g.hp.gp : v == 1 ? g.hp.bp : v == 2 ? g.hp.g1 : v == 3 ? g.hp.b1 : v == 4 ? g.hp.g2 : v == 5 ? g.hp.b2 : g.hp.wc) + 4 * (i4 & 15);
+    *reinterpret_cast<f32x4*>(TV + 4 * i4) = *reinterpret_cast<const f32x4*>(src);
+  }
+  float* T1 = TK;
+  float* T2 = TV;
+  float* myrow = krow;
   const float* tpar = T2 + 4 * h;                     // this lane's feature offset inside a 64-float vector
-  uint32_t keep1 = 0xFFFFFFFFu, keep2 = 0xFFFFFFFFu;
+  uint32_t keep1 = 0, keep2 = 0;
   FL y;
   {
-    fl_add_vec(dyn, tpar + 7 * 64);                   // + fc1 bias
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int f = 32 * (e >> 4) + 8 * ((e >> 2) & 3) + (e & 3);     // + 4 h
       float v = e < 16 ? dyn.lo[e] : dyn.hi[e - 16];
-      if (drop1) {
-        const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow1) >= thr1;
-        keep1 = kp ? keep1 : (keep1 & ~(1u << e));
-        v = kp ? v * ks1 : 0.f;
-      }
-      v = real ? v : 0.f;                             // the padding token's row is masked (Modules.py:614)
+      const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow1) >= thr1;
+      keep1 |= kp ? (1u << e) : 0u;
+      v = (kp && real) ? v * ks1 : 0.f;               // the padding token's row is masked (Modules.py:614)
       if (e < 16) y.lo[e] = v; else y.hi[e - 16] = v;
     }
     if (g.Y && r <= n) fl_store_global(g.Y + tok * 64 + 4 * h, y);
   }
   FL h1 = fl_zero();
-  W32_CHAIN(h1, y, true);                             // conv0
+  W32_CHAIN(h1, y, true);                             // conv0 (+ bias)
   {
-    fl_add_vec(h1, tpar + 8 * 64);
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int f = 32 * (e >> 4) + 8 * ((e >> 2) & 3) + (e & 3);
       float v = fast_tanh(e < 16 ? h1.lo[e] : h1.hi[e - 16]);
-      if (drop2) {
-        const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow2) >= thr2;
-        keep2 = kp ? keep2 : (keep2 & ~(1u << e));
-        v = kp ? v * ks2 : 0.f;
-      }
+      const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow2) >= thr2;
+      keep2 |= kp ? (1u << e) : 0u;
+      v = kp ? v * ks2 : 0.f;
       if (e < 16) h1.lo[e] = v; else h1.hi[e - 16] = v;
     }
     if (g.H1 && r <= n) fl_store_global(g.H1 + tok * 64 + 4 * h, h1);
   }
   FL h2 = y;                                          // residual as the accumulator's initial value
-  W32_CHAIN(h2, h1, false);                           // conv1 (the window is re-primed before the backward GEMMs)
-  fl_add_vec(h2, tpar + 9 * 64);
+  W32_CHAIN(h2, h1, false);                           // conv1 (+ bias); the window is primed again before the backward GEMMs
   if (g.H2 && r <= n) fl_store_global(g.H2 + tok * 64 + 4 * h, h2);
-
+  FF_T(7);
+  __syncthreads();                                    // the parameter vectors in T2 are visible
   // ---- out_t = sum_f (LN1(LN_pff(H2)) - LN2(X))_f^2 wc_f + bc ----
   float mh, rh, mu, ru;
   fl_stats(h2, mh, rh);
@@ -485,7 +594,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int i = 0; i < kk; ++i) douts[lo + i] = dout;
     }
   }
-  if (!g.ddyn0) return;
+  FF_T(8);
+  if (!g.ddyn0 || (F32_ABL & 4)) return;
 
   // =========================== backward of the tail and of pff_n1 (Modules.py:290-311, :353-376) ===========================
   __syncthreads();
@@ -584,6 +694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (lane == 0) tsl[kTailVec32 + 9 * 64] = sd;
   }
   // the weight stream resumes at conv1^T (the window was not refilled across the end of conv1)
+  FF_T(9);
   W32_PRIME();
   // ---- conv1: dW1[n][k] = sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2 ----
   __syncthreads();
@@ -614,6 +725,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     tsl[kTailVec32 + (CS_SLOT) * 64 + lane] = h == 0 ? cs__[0] : cs__[1];                                \
   } while (0)
   F32_TN(T1, T2, tsl, 7);
+  FF_T(10);
   // ---- dZ1^T = W1^T . dH2^T, x dropout mask x tanh' ----
   FL dz = fl_zero();
   W32_CHAIN(dz, dh2, true);
@@ -633,7 +745,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   fl_store(T2 + r * kLdH + 4 * h, dz);
   fl_store(myrow, y);
   __syncthreads();
+  FF_T(11);
   F32_TN(T2, T1, tsl + 4096, 8);
+  FF_T(12);
   // ---- d dyn^T = (W0^T . dZ1^T + dH2^T) x dropout mask x row mask ----
   FL dd = dh2;                                        // residual: H2 = conv1(H1) + Y
   W32_CHAIN(dd, dz, false);
@@ -645,6 +759,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (e < 16) dd.lo[e] = v; else dd.hi[e - 16] = v;
   }
   if (r <= n) fl_store_global(g.ddyn0 + tok * 64 + 4 * h, dd);     // the padding token's row: zeros (every half tile writes the same)
+  FF_T(13);
+#ifdef FF_TIMING
+  if (blockIdx.x == 2000 && lane == 0)
+    printf("fused_fwd32 wave 2000 us: setup %.1f prologue K0 Q0 %.1f | 8 heads: V+scores %.1f K'+PV %.1f Q' %.1f fc1 %.1f | pff fwd %.1f ln+logit %.1f | ln-bwd+colsums %.1f dW1 %.1f dZ1 %.1f dW0 %.1f ddyn %.1f\n",
+           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[7] * 0.01, tph[8] * 0.01, tph[9] * 0.01,
+           tph[10] * 0.01, tph[11] * 0.01, tph[12] * 0.01, tph[13] * 0.01);
+#endif
 }
 
 size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragF4 * 4; }
@@ -654,9 +775,11 @@ int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, 
   FragArgs a;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64;
   a.wq = folded; a.wk = folded + wsz; a.wv = folded + 2 * wsz;
-  a.fc1_w = p.fc1_w; a.p0w = p.pff0_w; a.p1w = p.pff1_w;
+  const size_t csz = (size_t)MATCHA_N_HEAD * 64;
+  a.cq = folded + 3 * wsz; a.ck = a.cq + csz; a.cv = a.cq + 2 * csz;
+  a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b; a.p0w = p.pff0_w; a.p0b = p.pff0_b; a.p1w = p.pff1_w; a.p1b = p.pff1_b;
   a.out = reinterpret_cast<f32x4*>(frag);
-  hipLaunchKernelGGL(fold_frag_kernel, dim3(kNMat + 1, 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(fold_frag_kernel, dim3(kNMat + 1, 9), dim3(128), 0, st, a);
   MATCHA_CHECK_LAUNCH("fold_frag_kernel");
   return MATCHA_OK;
 }
@@ -665,17 +788,16 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
                        hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv) {
   Fwd32Args g;
-  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.tok_tile = rg.tok_tile;
   g.L = L;
   g.wfrag = reinterpret_cast<const f32x4*>(frag);
-  g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
-  g.fc1_b = p.fc1_b; g.p0b = p.pff0_b; g.p1b = p.pff1_b;
+  (void)folded;
   g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B; g.qkv = qkv;
-  const size_t lds = ((size_t)2 * kHT + 64) * sizeof(float);
+  size_t lds = ((size_t)2 * kHT + 64) * sizeof(float);
+  lds += (size_t)options().fwd_lds_pad;      // occupancy experiments (tools/debug/timing_fwd32.sh): 20000 -> one wavefront per SIMD
   auto launch = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(rg.nhalves), dim3(64), lds, st, g); };
   // algorithmic flops per token: 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
   ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);

@@ -125,7 +125,8 @@ int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* 
                      float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
                      hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr);
 size_t fused_tail_slab_floats(int64_t B, int L);
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves = false);
+size_t fused_tail_partial_floats();
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial);
 
 // fused_fwd32.hip (embed_dim 64): the same forward with ONE wavefront per half tile (<= 31 tokens), weights streamed from L2 in
 // MFMA-fragment order (launch_fold_frag rewrites them once per step, after launch_fold_ln), no workgroup barriers

@@ -69,6 +69,7 @@ struct Workspace {
   float* frag;                            // the same weights + fc1 / pff_n1 blocks in MFMA-fragment order (fused_fwd32.hip streams them from L2)
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
+  float* tpart;                           // their two-pass reduction's split partials
   float* qkv;                             // training forward -> fused backward: Q, K, V tiles of every (tile, head), 384 KB per tile
   float* front_ws;                        // fused front-end backward: workgroup slabs
   void* tg_ws;      size_t tg_ws_bytes;   // table mode: sort scratch of the deterministic table gradient (table_grad.hip)
@@ -192,6 +193,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.folded = take_always(s.d == 64 ? fused_fold_floats() : 0);
   w.frag = take_always(s.d == 64 ? fused_frag_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
+  w.tpart = take(s.d == 64 ? fused_tail_partial_floats() : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
   w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever MATCHA_DISABLE_QKV_SAVE says: the layout must not depend on a switch read per call
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
@@ -524,7 +526,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
   if (lif) {
     // ddyn0 and dXs were produced by matcha_forward; only the per-tile parameter-gradient partials remain to be summed
-    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, fwd_ran_halves(ws)));
+    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, fwd_ran_halves(ws), w.tpart));
   } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
