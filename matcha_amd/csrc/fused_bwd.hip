@@ -1176,6 +1176,386 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
   if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
 }
 
+// ---- merged heads (round 3): the backward of  r = B_h x + b_h,  s_ij = r_i . x_j,  z_i = sum_j p_ij x_j,  dyn += M_h z  ---------------
+// (fused_fwd32.hip, MG = true).  Per (tile, head) FOUR 64 x 64 products instead of eight:  dZ = dDyn M_h;  d x_hat = dR B_h + (the
+// attention's own gradient into its keys / values, which ARE the x_hat rows);  dB_h += dR^T x_hat;  dM_h += dDyn^T Z.  Same walk as
+// fused_bwd8_kernel (workgroup = (head, chunk of tiles), eight wavefronts, 16x16x4 MFMAs, streamed attention rows) on SIX LDS tiles:
+// the attention runs attn_row8 / attn_col8 with Q := r, K := V := x_hat, dO := dZ; what those return as dK + dV is d x_hat's attention
+// part (tile Gs), what they accumulate for the padding key / value is d x_hat of the padding token.  fbm_chain_kernel then applies the
+// chain rule from (dB_h, db_h, dM_h, d bdyn) to the folded projections, and the LayerNorm un-folding runs as before.
+constexpr int kWgSlabM = 2 * 4096 + 4 * 64;     // dB_h dM_h | db_h (column sums of dR), d bdyn (column sums of dDyn), dxpad, spare
+constexpr int kVecOffM = 2 * 4096;
+struct FusedBwdMArgs {
+  const float* X; const float* dDyn; const int32_t* count; const int32_t* tile_meta; const int32_t* tok_pos;
+  int L; int ntiles; int nchunks;
+  const float* mB; const float* mM;               // merged matrices [8][64][64] (launch_merge_heads)
+  float* dxh; int64_t tcap;
+  float* wslab;                                    // [8][nchunks][kWgSlabM]
+  const float* rimg;                               // [ntiles][8][kImgRecM]: r rows (register images) + attention probabilities of the forward
+};
+
+template <int ML>
+__global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wb = lds;                    // B_h [a][b], resident
+  float* Xs = lds + 1 * kTile;        // x_hat (rows >= n_real are zero): also every key and value row
+  float* Ds = lds + 2 * kTile;        // dDyn  (rows >= n_real are zero)
+  float* Rs = lds + 3 * kTile;        // r -> dR            (Ds, Rs consecutive: the column sums pick one of them by offset)
+  float* Fs = lds + 4 * kTile;        // dZ -> Z
+  float* Gs = lds + 5 * kTile;        // attention's gradient into the x_hat rows (keys + values)
+  float* sm = lds + 6 * kTile;
+  int* tinfo = reinterpret_cast<int*>(sm);
+  float* xpad = sm + 64;
+  float* Ps = xpad + 64;
+  float* dSs = Ps + 512;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = wave & 3, hf = wave >> 2;
+  const int wr = quad & 1, wc = quad >> 1;
+  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x4 fragments
+  const int fb = 32 * wc + 16 * hf;                    // this wave's 16 feature columns
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;     // staging: 32 rows x 16 lanes (float4)
+  const int sub = lane & 7;
+
+  int head, chunk;
+  if ((g.nchunks & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    head = j & 7;
+    chunk = (j >> 3) * 8 + xcd;
+  } else {
+    head = blockIdx.x & 7;
+    chunk = blockIdx.x >> 3;
+  }
+  const int tr = g.count[1];
+  int ntr = g.count[2];
+  if (ntr > g.ntiles) ntr = g.ntiles;
+  const int per = (ntr + g.nchunks - 1) / g.nchunks;
+  const int tile_lo = chunk * per;
+  const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
+  const float inv_temp = 0.125f;
+
+  // ---- resident B_h, the padding token's x_hat ----
+  {
+    const float* src = g.mB + (int64_t)head * 4096;
+    const float4 t0 = *reinterpret_cast<const float4*>(src + (int64_t)srow * 64 + sc4);
+    const float4 t1 = *reinterpret_cast<const float4*>(src + (int64_t)(srow + 32) * 64 + sc4);
+    *reinterpret_cast<float4*>(&Wb[srow * kLd + sc4]) = t0;
+    *reinterpret_cast<float4*>(&Wb[(srow + 32) * kLd + sc4]) = t1;
+  }
+  if (tid < 16) {
+    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
+    float m, rs;
+    ln_row16(xv, m, rs);
+    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+  }
+
+  // weight-gradient accumulators: rows n = 32 wr + 16 mt + 4 kq + reg, column k = fb + c16 of dB_h and dM_h (two 16 x 16 tiles each)
+  f32x4 ab0 = {0.f, 0.f, 0.f, 0.f}, ab1 = ab0, am0 = ab0, am1 = ab0;
+  V8 accK = zero8(), accV = zero8();                  // the padding token's gradient as a key (sum dS_i,pad r_i) and as a value (sum p_i,pad dz_i)
+  f2 cs2 = {0.f, 0.f};                                // column sums of dDyn (waves with 2 wc + hf even) or of dR (odd): columns 32 wr + c16 and + 16
+
+  const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
+  const int4 mzero = make_int4(0, 0, 0, 0);
+  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
+  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
+  float4 xn0, xn1, dn0, dn1;
+  int tpn = 0;
+  f32x4 ri0, ri1, pn = {0.f, 0.f, 0.f, 0.f};
+#define FBM_RIMG_GLOAD(TILE)                                                                             \
+  do {                                                                                                   \
+    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.rimg + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * kImgRecM);  \
+    const f32x4* b__ = r__ + img_lane;                                                                   \
+    if (tid < 128) pn = __builtin_nontemporal_load(r__ + 1024 + tid);                                    \
+    ri0 = __builtin_nontemporal_load(b__); ri1 = __builtin_nontemporal_load(b__ + 64);                   \
+  } while (0)
+  // A fragments (16 feature rows x 64 k) of M_h for dZ^T = M_h^T . dDyn^T, held for the whole walk
+  float fcb[16];
+  {
+    const int r = lane & 31, h = lane >> 5;
+    (void)r; (void)h;
+    const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
+    FB8_ROWS_GLOAD(mc);
+    if (tile_lo < tile_hi) FBM_RIMG_GLOAD(tile_lo);
+    const float* mp = g.mM + (int64_t)head * 4096 + (4 * kq) * 64 + fb + c16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) fcb[4 * c + x] = mp[(16 * c + x) * 64];
+  }
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
+    const int t0 = mc.x, n_real = mc.y;
+    if (n_real <= 0) {
+      const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
+      FB8_ROWS_GLOAD(mn);
+      if (tile + 1 < tile_hi) FBM_RIMG_GLOAD(tile + 1);
+      mc = mn; mn = mnn;
+      continue;
+    }
+    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
+    // per-lane indices re-derived from an opaque copy of the thread id (see fused_bwd8_kernel: loop-invariant addresses are hoisted and spilled otherwise)
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
+    const int quad = wave & 3, hf = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = quad & 1, wc = quad >> 1;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int fb = 32 * wc + 16 * hf;
+    const int srow = tid_ >> 4, sc4 = (tid_ & 15) * 4;
+    const int sub = lane & 7;
+    const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
+    FB8_ROW_STAGE(0); FB8_ROW_STAGE(1);
+    if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
+    FB8_IMG_STAGE(Rs, ri0, ri1);
+    if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
+    __syncthreads();
+    // ---- dZ^T = M_h^T . dDyn^T: lane (c16, kq) ends with token 32 wr + c16 (+ 16) and features fb + 4 kq + {0..3} ----
+    {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const float* dp = Ds + (32 * wr + c16) * kLd + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 b0 = *reinterpret_cast<const float4*>(dp + 16 * c), b1 = *reinterpret_cast<const float4*>(dp + 16 * kLd + 16 * c);
+        acc0 = MFMA16(fcb[4 * c + 0], b0.x, acc0); acc1 = MFMA16(fcb[4 * c + 0], b1.x, acc1);
+        acc0 = MFMA16(fcb[4 * c + 1], b0.y, acc0); acc1 = MFMA16(fcb[4 * c + 1], b1.y, acc1);
+        acc0 = MFMA16(fcb[4 * c + 2], b0.z, acc0); acc1 = MFMA16(fcb[4 * c + 2], b1.z, acc1);
+        acc0 = MFMA16(fcb[4 * c + 3], b0.w, acc0); acc1 = MFMA16(fcb[4 * c + 3], b1.w, acc1);
+      }
+      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + c16) * kLd + fb + 4 * kq]) = acc0;
+      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]) = acc1;
+    }
+    __syncthreads();
+    // ---- attention forward + backward in x_hat space: 8 lanes per token, all 64 tokens in one pass ----
+    {
+      V8 o0, q0, k0, v0;
+      const int la = wave * 8 + (lane >> 3);
+      const bool acta = la < n_real;
+      int ia = 0;
+      if (acta) { ia = tinfo[la]; attn_row8<ML>(Rs, Xs, Xs, Fs, xpad, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      if (acta) {
+        attn_col8<ML>(Rs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
+        k0.a += v0.a; k0.b += v0.b; k0.c += v0.c; k0.d += v0.d;      // the row is key AND value: d x_hat_j = sum_i dS_ij r_i + p_ij dz_i
+        st8(&Gs[la * kLd + 8 * sub], k0);
+      } else {
+        ZR8(&Gs[la * kLd + 8 * sub]);
+      }
+      __syncthreads();                                // every column phase is done with the r and dZ rows
+      if (acta) {
+        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Rs[la * kLd + 8 * sub], q0);
+      } else {
+        ZR8(&Rs[la * kLd + 8 * sub]);
+      }
+    }
+    __syncthreads();
+    FB8_ROWS_GLOAD(mn);                               // next tile's rows: in flight during the GEMMs below
+    // ---- this head's share of d x_hat^T = B_h^T dR^T + Gs^T: 4 steps of 16 contraction indices ----
+    {
+      f32x4 dx0 = *reinterpret_cast<const f32x4*>(&Gs[(32 * wr + c16) * kLd + fb + 4 * kq]);
+      f32x4 dx1 = *reinterpret_cast<const f32x4*>(&Gs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]);
+      const float* arow = Rs + (32 * wr + c16) * kLd + 4 * kq;
+      const float* wcol = Wb + (4 * kq) * kLd + fb + c16;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
+        const float* wp = wcol + (16 * c) * kLd;
+        const float w0 = wp[0], w1 = wp[kLd], w2 = wp[2 * kLd], w3 = wp[3 * kLd];
+        dx0 = MFMA16(w0, a0.x, dx0); dx1 = MFMA16(w0, a1.x, dx1);
+        dx0 = MFMA16(w1, a0.y, dx0); dx1 = MFMA16(w1, a1.y, dx1);
+        dx0 = MFMA16(w2, a0.z, dx0); dx1 = MFMA16(w2, a1.z, dx1);
+        dx0 = MFMA16(w3, a0.w, dx0); dx1 = MFMA16(w3, a1.w, dx1);
+      }
+      float* out = g.dxh + ((int64_t)head * g.tcap + t0 + 32 * wr + c16) * 64 + fb + 4 * kq;
+      if (32 * wr + c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
+      if (32 * wr + 16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
+    }
+    if (tile + 1 < tile_hi) FBM_RIMG_GLOAD(tile + 1);     // next tile's r rows and probabilities: in flight during the weight-gradient GEMMs
+    // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]; 16 steps of 4 tokens ----
+    {
+      const float* pr = Rs + (4 * kq) * kLd + 32 * wr + c16;
+      const float* pd = Ds + (4 * kq) * kLd + 32 * wr + c16;
+      const float* px = Xs + (4 * kq) * kLd + fb + c16;
+      const float* pz = Fs + (4 * kq) * kLd + fb + c16;
+      const float* pc = pd + ((2 * wc + hf) & 1) * kTile;       // column sums: dDyn for even 2 wc + hf, dR for odd (Rs follows Ds)
+      f2 ra, da, ca, rb, db, cb;
+      float xa, za, xb, zb;
+#define FBM_TN_LOAD(S, ST)                                                                               \
+  do {                                                                                                   \
+    constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
+    r##S = (f2){pr[o__], pr[o__ + 16]}; d##S = (f2){pd[o__], pd[o__ + 16]};                              \
+    x##S = px[o__]; z##S = pz[o__]; c##S = (f2){pc[o__], pc[o__ + 16]};                                  \
+  } while (0)
+#define FBM_TN_MMA(S)                                                                                    \
+  do {                                                                                                   \
+    cs2 += c##S;                                                                                         \
+    ab0 = MFMA16(r##S.x, x##S, ab0); ab1 = MFMA16(r##S.y, x##S, ab1);                                    \
+    am0 = MFMA16(d##S.x, z##S, am0); am1 = MFMA16(d##S.y, z##S, am1);                                    \
+  } while (0)
+#define FBM_TN_PAIR(ST)                                                                                  \
+  do {                                                                                                   \
+    FBM_TN_LOAD(b, (ST) + 1);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FBM_TN_MMA(a);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if ((ST) + 2 < 16) FBM_TN_LOAD(a, ((ST) + 2 < 16 ? (ST) + 2 : 0));                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FBM_TN_MMA(b);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+      FBM_TN_LOAD(a, 0);
+      FBM_TN_PAIR(0); FBM_TN_PAIR(2); FBM_TN_PAIR(4); FBM_TN_PAIR(6); FBM_TN_PAIR(8); FBM_TN_PAIR(10); FBM_TN_PAIR(12); FBM_TN_PAIR(14);
+    }
+    mc = mn; mn = mnn;
+  }
+
+  // ---- workgroup slab ----
+  __syncthreads();
+  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlabM;
+  {
+    const int col = fb + c16;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = 32 * wr + 4 * kq + reg;
+      slab[0 * 4096 + row * 64 + col] = ab0[reg]; slab[0 * 4096 + (row + 16) * 64 + col] = ab1[reg];
+      slab[1 * 4096 + row * 64 + col] = am0[reg]; slab[1 * 4096 + (row + 16) * 64 + col] = am1[reg];
+    }
+  }
+  // column sums: lane (c16, kq) covered tokens 16 c + 4 kq + x for columns 32 wr + c16 (.x) and + 16 (.y); the four lane groups are added in
+  // a fixed xor order; two of the four waves of a row half computed the same sum (one writes)
+  float* red = Xs;                      // [2][64]: d bdyn (column sums of dDyn), db_h (column sums of dR)
+  {
+    float a = cs2.x, b = cs2.y;
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+    const int u = 2 * wc + hf;
+    if (kq == 0 && u < 2) {
+      float* dst = red + u * 64;
+      dst[32 * wr + c16] = a; dst[32 * wr + 16 + c16] = b;
+    }
+  }
+  // d x_hat of the padding token: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 8 waves in order
+  float* redp = Xs + 2 * 64;            // [8][64]
+  const float accp[8] = {accK.a.x + accV.a.x, accK.a.y + accV.a.y, accK.b.x + accV.b.x, accK.b.y + accV.b.y,
+                         accK.c.x + accV.c.x, accK.c.y + accV.c.y, accK.d.x + accV.d.x, accK.d.y + accV.d.y};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = accp[i];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 8) redp[wave * 64 + 8 * lane + i] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    slab[kVecOffM + 64 + tid] = red[tid];            // d bdyn partial
+    slab[kVecOffM + tid] = red[64 + tid];             // db_h partial
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += redp[w * 64 + tid];
+    slab[kVecOffM + 128 + tid] = t;                   // dxpad partial
+  }
+}
+
+// Chain rule from the merged matrices back to the folded projections, one block per head: sums the chunk slabs in order, then
+//   B_h = W'k^T W'q, b_h = W'k^T cq:   dW'q = W'k dB;   dW'k = W'q dB^T + cq (x) db;   dcq = W'k db;   dck = 0
+//   M_h = Wf_h W'v, bdyn = fc1_b + sum_h Wf_h cv_h:   dWf_h = dM W'v^T + dbdyn (x) cv_h;   dW'v = Wf_h^T dM;   dcv_h = Wf_h^T dbdyn
+// and writes ONE slab per head in fused_bwd8_kernel's format (dW'q dW'k dW'v dWfc1 | dcq dck dcv 0 0 dfc1_b), which fb_unfold_kernel /
+// fb_unfold2_kernel turn into the gradients of the original parameters as before (nchunks = 1); dxpad is summed here.
+struct ChainArgs {
+  const float* wslab; int nchunks;           // merged slabs [8][nchunks][kWgSlabM]
+  const float* wq; const float* wk; const float* wv; const float* cq; const float* cv;   // folded
+  const float* fc1_w;
+  float* out;                                // [8][kWgSlab]
+  float* dxpad;                              // [64]
+};
+__global__ __launch_bounds__(256) void fbm_chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dB = lds;                // [64][65]
+  float* dM = lds + 64 * 65;
+  float* W0 = lds + 2 * 64 * 65;  // staging of one weight matrix
+  float* vec = lds + 3 * 64 * 65; // db [64], dbdyn [64]
+  const int head = blockIdx.x, tid = threadIdx.x;
+  const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlabM;
+  for (int i = tid; i < 2 * 4096; i += 256) {
+    float s = 0.f;
+    for (int c = 0; c < a.nchunks; ++c) s += base[(int64_t)c * kWgSlabM + i];
+    (i < 4096 ? dB : dM)[((i & 4095) >> 6) * 65 + (i & 63)] = s;
+  }
+  if (tid < 128) {
+    float s = 0.f;
+    for (int c = 0; c < a.nchunks; ++c) s += base[(int64_t)c * kWgSlabM + kVecOffM + tid];
+    vec[tid] = s;
+  }
+  // d bdyn is a sum over ALL tokens: every head's workgroups saw the same dDyn -- take head 0's
+  if (tid < 64) {
+    float s = 0.f;
+    for (int c = 0; c < a.nchunks; ++c) s += a.wslab[(int64_t)c * kWgSlabM + kVecOffM + 64 + tid];
+    vec[64 + tid] = s;
+  }
+  if (head == 0 && tid >= 64 && tid < 128) {        // dxpad: every head's, every chunk's share
+    const int f = tid - 64;
+    float s = 0.f;
+    for (int hh = 0; hh < MATCHA_N_HEAD; ++hh)
+      for (int c = 0; c < a.nchunks; ++c) s += a.wslab[((int64_t)hh * a.nchunks + c) * kWgSlabM + kVecOffM + 128 + f];
+    a.dxpad[f] = s;
+  }
+  float* out = a.out + (int64_t)head * kWgSlab;
+  const float* Wq = a.wq + (int64_t)head * 4096; const float* Wk = a.wk + (int64_t)head * 4096; const float* Wv = a.wv + (int64_t)head * 4096;
+  auto stage = [&](const float* src, int ld) {      // 64 x 64 block -> W0 [64][65]
+    __syncthreads();
+    for (int i = tid; i < 4096; i += 256) W0[(i >> 6) * 65 + (i & 63)] = src[(int64_t)(i >> 6) * ld + (i & 63)];
+    __syncthreads();
+  };
+  // dW'q[m][b] = sum_a W'k[m][a] dB[a][b]
+  stage(Wk, 64);
+  for (int o = tid; o < 4096; o += 256) {
+    const int m = o >> 6, b = o & 63;
+    float s = 0.f;
+    for (int x = 0; x < 64; ++x) s += W0[m * 65 + x] * dB[x * 65 + b];
+    out[0 * 4096 + o] = s;
+  }
+  if (tid < 64) {                                    // dcq[m] = sum_a W'k[m][a] db[a]
+    float s = 0.f;
+    for (int x = 0; x < 64; ++x) s += W0[tid * 65 + x] * vec[x];
+    out[kVecOff + tid] = s;
+    out[kVecOff + 64 + tid] = 0.f;                   // dck: the K bias only shifts all scores of a query (no gradient)
+    out[kVecOff + 192 + tid] = 0.f; out[kVecOff + 256 + tid] = 0.f;     // dK_pad / dV_pad do not exist here
+    out[kVecOff + 320 + tid] = head == 0 ? vec[64 + tid] : 0.f;         // dfc1_b = d bdyn
+  }
+  // dW'k[m][a] = sum_b W'q[m][b] dB[a][b] + cq[m] db[a]
+  stage(Wq, 64);
+  for (int o = tid; o < 4096; o += 256) {
+    const int m = o >> 6, x = o & 63;
+    float s = a.cq[head * 64 + m] * vec[x];
+    for (int b = 0; b < 64; ++b) s += W0[m * 65 + b] * dB[x * 65 + b];
+    out[1 * 4096 + o] = s;
+  }
+  // dWf_h[n][m] = sum_b dM[n][b] W'v[m][b] + dbdyn[n] cv[m]
+  stage(Wv, 64);
+  for (int o = tid; o < 4096; o += 256) {
+    const int n = o >> 6, m = o & 63;
+    float s = vec[64 + n] * a.cv[head * 64 + m];
+    for (int b = 0; b < 64; ++b) s += dM[n * 65 + b] * W0[m * 65 + b];
+    out[3 * 4096 + o] = s;
+  }
+  // dW'v[m][b] = sum_n Wf[n][hm] dM[n][b];  dcv[m] = sum_n Wf[n][hm] dbdyn[n]
+  stage(a.fc1_w + head * 64, 512);                   // W0[n][m] = Wf[n][head*64 + m]
+  for (int o = tid; o < 4096; o += 256) {
+    const int m = o >> 6, b = o & 63;
+    float s = 0.f;
+    for (int n = 0; n < 64; ++n) s += W0[n * 65 + m] * dM[n * 65 + b];
+    out[2 * 4096 + o] = s;
+  }
+  if (tid < 64) {
+    float s = 0.f;
+    for (int n = 0; n < 64; ++n) s += W0[n * 65 + tid] * vec[64 + n];
+    out[kVecOff + 128 + tid] = s;
+  }
+}
+
 // ---- slab reduction + un-folding of the LayerNorm affines -------------------------------------------------------
 struct UnfoldArgs {
   const float* wslab; int nchunks;
@@ -1255,6 +1635,7 @@ __global__ __launch_bounds__(256) void fb_unfold_kernel(UnfoldArgs a) {
 struct Unfold2Args {
   const float* part; const float* wslab; int nchunks;
   float* dg[3]; float* db[3]; float* dfc1_b; float* dxpad;
+  int dxpad_add;     // merged heads: dxpad already holds the attention's gradient into the padding token's x_hat (fbm_chain_kernel)
 };
 // one block, 512 threads: vec 0..5 = {dg, db} x {q, k, v}; vec 6 = dx_hat of the padding token; vec 7 = fc1 bias gradient
 __global__ __launch_bounds__(512) void fb_unfold2_kernel(Unfold2Args a) {
@@ -1267,7 +1648,7 @@ __global__ __launch_bounds__(512) void fb_unfold2_kernel(Unfold2Args a) {
     *o += s;
   } else if (vec == 6) {
     for (int p = 0; p < 32; ++p) s += a.part[(((int64_t)p * 3 + 1) * 3 + 2) * 64 + k] + a.part[(((int64_t)p * 3 + 2) * 3 + 2) * 64 + k];
-    a.dxpad[k] = s;
+    a.dxpad[k] = a.dxpad_add ? a.dxpad[k] + s : s;
   } else {
     for (int c = 0; c < a.nchunks; ++c) s += a.wslab[(int64_t)c * kWgSlab + kVecOff + 320 + k];     // head 0's slabs
     a.dfc1_b[k] += s;
@@ -1393,11 +1774,76 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     b.part = part; b.wslab = wslab; b.nchunks = nslabs;
     b.dg[0] = grads.ln_q_g; b.dg[1] = grads.ln_k_g; b.dg[2] = grads.ln_v_g;
     b.db[0] = grads.ln_q_b; b.db[1] = grads.ln_k_b; b.db[2] = grads.ln_v_b;
-    b.dfc1_b = grads.fc1_b; b.dxpad = dxpad;
+    b.dfc1_b = grads.fc1_b; b.dxpad = dxpad; b.dxpad_add = 0;
     hipLaunchKernelGGL(fb_unfold2_kernel, dim3(1), dim3(512), 0, st, b);
     MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
   }
   if (dZ0) {                                           // null: the caller's front-end backward kernel consumes dxh / dxpad itself
+    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
+    MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
+  }
+  return MATCHA_OK;
+}
+
+// merged heads: fused_bwdm_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
+int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
+                            const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg) {
+  const int64_t tcap = B * L + 1;
+  const int nchunks = chunks_for(rg.ntiles);
+  float* wslab = ws;                                                         // [8][nchunks][kWgSlabM]
+  float* chain = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlabM;         // [8][kWgSlab]  (both inside the eight-product kernel's slab area)
+  float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
+  float* dxpad = part + 32 * 3 * 3 * 64;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
+  const MergedView mv = merged_view(merged);
+  {
+    FusedBwdMArgs g;
+    g.X = X; g.dDyn = dDyn; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
+    g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.rimg = rimg;
+    const size_t lds = ((size_t)6 * kTile + 64 + 64 + 2 * 512) * sizeof(float);
+    auto launch = [&](auto kfn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(512), lds, st, g);
+    };
+    // algorithmic flops: the reference's formulation -- 8 heads x 8 GEMMs of 2*64*64 per token; this kernel EXECUTES half of them
+    ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
+    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+      case 2: launch(fused_bwdm_kernel<2>); break;
+      case 3: launch(fused_bwdm_kernel<3>); break;
+      case 4: launch(fused_bwdm_kernel<4>); break;
+      case 5: launch(fused_bwdm_kernel<5>); break;
+      case 6: launch(fused_bwdm_kernel<6>); break;
+      default: launch(fused_bwdm_kernel<8>); break;
+    }
+    MATCHA_CHECK_LAUNCH("fused_bwdm_kernel");
+  }
+  {
+    ChainArgs c;
+    c.wslab = wslab; c.nchunks = nchunks;
+    c.wq = folded; c.wk = folded + wsz; c.wv = folded + 2 * wsz; c.cq = folded + 3 * wsz; c.cv = c.cq + 2 * csz;
+    c.fc1_w = p.fc1_w; c.out = chain; c.dxpad = dxpad;
+    hipLaunchKernelGGL(fbm_chain_kernel, dim3(MATCHA_N_HEAD), dim3(256), (3 * 64 * 65 + 128) * sizeof(float), st, c);
+    MATCHA_CHECK_LAUNCH("fbm_chain_kernel");
+  }
+  {
+    UnfoldArgs a;
+    a.wslab = chain; a.nchunks = 1; a.X = X; a.count = rg.count;
+    a.W[0] = p.w_q; a.W[1] = p.w_k; a.W[2] = p.w_v;
+    a.g[0] = p.ln_q_g; a.g[1] = p.ln_k_g; a.g[2] = p.ln_v_g;
+    a.b[0] = p.ln_q_b; a.b[1] = p.ln_k_b; a.b[2] = p.ln_v_b;
+    a.gW[0] = grads.w_q; a.gW[1] = grads.w_k; a.gW[2] = grads.w_v; a.gfc1 = grads.fc1_w;
+    a.part = part;
+    hipLaunchKernelGGL(fb_unfold_kernel, dim3(4, 4, MATCHA_N_HEAD), dim3(256), 0, st, a);
+    MATCHA_CHECK_LAUNCH("fb_unfold_kernel");
+    Unfold2Args b;
+    b.part = part; b.wslab = chain; b.nchunks = 1;
+    b.dg[0] = grads.ln_q_g; b.dg[1] = grads.ln_k_g; b.dg[2] = grads.ln_v_g;
+    b.db[0] = grads.ln_q_b; b.db[1] = grads.ln_k_b; b.db[2] = grads.ln_v_b;
+    b.dfc1_b = grads.fc1_b; b.dxpad = dxpad; b.dxpad_add = 1;
+    hipLaunchKernelGGL(fb_unfold2_kernel, dim3(1), dim3(512), 0, st, b);
+    MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
+  }
+  if (dZ0) {
     hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
     MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
   }

@@ -24,6 +24,9 @@
 //   64-row tiles that cut the token stream elsewhere): tok_tile[t] = (tile << 6) | row says where each token's rows go.
 #include "kernels.hpp"
 
+#ifndef F32_WIN
+#define F32_WIN 9                     // weight-window depth in fragments (divides 18)
+#endif
 #ifndef F32_ABL
 #define F32_ABL 0                     // timing ablations (tools/debug/abl_fwd32.sh): 1 no attention, 2 no image stores, 4 no tail backward, 8 no tail
 #endif
@@ -153,23 +156,23 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
   do {                                                                                                   \
     constexpr int c__ = (S) % 9;                                                                         \
     if constexpr (c__ == 8) {                                                                            \
-      if constexpr ((S) < 9) ACC.lo = MFMA32(W_[8].x, 1.f, ACC.lo); else ACC.hi = MFMA32(W_[8].x, 1.f, ACC.hi); \
+      if constexpr ((S) < 9) ACC.lo = MFMA32(W_[(S) % F32_WIN].x, 1.f, ACC.lo); else ACC.hi = MFMA32(W_[(S) % F32_WIN].x, 1.f, ACC.hi); \
     } else {                                                                                             \
       constexpr int e__ = 4 * (c__ & 3);                                                                 \
       const float b0__ = c__ < 4 ? B.lo[e__] : B.hi[e__], b1__ = c__ < 4 ? B.lo[e__ + 1] : B.hi[e__ + 1]; \
       const float b2__ = c__ < 4 ? B.lo[e__ + 2] : B.hi[e__ + 2], b3__ = c__ < 4 ? B.lo[e__ + 3] : B.hi[e__ + 3]; \
       if constexpr ((S) < 9) {                                                                           \
-        ACC.lo = MFMA32(W_[c__].x, b0__, ACC.lo); ACC.lo = MFMA32(W_[c__].y, b1__, ACC.lo);              \
-        ACC.lo = MFMA32(W_[c__].z, b2__, ACC.lo); ACC.lo = MFMA32(W_[c__].w, b3__, ACC.lo);              \
+        ACC.lo = MFMA32(W_[(S) % F32_WIN].x, b0__, ACC.lo); ACC.lo = MFMA32(W_[(S) % F32_WIN].y, b1__, ACC.lo);              \
+        ACC.lo = MFMA32(W_[(S) % F32_WIN].z, b2__, ACC.lo); ACC.lo = MFMA32(W_[(S) % F32_WIN].w, b3__, ACC.lo);              \
       } else {                                                                                           \
-        ACC.hi = MFMA32(W_[c__].x, b0__, ACC.hi); ACC.hi = MFMA32(W_[c__].y, b1__, ACC.hi);              \
-        ACC.hi = MFMA32(W_[c__].z, b2__, ACC.hi); ACC.hi = MFMA32(W_[c__].w, b3__, ACC.hi);              \
+        ACC.hi = MFMA32(W_[(S) % F32_WIN].x, b0__, ACC.hi); ACC.hi = MFMA32(W_[(S) % F32_WIN].y, b1__, ACC.hi);              \
+        ACC.hi = MFMA32(W_[(S) % F32_WIN].z, b2__, ACC.hi); ACC.hi = MFMA32(W_[(S) % F32_WIN].w, b3__, ACC.hi);              \
       }                                                                                                  \
     }                                                                                                    \
   } while (0)
 #define W32_REFILL(S, PF)                                                                                \
   do {                                                                                                   \
-    if (PF) W_[(S) % 9] = wp[9 * 64];                                                                    \
+    if (PF) W_[(S) % F32_WIN] = wp[F32_WIN * 64];                                                        \
     wp += 64;                                                                                            \
     asm volatile("" ::: "memory");         /* instruction selection clusters every LDS read of the block at its top otherwise */ \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -186,7 +189,7 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
   } while (0)
 #define W32_PRIME()                                                                                      \
   do {                                                                                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 9; ++i__) W_[i__] = wp[i__ * 64];                          \
+    _Pragma("unroll") for (int i__ = 0; i__ < F32_WIN; ++i__) W_[i__] = wp[i__ * 64];                    \
   } while (0)
 
 __device__ __forceinline__ FL fl_zero() {
@@ -198,6 +201,52 @@ __device__ __forceinline__ FL fl_zero() {
 
 }  // namespace
 
+// ---- merged per-head matrices (round 3) -----------------------------------------------------------------------------------
+// With d_k = d_v = d_model (MATCHA's configuration, main.py:615-623) nothing non-linear sits between a projection and the product
+// that consumes it, so per head the four 64 x 64 products of the reference (Modules.py:527-529, :572) collapse into two:
+//   scores   q_i . k_j = x_j^T (W'k^T W'q x_i + W'k^T cq) + terms that do not depend on j (they cancel in the softmax, whose masked
+//            diagonal is REPLACED, Modules.py:443-445)           ->  r_i = B_h x_i + b_h,   s_ij = r_i . x_j
+//   output   sum_j p_ij v_j = W'v (sum_j p_ij x_j) + cv  (the probabilities, padding slots included, sum to 1)
+//            dyn += Wfc1_h O_i                                   ->  z_i = sum_j p_ij x_j,  dyn += M_h z_i,   M_h = Wfc1_h W'v_h
+// (x = the LayerNorm-normalised row, the same for every head: it is the key AND the value of every head, written to LDS once per tile.)
+// The constants Wfc1_h cv_h join the fc1 bias.  merge_heads_kernel builds B_h, b_h, M_h and that bias once per step.
+struct MergeArgs {
+  const float* wq; const float* wk; const float* wv; const float* cq; const float* cv;   // folded [512][64], [512]
+  const float* fc1_w; const float* fc1_b;
+  float* B; float* M; float* bvec; float* bdyn;          // [8][64][64], [8][64][64], [8][64], [64]
+};
+// grid (8 heads, 3): y = 0: B_h and b_h, 1: M_h, 2 (x = 0 only): bdyn
+__global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
+  const int hd = blockIdx.x, tid = threadIdx.x;
+  if (blockIdx.y == 0) {
+    const float* Wk = a.wk + (int64_t)hd * 4096;
+    const float* Wq = a.wq + (int64_t)hd * 4096;
+    for (int o = tid; o < 4096; o += 256) {
+      const int r = o >> 6, c = o & 63;
+      float s = 0.f;
+      for (int m = 0; m < 64; ++m) s += Wk[m * 64 + r] * Wq[m * 64 + c];
+      a.B[(int64_t)hd * 4096 + o] = s;
+    }
+    if (tid < 64) {
+      float s = 0.f;
+      for (int m = 0; m < 64; ++m) s += Wk[m * 64 + tid] * a.cq[hd * 64 + m];
+      a.bvec[hd * 64 + tid] = s;
+    }
+  } else if (blockIdx.y == 1) {
+    const float* Wv = a.wv + (int64_t)hd * 4096;
+    for (int o = tid; o < 4096; o += 256) {
+      const int n = o >> 6, c = o & 63;
+      float s = 0.f;
+      for (int m = 0; m < 64; ++m) s += a.fc1_w[n * 512 + hd * 64 + m] * Wv[m * 64 + c];
+      a.M[(int64_t)hd * 4096 + o] = s;
+    }
+  } else if (hd == 0 && tid < 64) {
+    float s = a.fc1_b[tid];
+    for (int m = 0; m < 512; ++m) s += a.fc1_w[tid * 512 + m] * a.cv[m];
+    a.bdyn[tid] = s;
+  }
+}
+
 // ---- fragment-major weights, rewritten once per step (after fold_ln_kernel) ----------------------------------------------
 struct FragArgs {
   const float* wq; const float* wk; const float* wv;      // folded W' [512][64]
@@ -205,6 +254,7 @@ struct FragArgs {
   const float* fc1_w; const float* fc1_b;                 // [64][512], [64]
   const float* p0w; const float* p0b; const float* p1w; const float* p1b;   // [64][64], [64]
   f32x4* out;                                             // [kNMat + 1][kFragF4] (one matrix of zero padding behind the stream)
+  const float* mB; const float* mM; const float* mbvec; const float* mbdyn;   // merged form (null: the four-product stream)
 };
 // Stream order = consumption order of fused_fwd32_kernel: K0 Q0 | V_h K_{h+1} Q_{h+1} F_h (h = 0..6) | V7 F7 | conv0 conv1 conv1^T conv0^T.
 // grid (kNMat + 1, 9) x 128: fragment (wc, c, lane) of matrix m
@@ -212,7 +262,14 @@ __global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
   const int m = blockIdx.x, idx = blockIdx.y * 128 + threadIdx.x;       // 0 .. 1151
   const int wc = idx / 576, c = (idx % 576) >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
   const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
-  int type = -1, hd = 0;                                 // 0 K, 1 Q, 2 V, 3 fc1 block, 4 conv0, 5 conv1, 6 conv1^T, 7 conv0^T
+  int type = -1, hd = 0;                                 // 0 K, 1 Q, 2 V, 3 fc1 block, 4 conv0, 5 conv1, 6 conv1^T, 7 conv0^T, 8 B_h, 9 M_h
+  if (a.mB) {
+    // merged stream: R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0 conv1 conv1^T conv0^T
+    if (m == 0) { type = 8; }
+    else if (m < 15) { hd = (m - 1) >> 1; if ((m - 1) & 1) type = 9; else { type = 8; ++hd; } }
+    else if (m == 15) { type = 9; hd = 7; }
+    else if (m < 20) type = m - 12;
+  } else
   if (m == 0) { type = 0; } else if (m == 1) { type = 1; }
   else if (m < 30) { const int t = (m - 2) & 3; hd = (m - 2) >> 2; type = t == 0 ? 2 : (t == 1 ? 0 : (t == 2 ? 1 : 3)); if (t == 1 || t == 2) ++hd; }
   else if (m == 30) { type = 2; hd = 7; } else if (m == 31) { type = 3; hd = 7; }
@@ -232,12 +289,17 @@ __global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
       v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
     } else if (type == 7) {
       v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
+    } else if (type == 8) {
+      v = *reinterpret_cast<const f32x4*>(a.mB + ((int64_t)hd * 64 + n) * 64 + k0);
+    } else if (type == 9) {
+      v = *reinterpret_cast<const f32x4*>(a.mM + ((int64_t)hd * 64 + n) * 64 + k0);
     }
   } else if (h == 0) {                                   // bias fragment: lane (r, 0) supplies A[i = r][k = 0]; B is the constant 1
     float bv = 0.f;
     if (type == 0) bv = a.ck[hd * 64 + n]; else if (type == 1) bv = a.cq[hd * 64 + n]; else if (type == 2) bv = a.cv[hd * 64 + n];
     else if (type == 3) bv = hd == 0 ? a.fc1_b[n] : 0.f;   // the fc1 bias enters dyn once
     else if (type == 4) bv = a.p0b[n]; else if (type == 5) bv = a.p1b[n];
+    else if (type == 8) bv = a.mbvec[hd * 64 + n]; else if (type == 9) bv = hd == 0 ? a.mbdyn[n] : 0.f;
     v.x = bv;
   }
   a.out[(int64_t)m * kFragF4 + idx] = v;
@@ -258,7 +320,9 @@ struct Fwd32Args {
   float* qkv;
 };
 
-template <int ML>
+// MG = merged per-head matrices (two products per head: r = B_h x + b_h, dyn += M_h z); the saved record per (tile, head) is then the
+// r rows [64][64] + the probabilities [64][8] (kImgRecM floats) for fused_bwd_merged.hip instead of Q, K, V + probabilities.
+template <int ML, bool MG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_fwd32_kernel(Fwd32Args g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef FF_TIMING
@@ -284,7 +348,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   // ---- weight stream: prime the window with the first block of head 0's K ----
   const f32x4* wp = g.wfrag + lane;
-  f32x4 W_[9];
+  f32x4 W_[F32_WIN];
   W32_PRIME();
 
   // ---- x_hat in layout FL straight from global memory ----
@@ -324,19 +388,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int e = 0; e < 16; ++e) { xh.lo[e] = (xh.lo[e] - mean) * rx; xh.hi[e] = (xh.hi[e] - mean) * rx; }
   }
+  constexpr int kRec = MG ? kImgRecM : kImgRec;
   // where this token's rows go in the backward kernel's tile images: float4 index ((2 wr' + wc) * 4 + g) * 64 + 32 h + r'
   float* img_tok = nullptr;
   float* pimg_tok = nullptr;
   if (g.qkv && real) {
     const int tile = tt >> 6, rho = tt & 63;
-    float* base = g.qkv + (int64_t)tile * MATCHA_N_HEAD * kImgRec;
+    float* base = g.qkv + (int64_t)tile * MATCHA_N_HEAD * kRec;
     img_tok = base + ((rho >> 5) * 8 * 64 + 32 * h + (rho & 31)) * 4;
-    pimg_tok = base + 3 * 4096 + rho * 8;
+    pimg_tok = base + (MG ? 4096 : 3 * 4096) + rho * 8;
   }
 #define F32_IMG_STORE(ACC, HD, M)                                                                        \
   do {                                                                                                   \
     if (img_tok && !(F32_ABL & 2)) {                                                                     \
-      f32x4* d__ = reinterpret_cast<f32x4*>(img_tok + (int64_t)(HD) * kImgRec + (M) * 4096);             \
+      f32x4* d__ = reinterpret_cast<f32x4*>(img_tok + (int64_t)(HD) * kRec + (M) * 4096);             \
       _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
         if (F32_ABL & 16) {                                                                              \
           d__[g__ * 64] = (f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]};   \
@@ -404,7 +469,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         float wv__[8];                                                                                   \
         _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) wv__[i__] = i__ < ML ? p[i__ < ML ? i__ : 0] : 0.f; \
         if (hpad) wv__[7] = p[ML];                                                                       \
-        f32x4* dst__ = reinterpret_cast<f32x4*>(pimg_tok + (int64_t)hd * kImgRec);                       \
+        f32x4* dst__ = reinterpret_cast<f32x4*>(pimg_tok + (int64_t)hd * kRec);                       \
         __builtin_nontemporal_store((f32x4){wv__[0], wv__[1], wv__[2], wv__[3]}, dst__);                 \
         __builtin_nontemporal_store((f32x4){wv__[4], wv__[5], wv__[6], wv__[7]}, dst__ + 1);             \
       }                                                                                                  \
@@ -435,6 +500,62 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   FF_T(0);
   FL dyn = fl_zero();
+  if constexpr (MG) {
+    // ======================= merged heads: two products per head, keys = values = the x_hat rows (written to TK once) =======================
+    // pieces of head hd (two per step of the NEXT head's r product): score half-dots, softmax, probabilities out, z half-rows
+    FL q = fl_zero(), o;                              // q: the r rows of the current head; o: z = P x_hat
+    fl_store(krow, xh);
+    W32_CHAIN(q, xh, true);                           // r_0 = B_0 x_hat + b_0
+    F32_IMG_STORE(q, 0, 0);
+    __syncthreads();                                  // x_hat rows visible
+    FF_T(1);
+    float* const TVsave = TV;
+    (void)TVsave;
+#define F32_Z_PIECE(S)                                                                                   \
+  do {                                                                                                   \
+    constexpr int j__ = (S) >> 1, hf__ = (S) & 1;                                                        \
+    if constexpr (j__ <= ML) {                                                                           \
+      const float* rp__ = TK + ro[j__] + 32 * hf__;                                                      \
+      const float w__ = j__ < ML ? p[j__] : padf * p[ML];                                                \
+      const f2 w2__ = {w__, w__};                                                                        \
+      f32x16& oo__ = hf__ ? o.hi : o.lo;                                                                 \
+      _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
+        const f32x4 a__ = *reinterpret_cast<const f32x4*>(rp__ + 8 * g__);                               \
+        const f2 u0__ = __builtin_elementwise_fma(w2__, (f2){a__.x, a__.y}, (f2){oo__[4 * g__], oo__[4 * g__ + 1]});     \
+        const f2 u1__ = __builtin_elementwise_fma(w2__, (f2){a__.z, a__.w}, (f2){oo__[4 * g__ + 2], oo__[4 * g__ + 3]}); \
+        oo__[4 * g__] = u0__.x; oo__[4 * g__ + 1] = u0__.y; oo__[4 * g__ + 2] = u1__.x; oo__[4 * g__ + 3] = u1__.y;      \
+      }                                                                                                  \
+      asm volatile("" : "+v"(oo__));                                                                     \
+    }                                                                                                    \
+  } while (0)
+    // piece index Q: [0, 2 (ML + 1) + 2): the score pieces of F32_SC_PIECE (dots, softmax, probabilities out), then the z half-rows
+#define F32_MG_PIECE(Q)                                                                                  \
+  do {                                                                                                   \
+    if constexpr ((Q) < 2 * (ML + 1) + 2) F32_SC_PIECE(Q); else F32_Z_PIECE((Q) - (2 * (ML + 1) + 2));   \
+  } while (0)
+#define F32_MG_STEP(S) do { W32_MMA(acc, xh, S); F32_MG_PIECE(2 * (S)); F32_MG_PIECE(2 * (S) + 1); W32_REFILL(S, true); } while (0)
+#define F32_MG_ONLY(S) do { F32_MG_PIECE(2 * (S)); F32_MG_PIECE(2 * (S) + 1); } while (0)
+    int hd = 0;
+    for (; hd + 1 < MATCHA_N_HEAD; ++hd) {
+      o = fl_zero();
+      {
+        FL acc = fl_zero();                           // r_{hd+1}
+        F32_STAGE18(F32_MG_STEP);
+        F32_MG_PIECE(36); F32_MG_PIECE(37);           // ML = 8: 38 pieces
+        q = acc;
+        F32_IMG_STORE(q, hd + 1, 0);
+      }
+      FF_T(2);
+      W32_CHAIN(dyn, o, true);                        // dyn += M_hd z  (+ the merged bias with head 0)
+      FF_T(5);
+    }
+    o = fl_zero();
+    F32_STAGE18(F32_MG_ONLY);
+    F32_MG_PIECE(36); F32_MG_PIECE(37);
+    FF_T(2);
+    W32_CHAIN(dyn, o, true);
+    FF_T(5);
+  } else {
   FL q = fl_zero(), o;
   {
     // ---- prologue: K_0 -> TK, Q_0 ----
@@ -500,6 +621,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   FF_T(5);
 
   // =========================== tail: pff_n1, LayerNorms, classifier (all in registers) ===========================
+  }
   if (F32_ABL & 8) { if (dyn.lo[0] == 12345.f) g.logits[0] = dyn.hi[3]; return; }
   // the tail's seven parameter vectors -> TV [7][64]: gp bp g1 b1 g2 b2 wc  (the biases of fc1 / conv0 / conv1 come with the weight stream)
   __syncthreads();                                    // the last head's P V reads of TV are done
@@ -771,7 +893,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragF4 * 4; }
 size_t fused_tail_slab32_floats(int64_t B, int L) { return (size_t)(ragged_halves_cap(B, L) + 2) * kTailSlab32; }
 
-int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st) {
+size_t fused_merged_floats() { return (size_t)2 * MATCHA_N_HEAD * 4096 + MATCHA_N_HEAD * 64 + 64; }
+MergedView merged_view(const float* m) {
+  return MergedView{m, m + (size_t)MATCHA_N_HEAD * 4096, m + (size_t)2 * MATCHA_N_HEAD * 4096, m + (size_t)2 * MATCHA_N_HEAD * 4096 + MATCHA_N_HEAD * 64};
+}
+int launch_merge_heads(const matcha_tensors& p, const float* folded, float* merged, hipStream_t st) {
+  MergeArgs a;
+  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
+  a.wq = folded; a.wk = folded + wsz; a.wv = folded + 2 * wsz;
+  a.cq = folded + 3 * wsz; a.cv = a.cq + 2 * csz;
+  a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b;
+  const MergedView v = merged_view(merged);
+  a.B = const_cast<float*>(v.B); a.M = const_cast<float*>(v.M); a.bvec = const_cast<float*>(v.bvec); a.bdyn = const_cast<float*>(v.bdyn);
+  hipLaunchKernelGGL(merge_heads_kernel, dim3(MATCHA_N_HEAD, 3), dim3(256), 0, st, a);
+  MATCHA_CHECK_LAUNCH("merge_heads_kernel");
+  return MATCHA_OK;
+}
+
+int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st, const float* merged) {
   FragArgs a;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64;
   a.wq = folded; a.wk = folded + wsz; a.wv = folded + 2 * wsz;
@@ -779,6 +918,8 @@ int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, 
   a.cq = folded + 3 * wsz; a.ck = a.cq + csz; a.cv = a.cq + 2 * csz;
   a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b; a.p0w = p.pff0_w; a.p0b = p.pff0_b; a.p1w = p.pff1_w; a.p1b = p.pff1_b;
   a.out = reinterpret_cast<f32x4*>(frag);
+  a.mB = a.mM = a.mbvec = a.mbdyn = nullptr;
+  if (merged) { const MergedView v = merged_view(merged); a.mB = v.B; a.mM = v.M; a.mbvec = v.bvec; a.mbdyn = v.bdyn; }
   hipLaunchKernelGGL(fold_frag_kernel, dim3(kNMat + 1, 9), dim3(128), 0, st, a);
   MATCHA_CHECK_LAUNCH("fold_frag_kernel");
   return MATCHA_OK;
@@ -786,7 +927,7 @@ int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, 
 
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv) {
+                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv, bool merged) {
   Fwd32Args g;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.tok_tile = rg.tok_tile;
   g.L = L;
@@ -801,13 +942,25 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
   auto launch = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(rg.nhalves), dim3(64), lds, st, g); };
   // algorithmic flops per token: 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
   ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);
-  switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
-    case 2: launch(fused_fwd32_kernel<2>); break;
-    case 3: launch(fused_fwd32_kernel<3>); break;
-    case 4: launch(fused_fwd32_kernel<4>); break;
-    case 5: launch(fused_fwd32_kernel<5>); break;
-    case 6: launch(fused_fwd32_kernel<6>); break;
-    default: launch(fused_fwd32_kernel<8>); break;
+  const int ml = L <= 2 ? 2 : (L <= 6 ? L : 8);
+  if (merged) {
+    switch (ml) {
+      case 2: launch(fused_fwd32_kernel<2, true>); break;
+      case 3: launch(fused_fwd32_kernel<3, true>); break;
+      case 4: launch(fused_fwd32_kernel<4, true>); break;
+      case 5: launch(fused_fwd32_kernel<5, true>); break;
+      case 6: launch(fused_fwd32_kernel<6, true>); break;
+      default: launch(fused_fwd32_kernel<8, true>); break;
+    }
+  } else {
+    switch (ml) {
+      case 2: launch(fused_fwd32_kernel<2, false>); break;
+      case 3: launch(fused_fwd32_kernel<3, false>); break;
+      case 4: launch(fused_fwd32_kernel<4, false>); break;
+      case 5: launch(fused_fwd32_kernel<5, false>); break;
+      case 6: launch(fused_fwd32_kernel<6, false>); break;
+      default: launch(fused_fwd32_kernel<8, false>); break;
+    }
   }
   MATCHA_CHECK_LAUNCH("fused_fwd32_kernel");
   return MATCHA_OK;

@@ -66,6 +66,7 @@ struct Workspace {
   float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
   void* adj_ws;     size_t adj_ws_bytes;
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
+  float* merged;                          // merged per-head matrices B_h = W'k^T W'q, M_h = Wfc1_h W'v (two products per head instead of four)
   float* frag;                            // the same weights + fc1 / pff_n1 blocks in MFMA-fragment order (fused_fwd32.hip streams them from L2)
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
@@ -91,7 +92,7 @@ struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
-    {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32},
+    {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32}, {"disable_merged", &Options::disable_merged},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
@@ -122,10 +123,10 @@ static bool save_qkv() { return !options().disable_qkv_save; }
 // it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
 static std::mutex g_qkv_mu;
 static std::unordered_map<const void*, int> g_qkv_saved;     // bit 0: Q/K/V tiles saved; bit 1: the forward ran per HALF tile (fused_fwd32)
-static void note_qkv_saved(const void* ws, bool saved, bool halves) {
+static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
   if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
-  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0);
+  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0);      // bit 2: the saved records are the merged heads' r rows
 }
 static int ws_state(const void* ws) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
@@ -134,6 +135,7 @@ static int ws_state(const void* ws) {
 }
 static bool qkv_saved(const void* ws) { return (ws_state(ws) & 1) != 0; }
 static bool fwd_ran_halves(const void* ws) { return (ws_state(ws) & 2) != 0; }
+static bool fwd_ran_merged(const void* ws) { return (ws_state(ws) & 4) != 0; }
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
 // x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
@@ -192,6 +194,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.adj_ws = take_always(w.adj_ws_bytes / sizeof(float));
   w.folded = take_always(s.d == 64 ? fused_fold_floats() : 0);
   w.frag = take_always(s.d == 64 ? fused_frag_floats() : 0);
+  w.merged = take_always(s.d == 64 ? fused_merged_floats() : 0);
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tpart = take(s.d == 64 ? fused_tail_partial_floats() : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
@@ -378,15 +381,18 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
     const bool keep_qkv = !opts->forward_only && save_qkv();
     const bool fwd32 = !options().disable_fwd32;                     // wave-independent forward (one wavefront per half tile)
-    note_qkv_saved(ws, keep_qkv, fwd32);
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
+    // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities for fused_bwdm_kernel
+    const bool merged = fwd32 && !options().disable_merged;
+    note_qkv_saved(ws, keep_qkv, fwd32, merged);
     if (fwd32) {
-      MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st));
+      if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
+      MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
       MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                     lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                    lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
+                                    lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr, merged));
     } else {
       MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
@@ -553,7 +559,10 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
     const bool front = front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
-    MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
+    if (qkv_saved(ws) && fwd_ran_merged(ws))
+      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv));
+    else
+      MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
     MATCHA_TRY(encoder_done(*opts, st));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel

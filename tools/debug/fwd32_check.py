@@ -6,6 +6,7 @@ from matcha_amd import synth, _lib
 from matcha_amd.engine import Trainer
 from tests.test_hip_model import hip_model
 
+OPT = os.environ.get("CHECK_OPT", "disable_fwd32")
 num = synth.LAYOUTS["c1"]
 N = int(np.sum(num))
 for ks, per in (([2], 7), ([5], 3), ([2, 3, 4, 5], 40), ([2, 3, 5], 700)):
@@ -13,7 +14,7 @@ for ks, per in (([2], 7), ([5], 3), ([2, 3, 4, 5], 40), ([2, 3, 5], 700)):
     xt = torch.from_numpy(x).cuda()
     outs = {}
     for off in (1, 0):
-        with _lib.option("disable_fwd32", off):
+        with _lib.option(OPT, off):
             clf, _ = hip_model(num, 64, "table", 50)
             clf.eval()
             with torch.no_grad():
@@ -26,7 +27,7 @@ xt, yt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(),
 gr = {}
 for mode in ("eval", "train"):
     for off in (1, 0):
-        with _lib.option("disable_fwd32", off):
+        with _lib.option(OPT, off):
             clf, _ = hip_model(num, 64, "table", 50)
             clf.train(mode == "train")
             tr = Trainer(clf, base_seed=7)
