@@ -1466,93 +1466,74 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
 // fb_unfold2_kernel turn into the gradients of the original parameters as before (nchunks = 1); dxpad is summed here.
 struct ChainArgs {
   const float* wslab; int nchunks;           // merged slabs [8][nchunks][kWgSlabM]
+  float* red;                                // [8][kWgSlabM] chunk sums (fbm_reduce_kernel)
   const float* wq; const float* wk; const float* wv; const float* cq; const float* cv;   // folded
   const float* fc1_w;
   float* out;                                // [8][kWgSlab]
   float* dxpad;                              // [64]
 };
+// chunk sums of every slab element in chunk order; dxpad = the sum over heads and chunks of the padding token's share
+__global__ __launch_bounds__(256) void fbm_reduce_kernel(ChainArgs a) {
+  const int head = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kWgSlabM) return;
+  const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlabM + i;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < a.nchunks; c += 4) {
+    s0 += base[(int64_t)c * kWgSlabM]; s1 += base[(int64_t)(c + 1) * kWgSlabM]; s2 += base[(int64_t)(c + 2) * kWgSlabM]; s3 += base[(int64_t)(c + 3) * kWgSlabM];
+  }
+  for (; c < a.nchunks; ++c) s0 += base[(int64_t)c * kWgSlabM];
+  a.red[(int64_t)head * kWgSlabM + i] = (s0 + s1) + (s2 + s3);
+}
+// out[i][j] (16 rows of a 64 x 64 product per block) = sum_x A(i, x) B(x, j) [+ u[i] v[j]] with strided operands staged through LDS
+__device__ __forceinline__ void mm64_slice(const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
+                                           const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out, int slice,
+                                           float* __restrict__ As, float* __restrict__ Bs) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 16 * 64; i += 256) As[(i >> 6) * 65 + (i & 63)] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
+  for (int i = tid; i < 64 * 64; i += 256) Bs[(i >> 6) * 65 + (i & 63)] = B[(int64_t)(i >> 6) * b_rs + (int64_t)(i & 63) * b_cs];
+  __syncthreads();
+  for (int o = tid; o < 16 * 64; o += 256) {
+    const int i = o >> 6, j = o & 63;
+    float s = u ? u[16 * slice + i] * v[j] : 0.f;
+#pragma unroll 8
+    for (int x = 0; x < 64; ++x) s += As[i * 65 + x] * Bs[x * 65 + j];
+    out[(16 * slice + i) * 64 + j] = s;
+  }
+}
+// grid (4 row slices, 4 jobs, 8 heads): the four matrix gradients of a head in fused_bwd8_kernel's slab format; slice 0 also the vectors
 __global__ __launch_bounds__(256) void fbm_chain_kernel(ChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* dB = lds;                // [64][65]
-  float* dM = lds + 64 * 65;
-  float* W0 = lds + 2 * 64 * 65;  // staging of one weight matrix
-  float* vec = lds + 3 * 64 * 65; // db [64], dbdyn [64]
-  const int head = blockIdx.x, tid = threadIdx.x;
-  const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlabM;
-  for (int i = tid; i < 2 * 4096; i += 256) {
-    float s = 0.f;
-    for (int c = 0; c < a.nchunks; ++c) s += base[(int64_t)c * kWgSlabM + i];
-    (i < 4096 ? dB : dM)[((i & 4095) >> 6) * 65 + (i & 63)] = s;
-  }
-  if (tid < 128) {
-    float s = 0.f;
-    for (int c = 0; c < a.nchunks; ++c) s += base[(int64_t)c * kWgSlabM + kVecOffM + tid];
-    vec[tid] = s;
-  }
-  // d bdyn is a sum over ALL tokens: every head's workgroups saw the same dDyn -- take head 0's
-  if (tid < 64) {
-    float s = 0.f;
-    for (int c = 0; c < a.nchunks; ++c) s += a.wslab[(int64_t)c * kWgSlabM + kVecOffM + 64 + tid];
-    vec[64 + tid] = s;
-  }
-  if (head == 0 && tid >= 64 && tid < 128) {        // dxpad: every head's, every chunk's share
-    const int f = tid - 64;
-    float s = 0.f;
-    for (int hh = 0; hh < MATCHA_N_HEAD; ++hh)
-      for (int c = 0; c < a.nchunks; ++c) s += a.wslab[((int64_t)hh * a.nchunks + c) * kWgSlabM + kVecOffM + 128 + f];
-    a.dxpad[f] = s;
-  }
-  float* out = a.out + (int64_t)head * kWgSlab;
+  __shared__ float As[16 * 65];
+  __shared__ float Bs[64 * 65];
+  const int slice = blockIdx.x, job = blockIdx.y, head = blockIdx.z, tid = threadIdx.x;
+  const float* red = a.red + (int64_t)head * kWgSlabM;
+  const float* dB = red; const float* dM = red + 4096; const float* db = red + kVecOffM;
+  const float* dbdyn = a.red + kVecOffM + 64;              // a sum over ALL tokens: every head saw the same dDyn -- take head 0's
   const float* Wq = a.wq + (int64_t)head * 4096; const float* Wk = a.wk + (int64_t)head * 4096; const float* Wv = a.wv + (int64_t)head * 4096;
-  auto stage = [&](const float* src, int ld) {      // 64 x 64 block -> W0 [64][65]
-    __syncthreads();
-    for (int i = tid; i < 4096; i += 256) W0[(i >> 6) * 65 + (i & 63)] = src[(int64_t)(i >> 6) * ld + (i & 63)];
-    __syncthreads();
-  };
-  // dW'q[m][b] = sum_a W'k[m][a] dB[a][b]
-  stage(Wk, 64);
-  for (int o = tid; o < 4096; o += 256) {
-    const int m = o >> 6, b = o & 63;
-    float s = 0.f;
-    for (int x = 0; x < 64; ++x) s += W0[m * 65 + x] * dB[x * 65 + b];
-    out[0 * 4096 + o] = s;
+  const float* Wf = a.fc1_w + head * 64;                  // Wf[n][m] = fc1_w[n * 512 + head * 64 + m]
+  float* out = a.out + (int64_t)head * kWgSlab;
+  if (job == 0) {          // dW'q[m][b] = sum_a W'k[m][a] dB[a][b]
+    mm64_slice(Wk, 64, 1, dB, 64, 1, nullptr, nullptr, out + 0 * 4096, slice, As, Bs);
+  } else if (job == 1) {   // dW'k[m][a] = sum_b W'q[m][b] dB[a][b] + cq[m] db[a]
+    mm64_slice(Wq, 64, 1, dB, 1, 64, a.cq + head * 64, db, out + 1 * 4096, slice, As, Bs);
+  } else if (job == 2) {   // dW'v[m][b] = sum_n Wf[n][m] dM[n][b]
+    mm64_slice(Wf, 1, 512, dM, 64, 1, nullptr, nullptr, out + 2 * 4096, slice, As, Bs);
+  } else {                 // dWf[n][m] = sum_b dM[n][b] W'v[m][b] + dbdyn[n] cv[m]
+    mm64_slice(dM, 64, 1, Wv, 1, 64, dbdyn, a.cv + head * 64, out + 3 * 4096, slice, As, Bs);
   }
-  if (tid < 64) {                                    // dcq[m] = sum_a W'k[m][a] db[a]
-    float s = 0.f;
-    for (int x = 0; x < 64; ++x) s += W0[tid * 65 + x] * vec[x];
-    out[kVecOff + tid] = s;
+  if (slice == 0 && job == 0 && tid < 64) {
+    float s = 0.f, t = 0.f;
+    for (int x = 0; x < 64; ++x) { s += Wk[tid * 64 + x] * db[x]; t += Wf[x * 512 + tid] * dbdyn[x]; }
+    out[kVecOff + tid] = s;                          // dcq[m] = sum_a W'k[m][a] db[a]
     out[kVecOff + 64 + tid] = 0.f;                   // dck: the K bias only shifts all scores of a query (no gradient)
+    out[kVecOff + 128 + tid] = t;                    // dcv[m] = sum_n Wf[n][m] dbdyn[n]
     out[kVecOff + 192 + tid] = 0.f; out[kVecOff + 256 + tid] = 0.f;     // dK_pad / dV_pad do not exist here
-    out[kVecOff + 320 + tid] = head == 0 ? vec[64 + tid] : 0.f;         // dfc1_b = d bdyn
-  }
-  // dW'k[m][a] = sum_b W'q[m][b] dB[a][b] + cq[m] db[a]
-  stage(Wq, 64);
-  for (int o = tid; o < 4096; o += 256) {
-    const int m = o >> 6, x = o & 63;
-    float s = a.cq[head * 64 + m] * vec[x];
-    for (int b = 0; b < 64; ++b) s += W0[m * 65 + b] * dB[x * 65 + b];
-    out[1 * 4096 + o] = s;
-  }
-  // dWf_h[n][m] = sum_b dM[n][b] W'v[m][b] + dbdyn[n] cv[m]
-  stage(Wv, 64);
-  for (int o = tid; o < 4096; o += 256) {
-    const int n = o >> 6, m = o & 63;
-    float s = vec[64 + n] * a.cv[head * 64 + m];
-    for (int b = 0; b < 64; ++b) s += dM[n * 65 + b] * W0[m * 65 + b];
-    out[3 * 4096 + o] = s;
-  }
-  // dW'v[m][b] = sum_n Wf[n][hm] dM[n][b];  dcv[m] = sum_n Wf[n][hm] dbdyn[n]
-  stage(a.fc1_w + head * 64, 512);                   // W0[n][m] = Wf[n][head*64 + m]
-  for (int o = tid; o < 4096; o += 256) {
-    const int m = o >> 6, b = o & 63;
-    float s = 0.f;
-    for (int n = 0; n < 64; ++n) s += W0[n * 65 + m] * dM[n * 65 + b];
-    out[2 * 4096 + o] = s;
-  }
-  if (tid < 64) {
-    float s = 0.f;
-    for (int n = 0; n < 64; ++n) s += W0[n * 65 + tid] * vec[64 + n];
-    out[kVecOff + 128 + tid] = s;
+    out[kVecOff + 320 + tid] = head == 0 ? dbdyn[tid] : 0.f;            // dfc1_b = d bdyn
+    if (head == 0) {
+      float p = 0.f;
+      for (int hh = 0; hh < MATCHA_N_HEAD; ++hh) p += a.red[(int64_t)hh * kWgSlabM + kVecOffM + 128 + tid];
+      a.dxpad[tid] = p;
+    }
   }
 }
 
@@ -1819,10 +1800,12 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
   }
   {
     ChainArgs c;
-    c.wslab = wslab; c.nchunks = nchunks;
+    c.wslab = wslab; c.nchunks = nchunks; c.red = chain + (size_t)MATCHA_N_HEAD * kWgSlab;
     c.wq = folded; c.wk = folded + wsz; c.wv = folded + 2 * wsz; c.cq = folded + 3 * wsz; c.cv = c.cq + 2 * csz;
     c.fc1_w = p.fc1_w; c.out = chain; c.dxpad = dxpad;
-    hipLaunchKernelGGL(fbm_chain_kernel, dim3(MATCHA_N_HEAD), dim3(256), (3 * 64 * 65 + 128) * sizeof(float), st, c);
+    hipLaunchKernelGGL(fbm_reduce_kernel, dim3((unsigned)cdiv(kWgSlabM, 256), MATCHA_N_HEAD), dim3(256), 0, st, c);
+    MATCHA_CHECK_LAUNCH("fbm_reduce_kernel");
+    hipLaunchKernelGGL(fbm_chain_kernel, dim3(4, 4, MATCHA_N_HEAD), dim3(256), 0, st, c);
     MATCHA_CHECK_LAUNCH("fbm_chain_kernel");
   }
   {

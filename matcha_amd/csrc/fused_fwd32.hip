@@ -215,35 +215,38 @@ struct MergeArgs {
   const float* fc1_w; const float* fc1_b;
   float* B; float* M; float* bvec; float* bdyn;          // [8][64][64], [8][64][64], [8][64], [64]
 };
-// grid (8 heads, 3): y = 0: B_h and b_h, 1: M_h, 2 (x = 0 only): bdyn
+// grid (4 row slices, 2 matrices, 8 heads): 16 rows of B_h (y = 0; slice 0 also b_h) or of M_h (y = 1; slice 0 of head 0 also bdyn)
 __global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
-  const int hd = blockIdx.x, tid = threadIdx.x;
-  if (blockIdx.y == 0) {
-    const float* Wk = a.wk + (int64_t)hd * 4096;
-    const float* Wq = a.wq + (int64_t)hd * 4096;
-    for (int o = tid; o < 4096; o += 256) {
-      const int r = o >> 6, c = o & 63;
-      float s = 0.f;
-      for (int m = 0; m < 64; ++m) s += Wk[m * 64 + r] * Wq[m * 64 + c];
-      a.B[(int64_t)hd * 4096 + o] = s;
-    }
-    if (tid < 64) {
+  __shared__ float As[16 * 65];
+  __shared__ float Bs[64 * 65];
+  const int slice = blockIdx.x, hd = blockIdx.z, tid = threadIdx.x;
+  const float* Wk = a.wk + (int64_t)hd * 4096;
+  const bool isB = blockIdx.y == 0;
+  // B_h[r][c] = sum_m W'k[m][r] W'q[m][c];   M_h[n][c] = sum_m Wf[n][hd * 64 + m] W'v[m][c]
+  const float* A = isB ? Wk : a.fc1_w + hd * 64;
+  const int a_rs = isB ? 1 : 512, a_cs = isB ? 64 : 1;
+  const float* Bm = (isB ? a.wq : a.wv) + (int64_t)hd * 4096;
+  float* out = (isB ? a.B : a.M) + (int64_t)hd * 4096;
+  for (int i = tid; i < 16 * 64; i += 256) As[(i >> 6) * 65 + (i & 63)] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
+  for (int i = tid; i < 64 * 64; i += 256) Bs[(i >> 6) * 65 + (i & 63)] = Bm[i];
+  __syncthreads();
+  for (int o = tid; o < 16 * 64; o += 256) {
+    const int i = o >> 6, j = o & 63;
+    float s = 0.f;
+#pragma unroll 8
+    for (int x = 0; x < 64; ++x) s += As[i * 65 + x] * Bs[x * 65 + j];
+    out[(16 * slice + i) * 64 + j] = s;
+  }
+  if (slice == 0 && tid < 64) {
+    if (isB) {
       float s = 0.f;
       for (int m = 0; m < 64; ++m) s += Wk[m * 64 + tid] * a.cq[hd * 64 + m];
       a.bvec[hd * 64 + tid] = s;
+    } else if (hd == 0) {
+      float s = a.fc1_b[tid];
+      for (int m = 0; m < 512; ++m) s += a.fc1_w[tid * 512 + m] * a.cv[m];
+      a.bdyn[tid] = s;
     }
-  } else if (blockIdx.y == 1) {
-    const float* Wv = a.wv + (int64_t)hd * 4096;
-    for (int o = tid; o < 4096; o += 256) {
-      const int n = o >> 6, c = o & 63;
-      float s = 0.f;
-      for (int m = 0; m < 64; ++m) s += a.fc1_w[n * 512 + hd * 64 + m] * Wv[m * 64 + c];
-      a.M[(int64_t)hd * 4096 + o] = s;
-    }
-  } else if (hd == 0 && tid < 64) {
-    float s = a.fc1_b[tid];
-    for (int m = 0; m < 512; ++m) s += a.fc1_w[tid * 512 + m] * a.cv[m];
-    a.bdyn[tid] = s;
   }
 }
 
@@ -905,7 +908,7 @@ int launch_merge_heads(const matcha_tensors& p, const float* folded, float* merg
   a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b;
   const MergedView v = merged_view(merged);
   a.B = const_cast<float*>(v.B); a.M = const_cast<float*>(v.M); a.bvec = const_cast<float*>(v.bvec); a.bdyn = const_cast<float*>(v.bdyn);
-  hipLaunchKernelGGL(merge_heads_kernel, dim3(MATCHA_N_HEAD, 3), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(merge_heads_kernel, dim3(4, 2, MATCHA_N_HEAD), dim3(256), 0, st, a);
   MATCHA_CHECK_LAUNCH("merge_heads_kernel");
   return MATCHA_OK;
 }
