@@ -45,6 +45,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA peak (no xf
 # head + the two pff GEMMs; fused_bwd 8 GEMMs per head (dO, dWfc1, 3 dW', 3 d x_hat terms) -- the Q/K/V recompute of the
 # backward kernel and the O(k) attention arithmetic are not counted.
 GEMM_CLASSES = ("gemm_nt", "gemm_nn", "gemm_tn", "fused_fwd", "fused_bwd")
+# Merged heads (embed_dim 64, round 3): with d_k = d_v = d_model the four per-head products of the reference collapse into two in the
+# forward (r = B_h x, dyn += M_h z) and eight into four in the backward.  `achieved` stays what the contract asks for -- the reference
+# formulation's ALGORITHMIC flops over the kernel's time -- and `executed_fraction` says what share of them the matrix cores really
+# run (so achieved x executed_fraction is the executed rate, the one bounded by the f32 MFMA peak).
+EXECUTED_FRACTION_MERGED = {"fused_fwd": (8 * 2 + 2) / (8 * 4 + 2.0), "fused_bwd": 4 / 8.0}
 METRIC = "training hyperedges/sec at k∈{2..5}, embed_dim=64; 1/2/4/8 MI355X"
 
 
@@ -102,6 +107,14 @@ def make_model(front_end, dim, num, device):
     clf = M.Classifier(n_head=8, d_model=d, d_k=d, d_v=d, node_embedding=ne, diag_mask=True, bottle_neck=d,
                        attribute_dict=attribute_table(num))
     return clf.to(device)
+
+
+def executed_fraction(lib, kernel_class, dim):
+    """Share of a kernel class's algorithmic GEMM flops that the merged-heads kernels execute (1.0 for everything else)."""
+    if dim == 64 and kernel_class in EXECUTED_FRACTION_MERGED and lib.matcha_get_option(b"disable_merged") == 0 \
+            and lib.matcha_get_option(b"disable_fwd32") == 0 and lib.matcha_get_option(b"disable_fused") == 0:
+        return EXECUTED_FRACTION_MERGED[kernel_class]
+    return 1.0
 
 
 def csrc_sha16():
@@ -265,6 +278,13 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
                 roof = dict(bound="mfma", kernel=prof_cls, achieved=round(ach, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches_per_step=n.value / steps,
                             avg_launch_ms=round(per_launch_ms, 5), work_per_launch=wk.value / n.value)
+                ex = executed_fraction(lib, prof_cls, dim)
+                if ex < 1.0:
+                    roof["executed_fraction"] = round(ex, 4)
+                    roof["executed_tflops"] = round(ach * ex, 3)
+                    roof["executed_frac_of_peak"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
+                    roof["note"] = ("achieved = the reference formulation's algorithmic flops / time; merged heads execute "
+                                    "executed_fraction of them (DESIGN.md §4.1)")
             else:
                 ach = wk.value / (ms.value * 1e-3) / 1e9
                 roof = dict(bound="hbm", kernel=prof_cls, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -317,6 +337,9 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
         if name in GEMM_CLASSES:
             ach = work / (ms_step * 1e-3) / 1e12
             roof_all[name] = dict(bound="mfma", ms_per_step=round(ms_step, 4), achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
+            ex = executed_fraction(lib, name, dim)
+            if ex < 1.0:
+                roof_all[name]["executed_frac_of_peak"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
         else:
             ach = work / (ms_step * 1e-3) / 1e9
             roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))

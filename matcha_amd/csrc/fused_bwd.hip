@@ -1198,16 +1198,16 @@ template <int ML>
 __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wb = lds;                    // B_h [a][b], resident
-  float* Xs = lds + 1 * kTile;        // x_hat (rows >= n_real are zero): also every key and value row
-  float* Ds = lds + 2 * kTile;        // dDyn  (rows >= n_real are zero)
-  float* Rs = lds + 3 * kTile;        // r -> dR            (Ds, Rs consecutive: the column sums pick one of them by offset)
-  float* Fs = lds + 4 * kTile;        // dZ -> Z
-  float* Gs = lds + 5 * kTile;        // attention's gradient into the x_hat rows (keys + values)
-  float* sm = lds + 6 * kTile;
-  int* tinfo = reinterpret_cast<int*>(sm);
-  float* xpad = sm + 64;
-  float* Ps = xpad + 64;
-  float* dSs = Ps + 512;
+  // two sets {x_hat, dDyn, r -> dR} (+ probabilities, token info): the NEXT tile is staged into the other set at the end of a tile, so
+  // the walk has no staging phase (and one barrier less) on its critical path.  Ds, Rs consecutive: the column sums pick one by offset
+  float* set0 = lds + 1 * kTile;
+  float* Fs = lds + 7 * kTile;        // dZ -> Z
+  float* Gs = lds + 8 * kTile;        // attention's gradient into the x_hat rows (keys + values)
+  float* sm = lds + 9 * kTile;
+  float* xpad = sm;
+  float* dSs = xpad + 64;
+  float* Ps0 = dSs + 512;             // [2][512]
+  int* tinfo0 = reinterpret_cast<int*>(Ps0 + 1024);   // [2][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = wave & 3, hf = wave >> 2;
@@ -1283,17 +1283,29 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       for (int x = 0; x < 4; ++x) fcb[4 * c + x] = mp[(16 * c + x) * 64];
   }
 
+#define FBM_STAGE(PAR, META)                                                                             \
+  do {                                                                                                   \
+    float* Xs = set0 + 3 * (PAR) * kTile;                                                                \
+    float* Ds = Xs + kTile;                                                                              \
+    float* Rs = Ds + kTile;                                                                              \
+    const int n_real = (META).y;                                                                         \
+    const int r = lane & 31, h = lane >> 5;                                                              \
+    FB8_ROW_STAGE(0); FB8_ROW_STAGE(1);                                                                  \
+    if (tid < 64) tinfo0[64 * (PAR) + tid] = tid < n_real ? ((tid - (tpn & 255)) | (tpn & ~255)) : 0;     \
+    FB8_IMG_STAGE(Rs, ri0, ri1);                                                                         \
+    if (tid < 128) reinterpret_cast<f32x4*>(Ps0 + 512 * (PAR))[tid] = pn;                                \
+  } while (0)
+  int par = 0;
+  if (tile_lo < tile_hi) FBM_STAGE(0, mc);
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
     const int t0 = mc.x, n_real = mc.y;
-    if (n_real <= 0) {
-      const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
-      FB8_ROWS_GLOAD(mn);
-      if (tile + 1 < tile_hi) FBM_RIMG_GLOAD(tile + 1);
-      mc = mn; mn = mnn;
-      continue;
-    }
-    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
+    float* Xs = set0 + 3 * par * kTile;
+    float* Ds = Xs + kTile;
+    float* Rs = Ds + kTile;
+    const float* Ps = Ps0 + 512 * par;
+    const int* tinfo = tinfo0 + 64 * par;
+    __syncthreads();                                  // this tile's set is staged; the previous tile's GEMMs are done with Fs / Gs and with the other set
     // per-lane indices re-derived from an opaque copy of the thread id (see fused_bwd8_kernel: loop-invariant addresses are hoisted and spilled otherwise)
     int tid_ = tid;
     asm volatile("" : "+v"(tid_));
@@ -1306,11 +1318,7 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
     const int srow = tid_ >> 4, sc4 = (tid_ & 15) * 4;
     const int sub = lane & 7;
     const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
-    FB8_ROW_STAGE(0); FB8_ROW_STAGE(1);
-    if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
-    FB8_IMG_STAGE(Rs, ri0, ri1);
-    if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
-    __syncthreads();
+    (void)r; (void)h; (void)srow; (void)sc4;
     // ---- dZ^T = M_h^T . dDyn^T: lane (c16, kq) ends with token 32 wr + c16 (+ 16) and features fb + 4 kq + {0..3} ----
     {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -1408,11 +1416,15 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       FBM_TN_LOAD(a, 0);
       FBM_TN_PAIR(0); FBM_TN_PAIR(2); FBM_TN_PAIR(4); FBM_TN_PAIR(6); FBM_TN_PAIR(8); FBM_TN_PAIR(10); FBM_TN_PAIR(12); FBM_TN_PAIR(14);
     }
+    // ---- the next tile -> the other set (its rows and images were fetched during this tile) ----
+    if (tile + 1 < tile_hi) FBM_STAGE(par ^ 1, mn);
+    par ^= 1;
     mc = mn; mn = mnn;
   }
 
   // ---- workgroup slab ----
   __syncthreads();
+  float* Xs = set0;
   float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlabM;
   {
     const int col = fb + c16;
@@ -1781,7 +1793,7 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
     FusedBwdMArgs g;
     g.X = X; g.dDyn = dDyn; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
     g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.rimg = rimg;
-    const size_t lds = ((size_t)6 * kTile + 64 + 64 + 2 * 512) * sizeof(float);
+    const size_t lds = ((size_t)9 * kTile + 64 + 512 + 2 * 512 + 2 * 64) * sizeof(float);
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(512), lds, st, g);
