@@ -423,6 +423,49 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def front_gather_roofline(device):
+    """The gather the model step actually executes, on tables that do not fit any cache (north_star: "coalesced HBM reads of embedding
+    rows into LDS tiles"): (a) embed_dim 64 -- front_fwd_kernel gathers the node rows and attribute rows of a 64-token tile straight into
+    LDS, runs attribute_nn and next_w on them and writes only X (an inference forward; the training forward also writes the
+    pre-activation rows) -- on a 16 M x 64 table; (b) embed_dim 256 -- embed_fwd_kernel (gather + attribute_nn, two tokens in flight per
+    16-lane group) on BASELINE configs[4]'s 1 M x 256 table.  Timed live with HIP events through the library's per-class profiler inside
+    real forward calls; achieved = tokens * (8 + 4 d + 4 n_attr) READ bytes / time against the 8 TB/s HBM-read roof."""
+    import Modules as M
+    lib = _lib.load()
+    out = []
+    for name, num, d, B, L, cls in (("front_fwd (fused front end, d = 64) on a 16 M x 64 table (4 GiB)", [(1 << 24) // 23] * 23, 64, 65536, 5, "front_fwd"),
+                                    ("embed_fwd (d = 256) on the C5 table, 1 M x 256 (1 GiB)", synth.LAYOUTS["c5"], 256, 16384, 8, "embed_fwd")):
+        N = int(np.sum(num))
+        clf = make_model("table", d, num, device).eval()
+        n_attr = len(num) + 1
+        g = torch.Generator(device=device)
+        g.manual_seed(3)
+        x = torch.randint(1, N + 1, (B, L), generator=g, device=device, dtype=torch.int64)
+        reps = 10
+        with torch.no_grad(), clf.deferred_id_check():
+            for _ in range(2):
+                clf(x)
+            lib.matcha_profile_select(_lib.PROF[cls])
+            for _ in range(reps):
+                clf(x)
+            ms, n, wk = C.c_double(), C.c_int64(), C.c_double()
+            _lib.check(lib.matcha_profile_read(C.byref(ms), C.byref(n), C.byref(wk)))
+            lib.matcha_profile_select(0)
+        torch.cuda.synchronize(device)
+        tokens = B * L + 1
+        t = ms.value * 1e-3 / max(n.value, 1)
+        read = tokens * (8.0 + 4.0 * d + 4.0 * n_attr)
+        written = tokens * 4.0 * d
+        out.append(dict(table=name, d=d, tokens_per_launch=tokens, resident="hbm", bound="hbm", kernel=cls, avg_launch_ms=round(t * 1e3, 4),
+                        achieved=round(read / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(read / t / 1e9 / HBM_PEAK_GBS, 4),
+                        read_bytes_per_token=8 + 4 * d + 4 * n_attr, written_bytes_per_token=4 * d,
+                        read_plus_write_gbs=round((read + written) / t / 1e9, 1)))
+        del clf, x
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -477,6 +520,7 @@ def main():
     default_run = (args.layout, args.dim, args.front_end, args.rows, args.ks) == ("hg38_1mb", 64, "table", 65536, "2,3,4,5")
     if rank == 0 and world == 1 and not args.no_extras and not args.graph:
         result["roofline_gather"] = gather_roofline(dist.device)
+        result["roofline_gather_in_step"] = front_gather_roofline(dist.device)
         if default_run:
             extras = {}
             for key, kw in (("deterministic_embedding_backward", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="table", deterministic=True)),

@@ -364,7 +364,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   if (front) {
     // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
     MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, w.rg, Tn,
-                                w.x0, w.X, st));
+                                opts->forward_only ? nullptr : w.x0, w.X, st));     // x0 (pre-activation) is only read by the backward pass
   } else {
     MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, p.attr_w,
                                 p.attr_b, w.x0, st, cnt));

@@ -181,34 +181,80 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   Row bias;
   load_row<NCH>(ba, s, d, bias);
   const int64_t t0 = (int64_t)blockIdx.x * tok_per_blk;
-  for (int i = slot; i < tok_per_blk; i += 16) {
-    const int64_t t = t0 + i;
-    if (t >= T) break;
-    const int64_t id = x[t];
-    Row e;
-    if (table) load_row<NCH>(table + id * d, s, d, e);           // <- the embedding-row gather (K1)
-    else if (dense) load_row<NCH>(dense + t * d, s, d, e);
-    else zero_row<NCH>(e);
-    Row out = bias;
-    const float* arow = attr_table + id * n_attr;
-    for (int base = 0; base < n_attr; base += 16) {
-      const float av = (base + s < n_attr) ? arow[base + s] : 0.f;   // 16 attribute values per coalesced load
+  // TWO tokens per trip and every load of a trip requested before the first use: both ids (already fetched during the previous trip),
+  // both embedding rows and ALL attribute values of both tokens (n_attr <= 32: two 16-value pieces each; fetched piece by piece
+  // inside the product loop each piece cost another HBM round trip).  A table that lives in HBM answers in ~2 us: one row per group
+  // at a time with the attribute pieces in sequence read the 1 GiB C5 table at 19 % of the HBM roof.
+  int64_t ida = 0, idb = 0;
+  {
+    const int64_t ta = t0 + slot, tb = ta + 16;
+    ida = (slot < tok_per_blk && ta < T) ? x[ta] : 0;
+    idb = (slot + 16 < tok_per_blk && tb < T) ? x[tb] : 0;
+  }
+  for (int i = slot; i < tok_per_blk; i += 32) {
+    const int64_t ta = t0 + i, tb = ta + 16;
+    if (ta >= T) break;
+    const bool hb = (i + 16 < tok_per_blk) && tb < T;
+    const int64_t ca = ida, cb = idb;
+    {                                                   // ids of the next trip
+      const int64_t na = ta + 32, nb = tb + 32;
+      ida = (i + 32 < tok_per_blk && na < T) ? x[na] : 0;
+      idb = (i + 48 < tok_per_blk && nb < T) ? x[nb] : 0;
+    }
+    Row ea, eb;
+    if (table) { load_row<NCH>(table + ca * d, s, d, ea); load_row<NCH>(table + cb * d, s, d, eb); }
+    else if (dense) { load_row<NCH>(dense + ta * d, s, d, ea); load_row<NCH>(dense + (hb ? tb : ta) * d, s, d, eb); }
+    else { zero_row<NCH>(ea); zero_row<NCH>(eb); }
+    const float* arow_a = attr_table + ca * n_attr;
+    const float* arow_b = attr_table + cb * n_attr;
+    float ava[2], avb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      ava[q] = (16 * q + s < n_attr) ? arow_a[16 * q + s] : 0.f;      // 16 attribute values per coalesced load
+      avb[q] = (16 * q + s < n_attr) ? arow_b[16 * q + s] : 0.f;
+    }
+    Row oa = bias, ob = bias;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int base = 16 * q;
       const int nc = n_attr - base < 16 ? n_attr - base : 16;
       for (int c0 = 0; c0 < nc; ++c0) {
-        const float a = __shfl(av, grp + c0, kWave);
+        const float a = __shfl(ava[q], grp + c0, kWave), b = __shfl(avb[q], grp + c0, kWave);
         const float* wrow = wt + (base + c0) * d;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int j = 4 * s + 64 * c;
           if (j < d) {
             const float4 wv = *reinterpret_cast<const float4*>(wrow + j);
-            out.v[c].x += a * wv.x; out.v[c].y += a * wv.y; out.v[c].z += a * wv.z; out.v[c].w += a * wv.w;
+            oa.v[c].x += a * wv.x; oa.v[c].y += a * wv.y; oa.v[c].z += a * wv.z; oa.v[c].w += a * wv.w;
+            ob.v[c].x += b * wv.x; ob.v[c].y += b * wv.y; ob.v[c].z += b * wv.z; ob.v[c].w += b * wv.w;
           }
         }
       }
     }
-    acc_row<NCH>(out, e);
-    store_row<NCH>(x0 + t * d, s, d, out);
+    for (int base = 32; base < n_attr; base += 16) {    // n_attr > 32 (not a MATCHA shape): the remaining pieces in sequence
+      const float av0 = (base + s < n_attr) ? arow_a[base + s] : 0.f, av1 = (base + s < n_attr) ? arow_b[base + s] : 0.f;
+      const int nc = n_attr - base < 16 ? n_attr - base : 16;
+      for (int c0 = 0; c0 < nc; ++c0) {
+        const float a = __shfl(av0, grp + c0, kWave), b = __shfl(av1, grp + c0, kWave);
+        const float* wrow = wt + (base + c0) * d;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int j = 4 * s + 64 * c;
+          if (j < d) {
+            const float4 wv = *reinterpret_cast<const float4*>(wrow + j);
+            oa.v[c].x += a * wv.x; oa.v[c].y += a * wv.y; oa.v[c].z += a * wv.z; oa.v[c].w += a * wv.w;
+            ob.v[c].x += b * wv.x; ob.v[c].y += b * wv.y; ob.v[c].z += b * wv.z; ob.v[c].w += b * wv.w;
+          }
+        }
+      }
+    }
+    acc_row<NCH>(oa, ea);
+    store_row<NCH>(x0 + ta * d, s, d, oa);
+    if (hb) {
+      acc_row<NCH>(ob, eb);
+      store_row<NCH>(x0 + tb * d, s, d, ob);
+    }
   }
 }
 
@@ -591,7 +637,7 @@ static inline int nch_of(int d) { return d <= 64 ? 1 : (d <= 128 ? 2 : 4); }
 int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev) {
   if (T <= 0) return MATCHA_OK;
-  const int tok_per_blk = T >= 256 * 1024 ? 256 : (T >= 16 * 1024 ? 64 : 16);
+  const int tok_per_blk = T >= 256 * 1024 ? 256 : (T >= 64 * 1024 ? 128 : (T >= 16 * 1024 ? 64 : 16));
   dim3 grid((unsigned)cdiv(T, tok_per_blk));
   const size_t lds = (size_t)n_attr * d * sizeof(float);
   // algorithmic bytes per token: index 8 + embedding row 4d + attribute row 4*n_attr read, x0 row 4d written
