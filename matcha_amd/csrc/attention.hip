@@ -382,13 +382,14 @@ size_t attn_bwd_slab_bytes(int64_t B, int d) { return align_up((size_t)attn_bloc
   }
 
 int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float* O, float* P,
-                    hipStream_t st) {
+                    hipStream_t st, bool shared_kv) {
   if (B <= 0) return MATCHA_OK;
   const float inv_temp = 1.0f / sqrtf((float)d);
   dim3 grid((unsigned)attn_blocks(B));
   // algorithmic bytes (upper bound, all L slots real): read Q,K,V, write O (+P)
   ProfScope ps(MATCHA_PROF_ATTN_FWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 4.0 + (double)B * MATCHA_N_HEAD * L * L), st);
-  if (attn_wide_eligible(d)) return launch_attn_fwd_wide(Q, K, V, row_off, B, L, d, inv_temp, O, P, attn_blocks(B), st);
+  if (attn_wide_eligible(d)) return launch_attn_fwd_wide(Q, K, V, row_off, B, L, d, inv_temp, O, P, attn_blocks(B), st, shared_kv);
+  if (shared_kv) { set_error("launch_attn_fwd: shared keys / values need the embed_dim >= 128 kernels"); return MATCHA_EINVAL; }
   switch (chunk_of(d)) {
     case 8: ATTN_FWD_L(8, Q, K, V, row_off, B, L, d, inv_temp, O, P); break;
     case 4: ATTN_FWD_L(4, Q, K, V, row_off, B, L, d, inv_temp, O, P); break;
@@ -410,8 +411,9 @@ int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_
   }
 
 int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
-                    int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st) {
+                    int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st, bool shared_kv) {
   if (B <= 0) return MATCHA_OK;
+  if (shared_kv && !attn_wide_eligible(d)) { set_error("launch_attn_bwd: shared keys / values need the embed_dim >= 128 kernels"); return MATCHA_EINVAL; }
   const float inv_temp = 1.0f / sqrtf((float)d);
   const int nblk = attn_blocks(B);
   dim3 grid((unsigned)nblk);
@@ -422,7 +424,7 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
     ProfScope ps(MATCHA_PROF_ATTN_BWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 7.0 + (double)B * MATCHA_N_HEAD * L * L), st);
     const int per_lane = d / 8;
     if (attn_wide_eligible(d)) {
-      MATCHA_TRY(launch_attn_bwd_wide(Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, nblk, st));
+      MATCHA_TRY(launch_attn_bwd_wide(Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, nblk, st, shared_kv));
     } else
     switch (chunk_of(d)) {
       case 8:
@@ -447,6 +449,31 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
   MATCHA_CHECK_LAUNCH("attn_bwd_kernel");
   hipLaunchKernelGGL(attn_pad_reduce_kernel, dim3((unsigned)cdiv(2 * hd, 64)), dim3(1024), 0, st, slab, nblk, hd, row_off, B, dQ, dK, dV);
   MATCHA_CHECK_LAUNCH("attn_pad_reduce_kernel");
+  return MATCHA_OK;
+}
+
+// out[t][f] = sum over the 8 heads of per_head[t][h d + f]  (merged heads, embed_dim >= 128: the attention backward returns dK / dV
+// per head although every head attended the same [T, d] key / value rows)
+__global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ in, int64_t T, int d, float* __restrict__ out, const int32_t* __restrict__ t_dev) {
+  if (t_dev) T = *t_dev;
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;       // float4 index into out
+  const int per_row = d / 4;
+  const int64_t t = i4 / per_row;
+  if (t >= T) return;
+  const int f = (int)(i4 - t * per_row) * 4;
+  const float* src = in + t * (int64_t)MATCHA_N_HEAD * d + f;
+  float4 s = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+  for (int h = 1; h < MATCHA_N_HEAD; ++h) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)h * d);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + t * d + f) = s;
+}
+int launch_head_sum(const float* per_head, int64_t T, int d, float* out, hipStream_t st, const int32_t* t_dev) {
+  if (T <= 0) return MATCHA_OK;
+  hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)cdiv(T * (d / 4), 256)), dim3(256), 0, st, per_head, T, d, out, t_dev);
+  MATCHA_CHECK_LAUNCH("head_sum_kernel");
   return MATCHA_OK;
 }
 

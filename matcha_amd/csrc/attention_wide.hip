@@ -48,12 +48,15 @@ __device__ __forceinline__ void axpy8(C8& y, float w, const C8& x) {
 template <int kMaxL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                             const int32_t* __restrict__ row_off, int64_t B, int L, int d, float inv_temp,
-                                                            float* __restrict__ O, float* __restrict__ P) {
+                                                            float* __restrict__ O, float* __restrict__ P, int64_t ldk, int hoffk) {
+  // ldk / hoffk: row stride and per-head offset of K and V -- (8 d, d) for per-head projections, (d, 0) when every head attends
+  // the SAME key / value rows (merged heads: keys = LN_k(x), values = LN_v(x), model.hip)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int head = lane >> 3, sub = lane & 7;
   const int nchunk = d / 64;
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
   const int64_t pad_base = (int64_t)row_off[B] * hd + (int64_t)head * d;
+  const int64_t pad_base_k = (int64_t)row_off[B] * ldk + (int64_t)head * hoffk;
   if (blockIdx.x == 0 && wave == 0) {
     // the padding token's query is never evaluated, but its O row is a contraction row of the fc1 weight gradient (times a zero
     // gradient): it must be finite, so zero it (the workspace is not initialised)
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const float* __re
     const int n_pad = L - k;
     const float padf = (float)n_pad;
     const int64_t base = (int64_t)t0 * hd + (int64_t)head * d;
+    const int64_t base_k = (int64_t)t0 * ldk + (int64_t)head * hoffk;
     float S[kMaxL][kMaxL], Sp[kMaxL];
 #pragma unroll
     for (int i = 0; i < kMaxL; ++i) {
@@ -82,8 +86,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const float* __re
       const int foff = c * 64 + sub * 8;
       C8 kk[kMaxL], kp;
 #pragma unroll
-      for (int j = 0; j < kMaxL; ++j) kk[j] = ld8(K + base + (int64_t)(j < k ? j : 0) * hd + foff);
-      kp = ld8(K + pad_base + foff);
+      for (int j = 0; j < kMaxL; ++j) kk[j] = ld8(K + base_k + (int64_t)(j < k ? j : 0) * ldk + foff);
+      kp = ld8(K + pad_base_k + foff);
 #pragma unroll
       for (int i = 0; i < kMaxL; ++i)
         if (i < k) {
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const float* __re
       const int foff = c * 64 + sub * 8;
       C8 v[kMaxL], vp;
 #pragma unroll
-      for (int j = 0; j < kMaxL; ++j) v[j] = ld8(V + base + (int64_t)(j < k ? j : 0) * hd + foff);
-      vp = ld8(V + pad_base + foff);
+      for (int j = 0; j < kMaxL; ++j) v[j] = ld8(V + base_k + (int64_t)(j < k ? j : 0) * ldk + foff);
+      vp = ld8(V + pad_base_k + foff);
 #pragma unroll
       for (int i = 0; i < kMaxL; ++i)
         if (i < k) {
@@ -160,13 +164,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, c
                                                             const float* __restrict__ P, const float* __restrict__ dO,
                                                             const int32_t* __restrict__ row_off, int64_t B, int L, int d, float inv_temp,
                                                             float* dQ, float* dK, float* dV,
-                                                            float* __restrict__ slab) {
+                                                            float* __restrict__ slab, int64_t ldk, int hoffk) {
   extern __shared__ float lds[];                 // [4 waves][2][8d] padding-token partial sums | [4 waves][8 heads][kMaxL * kMaxL] probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int head = lane >> 3, sub = lane & 7;
   const int nchunk = d / 64;
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
   const int64_t pad_base = (int64_t)row_off[B] * hd + (int64_t)head * d;
+  const int64_t pad_base_k = (int64_t)row_off[B] * ldk + (int64_t)head * hoffk;     // K / V reads (dK / dV are always written per head)
+  (void)pad_base;
   float* padacc = lds + (int64_t)wave * 2 * hd;   // this wave's {dK_pad, dV_pad}; lane (head, sub) owns its 8 features of every chunk
   float* pm = lds + 4 * 2 * hd + (wave * MATCHA_N_HEAD + head) * (kMaxL * kMaxL);
   for (int c = 0; c < nchunk; ++c) {
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, c
     const int n_pad = L - k;
     const float padf = (float)n_pad;
     const int64_t base = (int64_t)t0 * hd + (int64_t)head * d;
+    const int64_t base_k = (int64_t)t0 * ldk + (int64_t)head * hoffk;
     const float* pp = P + ((b * MATCHA_N_HEAD + head) * L) * L;
     // probabilities of this (hyperedge, head) -> LDS: pm[i * kMaxL + j] = P_ij (0 outside the k x k block); one lane per row
     float Pp[kMaxL];
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, c
       const int foff = c * 64 + sub * 8;
       C8 v[kMaxL], vp;
 #pragma unroll
-      for (int j = 0; j < kMaxL; ++j) v[j] = ld8(V + base + (int64_t)(j < k ? j : 0) * hd + foff);
-      vp = ld8(V + pad_base + foff);
+      for (int j = 0; j < kMaxL; ++j) v[j] = ld8(V + base_k + (int64_t)(j < k ? j : 0) * ldk + foff);
+      vp = ld8(V + pad_base_k + foff);
 #pragma unroll
       for (int i = 0; i < kMaxL; ++i)
         if (i < k) {
@@ -237,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, c
       {   // dQ_i = sum_j dS_ij K_j + n_pad dSp_i K_pad: K rows held
         C8 kk[kMaxL], kp;
 #pragma unroll
-        for (int j = 0; j < kMaxL; ++j) kk[j] = ld8(K + base + (int64_t)(j < k ? j : 0) * hd + foff);
-        kp = ld8(K + pad_base + foff);
+        for (int j = 0; j < kMaxL; ++j) kk[j] = ld8(K + base_k + (int64_t)(j < k ? j : 0) * ldk + foff);
+        kp = ld8(K + pad_base_k + foff);
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i)
           if (i < k) {
@@ -309,9 +316,11 @@ int attn_wide_width(int L) { return L <= 2 ? 2 : (L <= 6 ? L : 8); }
 bool attn_wide_eligible(int d) { return d >= 128 && d % 64 == 0 && !options().disable_wide_gemm; }
 
 int launch_attn_fwd_wide(const float* Q, const float* K, const float* V, const int32_t* row_off, int64_t B, int L, int d, float inv_temp, float* O,
-                         float* P, int nblk, hipStream_t st) {
+                         float* P, int nblk, hipStream_t st, bool shared_kv) {
   dim3 grid((unsigned)nblk);
-#define FWD_W(ML) hipLaunchKernelGGL((attn_fwd_wide_kernel<ML>), grid, dim3(256), 0, st, Q, K, V, row_off, B, L, d, inv_temp, O, P)
+  const int64_t ldk = shared_kv ? d : (int64_t)MATCHA_N_HEAD * d;
+  const int hoffk = shared_kv ? 0 : d;
+#define FWD_W(ML) hipLaunchKernelGGL((attn_fwd_wide_kernel<ML>), grid, dim3(256), 0, st, Q, K, V, row_off, B, L, d, inv_temp, O, P, ldk, hoffk)
   switch (attn_wide_width(L)) {
     case 2: FWD_W(2); break;
     case 3: FWD_W(3); break;
@@ -326,15 +335,17 @@ int launch_attn_fwd_wide(const float* Q, const float* K, const float* V, const i
 }
 
 int launch_attn_bwd_wide(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
-                         int d, float inv_temp, float* dQ, float* dK, float* dV, float* slab, int nblk, hipStream_t st) {
+                         int d, float inv_temp, float* dQ, float* dK, float* dV, float* slab, int nblk, hipStream_t st, bool shared_kv) {
   dim3 grid((unsigned)nblk);
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
+  const int64_t ldk = shared_kv ? d : hd;
+  const int hoffk = shared_kv ? 0 : d;
   const int ml = attn_wide_width(L);
   const size_t lds = ((size_t)4 * 2 * hd + (size_t)4 * MATCHA_N_HEAD * ml * ml) * sizeof(float);
 #define BWD_W(ML)                                                                                                         \
   do {                                                                                                                    \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wide_kernel<ML>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((attn_bwd_wide_kernel<ML>), grid, dim3(256), lds, st, Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab); \
+    hipLaunchKernelGGL((attn_bwd_wide_kernel<ML>), grid, dim3(256), lds, st, Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, ldk, hoffk); \
   } while (0)
   switch (ml) {
     case 2: BWD_W(2); break;

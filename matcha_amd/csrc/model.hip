@@ -66,6 +66,7 @@ struct Workspace {
   float* gemm_ws;   size_t gemm_ws_bytes; // TN GEMM slabs
   void* adj_ws;     size_t adj_ws_bytes;
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
+  float* lwB; float* lwM; float* lwdB; float* lwdM;   // embed_dim >= 128, merged heads: B_all [8d, d], M_all [d, 8d] and their gradients
   float* merged;                          // merged per-head matrices B_h = W'k^T W'q, M_h = Wfc1_h W'v (two products per head instead of four)
   float* frag;                            // the same weights + fc1 / pff_n1 blocks in MFMA-fragment order (fused_fwd32.hip streams them from L2)
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
@@ -111,6 +112,11 @@ Options& options() {
   }();
   return o;
 }
+// embed_dim >= 128: the layer-by-layer path with merged heads -- r = qin B_all^T (one projection instead of three), every head attends the
+// SAME key / value rows kin = LN_k(x), vin = LN_v(x) ([T, d], not [T, 8d]), dyn = Z M_all^T with M_all[:, h] = Wfc1_h W_v[h]; the
+// backward computes dB_all, dM_all and applies the chain rule per head (merged_chain).  Shapes the wide attention kernels take.
+static bool merged_layerwise_shape(const matcha_shape& s) { return s.d >= 128 && s.d % 64 == 0; }
+static bool merged_layerwise(const matcha_shape& s) { return merged_layerwise_shape(s) && attn_wide_eligible(s.d) && !options().disable_merged; }
 static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && !options().disable_fused; }
 static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && !options().disable_fused_train; }
 static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
@@ -136,6 +142,38 @@ static int ws_state(const void* ws) {
 static bool qkv_saved(const void* ws) { return (ws_state(ws) & 1) != 0; }
 static bool fwd_ran_halves(const void* ws) { return (ws_state(ws) & 2) != 0; }
 static bool fwd_ran_merged(const void* ws) { return (ws_state(ws) & 4) != 0; }
+
+// B_all[h d + a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b];   M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]   (16 small GEMMs)
+static int merged_weights(const matcha_shape& s, const matcha_tensors& p, Workspace& w, hipStream_t st) {
+  const int64_t d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
+  for (int h = 0; h < MATCHA_N_HEAD; ++h) {
+    MATCHA_TRY(launch_gemm_tn(p.w_k + h * d * d, p.w_q + h * d * d, w.lwB + h * d * d, nullptr, d, d, d, d, d, nullptr, false, w.gemm_ws, w.gemm_ws_bytes, st));
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = p.fc1_w + h * d; g.B[0] = p.w_v + h * d * d; g.C[0] = w.lwM + h * d; g.batch = 1;
+    g.M = d; g.N = d; g.K = d; g.lda = hd; g.ldb = d; g.ldc = hd; g.aux_scale = 1.f;
+    MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
+  return MATCHA_OK;
+}
+// chain rule from dB_all, dM_all to the projections (accumulating):  dW_q[h] += W_k[h] dB_h;  dW_k[h] += W_q[h] dB_h^T;
+//   dWfc1[:, h] += dM_h W_v[h]^T;  dW_v[h] += Wfc1[:, h]^T dM_h
+static int merged_chain(const matcha_shape& s, const matcha_tensors& p, matcha_tensors& g_, Workspace& w, hipStream_t st) {
+  const int64_t d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
+  for (int h = 0; h < MATCHA_N_HEAD; ++h) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.batch = 1; g.M = d; g.N = d; g.K = d; g.aux_scale = 1.f; g.flags = MATCHA_EPI_ACCUM;
+    g.A[0] = p.w_k + h * d * d; g.B[0] = w.lwdB + h * d * d; g.C[0] = g_.w_q + h * d * d; g.lda = d; g.ldb = d; g.ldc = d;
+    MATCHA_TRY(launch_gemm_rm(true, g, st));                                   // NN: [m][a] x [a][b]
+    g.A[0] = p.w_q + h * d * d; g.B[0] = w.lwdB + h * d * d; g.C[0] = g_.w_k + h * d * d;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));                                  // NT: [m][b] x ([a][b])^T
+    g.A[0] = w.lwdM + h * d; g.B[0] = p.w_v + h * d * d; g.C[0] = g_.fc1_w + h * d; g.lda = hd; g.ldb = d; g.ldc = hd;
+    MATCHA_TRY(launch_gemm_rm(false, g, st));                                  // NT: [n][b] x ([m][b])^T
+    MATCHA_TRY(launch_gemm_tn(p.fc1_w + h * d, w.lwdM + h * d, g_.w_v + h * d * d, nullptr, d, d, d, hd, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
+  }
+  return MATCHA_OK;
+}
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
 // x0, X, the adj front end's buffers, the folded weights and the per-row outputs exist; everything else has size 0.
@@ -195,6 +233,11 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.folded = take_always(s.d == 64 ? fused_fold_floats() : 0);
   w.frag = take_always(s.d == 64 ? fused_frag_floats() : 0);
   w.merged = take_always(s.d == 64 ? fused_merged_floats() : 0);
+  {
+    const size_t nm = merged_layerwise_shape(s) ? (size_t)hd * d : 0;
+    w.lwB = take_always(nm); w.lwM = take_always(nm);
+    w.lwdB = take(nm); w.lwdM = take(nm);
+  }
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tpart = take(s.d == 64 ? fused_tail_partial_floats() : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
@@ -408,7 +451,13 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   nan_check("X", w.X, cnt, 0, d, st);
   // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
   MATCHA_TRY(launch_ln3_fwd(w.X, Tn, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st, cnt));
-  {
+  const bool mlw = merged_layerwise(s);
+  note_qkv_saved(ws, false, false, mlw);             // the backward pass on this workspace must use the same formulation
+  if (mlw) {
+    MATCHA_TRY(merged_weights(s, p, w, st));
+    GemmArgs g = gemm1(w, w.qin, w.lwB, w.Q, Tn, hd, d, false);                 // r = qin B_all^T  (in Q's buffer)
+    MATCHA_TRY(launch_gemm_rm(false, g, st));
+  } else {
     GemmArgs g = gemm1(w, w.qin, p.w_q, w.Q, Tn, hd, d, false);
     g.A[1] = w.kin; g.B[1] = p.w_k; g.C[1] = w.K;
     g.A[2] = w.vin; g.B[2] = p.w_v; g.C[2] = w.V;
@@ -419,11 +468,12 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   nan_check("Q", w.Q, cnt, 0, hd, st);
   nan_check("K", w.K, cnt, 0, hd, st);
   nan_check("V", w.V, cnt, 0, hd, st);
-  MATCHA_TRY(launch_attn_fwd(w.Q, w.K, w.V, w.rg.row_off, B, L, d, w.O, w.P, st));
+  if (mlw) MATCHA_TRY(launch_attn_fwd(w.Q, w.kin, w.vin, w.rg.row_off, B, L, d, w.O, w.P, st, true));     // O = Z = P . vin per head
+  else MATCHA_TRY(launch_attn_fwd(w.Q, w.K, w.V, w.rg.row_off, B, L, d, w.O, w.P, st));
   nan_check("O", w.O, cnt + 1, 0, hd, st);
   // Y = (dropout(fc1(O))) * non_pad_mask    (Modules.py:572, :614); the mask only zeroes the shared padding token's row
   {
-    GemmArgs g = gemm1(w, w.O, p.fc1_w, w.Y, Tn, d, hd, false);
+    GemmArgs g = gemm1(w, w.O, mlw ? w.lwM : p.fc1_w, w.Y, Tn, d, hd, false);
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_ROWMASK; g.bias[0] = p.fc1_b; g.row_ids = ids;
     if (train && opts->p_drop_fc1 > 0.f) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
     MATCHA_TRY(launch_gemm_rm(false, g, st));
@@ -580,6 +630,29 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       return MATCHA_OK;
     }
   } else {
+  if (fwd_ran_merged(ws)) {
+    // merged heads: dM_all = ddyn0^T Z ; d fc1_b += colsum ; dZ = ddyn0 M_all   (the scratch gradients start from zero: the TN GEMM
+    // accumulates C and the column sums alike, and fc1_b's gradient must accumulate)
+    if (hipMemsetAsync(w.lwdM, 0, (size_t)hd * d * sizeof(float), st) != hipSuccess || hipMemsetAsync(w.lwdB, 0, (size_t)hd * d * sizeof(float), st) != hipSuccess) {
+      set_error("matcha_backward: memset failed"); return MATCHA_EHIP;
+    }
+    MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, w.lwdM, g_.fc1_b, d, hd, Tn, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
+    {
+      GemmArgs g = gemm1(w, w.ddyn0, w.lwM, w.dO, Tn, hd, d, true);
+      MATCHA_TRY(launch_gemm_rm(true, g, st));
+    }
+    // attention backward on the shared key / value rows: dR in K's (unused) buffer, dK / dV per head in Q's and V's buffers
+    MATCHA_TRY(launch_attn_bwd(w.Q, w.kin, w.vin, w.P, w.dO, w.rg.row_off, B, L, d, w.dQ, w.dK, w.dV, w.slab, st, true));
+    MATCHA_TRY(launch_head_sum(w.dK, Tn, d, w.dkin, st, cnt));        // d kin = sum over the heads (kin itself is dead now)
+    MATCHA_TRY(launch_head_sum(w.dV, Tn, d, w.dvin, st, cnt));
+    // dB_all = dR^T qin ; dqin = dR B_all ; then the chain rule to w_qs / w_ks / w_vs / fc1
+    MATCHA_TRY(launch_gemm_tn(w.dQ, w.qin, w.lwdB, nullptr, hd, d, Tn, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
+    {
+      GemmArgs g = gemm1(w, w.dQ, w.lwB, w.dqin, Tn, d, hd, true);
+      MATCHA_TRY(launch_gemm_rm(true, g, st));
+    }
+    MATCHA_TRY(merged_chain(s, p, g_, w, st));
+  } else {
   // fc1: dW += ddyn0^T O ; db += colsum ; dO = ddyn0 Wfc1
   MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, g_.fc1_w, g_.fc1_b, d, hd, Tn, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   {
@@ -597,6 +670,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     g.A[2] = w.dV; g.B[2] = p.w_v; g.C[2] = w.dvin;
     g.batch = 3;
     MATCHA_TRY(launch_gemm_rm(true, g, st));
+  }
   }
   // LayerNorm x3 backward + static-branch gradient + tanh'
   MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, Tn, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
