@@ -184,26 +184,26 @@ struct FrontFwdArgs {
   float* x0; float* X;
 };
 
-__global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
+__global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Ws = lds;                                // next_w [n][k], resident
-  float* Es = lds + kTile;                        // node rows, then x0 in place
-  float* Was = lds + 2 * kTile;                   // attribute_nn.weight [64][kLdA] (columns >= n_attr zero), resident
-  float* As = Was + 64 * kLdA;                    // attribute rows [64][kLdA]
+  // The two weight matrices live in REGISTERS as MFMA operand fragments (32 + 16 per lane) instead of LDS tiles: 44 KB of LDS per
+  // workgroup instead of 70, i.e. three workgroups per CU gathering rows -- this kernel is a gather, bytes in flight are what it needs
+  float* Es = lds;                                // node rows, then x0 in place
+  float* As = lds + kTile;                        // attribute rows [64][kLdA]
   float* Xs = As + 64 * kLdA;                     // X tile on its way out
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
   const int T = g.count[0];
   const int ntiles = (T + 63) / 64;
+  float4 wn[8], wa[kAttrCols / 8];                // B fragments: next_w[32 wc + r][8 c + 4 h ..], attribute_nn.weight[32 wc + r][8 c + 4 h ..]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    *reinterpret_cast<float4*>(&Ws[(srow + 16 * i) * kLd + sc4]) = *reinterpret_cast<const float4*>(g.Wn + (srow + 16 * i) * 64 + sc4);
-  for (int i = tid; i < 64 * (kAttrCols / 4); i += 256) {
-    const int row = i >> 3, q = (i & 7) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < g.n_attr) v = *reinterpret_cast<const float4*>(g.Wa + row * g.n_attr + q);
-    *reinterpret_cast<float4*>(&Was[row * kLdA + q]) = v;
+  for (int c = 0; c < 8; ++c) wn[c] = *reinterpret_cast<const float4*>(g.Wn + (32 * wc + r) * 64 + 8 * c + 4 * h);
+#pragma unroll
+  for (int c = 0; c < kAttrCols / 8; ++c) {
+    const int q = 8 * c + 4 * h;
+    wa[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < g.n_attr) wa[c] = *reinterpret_cast<const float4*>(g.Wa + (32 * wc + r) * g.n_attr + q);
   }
   const int col = 32 * wc + r;
   const float bav = g.ba[col], bnv = g.bn[col];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
       for (int c = 0; c < kAttrCols / 8; ++c) {
         const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLdA + 8 * c + 4 * h]);
-        const float4 b = *reinterpret_cast<const float4*>(&Was[(32 * wc + r) * kLdA + 8 * c + 4 * h]);
+        const float4 b = wa[c];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float4 a = *reinterpret_cast<const float4*>(&Es[(32 * wr + r) * kLd + 8 * c + 4 * h]);
-        const float4 b = *reinterpret_cast<const float4*>(&Ws[(32 * wc + r) * kLd + 8 * c + 4 * h]);
+        const float4 b = wn[c];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
@@ -386,10 +386,10 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   FrontFwdArgs g;
   g.ids = ids; g.table = table; g.dense = dense; g.attr_table = attr_table; g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
-  int grid = front_grid();
+  int grid = front_grid() / 2 * 3;                      // three workgroups per CU (44 KB of LDS each)
   const int64_t max_tiles = cdiv(tcap, 64);
   if (grid > max_tiles) grid = (int)max_tiles;
-  const size_t lds = ((size_t)3 * kTile + 2 * 64 * kLdA) * sizeof(float);
+  const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
   // (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
   ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + (x0 ? 512.0 : 256.0)), st);

@@ -18,4 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$
 # BASELINE configs[3] (hg38 100 kb, d = 128) and configs[4] (C5: 1 M nodes, d = 256): kernel stats of the same step
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_d128_stats -- python $R/bench.py --steps 3 --warmup 2 --prof none --no-cpu-baseline --no-extras --layout hg38_100kb --dim 128 > $R/gpurun_out/${TAG}_d128.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_c5_stats -- python $R/bench.py --steps 3 --warmup 2 --prof none --no-cpu-baseline --no-extras --layout c5 --dim 256 --ks 2,3,4,5,6,7,8 --rows 16384 --edges 10000000 > $R/gpurun_out/${TAG}_c5.log 2>&1
-echo "collected gather/d128/c5 $TAG"
+# the gather the model step executes, on HBM-resident tables (bench.py roofline_gather_in_step): kernel stats + the HBM-read pass
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_front_stats -- python $R/tools/debug/front_gather.py > $R/gpurun_out/${TAG}_front.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_front_fetch -- python $R/tools/debug/front_gather.py > /dev/null 2>&1
+echo "collected gather/d128/c5/front $TAG"
