@@ -745,19 +745,19 @@ __global__ __launch_bounds__(512) void tail_slab_reduce_kernel(TailReduceArgs a)
   int nt = a.count[a.count_idx];                       // tiles (or half tiles) planned by ragged.hip: every one of them wrote its slab
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
   const int lo = (int)((int64_t)nt * sp / kTailSplits), hi = (int)((int64_t)nt * (sp + 1) / kTailSplits);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0, s6 = s0, s7 = s0;
+#define TSR_ADD(S, V) do { S.x += V.x; S.y += V.y; S.z += V.z; S.w += V.w; } while (0)
   if (c4 < kTailF4) {
     const float4* base = reinterpret_cast<const float4*>(a.tslab) + c4;
     int t = lo + wave;
-    for (; t + 24 < hi; t += 32) {
+    for (; t + 56 < hi; t += 64) {                     // eight independent 1 KB rows in flight per wavefront (64 KB per CU)
       const float4 v0 = base[(int64_t)t * kTailF4], v1 = base[(int64_t)(t + 8) * kTailF4], v2 = base[(int64_t)(t + 16) * kTailF4], v3 = base[(int64_t)(t + 24) * kTailF4];
-      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-      s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
-      s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+      const float4 v4 = base[(int64_t)(t + 32) * kTailF4], v5 = base[(int64_t)(t + 40) * kTailF4], v6 = base[(int64_t)(t + 48) * kTailF4], v7 = base[(int64_t)(t + 56) * kTailF4];
+      TSR_ADD(s0, v0); TSR_ADD(s1, v1); TSR_ADD(s2, v2); TSR_ADD(s3, v3); TSR_ADD(s4, v4); TSR_ADD(s5, v5); TSR_ADD(s6, v6); TSR_ADD(s7, v7);
     }
-    for (; t < hi; t += 8) { const float4 v = base[(int64_t)t * kTailF4]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
+    for (; t < hi; t += 8) { const float4 v = base[(int64_t)t * kTailF4]; TSR_ADD(s0, v); }
   }
+  TSR_ADD(s0, s4); TSR_ADD(s1, s5); TSR_ADD(s2, s6); TSR_ADD(s3, s7);
   part[wave][lane] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
   __syncthreads();
   if (wave == 0 && c4 < kTailF4) {

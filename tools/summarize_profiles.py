@@ -173,3 +173,33 @@ if grows and glob.glob(f"gpurun_out/{tag}_gather_fetch/*/*_counter_collection.cs
                "cases": res}, open(f"profiles/{rnd}_gather_pmc.json", "w"), indent=1)
     for r in res:
         print(r["table"], "fetch/alg", r["fetch_over_algorithmic_read"], "write/alg", r["write_over_algorithmic_write"])
+
+
+# ---- the gather the model step executes on HBM-resident tables (tools/debug/front_gather.py = bench.py roofline_gather_in_step) ----
+frows = stats_md("front_stats", f"profiles/{rnd}_gather_in_step_kernel_stats.md", f"rocprofv3 --kernel-trace --stats of the in-step gather on HBM-resident tables ({rnd})",
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/debug/front_gather.py  (front_fwd_kernel: d = 64, 16 M x 64 table, "
+                 "327 681 tokens per launch; embed_fwd_kernel<4>: d = 256, C5 table 1 M x 256, 131 073 tokens per launch)", n=8)
+ff = glob.glob(f"gpurun_out/{tag}_front_fetch/*/*_counter_collection.csv")
+if frows and ff:
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(ff[0])):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            for key in ("front_fwd_kernel", "embed_fwd_kernel"):
+                if key in r["Kernel_Name"]:
+                    acc[key].append(float(r["Counter_Value"]) * 1024 * 2)
+    cases = {"front_fwd_kernel": ("front_fwd (d = 64) on a 16 M x 64 table (4 GiB)", 327681, 8 + 256 + 4 * 24),
+             "embed_fwd_kernel": ("embed_fwd (d = 256) on the C5 table 1 M x 256 (1 GiB)", 131073, 8 + 1024 + 4 * 21)}
+    res = []
+    for key, vals in acc.items():
+        name, tokens, rb = cases[key]
+        vals = vals[2:]                                   # two warm-up forwards
+        avg = sum(vals) / max(len(vals), 1)
+        us = [float(r["AverageNs"]) / 1e3 for r in frows if key in r["Name"]]
+        res.append({"kernel": key, "table": name, "tokens_per_launch": tokens, "algorithmic_read_bytes_per_token": rb, "pmc_fetch_bytes_per_launch": avg,
+                    "fetch_over_algorithmic_read": round(avg / (tokens * rb), 3), "rocprof_avg_us": round(us[0], 1) if us else None,
+                    "frac_of_8tbs_read_roof": round(tokens * rb / us[0] / 1e3 / 8000.0, 4) if us else None})
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE pass of tools/debug/front_gather.py (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); uniform random ids, "
+                       "inference forwards; the kernels also write 4 d bytes per token (X / x0 rows)", "cases": res},
+              open(f"profiles/{rnd}_gather_in_step_pmc.json", "w"), indent=1)
+    for r in res:
+        print(r["kernel"], "fetch/alg", r["fetch_over_algorithmic_read"], "frac", r["frac_of_8tbs_read_roof"])
