@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU)")
     ap.add_argument("--table-exchange", choices=["auto", "dense", "sparse"], default="auto")
     ap.add_argument("--deterministic", action="store_true", help="sorted (bitwise reproducible) embedding backward instead of float atomics")
+    ap.add_argument("--zipf", action="store_true", help="layout c5: node ids of the known hyperedges drawn Zipf(1.0) instead of uniform (cached regime, SURVEY §8 d2)")
     return ap.parse_args()
 
 
@@ -147,7 +148,7 @@ class Dist:
 
 
 def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof="auto", graph=False, edges_per_k=100000, edges=0,
-                 table_exchange="auto", model_only=True, deterministic=False):
+                 table_exchange="auto", model_only=True, deterministic=False, zipf=False):
     """Build the workload on the device, run `warmup` untimed + `steps` timed steps, return the measurements."""
     from matcha_amd.engine import Trainer
     from matcha_amd.sampler import HyperedgeSet, NegativeSampler
@@ -166,7 +167,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
         # BASELINE configs[4]: 1 M nodes, k uniform in {2..8}; the known set is built on the device and this
         # rank's shard is kept as int32 CSR; the positives of a step are expanded to the int64 rows the sampler / model take
         n_edges = edges or 100_000_000
-        pool_all = synth.make_edges_device(N, n_edges, ks=tuple(ks), seed=5, device=device)
+        pool_all = synth.make_edges_device(N, n_edges, ks=tuple(ks), seed=5, device=device, zipf=zipf)
         csr_off, csr_ids = synth.edges_to_csr(pool_all, rank, world)
         M_shard = csr_off.numel() - 1
         g = torch.Generator(device=device)
@@ -488,7 +489,7 @@ def main():
 
     m = run_workload(dist, layout=args.layout, dim=args.dim, ks=ks, rows=args.rows, front_end=args.front_end, steps=args.steps,
                      warmup=args.warmup, prof=args.prof, graph=args.graph, edges_per_k=args.edges_per_k, edges=args.edges,
-                     table_exchange=args.table_exchange, deterministic=args.deterministic)
+                     table_exchange=args.table_exchange, deterministic=args.deterministic, zipf=args.zipf)
     B, P, L, N = m["B"], m["P"], m["L"], m["N"]
     elapsed = m["elapsed"]
     result = {
@@ -530,7 +531,10 @@ def main():
                             ("reference_batch_384_rows_hipgraph", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="table", graph=True)),
                             ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table")),
                             ("configs4_c5_1M_nodes_d256", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=16384, front_end="table",
-                                                                edges=10_000_000))):
+                                                                edges=10_000_000)),
+                            # the same with Zipf(1.0) node ids: the cached regime of the gather and the contended one of the scatter
+                            ("configs4_c5_zipf_ids", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=16384, front_end="table",
+                                                           edges=10_000_000, zipf=True))):
                 e = run_workload(dist, steps=8, warmup=3, prof="none", model_only=False, **kw)
                 extras[key] = {"hyperedges_per_s": round(e["B"] * 8 / e["elapsed"], 1), "ms_per_step": round(e["elapsed"] / 8 * 1e3, 4),
                                "rows_per_step": e["B"], "known_hyperedges": e["known_edges"], "steps": 8,

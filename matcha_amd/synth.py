@@ -189,12 +189,14 @@ def make_batch(rng: np.random.Generator, n_nodes: int, ks: List[int], rows_per_k
 # BASELINE.json configs[4] ("C5"): 1 M nodes, up to 100 M hyperedges with k uniform in {2..8}, built ON THE DEVICE
 # (node ids uniform -- the worst case for caches --, int32 CSR shards per rank).
 # ------------------------------------------------------------------------------------------------------------------
-def make_edges_device(n_nodes: int, n_edges: int, ks=(2, 3, 4, 5, 6, 7, 8), seed: int = 5, device="cuda", chunk: int = 1 << 24):
+def make_edges_device(n_nodes: int, n_edges: int, ks=(2, 3, 4, 5, 6, 7, 8), seed: int = 5, device="cuda", chunk: int = 1 << 24, zipf: bool = False):
     """int64 [n_edges, max(ks)] zero-padded rows on ``device``: k uniform over ``ks``, the k nodes a uniform k-subset of
     1..n_nodes in ascending order.  Built without rejection: k sorted draws u_0 <= ... <= u_{k-1} from [0, n_nodes - k] plus
     their rank i are strictly ascending and uniform over the k-subsets (the classic bijection between k-multisets of
     [0, n - k] and k-subsets of [0, n - 1]).  Duplicate ROWS are possible (k = 2: ~1e-4 of 100 M rows at 1 M nodes) and
-    harmless: the hash set keeps one copy.  Generated in chunks so that the sort's scratch stays small."""
+    harmless: the hash set keeps one copy.  Generated in chunks so that the sort's scratch stays small.
+    ``zipf``: node ids drawn with P(id) ~ 1 / id (Zipf(1.0), SURVEY.md §8 d2's optional cached-regime run: id = floor((N + 1)^u)),
+    made distinct inside a row by pushing equal neighbours up by one."""
     import torch
     L = max(ks)
     g = torch.Generator(device=device)
@@ -205,6 +207,18 @@ def make_edges_device(n_nodes: int, n_edges: int, ks=(2, 3, 4, 5, 6, 7, 8), seed
     for lo in range(0, n_edges, chunk):
         m = min(chunk, n_edges - lo)
         k = ks_t[torch.randint(len(ks), (m,), generator=g, device=device)].view(m, 1)
+        if zipf:
+            import math
+            r = torch.rand((m, L), generator=g, device=device, dtype=torch.float64)
+            ids = torch.exp(r * math.log(n_nodes + 1.0)).long().clamp_(1, n_nodes)
+            ids = torch.where(col < k, ids, torch.full_like(ids, n_nodes + 2 * L))
+            ids, _ = torch.sort(ids, dim=1)
+            for c in range(1, L):                        # strictly ascending: equal neighbours move up by one
+                ids[:, c] = torch.maximum(ids[:, c], ids[:, c - 1] + 1)
+            over = (torch.where(col < k, ids, torch.zeros_like(ids)).amax(1, keepdim=True) - n_nodes).clamp_(min=0)
+            ids = ids - over                             # a row pushed past n_nodes slides back down (still ascending, >= 1 for n_nodes >> L)
+            out[lo:lo + m] = torch.where(col < k, ids.clamp_(min=1), torch.zeros_like(ids))
+            continue
         u = (torch.rand((m, L), generator=g, device=device, dtype=torch.float64) * (n_nodes - k + 1).to(torch.float64)).long()
         u = torch.minimum(u, (n_nodes - k).expand(m, L))
         u = torch.where(col < k, u, torch.full_like(u, n_nodes + L))            # unused slots sort to the end
