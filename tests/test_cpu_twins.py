@@ -1,0 +1,81 @@
+"""The `*_cpu` twins of SURVEY.md section 8 b2 (oracle/c/ops_cpu.c, test infrastructure) against numpy / torch on the host: they are the
+plain-C statement of what the byte / index / optimizer entry points of include/matcha_hip.h must compute; the `-m gpu` tests compare the
+HIP kernels with them (tests/test_hip_kernels.py::test_hip_ops_equal_cpu_twins)."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def twins():
+    path = os.path.join(ROOT, "oracle", "_build", "libmatcha_oracle.so")
+    assert os.path.exists(path), "build it with __graft_entry__.build() (make -C oracle/c)"
+    return C.CDLL(path)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_gather_and_scatter_twins_vs_numpy():
+    lib = twins()
+    rng = np.random.default_rng(0)
+    N, d, T = 300, 24, 5000
+    table = rng.standard_normal((N + 1, d)).astype(np.float32)
+    ids = rng.integers(0, N + 1, size=T).astype(np.int64)
+    ids[7], ids[11] = N + 3, -1                                    # out of range: flagged, read as row 0
+    rows = np.zeros((T, d), np.float32)
+    status = np.zeros(4, np.int32)
+    assert lib.matcha_gather_rows_cpu(p(ids), C.c_int64(T), C.c_int32(d), p(table), C.c_int64(N), p(rows), p(status)) == 0
+    ref = table[np.where((ids < 0) | (ids > N), 0, ids)]
+    assert np.array_equal(rows, ref) and status[0] == 1
+    x = rng.integers(0, N + 1, size=T).astype(np.int64)
+    dx0 = rng.standard_normal((T, d)).astype(np.float32)
+    dtab = np.zeros((N + 1, d), np.float32)
+    assert lib.matcha_embed_scatter_bwd_cpu(p(x), C.c_int64(T), C.c_int32(d), p(dx0), p(dtab)) == 0
+    want = torch.zeros(N + 1, d).index_add_(0, torch.from_numpy(x), torch.from_numpy(dx0)).numpy()
+    want[0] = 0
+    assert np.abs(dtab - want).max() <= 1e-5 and float(np.abs(dtab[0]).max()) == 0.0
+
+
+def test_adamw_twin_vs_torch_adamw():
+    """Three tensors as segments of one flat buffer; the second one's group is untouched in step 2 ("grad is None": skipped, its step
+    count does not advance) -- torch.optim.AdamW on the same tensors, main.py:630."""
+    lib = twins()
+    g = torch.Generator().manual_seed(1)
+    sizes = [40, 12, 100]
+    params = [torch.randn(n, generator=g, requires_grad=True) for n in sizes]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    flat = np.concatenate([q.detach().numpy() for q in params]).astype(np.float32)
+    m, v = np.zeros_like(flat), np.zeros_like(flat)
+    seg_off = np.array([0, 40, 52, 152], np.int64)
+    seg_group = np.array([0, 1, 0], np.int32)
+    seg_step = np.zeros(3, np.int32)
+    for step in range(4):
+        grads = [torch.randn(n, generator=g) * 0.1 for n in sizes]
+        skip = step == 2
+        for q, gr, i in zip(params, grads, range(3)):
+            q.grad = None if (skip and i == 1) else gr.clone()
+        opt.step()
+        gflat = np.concatenate([gr.numpy() for gr in grads]).astype(np.float32)
+        touched = np.array([1, 0 if skip else 1], np.int32)
+        assert lib.matcha_adamw_step_cpu(p(flat), p(gflat), p(m), p(v), C.c_int64(len(flat)), p(seg_off), C.c_int32(3), p(seg_group), p(touched),
+                                         p(seg_step), C.c_double(1e-3), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(1e-2),
+                                         C.c_double(1.0)) == 0
+        ref = np.concatenate([q.detach().numpy() for q in params])
+        assert np.abs(flat - ref).max() <= 2e-7, step
+        if skip:
+            assert np.all(gflat[40:52] != 0) and np.all(gflat[:40] == 0)       # only the updated segments had their gradients zeroed
+    assert seg_step.tolist() == [4, 3, 4]
+
+
+def test_hashset_twin():
+    lib = twins()
+    edges = np.array([[1, 5, 0, 0], [2, 3, 9, 0], [4, 6, 7, 8]], np.int64)
+    rows = np.array([[2, 3, 9], [2, 3, 0], [1, 5, 0], [4, 6, 7]], np.int64)
+    out = np.zeros(4, np.uint8)
+    assert lib.matcha_hashset_contains_cpu(p(edges), C.c_int64(3), C.c_int32(4), p(rows), C.c_int64(4), C.c_int32(3), p(out)) == 0
+    assert out.tolist() == [1, 0, 1, 0]                            # a prefix of a wider hyperedge is another hyperedge

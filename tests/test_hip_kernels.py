@@ -376,3 +376,52 @@ def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad):
     hm = ref_half.reshape(-1, 4)[:nh]
     assert hm[:, 1].max() <= 31 and hm[:, 3].sum() == B and hm[:, 1].sum() == Tr
     assert np.array_equal(hm[1:, 0], hm[:-1, 0] + hm[:-1, 1]) and np.array_equal(hm[1:, 2], hm[:-1, 2] + hm[:-1, 3])     # contiguous cover
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_hip_ops_equal_cpu_twins():
+    """the byte / index / optimizer entry points against their plain-C `*_cpu` twins (oracle/c/ops_cpu.c, pinned to
+    numpy / torch.optim.AdamW by tests/test_cpu_twins.py).  Gather: bit-exact.  Scatter-add: float atomics, order-dependent -> 1e-5.
+    AdamW: the same float roundings in both -> <= 1 ulp-level difference (sqrt / division rounding of the device)."""
+    lib, cpu = _lib.load(), _oracle_lib()
+    rng = np.random.default_rng(5)
+    N, d, T = 5000, 64, 40000
+    table = rng.standard_normal((N + 1, d)).astype(np.float32)
+    ids = rng.integers(0, N + 1, size=T).astype(np.int64)
+    rows_cpu = np.zeros((T, d), np.float32)
+    assert cpu.matcha_gather_rows_cpu(_p(ids), C.c_int64(T), C.c_int32(d), _p(table), C.c_int64(N), _p(rows_cpu), None) == 0
+    tab_d, ids_d = torch.from_numpy(table).cuda(), torch.from_numpy(ids).cuda()
+    x0 = torch.empty(T, d, device="cuda")
+    _lib.check(lib.matcha_embed_fwd(_lib.ptr(ids_d), T, d, _lib.ptr(tab_d), None, None, 0, None, None, _lib.ptr(x0), _stream()), "embed_fwd")
+    assert np.array_equal(x0.cpu().numpy(), rows_cpu)
+
+    dx0 = rng.standard_normal((T, d)).astype(np.float32)
+    dtab_cpu = np.zeros((N + 1, d), np.float32)
+    assert cpu.matcha_embed_scatter_bwd_cpu(_p(ids), C.c_int64(T), C.c_int32(d), _p(dx0), _p(dtab_cpu)) == 0
+    dtab = torch.zeros(N + 1, d, device="cuda")
+    _lib.check(lib.matcha_embed_scatter_bwd(_lib.ptr(ids_d), T, d, _lib.ptr(torch.from_numpy(dx0).cuda()), _lib.ptr(dtab), _stream()), "scatter")
+    assert np.abs(dtab.cpu().numpy() - dtab_cpu).max() <= 1e-5 and float(dtab[0].abs().max()) == 0.0
+
+    n = 100_003
+    seg_off = np.array([0, 1000, 1001, 50_000, n], np.int64)
+    seg_group = np.array([0, 1, 1, 2], np.int32)
+    flat = rng.standard_normal(n).astype(np.float32)
+    m, v, step = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(4, np.int32)
+    dev = {k: torch.from_numpy(a.copy()).cuda() for k, a in dict(p=flat, m=m, v=v, step=step, off=seg_off, grp=seg_group).items()}
+    coef = torch.zeros(12, device="cuda")
+    for it in range(5):
+        g = (rng.standard_normal(n) * 0.05).astype(np.float32)
+        touched = np.array([1, it != 2, it != 3], np.int32)
+        g_d, t_d = torch.from_numpy(g.copy()).cuda(), torch.from_numpy(touched).cuda()
+        assert cpu.matcha_adamw_step_cpu(_p(flat), _p(g), _p(m), _p(v), C.c_int64(n), _p(seg_off), C.c_int32(4), _p(seg_group), _p(touched), _p(step),
+                                         C.c_double(1e-3), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(1e-2), C.c_double(0.5)) == 0
+        _lib.check(lib.matcha_adamw_step(_lib.ptr(dev["p"]), _lib.ptr(g_d), _lib.ptr(dev["m"]), _lib.ptr(dev["v"]), n, _lib.ptr(dev["off"]), 4,
+                                         _lib.ptr(dev["grp"]), _lib.ptr(t_d), _lib.ptr(dev["step"]), _lib.ptr(coef), 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.5,
+                                         _stream()), "adamw")
+        assert np.array_equal(g_d.cpu().numpy() == 0, g == 0)                      # the same segments had their gradients consumed
+    assert dev["step"].cpu().numpy().tolist() == step.tolist() == [5, 4, 4, 4]
+    for k, a in (("p", flat), ("m", m), ("v", v)):
+        assert np.abs(dev[k].cpu().numpy() - a).max() <= 3e-7 * max(1.0, np.abs(a).max()), k
