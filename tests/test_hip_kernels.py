@@ -395,8 +395,11 @@ def test_hip_ops_equal_cpu_twins():
     assert cpu.matcha_gather_rows_cpu(_p(ids), C.c_int64(T), C.c_int32(d), _p(table), C.c_int64(N), _p(rows_cpu), None) == 0
     tab_d, ids_d = torch.from_numpy(table).cuda(), torch.from_numpy(ids).cuda()
     x0 = torch.empty(T, d, device="cuda")
-    _lib.check(lib.matcha_embed_fwd(_lib.ptr(ids_d), T, d, _lib.ptr(tab_d), None, None, 0, None, None, _lib.ptr(x0), _stream()), "embed_fwd")
-    assert np.array_equal(x0.cpu().numpy(), rows_cpu)
+    shp, ten, fro, status = _lib.Shape(d, 1, N, 0, 0, 0), _lib.Tensors(), _lib.Frozen(), torch.zeros(4, dtype=torch.int32, device="cuda")
+    ten.table = tab_d.data_ptr()
+    _lib.check(lib.matcha_node_embeddings(C.byref(shp), C.byref(ten), C.byref(fro), _lib.ptr(ids_d), T, _lib.ptr(x0), None, 0, _lib.ptr(status),
+                                          _stream()), "matcha_node_embeddings")                       # table mode -> gather_rows_kernel
+    assert np.array_equal(x0.cpu().numpy(), rows_cpu) and status.tolist()[0] == 0
 
     dx0 = rng.standard_normal((T, d)).astype(np.float32)
     dtab_cpu = np.zeros((N + 1, d), np.float32)
