@@ -31,7 +31,7 @@ constexpr int kFrontSlab = 4096 + 64 * kAttrCols + 128;     // dWn [64][64] | dW
 constexpr float kEps = 1e-5f;
 
 struct FrontBwdArgs {
-  const float* X; const float* dxh; int64_t tcap; const float* dxpad; const float* dXs; const float* x0;
+  const float* X; const float* dxh; int nslab; int64_t tcap; const float* dxpad; const float* dXs; const float* x0;
   const int64_t* ids; const float* attr_table; int n_attr;
   const float* Wn;                                // next_w [64][64] ([out][in])
   const int32_t* count;                           // {Tr + 1, Tr, tiles}
@@ -73,8 +73,7 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
       float4 d;
       if (tc < T - 1) {
         d = *reinterpret_cast<const float4*>(g.dxh + tc * 64 + sc4);
-#pragma unroll
-        for (int hd = 1; hd < MATCHA_N_HEAD; ++hd) {
+        for (int hd = 1; hd < g.nslab; ++hd) {
           const float4 v = *reinterpret_cast<const float4*>(g.dxh + ((int64_t)hd * g.tcap + tc) * 64 + sc4);
           d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
         }
@@ -401,11 +400,11 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
 bool front_bwd_supported(int d, int n_attr) { return d == 64 && n_attr >= 4 && n_attr <= kAttrCols && n_attr % 4 == 0; }
 size_t front_bwd_ws_floats() { return (size_t)1024 * kFrontSlab; }
 
-int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
+int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
                      matcha_tensors& grads, hipStream_t st) {
   FrontBwdArgs g;
-  g.X = X; g.dxh = dxh; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr_table = attr_table; g.n_attr = n_attr;
+  g.X = X; g.dxh = dxh; g.nslab = nslab; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr_table = attr_table; g.n_attr = n_attr;
   g.Wn = p.next_w; g.count = rg.count; g.dX0 = dX0; g.dtable = dtable; g.slab = ws;
   int grid = front_grid();
   const int64_t max_tiles = cdiv(tcap, 64);
@@ -413,8 +412,9 @@ int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, 
   const size_t lds = ((size_t)4 * kTile + 64 * kLdA + 64) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(front_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   {
-    // algorithmic bytes per token: 8 partials + X + dXs + x0 (11 x 256 B), id, attribute row; table mode adds 256 B of atomics
-    ProfScope ps(MATCHA_PROF_FRONT_BWD, (double)tcap * (11.0 * 256.0 + 8.0 + 4.0 * n_attr + 256.0), st);
+    // algorithmic bytes per token: the d x_hat partials (8 per-head slabs, or 1 when the heads were added with atomics) + X + dXs + x0, id,
+    // attribute row; table mode adds 256 B of atomics
+    ProfScope ps(MATCHA_PROF_FRONT_BWD, (double)tcap * ((3.0 + nslab) * 256.0 + 8.0 + 4.0 * n_attr + 256.0), st);
     hipLaunchKernelGGL(front_bwd_kernel, dim3(grid), dim3(256), lds, st, g);
     MATCHA_CHECK_LAUNCH("front_bwd_kernel");
   }

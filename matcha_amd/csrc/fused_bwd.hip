@@ -1190,6 +1190,7 @@ struct FusedBwdMArgs {
   int L; int ntiles; int nchunks;
   const float* mB; const float* mM;               // merged matrices [8][64][64] (launch_merge_heads)
   float* dxh; int64_t tcap;
+  int dx_atomic;                                   // 1: every head adds into ONE [tcap][64] buffer with float atomics (zeroed by the launcher); 0: one slab per head
   float* wslab;                                    // [8][nchunks][kWgSlabM]
   const float* rimg;                               // [ntiles][8][kImgRecM]: r rows (register images) + attention probabilities of the forward
 };
@@ -1233,6 +1234,10 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
   const int tile_lo = chunk * per;
   const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
   const float inv_temp = 0.125f;
+#ifdef FB_TIMING
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+#endif
 
   // ---- resident B_h, the padding token's x_hat ----
   {
@@ -1306,6 +1311,7 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
     const float* Ps = Ps0 + 512 * par;
     const int* tinfo = tinfo0 + 64 * par;
     __syncthreads();                                  // this tile's set is staged; the previous tile's GEMMs are done with Fs / Gs and with the other set
+    FB_T(7);
     // per-lane indices re-derived from an opaque copy of the thread id (see fused_bwd8_kernel: loop-invariant addresses are hoisted and spilled otherwise)
     int tid_ = tid;
     asm volatile("" : "+v"(tid_));
@@ -1334,7 +1340,9 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       *reinterpret_cast<f32x4*>(&Fs[(32 * wr + c16) * kLd + fb + 4 * kq]) = acc0;
       *reinterpret_cast<f32x4*>(&Fs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]) = acc1;
     }
+    FB_T(1);
     __syncthreads();
+    FB_T(7);
     // ---- attention forward + backward in x_hat space: 8 lanes per token, all 64 tokens in one pass ----
     {
       V8 o0, q0, k0, v0;
@@ -1343,7 +1351,9 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       int ia = 0;
       if (acta) { ia = tinfo[la]; attn_row8<ML>(Rs, Xs, Xs, Fs, xpad, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
       __builtin_amdgcn_sched_barrier(0);
+      FB_T(2);
       __syncthreads();
+      FB_T(7);
       if (acta) {
         attn_col8<ML>(Rs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
         k0.a += v0.a; k0.b += v0.b; k0.c += v0.c; k0.d += v0.d;      // the row is key AND value: d x_hat_j = sum_i dS_ij r_i + p_ij dz_i
@@ -1351,17 +1361,45 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       } else {
         ZR8(&Gs[la * kLd + 8 * sub]);
       }
+      FB_T(3);
       __syncthreads();                                // every column phase is done with the r and dZ rows
+      FB_T(7);
       if (acta) {
         st8(&Fs[la * kLd + 8 * sub], o0); st8(&Rs[la * kLd + 8 * sub], q0);
       } else {
         ZR8(&Rs[la * kLd + 8 * sub]);
       }
     }
+    FB_T(4);
     __syncthreads();
+    FB_T(7);
     FB8_ROWS_GLOAD(mn);                               // next tile's rows: in flight during the GEMMs below
-    // ---- this head's share of d x_hat^T = B_h^T dR^T + Gs^T: 4 steps of 16 contraction indices ----
-    {
+    // ---- this head's share of d x_hat = dR B_h + Gs: 4 steps of 16 contraction indices ----
+    if (g.dx_atomic) {
+      // rows = tokens 4 kq + reg (+ 16), columns = features fb + c16: one atomic instruction covers 4 token rows x 64 contiguous bytes.  The
+      // eight heads of a chunk run on the same XCD at about the same time: the adds meet in that L2, and d x_hat leaves it once
+      const float* gp = Gs + (32 * wr + 4 * kq) * kLd + fb + c16;
+      f32x4 dx0 = {gp[0], gp[kLd], gp[2 * kLd], gp[3 * kLd]};
+      f32x4 dx1 = {gp[16 * kLd], gp[17 * kLd], gp[18 * kLd], gp[19 * kLd]};
+      const float* arow = Rs + (32 * wr + c16) * kLd + 4 * kq;
+      const float* wcol = Wb + (4 * kq) * kLd + fb + c16;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
+        const float* wp = wcol + (16 * c) * kLd;
+        const float w0 = wp[0], w1 = wp[kLd], w2 = wp[2 * kLd], w3 = wp[3 * kLd];
+        dx0 = MFMA16(a0.x, w0, dx0); dx1 = MFMA16(a1.x, w0, dx1);
+        dx0 = MFMA16(a0.y, w1, dx0); dx1 = MFMA16(a1.y, w1, dx1);
+        dx0 = MFMA16(a0.z, w2, dx0); dx1 = MFMA16(a1.z, w2, dx1);
+        dx0 = MFMA16(a0.w, w3, dx0); dx1 = MFMA16(a1.w, w3, dx1);
+      }
+      float* out = g.dxh + ((int64_t)t0 + 32 * wr + 4 * kq) * 64 + fb + c16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        if (32 * wr + 4 * kq + reg < n_real) unsafeAtomicAdd(out + reg * 64, dx0[reg]);
+        if (32 * wr + 16 + 4 * kq + reg < n_real) unsafeAtomicAdd(out + (16 + reg) * 64, dx1[reg]);
+      }
+    } else {
       f32x4 dx0 = *reinterpret_cast<const f32x4*>(&Gs[(32 * wr + c16) * kLd + fb + 4 * kq]);
       f32x4 dx1 = *reinterpret_cast<const f32x4*>(&Gs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]);
       const float* arow = Rs + (32 * wr + c16) * kLd + 4 * kq;
@@ -1380,6 +1418,7 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       if (32 * wr + c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
       if (32 * wr + 16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
     }
+    FB_T(5);
     if (tile + 1 < tile_hi) FBM_RIMG_GLOAD(tile + 1);     // next tile's r rows and probabilities: in flight during the weight-gradient GEMMs
     // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]; 16 steps of 4 tokens ----
     {
@@ -1416,14 +1455,21 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
       FBM_TN_LOAD(a, 0);
       FBM_TN_PAIR(0); FBM_TN_PAIR(2); FBM_TN_PAIR(4); FBM_TN_PAIR(6); FBM_TN_PAIR(8); FBM_TN_PAIR(10); FBM_TN_PAIR(12); FBM_TN_PAIR(14);
     }
+    FB_T(6);
     // ---- the next tile -> the other set (its rows and images were fetched during this tile) ----
     if (tile + 1 < tile_hi) FBM_STAGE(par ^ 1, mn);
+    FB_T(0);
     par ^= 1;
     mc = mn; mn = mnn;
   }
 
   // ---- workgroup slab ----
   __syncthreads();
+#ifdef FB_TIMING
+  if (blockIdx.x == 0 && (tid == 0 || tid == 256))
+    printf("fused_bwdm wg0 wave %d us: stage %.1f dZ %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (tiles %d)\n", tid >> 6,
+           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
+#endif
   float* Xs = set0;
   float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlabM;
   {
@@ -1651,7 +1697,7 @@ __global__ __launch_bounds__(512) void fb_unfold2_kernel(Unfold2Args a) {
 // dZ0 = ( LNbwd_noaffine( sum_h dxh[h] ) + dXs ) * (1 - X^2)     (Modules.py:519-521 backward, :270 tanh')
 __global__ __launch_bounds__(256) void lnhat_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dxh, int64_t tcap,
                                                         const float* __restrict__ dxpad, const float* __restrict__ dXs,
-                                                        float* __restrict__ dZ0, const int32_t* __restrict__ count) {
+                                                        float* __restrict__ dZ0, const int32_t* __restrict__ count, int nslab) {
   const int T = count[0];
   const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int c4 = (threadIdx.x & 15) * 4;
@@ -1663,8 +1709,7 @@ __global__ __launch_bounds__(256) void lnhat_bwd_kernel(const float* __restrict_
   float4 d;
   if (t < T - 1) {
     d = *reinterpret_cast<const float4*>(dxh + t * 64 + c4);
-#pragma unroll
-    for (int hd = 1; hd < MATCHA_N_HEAD; ++hd) {
+    for (int hd = 1; hd < nslab; ++hd) {
       const float4 v = *reinterpret_cast<const float4*>(dxh + ((int64_t)hd * tcap + t) * 64 + c4);
       d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
     }
@@ -1772,7 +1817,7 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
   }
   if (dZ0) {                                           // null: the caller's front-end backward kernel consumes dxh / dxpad itself
-    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
+    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count, MATCHA_N_HEAD);
     MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
   }
   return MATCHA_OK;
@@ -1780,8 +1825,10 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
 
 // merged heads: fused_bwdm_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
-                            const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg) {
+                            const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
+                            bool dx_atomic) {
   const int64_t tcap = B * L + 1;
+  if (dx_atomic && hipMemsetAsync(dxh, 0, (size_t)tcap * 64 * sizeof(float), st) != hipSuccess) { set_error("fused_bwd_merged: memset failed"); return MATCHA_EHIP; }
   const int nchunks = chunks_for(rg.ntiles);
   float* wslab = ws;                                                         // [8][nchunks][kWgSlabM]
   float* chain = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlabM;         // [8][kWgSlab]  (both inside the eight-product kernel's slab area)
@@ -1792,7 +1839,7 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
   {
     FusedBwdMArgs g;
     g.X = X; g.dDyn = dDyn; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
-    g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.rimg = rimg;
+    g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
     const size_t lds = ((size_t)9 * kTile + 64 + 512 + 2 * 512 + 2 * 64) * sizeof(float);
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1839,7 +1886,7 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
     MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
   }
   if (dZ0) {
-    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count);
+    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count, dx_atomic ? 1 : MATCHA_N_HEAD);
     MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
   }
   return MATCHA_OK;

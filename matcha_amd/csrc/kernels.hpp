@@ -96,7 +96,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
-  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged;
+  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic;
   int debug_nan, fused_dbg, fwd_lds_pad;
 };
 Options& options();
@@ -150,7 +150,8 @@ size_t fused_bwd_ws_floats(int64_t B, int L);
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
-                            const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg);
+                            const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
+                            bool dx_atomic);
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
 constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
 constexpr int kImgRecM = 4096 + 512;               // merged heads: the r rows (r = B_h x_hat + b_h) + the attention probabilities
@@ -164,7 +165,7 @@ bool front_bwd_supported(int d, int n_attr);
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
                      const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st);
 size_t front_bwd_ws_floats();
-int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
+int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
                      matcha_tensors& grads, hipStream_t st);
 

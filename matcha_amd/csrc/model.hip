@@ -87,6 +87,7 @@ struct Workspace {
 //   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
 //   disable_fwd32            the four-wave tile forward (fused_fwd.hip) instead of the wave-independent one (fused_fwd32.hip)
+//   disable_dx_atomic        merged backward: one d x_hat slab per head (summed by the front-end backward) instead of float atomics into one buffer
 //   disable_bwd8             the fused backward with four wavefronts per workgroup (fused_bwd_kernel) instead of eight (fused_bwd8_kernel)
 //   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
 struct OptionName { const char* name; int Options::*field; };
@@ -94,6 +95,7 @@ static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
     {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32}, {"disable_merged", &Options::disable_merged},
+    {"disable_dx_atomic", &Options::disable_dx_atomic},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
@@ -609,8 +611,13 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
     const bool front = front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
-    if (qkv_saved(ws) && fwd_ran_merged(ws))
-      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv));
+    // merged kernel: the eight heads add their d x_hat into ONE buffer with float atomics (they meet in L2; the per-head slabs are 8 x 256 B
+    // per token written and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs
+    // and their fixed summation order
+    const bool merged_bwd = qkv_saved(ws) && fwd_ran_merged(ws);
+    const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
+    if (merged_bwd)
+      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic));
     else
       MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
     MATCHA_TRY(encoder_done(*opts, st));
@@ -618,7 +625,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
       const bool rows_out = s.mode == 1 || opts->deterministic || opts->sparse_table_grad;     // dX0 rows instead of float atomics
-      MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
+      MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, dx_atomic ? 1 : MATCHA_N_HEAD, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
                                   rows_out ? w.dX0 : nullptr, rows_out ? nullptr : g_.table, w.front_ws, g_, st));
       if (s.mode == 0) {
         MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));

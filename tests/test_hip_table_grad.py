@@ -74,7 +74,13 @@ def test_sorted_table_gradient_equals_atomic_scatter_and_is_bitwise_reproducible
     a, b = grads[0][:nt], grads[2][:nt]
     assert float(a.abs().max()) > 0
     assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())            # same sums up to the atomics' order
-    assert torch.equal(grads[0][nt:], grads[2][nt:])                            # everything else is untouched by the switch
+    if d == 64:
+        # the fused path's default also sums the heads' d x_hat with float atomics (fused_bwdm_kernel): next_w and attribute_nn see that order
+        c, e = grads[0][nt:], grads[2][nt:]
+        assert float((c - e).abs().max()) <= 2e-5 * float(c.abs().max())
+        assert int((c != e).sum()) <= 2 * (64 * 64 + 64) + 64 * 8 + 64         # next_w / attribute_nn and their biases at most
+    else:
+        assert torch.equal(grads[0][nt:], grads[2][nt:])                        # everything else is untouched by the switch
 
 
 def test_out_of_range_ids_are_flagged_not_dereferenced():
