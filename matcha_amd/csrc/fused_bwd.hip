@@ -1517,6 +1517,351 @@ __global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
   }
 }
 
+// ---- merged heads on HALF tiles: the same four products per (rows, head) as fused_bwdm_kernel, on the forward's own half tiles ----
+// (whole hyperedges, <= 31 tokens: ragged.hip half_meta), FOUR wavefronts per workgroup and TWO workgroups per CU.  fused_bwdm_kernel's
+// eight wavefronts walk one tile in lock step: GEMM phases (MFMA) and the attention phases (latency-bound VALU + LDS, a sixth of the
+// issue slots used) alternate behind five barriers and the MFMA pipe idles for 40 % of a tile (tools/debug/timing_bwdm.sh).  Here every
+// wavefront does the same work per 32 rows as there (16 feature columns of each product), but the two workgroups of a CU are at
+// different phases, so one's attention runs under the other's GEMMs.  LDS per workgroup: two sets {x_hat, dDyn, r -> dR} (the next
+// half tile is staged while this one computes), dZ -> Z, G: 8 tiles of 32 x 68 floats + 3.5 KB = 73 KB.  B_h and M_h are MFMA
+// fragments in registers.  The forward's saved record is per (half tile, head): its wavefront's own register image (kImgRecH).
+constexpr int kTileH = 32 * kLd;
+struct FusedBwdHArgs {
+  const float* X; const float* dDyn; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos;
+  int L; int nhalves; int nchunks;
+  const float* mB; const float* mM;               // merged matrices [8][64][64] (launch_merge_heads)
+  float* dxh; int64_t tcap;
+  int dx_atomic;                                   // 1: every head adds into ONE [tcap][64] buffer with float atomics (zeroed by the launcher); 0: one slab per head
+  float* wslab;                                    // [8][nchunks][kWgSlabM]
+  const float* rimg;                               // [nhalves][8][kImgRecH]: r rows (register images) + attention probabilities of the forward
+};
+
+template <int ML>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_bwdh_kernel(FusedBwdHArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* set0 = lds;                  // two sets {x_hat, dDyn, r -> dR}; Ds, Rs consecutive
+  float* Fs = lds + 6 * kTileH;       // dZ -> Z
+  float* Gs = lds + 7 * kTileH;       // attention's gradient into the x_hat rows (keys + values)
+  float* sm = lds + 8 * kTileH;
+  float* xpad = sm;
+  float* dSs = xpad + 64;             // [32][8]
+  float* Ps0 = dSs + 256;             // [2][32][8]
+  int* tinfo0 = reinterpret_cast<int*>(Ps0 + 512);   // [2][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x4 fragments
+  const int fb = 16 * wave;                            // this wave's 16 feature columns
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;     // staging: 16 rows x 16 lanes (float4), twice
+
+  int head, chunk;
+  if ((g.nchunks & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    head = j & 7;
+    chunk = (j >> 3) * 8 + xcd;
+  } else {
+    head = blockIdx.x & 7;
+    chunk = blockIdx.x >> 3;
+  }
+  const int tr = g.count[1];
+  int nh = g.count[3];
+  if (nh > g.nhalves) nh = g.nhalves;
+  const int per = (nh + g.nchunks - 1) / g.nchunks;
+  const int tile_lo = chunk * per;
+  const int tile_hi = (tile_lo + per < nh) ? tile_lo + per : nh;
+  const float inv_temp = 0.125f;
+#ifdef FB_TIMING
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+#endif
+
+  if (tid < 16) {                     // the padding token's x_hat
+    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
+    float m, rs;
+    ln_row16(xv, m, rs);
+    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
+  }
+
+  // weight-gradient accumulators: rows 16 mt + 4 kq + reg, column fb + c16 of dB_h and dM_h (four 16 x 16 tiles each)
+  f32x4 ab0 = {0.f, 0.f, 0.f, 0.f}, ab1 = ab0, ab2 = ab0, ab3 = ab0, am0 = ab0, am1 = ab0, am2 = ab0, am3 = ab0;
+  V8 accK = zero8(), accV = zero8();                  // the padding token's gradient as a key (sum dS_i,pad r_i) and as a value (sum p_i,pad dz_i)
+  // column sums of dDyn (columns sc4 + {0..3} over the rows this thread stages) and of dR (features 8 sub + {0..7} over this lane group's tokens)
+  f2 cd0 = {0.f, 0.f}, cd1 = cd0;
+  V8 accR = zero8();
+
+  const int4* meta = reinterpret_cast<const int4*>(g.half_meta);
+  const int4 mzero = make_int4(0, 0, 0, 0);
+  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
+  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
+  float4 xn0, xn1, dn0, dn1;
+  int tpn = 0;
+  f32x4 ri0, ri1, pn = {0.f, 0.f, 0.f, 0.f};
+#define FBH_ROW_GLOAD(I, M)                                                                              \
+  do {                                                                                                   \
+    const int row__ = srow + 16 * (I);                                                                   \
+    const int64_t tok__ = (M).x + (row__ < (M).y ? row__ : ((M).y > 0 ? (M).y - 1 : 0));                 \
+    xn##I = *reinterpret_cast<const float4*>(g.X + tok__ * 64 + sc4);                                    \
+    dn##I = *reinterpret_cast<const float4*>(g.dDyn + tok__ * 64 + sc4);                                 \
+  } while (0)
+#define FBH_ROWS_GLOAD(M)                                                                                \
+  do {                                                                                                   \
+    FBH_ROW_GLOAD(0, M); FBH_ROW_GLOAD(1, M);                                                            \
+    if (tid < 32) tpn = g.tok_pos[(M).x + (tid < (M).y ? tid : ((M).y > 0 ? (M).y - 1 : 0))];           \
+  } while (0)
+#define FBH_ROW_STAGE(I)                                                                                 \
+  do {                                                                                                   \
+    const int row__ = srow + 16 * (I);                                                                   \
+    const float msk__ = row__ < n_real ? 1.f : 0.f;                                                      \
+    const float4 xv__ = xn##I, dv__ = dn##I;                                                             \
+    const float mean__ = group_sum16_dpp((xv__.x + xv__.y) + (xv__.z + xv__.w)) * (1.f / 64.f);          \
+    const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
+    const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
+    const float rs__ = msk__ * __builtin_amdgcn_rsqf(q__ * (1.f / 64.f) + kEpsLn);                       \
+    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
+    const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
+    *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
+    cd0 += (f2){dm__.x, dm__.y}; cd1 += (f2){dm__.z, dm__.w};                                            \
+  } while (0)
+  // the forward wavefront's register image: float4 index (wc * 4 + gq) * 64 + 32 h + r holds features 32 wc + 8 gq + 4 h + {0..3} of row r
+#define FBH_RIMG_GLOAD(HALF)                                                                             \
+  do {                                                                                                   \
+    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.rimg + ((int64_t)(HALF) * MATCHA_N_HEAD + head) * kImgRecH);  \
+    if (tid < 64) pn = __builtin_nontemporal_load(r__ + 512 + tid);                                      \
+    ri0 = __builtin_nontemporal_load(r__ + tid); ri1 = __builtin_nontemporal_load(r__ + 256 + tid);      \
+  } while (0)
+  // A fragments (16 feature rows x 64 k) of M_h for dZ^T = M_h^T . dDyn^T and of B_h for d x_hat^T = B_h^T dR^T, held for the whole walk
+  float fcb[16], bfr[16];
+  {
+    FBH_ROWS_GLOAD(mc);
+    if (tile_lo < tile_hi) FBH_RIMG_GLOAD(tile_lo);
+    const float* mp = g.mM + (int64_t)head * 4096 + (4 * kq) * 64 + fb + c16;
+    const float* bp = g.mB + (int64_t)head * 4096 + (4 * kq) * 64 + fb + c16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { fcb[4 * c + x] = mp[(16 * c + x) * 64]; bfr[4 * c + x] = bp[(16 * c + x) * 64]; }
+  }
+
+#define FBH_STAGE(PAR, META)                                                                             \
+  do {                                                                                                   \
+    float* Xs = set0 + 3 * (PAR) * kTileH;                                                               \
+    float* Ds = Xs + kTileH;                                                                             \
+    float* Rs = Ds + kTileH;                                                                             \
+    const int n_real = (META).y;                                                                         \
+    FBH_ROW_STAGE(0); FBH_ROW_STAGE(1);                                                                  \
+    if (tid < 32) tinfo0[32 * (PAR) + tid] = tid < n_real ? ((tid - (tpn & 255)) | (tpn & ~255)) : 0;     \
+    f32x4* d__ = reinterpret_cast<f32x4*>(&Rs[(lane & 31) * kLd + 8 * wave + 4 * (lane >> 5)]);          \
+    d__[0] = ri0; d__[8] = ri1;                                                                          \
+    if (tid < 64) reinterpret_cast<f32x4*>(Ps0 + 256 * (PAR))[tid] = pn;                                 \
+  } while (0)
+  int par = 0;
+  if (tile_lo < tile_hi) FBH_STAGE(0, mc);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
+    const int t0 = mc.x, n_real = mc.y;
+    float* Xs = set0 + 3 * par * kTileH;
+    float* Ds = Xs + kTileH;
+    float* Rs = Ds + kTileH;
+    const float* Ps = Ps0 + 256 * par;
+    const int* tinfo = tinfo0 + 32 * par;
+    FB_T(0);
+    __syncthreads();                                  // this half tile's set is staged; the previous one's GEMMs are done with Fs / Gs and with the other set
+    FB_T(7);
+    // per-lane indices re-derived from an opaque copy of the thread id (see fused_bwd8_kernel: loop-invariant addresses are hoisted and spilled otherwise)
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int fb = 16 * wave;
+    const int srow = tid_ >> 4, sc4 = (tid_ & 15) * 4;
+    const int sub = lane & 7;
+    (void)srow; (void)sc4;
+    // ---- dZ^T = M_h^T . dDyn^T: lane (c16, kq) ends with token c16 (+ 16) and features fb + 4 kq + {0..3} ----
+    {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const float* dp = Ds + c16 * kLd + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 b0 = *reinterpret_cast<const float4*>(dp + 16 * c), b1 = *reinterpret_cast<const float4*>(dp + 16 * kLd + 16 * c);
+        acc0 = MFMA16(fcb[4 * c + 0], b0.x, acc0); acc1 = MFMA16(fcb[4 * c + 0], b1.x, acc1);
+        acc0 = MFMA16(fcb[4 * c + 1], b0.y, acc0); acc1 = MFMA16(fcb[4 * c + 1], b1.y, acc1);
+        acc0 = MFMA16(fcb[4 * c + 2], b0.z, acc0); acc1 = MFMA16(fcb[4 * c + 2], b1.z, acc1);
+        acc0 = MFMA16(fcb[4 * c + 3], b0.w, acc0); acc1 = MFMA16(fcb[4 * c + 3], b1.w, acc1);
+      }
+      *reinterpret_cast<f32x4*>(&Fs[c16 * kLd + fb + 4 * kq]) = acc0;
+      *reinterpret_cast<f32x4*>(&Fs[(16 + c16) * kLd + fb + 4 * kq]) = acc1;
+    }
+    FB_T(1);
+    __syncthreads();
+    FB_T(7);
+    // ---- attention forward + backward in x_hat space: 8 lanes per token, all 32 rows in one pass ----
+    {
+      V8 o0, q0, k0, v0;
+      const int la = wave * 8 + (lane >> 3);
+      const bool acta = la < n_real;
+      int ia = 0;
+      if (acta) { ia = tinfo[la]; attn_row8<ML>(Rs, Xs, Xs, Fs, xpad, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
+      __builtin_amdgcn_sched_barrier(0);
+      FB_T(2);
+      __syncthreads();
+      FB_T(7);
+      if (acta) {
+        attn_col8<ML>(Rs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
+        k0.a += v0.a; k0.b += v0.b; k0.c += v0.c; k0.d += v0.d;      // the row is key AND value: d x_hat_j = sum_i dS_ij r_i + p_ij dz_i
+        st8(&Gs[la * kLd + 8 * sub], k0);
+      } else {
+        ZR8(&Gs[la * kLd + 8 * sub]);
+      }
+      FB_T(3);
+      __syncthreads();                                // every column phase is done with the r and dZ rows
+      FB_T(7);
+      if (acta) {
+        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Rs[la * kLd + 8 * sub], q0);
+        accR.a += q0.a; accR.b += q0.b; accR.c += q0.c; accR.d += q0.d;
+      } else {
+        ZR8(&Rs[la * kLd + 8 * sub]);
+      }
+    }
+    FB_T(4);
+    __syncthreads();
+    FB_T(7);
+    FBH_ROWS_GLOAD(mn);                               // next half tile's rows: in flight during the GEMMs below
+    // ---- this head's share of d x_hat = dR B_h + Gs: 4 steps of 16 contraction indices ----
+    if (g.dx_atomic) {
+      // rows = tokens 4 kq + reg (+ 16), columns = features fb + c16: one atomic instruction covers 4 token rows x 64 contiguous bytes.  The
+      // eight heads of a chunk run on the same XCD at about the same time: the adds meet in that L2, and d x_hat leaves it once
+      const float* gp = Gs + (4 * kq) * kLd + fb + c16;
+      f32x4 dx0 = {gp[0], gp[kLd], gp[2 * kLd], gp[3 * kLd]};
+      f32x4 dx1 = {gp[16 * kLd], gp[17 * kLd], gp[18 * kLd], gp[19 * kLd]};
+      const float* arow = Rs + c16 * kLd + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
+        dx0 = MFMA16(a0.x, bfr[4 * c + 0], dx0); dx1 = MFMA16(a1.x, bfr[4 * c + 0], dx1);
+        dx0 = MFMA16(a0.y, bfr[4 * c + 1], dx0); dx1 = MFMA16(a1.y, bfr[4 * c + 1], dx1);
+        dx0 = MFMA16(a0.z, bfr[4 * c + 2], dx0); dx1 = MFMA16(a1.z, bfr[4 * c + 2], dx1);
+        dx0 = MFMA16(a0.w, bfr[4 * c + 3], dx0); dx1 = MFMA16(a1.w, bfr[4 * c + 3], dx1);
+      }
+      float* out = g.dxh + ((int64_t)t0 + 4 * kq) * 64 + fb + c16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        if (4 * kq + reg < n_real) unsafeAtomicAdd(out + reg * 64, dx0[reg]);
+        if (16 + 4 * kq + reg < n_real) unsafeAtomicAdd(out + (16 + reg) * 64, dx1[reg]);
+      }
+    } else {
+      f32x4 dx0 = *reinterpret_cast<const f32x4*>(&Gs[c16 * kLd + fb + 4 * kq]);
+      f32x4 dx1 = *reinterpret_cast<const f32x4*>(&Gs[(16 + c16) * kLd + fb + 4 * kq]);
+      const float* arow = Rs + c16 * kLd + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
+        dx0 = MFMA16(bfr[4 * c + 0], a0.x, dx0); dx1 = MFMA16(bfr[4 * c + 0], a1.x, dx1);
+        dx0 = MFMA16(bfr[4 * c + 1], a0.y, dx0); dx1 = MFMA16(bfr[4 * c + 1], a1.y, dx1);
+        dx0 = MFMA16(bfr[4 * c + 2], a0.z, dx0); dx1 = MFMA16(bfr[4 * c + 2], a1.z, dx1);
+        dx0 = MFMA16(bfr[4 * c + 3], a0.w, dx0); dx1 = MFMA16(bfr[4 * c + 3], a1.w, dx1);
+      }
+      float* out = g.dxh + ((int64_t)head * g.tcap + t0 + c16) * 64 + fb + 4 * kq;
+      if (c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
+      if (16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
+    }
+    FB_T(5);
+    if (tile + 1 < tile_hi) FBH_RIMG_GLOAD(tile + 1);     // next half tile's r rows and probabilities: in flight during the weight-gradient GEMMs
+    // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]; 8 steps of 4 tokens, all 64 rows a / n ----
+    {
+      const float* pr = Rs + (4 * kq) * kLd + c16;
+      const float* pd = Ds + (4 * kq) * kLd + c16;
+      const float* px = Xs + (4 * kq) * kLd + fb + c16;
+      const float* pz = Fs + (4 * kq) * kLd + fb + c16;
+      f32x4 ra, da, rb, db;
+      float xa, za, xb, zb;
+#define FBH_TN_LOAD(S, ST)                                                                               \
+  do {                                                                                                   \
+    constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
+    r##S = (f32x4){pr[o__], pr[o__ + 16], pr[o__ + 32], pr[o__ + 48]};                                   \
+    d##S = (f32x4){pd[o__], pd[o__ + 16], pd[o__ + 32], pd[o__ + 48]};                                   \
+    x##S = px[o__]; z##S = pz[o__];                                                                      \
+  } while (0)
+#define FBH_TN_MMA(S)                                                                                    \
+  do {                                                                                                   \
+    ab0 = MFMA16(r##S[0], x##S, ab0); ab1 = MFMA16(r##S[1], x##S, ab1);                                  \
+    ab2 = MFMA16(r##S[2], x##S, ab2); ab3 = MFMA16(r##S[3], x##S, ab3);                                  \
+    am0 = MFMA16(d##S[0], z##S, am0); am1 = MFMA16(d##S[1], z##S, am1);                                  \
+    am2 = MFMA16(d##S[2], z##S, am2); am3 = MFMA16(d##S[3], z##S, am3);                                  \
+  } while (0)
+#define FBH_TN_PAIR(ST)                                                                                  \
+  do {                                                                                                   \
+    FBH_TN_LOAD(b, (ST) + 1);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FBH_TN_MMA(a);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if ((ST) + 2 < 8) FBH_TN_LOAD(a, ((ST) + 2 < 8 ? (ST) + 2 : 0));                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    FBH_TN_MMA(b);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+      FBH_TN_LOAD(a, 0);
+      FBH_TN_PAIR(0); FBH_TN_PAIR(2); FBH_TN_PAIR(4); FBH_TN_PAIR(6);
+    }
+    FB_T(6);
+    // ---- the next half tile -> the other set (its rows and images were fetched during this one) ----
+    if (tile + 1 < tile_hi) FBH_STAGE(par ^ 1, mn);
+    par ^= 1;
+    mc = mn; mn = mnn;
+  }
+
+  // ---- workgroup slab ----
+  __syncthreads();
+#ifdef FB_TIMING
+  if (blockIdx.x == 0 && (tid == 0 || tid == 192))
+    printf("fused_bwdh wg0 wave %d us: stage %.1f dZ %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (halves %d)\n", tid >> 6,
+           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
+#endif
+  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlabM;
+  {
+    const int col = fb + c16;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = 4 * kq + reg;
+      slab[0 * 4096 + row * 64 + col] = ab0[reg]; slab[0 * 4096 + (row + 16) * 64 + col] = ab1[reg];
+      slab[0 * 4096 + (row + 32) * 64 + col] = ab2[reg]; slab[0 * 4096 + (row + 48) * 64 + col] = ab3[reg];
+      slab[1 * 4096 + row * 64 + col] = am0[reg]; slab[1 * 4096 + (row + 16) * 64 + col] = am1[reg];
+      slab[1 * 4096 + (row + 32) * 64 + col] = am2[reg]; slab[1 * 4096 + (row + 48) * 64 + col] = am3[reg];
+    }
+  }
+  // column sums of dDyn: thread (srow, sc4) staged rows srow, srow + 16 of every half tile -- the four row groups of a wave in a fixed xor order,
+  // then the four waves in order
+  float* redd = set0;                   // [4][64]
+  {
+    const float cdv[4] = {cd0.x, cd0.y, cd1.x, cd1.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = cdv[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) redd[wave * 64 + 4 * lane + i] = v;
+    }
+  }
+  // column sums of dR and d x_hat of the padding token: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
+  float* redr = set0 + 4 * 64;          // [4][64]
+  float* redp = set0 + 8 * 64;          // [4][64]
+  const float accp[16] = {accK.a.x + accV.a.x, accK.a.y + accV.a.y, accK.b.x + accV.b.x, accK.b.y + accV.b.y,
+                          accK.c.x + accV.c.x, accK.c.y + accV.c.y, accK.d.x + accV.d.x, accK.d.y + accV.d.y,
+                          accR.a.x, accR.a.y, accR.b.x, accR.b.y, accR.c.x, accR.c.y, accR.d.x, accR.d.y};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float v = accp[i];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 8) (i < 8 ? redp : redr)[wave * 64 + 8 * lane + (i & 7)] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    slab[kVecOffM + 64 + tid] = (redd[tid] + redd[64 + tid]) + (redd[128 + tid] + redd[192 + tid]);    // d bdyn partial
+    slab[kVecOffM + tid] = (redr[tid] + redr[64 + tid]) + (redr[128 + tid] + redr[192 + tid]);         // db_h partial
+    slab[kVecOffM + 128 + tid] = (redp[tid] + redp[64 + tid]) + (redp[128 + tid] + redp[192 + tid]);   // dxpad partial
+  }
+}
+
 // Chain rule from the merged matrices back to the folded projections, one block per head: sums the chunk slabs in order, then
 //   B_h = W'k^T W'q, b_h = W'k^T cq:   dW'q = W'k dB;   dW'k = W'q dB^T + cq (x) db;   dcq = W'k db;   dck = 0
 //   M_h = Wf_h W'v, bdyn = fc1_b + sum_h Wf_h cv_h:   dWf_h = dM W'v^T + dbdyn (x) cv_h;   dW'v = Wf_h^T dM;   dcv_h = Wf_h^T dbdyn
@@ -1826,17 +2171,42 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
 // merged heads: fused_bwdm_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic) {
+                            bool dx_atomic, bool halves) {
   const int64_t tcap = B * L + 1;
   if (dx_atomic && hipMemsetAsync(dxh, 0, (size_t)tcap * 64 * sizeof(float), st) != hipSuccess) { set_error("fused_bwd_merged: memset failed"); return MATCHA_EHIP; }
-  const int nchunks = chunks_for(rg.ntiles);
+  int nchunks = chunks_for(rg.ntiles);
+  if (halves) {                                              // two four-wave workgroups per CU
+    nchunks = 2 * chunks_for(rg.nhalves);
+    if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+    if (nchunks > rg.nhalves) nchunks = rg.nhalves > 0 ? rg.nhalves : 1;
+  }
   float* wslab = ws;                                                         // [8][nchunks][kWgSlabM]
   float* chain = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlabM;         // [8][kWgSlab]  (both inside the eight-product kernel's slab area)
   float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
   float* dxpad = part + 32 * 3 * 3 * 64;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   const MergedView mv = merged_view(merged);
-  {
+  if (halves) {
+    FusedBwdHArgs g;
+    g.X = X; g.dDyn = dDyn; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.L = L; g.nhalves = rg.nhalves; g.nchunks = nchunks;
+    g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
+    const size_t lds = ((size_t)8 * kTileH + 64 + 256 + 2 * 256 + 2 * 32) * sizeof(float);
+    auto launch = [&](auto kfn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
+    };
+    // algorithmic flops: the reference's formulation -- 8 heads x 8 GEMMs of 2*64*64 per token; this kernel EXECUTES half of them
+    ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
+    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+      case 2: launch(fused_bwdh_kernel<2>); break;
+      case 3: launch(fused_bwdh_kernel<3>); break;
+      case 4: launch(fused_bwdh_kernel<4>); break;
+      case 5: launch(fused_bwdh_kernel<5>); break;
+      case 6: launch(fused_bwdh_kernel<6>); break;
+      default: launch(fused_bwdh_kernel<8>); break;
+    }
+    MATCHA_CHECK_LAUNCH("fused_bwdh_kernel");
+  } else {
     FusedBwdMArgs g;
     g.X = X; g.dDyn = dDyn; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
     g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;

@@ -321,6 +321,7 @@ struct Fwd32Args {
   float p_fc1, p_pff;
   float* ddyn0; float* dXs; float* tslab; float alpha_over_B;
   float* qkv;
+  int img_half;       // MG: the saved record is per (HALF tile, head) -- this wavefront's own rows, kImgRecH floats (fused_bwdh_kernel) -- instead of per 64-row tile
 };
 
 // MG = merged per-head matrices (two products per head: r = B_h x + b_h, dyn += M_h z); the saved record per (tile, head) is then the
@@ -391,15 +392,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int e = 0; e < 16; ++e) { xh.lo[e] = (xh.lo[e] - mean) * rx; xh.hi[e] = (xh.hi[e] - mean) * rx; }
   }
-  constexpr int kRec = MG ? kImgRecM : kImgRec;
+  const int kRec = MG ? (g.img_half ? kImgRecH : kImgRecM) : kImgRec;
   // where this token's rows go in the backward kernel's tile images: float4 index ((2 wr' + wc) * 4 + g) * 64 + 32 h + r'
   float* img_tok = nullptr;
   float* pimg_tok = nullptr;
   if (g.qkv && real) {
-    const int tile = tt >> 6, rho = tt & 63;
-    float* base = g.qkv + (int64_t)tile * MATCHA_N_HEAD * kRec;
-    img_tok = base + ((rho >> 5) * 8 * 64 + 32 * h + (rho & 31)) * 4;
-    pimg_tok = base + (MG ? 4096 : 3 * 4096) + rho * 8;
+    if (MG && g.img_half) {
+      // half-tile record: float4 index (wc * 4 + g) * 64 + 32 h + r of this wavefront's own record, probabilities [32][8] behind the rows
+      float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
+      img_tok = base + (32 * h + r) * 4;
+      pimg_tok = base + 2048 + r * 8;
+    } else {
+      const int tile = tt >> 6, rho = tt & 63;
+      float* base = g.qkv + (int64_t)tile * MATCHA_N_HEAD * kRec;
+      img_tok = base + ((rho >> 5) * 8 * 64 + 32 * h + (rho & 31)) * 4;
+      pimg_tok = base + (MG ? 4096 : 3 * 4096) + rho * 8;
+    }
   }
 #define F32_IMG_STORE(ACC, HD, M)                                                                        \
   do {                                                                                                   \
@@ -930,8 +938,9 @@ int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, 
 
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv, bool merged) {
+                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv, bool merged, bool img_half) {
   Fwd32Args g;
+  g.img_half = (merged && img_half) ? 1 : 0;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.tok_tile = rg.tok_tile;
   g.L = L;
   g.wfrag = reinterpret_cast<const f32x4*>(frag);

@@ -96,7 +96,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
-  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic;
+  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic, disable_bwdh;
   int debug_nan, fused_dbg, fwd_lds_pad;
 };
 Options& options();
@@ -142,7 +142,7 @@ int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, 
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
                        hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr,
-                       bool merged = false);
+                       bool merged = false, bool img_half = false);
 
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)
@@ -151,10 +151,11 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic);
+                            bool dx_atomic, bool halves);
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
 constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
 constexpr int kImgRecM = 4096 + 512;               // merged heads: the r rows (r = B_h x_hat + b_h) + the attention probabilities
+constexpr int kImgRecH = 2048 + 256;               // merged heads, per HALF tile: 32 r rows + their probabilities [32][8] (fused_bwdh_kernel)
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 

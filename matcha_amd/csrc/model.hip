@@ -87,6 +87,7 @@ struct Workspace {
 //   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
 //   disable_fwd32            the four-wave tile forward (fused_fwd.hip) instead of the wave-independent one (fused_fwd32.hip)
+//   disable_bwdh             merged backward on 64-row tiles with eight wavefronts (fused_bwdm_kernel) instead of half tiles with four (fused_bwdh_kernel)
 //   disable_dx_atomic        merged backward: one d x_hat slab per head (summed by the front-end backward) instead of float atomics into one buffer
 //   disable_bwd8             the fused backward with four wavefronts per workgroup (fused_bwd_kernel) instead of eight (fused_bwd8_kernel)
 //   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
@@ -95,7 +96,7 @@ static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
     {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32}, {"disable_merged", &Options::disable_merged},
-    {"disable_dx_atomic", &Options::disable_dx_atomic},
+    {"disable_dx_atomic", &Options::disable_dx_atomic}, {"disable_bwdh", &Options::disable_bwdh},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
@@ -131,10 +132,11 @@ static bool save_qkv() { return !options().disable_qkv_save; }
 // it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
 static std::mutex g_qkv_mu;
 static std::unordered_map<const void*, int> g_qkv_saved;     // bit 0: Q/K/V tiles saved; bit 1: the forward ran per HALF tile (fused_fwd32)
-static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false) {
+static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false, bool img_half = false) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
   if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
-  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0);      // bit 2: the saved records are the merged heads' r rows
+  // bit 2: the saved records are the merged heads' r rows; bit 3: one record per HALF tile (fused_bwdh_kernel) instead of per 64-row tile
+  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0) | (img_half ? 8 : 0);
 }
 static int ws_state(const void* ws) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
@@ -144,6 +146,7 @@ static int ws_state(const void* ws) {
 static bool qkv_saved(const void* ws) { return (ws_state(ws) & 1) != 0; }
 static bool fwd_ran_halves(const void* ws) { return (ws_state(ws) & 2) != 0; }
 static bool fwd_ran_merged(const void* ws) { return (ws_state(ws) & 4) != 0; }
+static bool fwd_saved_half_records(const void* ws) { return (ws_state(ws) & 8) != 0; }
 
 // B_all[h d + a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b];   M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]   (16 small GEMMs)
 static int merged_weights(const matcha_shape& s, const matcha_tensors& p, Workspace& w, hipStream_t st) {
@@ -431,13 +434,14 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     float* lg_out = (logits && !save) ? logits : w.logits;
     // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities for fused_bwdm_kernel
     const bool merged = fwd32 && !options().disable_merged;
-    note_qkv_saved(ws, keep_qkv, fwd32, merged);
+    const bool img_half = merged && !options().disable_bwdh;
+    note_qkv_saved(ws, keep_qkv, fwd32, merged, img_half);
     if (fwd32) {
       if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
       MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
       MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                     lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                    lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr, merged));
+                                    lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr, merged, img_half));
     } else {
       MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
@@ -617,7 +621,8 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     const bool merged_bwd = qkv_saved(ws) && fwd_ran_merged(ws);
     const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
     if (merged_bwd)
-      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic));
+      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic,
+                                         fwd_saved_half_records(ws)));
     else
       MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
     MATCHA_TRY(encoder_done(*opts, st));

@@ -394,9 +394,11 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
     disable_merged, the reference's formulation: Q, K, V, fc1 per head): (0) the four-wave kernel recomputing Q/K/V and the softmax
     (disable_qkv_save), (1) the eight-wave kernel fed by the tiles and probabilities the training forward saved (fused_bwd8_kernel),
     (2) the four-wave kernel fed by the same saved tiles (disable_bwd8).  Merged heads (the default: B_h = W'k^T W'q, M_h = Wfc1_h
-    W'v -- two products per head forward, four backward): (3) fused_bwdm_kernel fed by the r rows and probabilities of the merged
-    forward, (4) the merged forward in front of the recompute kernel (disable_qkv_save).  Batch widths L = 2, 3, 4, 5, 6, 8 cover every
-    template instance.  The workspace keeps its size in all cases, so one Trainer per case."""
+    W'v -- two products per head forward, four backward): (3) fused_bwdh_kernel (four wavefronts per half tile, heads summed with float
+    atomics) fed by the r rows and probabilities of the merged forward, (4) the merged forward in front of the recompute kernel
+    (disable_qkv_save), (5) fused_bwdm_kernel (eight wavefronts per 64-row tile: disable_bwdh), (6) fused_bwdh_kernel with one d x_hat
+    slab per head (disable_dx_atomic).  Batch widths L = 2, 3, 4, 5, 6, 8 cover every template instance.  The workspace keeps its size
+    in all cases, so one Trainer per case."""
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS["hg38_1mb"]
     N = int(np.sum(num))
@@ -405,7 +407,8 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
     y = (torch.rand(len(x), device="cuda") < 0.3).float()
     w = torch.rand(len(x), device="cuda") + 0.5
     res = []
-    for options in (("disable_merged", "disable_qkv_save"), ("disable_merged",), ("disable_merged", "disable_bwd8"), (), ("disable_qkv_save",)):
+    for options in (("disable_merged", "disable_qkv_save"), ("disable_merged",), ("disable_merged", "disable_bwd8"), (), ("disable_qkv_save",),
+                    ("disable_bwdh",), ("disable_dx_atomic",)):
         clf, _ = hip_model(num, 64, mode, 41)
         clf.train(True)
         tr = Trainer(clf, base_seed=8)
@@ -420,6 +423,7 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
         res.append((logits.clone(), tr.gflat.clone()))
     # the forward pass computes the same thing whatever the backward will be: bitwise within a formulation, to rounding across them
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[1][0], res[2][0]) and torch.equal(res[3][0], res[4][0])
+    assert torch.equal(res[3][0], res[5][0]) and torch.equal(res[3][0], res[6][0])
     assert float((res[3][0] - res[0][0]).abs().max()) <= 2e-5 * max(1.0, float(res[0][0].abs().max()))
     g0 = res[0][1]
     assert float(g0.abs().max()) > 0
@@ -431,7 +435,7 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
             continue
         a = g0[o:o + p.numel()]
         scale = max(float(a.abs().max()), 1e-6)
-        for which in (1, 2, 3, 4):
+        for which in (1, 2, 3, 4, 5, 6):
             b = res[which][1][o:o + p.numel()]
             assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
     # the K bias (cq . k_j is constant over the keys of a query) has NO gradient: the merged backward returns exact zeros where the
