@@ -72,6 +72,17 @@ int launch_gemm_tn(const float* A, const float* B, float* C, float* colsum, int6
 int launch_slab_reduce(const float* slab, float* out1, int64_t n1, float* out2, int64_t stride, int P, bool accumulate, hipStream_t st,
                        const float* scale_dev = nullptr, float scale = 1.f);
 
+// bmm_heads.hip: up to four d x d x d products x 8 heads in one launch, out_h[i][j] (+)= sum_x A_h(i, x) B_h(x, j); an operand element is
+// ptr[head * hs + row * rs + col * cs] (one of rs, cs is 1), C is row-major with row stride c_rs
+struct BmmProduct {
+  const float* A; int64_t a_rs, a_cs, a_hs;
+  const float* B; int64_t b_rs, b_cs, b_hs;
+  float* C; int64_t c_rs, c_hs;
+  int accumulate;
+};
+bool bmm_heads_supported(int d);
+int launch_bmm_heads(const BmmProduct* prods, int n, int d, hipStream_t st);
+
 // gemm_wide.hip: 128 x 128 workgroup tiles for embed_dim >= 128 (returns / eligibility: see the file header)
 bool gemm_wide_eligible(bool b_kn, const GemmArgs& g);
 int launch_gemm_wide(bool b_kn, const GemmArgs& g, hipStream_t st);
@@ -96,7 +107,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
-  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic, disable_bwdh;
+  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic, disable_bwdh, disable_bmm_heads;
   int debug_nan, fused_dbg, fwd_lds_pad;
 };
 Options& options();

@@ -88,6 +88,7 @@ struct Workspace {
 //                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
 //   disable_fwd32            the four-wave tile forward (fused_fwd.hip) instead of the wave-independent one (fused_fwd32.hip)
 //   disable_bwdh             merged backward on 64-row tiles with eight wavefronts (fused_bwdm_kernel) instead of half tiles with four (fused_bwdh_kernel)
+//   disable_bmm_heads        merged layer-wise path (embed_dim >= 128): the per-head weight products as 48 separate GEMM launches instead of two batched ones
 //   disable_dx_atomic        merged backward: one d x_hat slab per head (summed by the front-end backward) instead of float atomics into one buffer
 //   disable_bwd8             the fused backward with four wavefronts per workgroup (fused_bwd_kernel) instead of eight (fused_bwd8_kernel)
 //   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
@@ -96,7 +97,7 @@ static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
     {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32}, {"disable_merged", &Options::disable_merged},
-    {"disable_dx_atomic", &Options::disable_dx_atomic}, {"disable_bwdh", &Options::disable_bwdh},
+    {"disable_dx_atomic", &Options::disable_dx_atomic}, {"disable_bwdh", &Options::disable_bwdh}, {"disable_bmm_heads", &Options::disable_bmm_heads},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}};
 Options& options() {
   static Options o = [] {
@@ -151,6 +152,13 @@ static bool fwd_saved_half_records(const void* ws) { return (ws_state(ws) & 8) !
 // B_all[h d + a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b];   M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]   (16 small GEMMs)
 static int merged_weights(const matcha_shape& s, const matcha_tensors& p, Workspace& w, hipStream_t st) {
   const int64_t d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
+  if (bmm_heads_supported(s.d) && !options().disable_bmm_heads) {
+    // both products, all heads, one launch (bmm_heads.hip)
+    const BmmProduct pr[2] = {
+        {p.w_k, 1, d, d * d, p.w_q, d, 1, d * d, w.lwB, d, d * d, 0},            // B_h[a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b]
+        {p.fc1_w, hd, 1, d, p.w_v, d, 1, d * d, w.lwM, hd, d, 0}};               // M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]
+    return launch_bmm_heads(pr, 2, s.d, st);
+  }
   for (int h = 0; h < MATCHA_N_HEAD; ++h) {
     MATCHA_TRY(launch_gemm_tn(p.w_k + h * d * d, p.w_q + h * d * d, w.lwB + h * d * d, nullptr, d, d, d, d, d, nullptr, false, w.gemm_ws, w.gemm_ws_bytes, st));
     GemmArgs g;
@@ -165,6 +173,14 @@ static int merged_weights(const matcha_shape& s, const matcha_tensors& p, Worksp
 //   dWfc1[:, h] += dM_h W_v[h]^T;  dW_v[h] += Wfc1[:, h]^T dM_h
 static int merged_chain(const matcha_shape& s, const matcha_tensors& p, matcha_tensors& g_, Workspace& w, hipStream_t st) {
   const int64_t d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
+  if (bmm_heads_supported(s.d) && !options().disable_bmm_heads) {
+    const BmmProduct pr[4] = {
+        {p.w_k, d, 1, d * d, w.lwdB, d, 1, d * d, g_.w_q, d, d * d, 1},          // dW_q[h][m][b] += sum_a W_k[h][m][a] dB_h[a][b]
+        {p.w_q, d, 1, d * d, w.lwdB, 1, d, d * d, g_.w_k, d, d * d, 1},          // dW_k[h][m][a] += sum_b W_q[h][m][b] dB_h[a][b]
+        {w.lwdM, hd, 1, d, p.w_v, 1, d, d * d, g_.fc1_w, hd, d, 1},              // dWfc1[n][h d + m] += sum_b dM[n][h d + b] W_v[h d + m][b]
+        {p.fc1_w, 1, hd, d, w.lwdM, hd, 1, d, g_.w_v, d, d * d, 1}};             // dW_v[h][m][b] += sum_n Wfc1[n][h d + m] dM[n][h d + b]
+    return launch_bmm_heads(pr, 4, s.d, st);
+  }
   for (int h = 0; h < MATCHA_N_HEAD; ++h) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));

@@ -583,3 +583,46 @@ def test_capture_refuses_to_freeze_the_reconstruction_chromosome():
     w = torch.ones(len(x), device="cuda")
     with pytest.raises(RuntimeError, match="random_chrom"):
         tr.capture(x, y, w, alpha=1.0, beta=0.001, random_chrom=1)
+
+
+@pytest.mark.parametrize("d", [128, 256])
+def test_merged_layerwise_batched_head_products_match_separate_gemms_and_four_products(d):
+    """embed_dim >= 128 (layer-wise kernels, merged heads): the per-head weight products B_h = W_k^T W_q, M_h = Wfc1_h W_v and their chain
+    rule run as two batched launches (bmm_heads.hip); option disable_bmm_heads runs them as the 48 separate GEMMs they replace, and
+    disable_merged runs the reference's four-product formulation.  Same weights, dropout seed and batch: logits and every gradient
+    agree to rounding."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["c1"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(17)
+    x = _mixed_batch(N, (2, 3, 4, 5), 300, rng)
+    y = (torch.rand(len(x), device="cuda") < 0.3).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    res = []
+    for options in ((), ("disable_bmm_heads",), ("disable_merged",)):
+        clf, _ = hip_model(num, d, "table", 23)
+        clf.train(True)
+        tr = Trainer(clf, base_seed=4)
+        for o in options:
+            _lib.set_option(o, 1)
+        try:
+            logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
+            torch.cuda.synchronize()
+        finally:
+            for o in options:
+                _lib.set_option(o, 0)
+        res.append((logits.clone(), tr.gflat.clone()))
+    scale_l = max(1.0, float(res[2][0].abs().max()))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-6 * scale_l
+    assert float((res[0][0] - res[2][0]).abs().max()) <= 2e-5 * scale_l
+    clf, _ = hip_model(num, d, "table", 23)
+    rt = clf._runtime()
+    for n, p in clf.named_parameters():
+        o = (p.data_ptr() - rt.flat.data_ptr()) // 4
+        if n == GAUGE or o < 0 or o >= rt.n_flat:
+            continue
+        a = res[2][1][o:o + p.numel()]
+        scale = max(float(a.abs().max()), 1e-6)
+        for which in (0, 1):
+            b = res[which][1][o:o + p.numel()]
+            assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
