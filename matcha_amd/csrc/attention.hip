@@ -361,6 +361,20 @@ __global__ __launch_bounds__(1024) void attn_pad_reduce_kernel(const float* __re
   }
 }
 
+// the padding token's row (index *row_dev) of the per-head dK / dV -> its row of the head sums (blockIdx.x = 0: K, 1: V)
+__global__ __launch_bounds__(256) void head_sum_row_kernel(const float* __restrict__ dK, const float* __restrict__ dV, const int32_t* __restrict__ row_dev, int d,
+                                                           float* __restrict__ dKs, float* __restrict__ dVs) {
+  const int64_t tr = *row_dev;
+  const float* src = (blockIdx.x == 0 ? dK : dV) + tr * (int64_t)MATCHA_N_HEAD * d;
+  float* dst = (blockIdx.x == 0 ? dKs : dVs) + tr * d;
+  for (int f = threadIdx.x; f < d; f += 256) {
+    float s = src[f];
+#pragma unroll
+    for (int h = 1; h < MATCHA_N_HEAD; ++h) s += src[(int64_t)h * d + f];
+    dst[f] = s;
+  }
+}
+
 static inline int chunk_of(int d) {
   const int per_lane = d / 8;
   return per_lane >= 8 ? 8 : per_lane;   // 8, 4, 2, 1 (or the exact count when it is 3, 5, 6, 7: handled as CH = 1)
@@ -411,8 +425,11 @@ int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_
   }
 
 int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
-                    int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st, bool shared_kv) {
+                    int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st, bool shared_kv, float* dKsum, float* dVsum) {
   if (B <= 0) return MATCHA_OK;
+  // dKsum / dVsum (shared keys / values only): [T, d] sums over the heads, written by the kernel itself; dK / dV ([T, 8d]) then only hold
+  // the padding token's per-head row (attn_pad_reduce_kernel), which head_sum_row_kernel adds up
+  if ((dKsum || dVsum) && !(shared_kv && dKsum && dVsum)) { set_error("launch_attn_bwd: head sums need shared keys / values and both outputs"); return MATCHA_EINVAL; }
   if (shared_kv && !attn_wide_eligible(d)) { set_error("launch_attn_bwd: shared keys / values need the embed_dim >= 128 kernels"); return MATCHA_EINVAL; }
   const float inv_temp = 1.0f / sqrtf((float)d);
   const int nblk = attn_blocks(B);
@@ -424,7 +441,7 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
     ProfScope ps(MATCHA_PROF_ATTN_BWD, 4.0 * ((double)B * L * MATCHA_N_HEAD * d * 7.0 + (double)B * MATCHA_N_HEAD * L * L), st);
     const int per_lane = d / 8;
     if (attn_wide_eligible(d)) {
-      MATCHA_TRY(launch_attn_bwd_wide(Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, nblk, st, shared_kv));
+      MATCHA_TRY(launch_attn_bwd_wide(Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, nblk, st, shared_kv, dKsum, dVsum));
     } else
     switch (chunk_of(d)) {
       case 8:
@@ -449,6 +466,10 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
   MATCHA_CHECK_LAUNCH("attn_bwd_kernel");
   hipLaunchKernelGGL(attn_pad_reduce_kernel, dim3((unsigned)cdiv(2 * hd, 64)), dim3(1024), 0, st, slab, nblk, hd, row_off, B, dQ, dK, dV);
   MATCHA_CHECK_LAUNCH("attn_pad_reduce_kernel");
+  if (dKsum) {
+    hipLaunchKernelGGL(head_sum_row_kernel, dim3(2), dim3(256), 0, st, dK, dV, row_off + B, d, dKsum, dVsum);
+    MATCHA_CHECK_LAUNCH("head_sum_row_kernel");
+  }
   return MATCHA_OK;
 }
 

@@ -159,12 +159,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const float* __re
 
 // backward: formulas in attention.hip (attn_bwd_kernel).  slab[blk] = {dK_pad [8d], dV_pad [8d]} of the block's hyperedges
 // (waves added in a fixed order).
-template <int kMaxL>
+template <int kMaxL, bool kSum>
 __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, const float* K, const float* V,
                                                             const float* __restrict__ P, const float* __restrict__ dO,
                                                             const int32_t* __restrict__ row_off, int64_t B, int L, int d, float inv_temp,
                                                             float* dQ, float* dK, float* dV,
-                                                            float* __restrict__ slab, int64_t ldk, int hoffk) {
+                                                            float* __restrict__ slab, int64_t ldk, int hoffk, float* dKs, float* dVs) {
   extern __shared__ float lds[];                 // [4 waves][2][8d] padding-token partial sums | [4 waves][8 heads][kMaxL * kMaxL] probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int head = lane >> 3, sub = lane & 7;
@@ -270,7 +270,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, c
             for (int e = 0; e < 8; ++e) gk.v[e] = 0.f;
 #pragma unroll
             for (int j = 0; j < kMaxL; ++j) axpy8(gk, dS[j][i], q[j]);   // dS[j][.] = 0 for j >= k
-            st8(dK + base + (int64_t)i * hd + foff, gk);
+            if constexpr (kSum) {
+              // shared keys: every head's dK_i is a gradient of the SAME row -- the eight lane groups (heads) of the wave are added in a fixed
+              // xor order and the row is written once ([T, d]) instead of per head ([T, 8d]) plus a pass that re-reads and sums it
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float v = gk.v[e];
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                gk.v[e] = v;
+              }
+              if (head == 0) st8(dKs + (int64_t)(t0 + i) * d + foff, gk);
+            } else {
+              st8(dK + base + (int64_t)i * hd + foff, gk);
+            }
           }
         if (n_pad > 0) {
           C8 acc = ld8(padacc + f);
@@ -291,7 +303,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_wide_kernel(const float* Q, c
             for (int e = 0; e < 8; ++e) gv.v[e] = 0.f;
 #pragma unroll
             for (int j = 0; j < kMaxL; ++j) axpy8(gv, pm[j * kMaxL + i], go[j]);
-            st8(dV + base + (int64_t)i * hd + foff, gv);
+            if constexpr (kSum) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float v = gv.v[e];
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                gv.v[e] = v;
+              }
+              if (head == 0) st8(dVs + (int64_t)(t0 + i) * d + foff, gv);
+            } else {
+              st8(dV + base + (int64_t)i * hd + foff, gv);
+            }
           }
         if (n_pad > 0) {
           C8 acc = ld8(padacc + hd + f);
@@ -335,18 +357,20 @@ int launch_attn_fwd_wide(const float* Q, const float* K, const float* V, const i
 }
 
 int launch_attn_bwd_wide(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
-                         int d, float inv_temp, float* dQ, float* dK, float* dV, float* slab, int nblk, hipStream_t st, bool shared_kv) {
+                         int d, float inv_temp, float* dQ, float* dK, float* dV, float* slab, int nblk, hipStream_t st, bool shared_kv, float* dKs,
+                         float* dVs) {
   dim3 grid((unsigned)nblk);
   const int64_t hd = (int64_t)MATCHA_N_HEAD * d;
   const int64_t ldk = shared_kv ? d : hd;
   const int hoffk = shared_kv ? 0 : d;
   const int ml = attn_wide_width(L);
   const size_t lds = ((size_t)4 * 2 * hd + (size_t)4 * MATCHA_N_HEAD * ml * ml) * sizeof(float);
-#define BWD_W(ML)                                                                                                         \
+#define BWD_W1(ML, SUM)                                                                                                   \
   do {                                                                                                                    \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wide_kernel<ML>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((attn_bwd_wide_kernel<ML>), grid, dim3(256), lds, st, Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, ldk, hoffk); \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wide_kernel<ML, SUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((attn_bwd_wide_kernel<ML, SUM>), grid, dim3(256), lds, st, Q, K, V, P, dO, row_off, B, L, d, inv_temp, dQ, dK, dV, slab, ldk, hoffk, dKs, dVs); \
   } while (0)
+#define BWD_W(ML) do { if (dKs) BWD_W1(ML, true); else BWD_W1(ML, false); } while (0)
   switch (ml) {
     case 2: BWD_W(2); break;
     case 3: BWD_W(3); break;
@@ -356,6 +380,7 @@ int launch_attn_bwd_wide(const float* Q, const float* K, const float* V, const f
     default: BWD_W(8); break;
   }
 #undef BWD_W
+#undef BWD_W1
   MATCHA_CHECK_LAUNCH("attn_bwd_wide_kernel");
   return MATCHA_OK;
 }

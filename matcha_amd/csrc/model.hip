@@ -670,9 +670,8 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       MATCHA_TRY(launch_gemm_rm(true, g, st));
     }
     // attention backward on the shared key / value rows: dR in K's (unused) buffer, dK / dV per head in Q's and V's buffers
-    MATCHA_TRY(launch_attn_bwd(w.Q, w.kin, w.vin, w.P, w.dO, w.rg.row_off, B, L, d, w.dQ, w.dK, w.dV, w.slab, st, true));
-    MATCHA_TRY(launch_head_sum(w.dK, Tn, d, w.dkin, st, cnt));        // d kin = sum over the heads (kin itself is dead now)
-    MATCHA_TRY(launch_head_sum(w.dV, Tn, d, w.dvin, st, cnt));
+    // d kin / d vin = the sums over the heads, added inside the kernel (kin / vin themselves are read by it: separate buffers)
+    MATCHA_TRY(launch_attn_bwd(w.Q, w.kin, w.vin, w.P, w.dO, w.rg.row_off, B, L, d, w.dQ, w.dK, w.dV, w.slab, st, true, w.dkin, w.dvin));
     // dB_all = dR^T qin ; dqin = dR B_all ; then the chain rule to w_qs / w_ks / w_vs / fc1
     MATCHA_TRY(launch_gemm_tn(w.dQ, w.qin, w.lwdB, nullptr, hd, d, Tn, hd, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
     {
