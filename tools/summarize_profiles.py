@@ -39,7 +39,7 @@ def cls(n):
         return "gemm_nn"
     if "fused_fwd_kernel" in n or "fused_fwd32_kernel" in n:
         return "fused_fwd"
-    if "fused_bwd_kernel" in n or "fused_bwd8_kernel" in n or "fused_bwdm_kernel" in n:
+    if "fused_bwd_kernel" in n or "fused_bwd8_kernel" in n or "fused_bwdm_kernel" in n or "fused_bwdh_kernel" in n:
         return "fused_bwd"
     if "front_fwd_kernel" in n:
         return "front_fwd"
