@@ -3,7 +3,15 @@
 Usage: python tools/summarize_profiles.py <tag> <round-prefix e.g. r01>"""
 import collections
 import csv
-import glob
+import glob as _glob
+
+
+class glob:      # gpurun merges a call's files into existing directories: several runs' CSVs may sit side by side -- newest first
+    @staticmethod
+    def glob(pattern):
+        import os as _os
+        return sorted(_glob.glob(pattern), key=lambda f: -_os.path.getmtime(f))
+
 import json
 import shutil
 import sys
@@ -75,7 +83,7 @@ out = {c: {"launches_per_step": v[0], "hbm_read_bytes_per_launch": v[1] / v[0], 
 import hashlib
 import os
 h = hashlib.sha256()
-for fsrc in sorted(glob.glob(os.path.join("matcha_amd", "csrc", "*.h*"))):
+for fsrc in sorted(_glob.glob(os.path.join("matcha_amd", "csrc", "*.h*"))):
     h.update(open(fsrc, "rb").read())
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of bench.py --steps 2 --warmup 1, 65536 rows/step); "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; bytes per launch averaged over the launches of the class in one step",
