@@ -401,6 +401,72 @@ __device__ __forceinline__ void attn_row8(const float* __restrict__ Qs, const fl
   }
 }
 
+// Keys = values (merged heads: both are the x_hat rows, kpad = vpad = the padding token's x_hat): ONE pass over the rows.  With the weights
+// w_j = p_ij (w_pad = n_pad p_i,pad) and d_j = dz_i . x_j:   z_i = sum_j w_j x_j,   sig = sum_j w_j d_j,   A = sum_j (w_j d_j) x_j, and
+//   d r_i = sum_j dS_ij x_j = (A - sig z_i) / temp        (dS_ij = w_j (d_j - sig) / temp; the sums include the padding term),
+// so the second read of every row (attn_row8's K pass) and its address arithmetic go away.  Same outputs as attn_row8.
+template <int ML>
+__device__ __forceinline__ void attn_row8_kv(const float* __restrict__ Qs, const float* __restrict__ Xs, const float* __restrict__ Fs,
+                                             const float* __restrict__ xpad, const float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0,
+                                             int k, int n_pad, int sub, float inv_temp, V8& o, V8& gq, V8& accK, V8& accV) {
+  const float padf = (float)n_pad;
+  const bool hp = n_pad > 0;
+  float p[ML], ds[ML], pp;
+  {
+    const float4 pa = *reinterpret_cast<const float4*>(&Ps[li * 8]), pb = *reinterpret_cast<const float4*>(&Ps[li * 8 + 4]);
+    const float w[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+    for (int j = 0; j < ML; ++j) p[j] = (j < k) ? w[j] : 0.f;
+    pp = hp ? w[7] : 0.f;
+  }
+  const float ppf = padf * pp;
+  const int ro0 = li0 * kLd + 8 * sub;                   // row j (clamped to the hyperedge): ro0 + min(j, k - 1) rows
+  const V8 go = ld8(&Fs[li * kLd + 8 * sub]);
+  const V8 vp = ld8(xpad + 8 * sub);
+  const float dsp_raw = group_sum8_dpp(dot8(go, vp));
+  float sig = ppf * dsp_raw;
+  o = scale8(ppf, vp);
+  V8 a = scale8(ppf * dsp_raw, vp);
+  V8 vn = ld8(&Xs[ro0]), vn2 = ld8(&Xs[ro0 + (1 < k ? 1 : 0) * kLd]);      // two rows in flight
+#pragma unroll
+  for (int j = 0; j < ML; ++j) {
+    const V8 v = vn;
+    vn = vn2;
+    if (j + 2 < ML) {
+      int ad = ro0 + (j + 2 < k ? j + 2 : 0) * kLd;
+      FB_PIN(ad, o);
+      vn2 = ld8(&Xs[ad]);
+    }
+    axpy8(o, p[j], v);
+    const float d = group_sum8_dpp(dot8(go, v));
+    ds[j] = d;
+    const float wd = p[j] * d;
+    sig += wd;
+    axpy8(a, wd, v);
+  }
+#pragma unroll
+  for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
+  const float dspf = padf * (pp * (dsp_raw - sig) * inv_temp);
+  axpy8(accV, ppf, go);
+  // d r_i = (A - sig z_i) / temp
+  {
+    const float ns = -sig;
+    axpy8(a, ns, o);
+    gq = scale8(inv_temp, a);
+  }
+  {
+    int ad = li * kLd + 8 * sub;
+    FB_PIN(ad, gq);
+    const V8 q = ld8(&Qs[ad]);
+    axpy8(accK, dspf, q);
+  }
+  if (sub == 1) {                                          // row i of dS for the column phase (P is in Ps already)
+    float* dst = dSs + li * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(ds[0], ds[1 % ML], ML > 2 ? ds[2 % ML] : 0.f, ML > 3 ? ds[3 % ML] : 0.f);
+    if (ML > 4) *reinterpret_cast<float4*>(dst + 4) = make_float4(ds[4 % ML], ML > 5 ? ds[5 % ML] : 0.f, ML > 6 ? ds[6 % ML] : 0.f, ML > 7 ? ds[7 % ML] : 0.f);
+  }
+}
+
 template <int ML>
 __device__ __forceinline__ void attn_col8(const float* __restrict__ Qs, const float* __restrict__ Fs, const float* __restrict__ Ps,
                                           const float* __restrict__ dSs, int li, int li0, int k, int sub, V8& gk, V8& gv) {
@@ -413,7 +479,10 @@ __device__ __forceinline__ void attn_col8(const float* __restrict__ Qs, const fl
   for (int i = 0; i < ML; ++i) {
     const V8 q = qn, go = gn;
     const int ri = li0 + (i < k ? i : 0);
-    const float pij = (i < k) ? Ps[ri * 8 + jj] : 0.f, dsij = (i < k) ? dSs[ri * 8 + jj] : 0.f;
+    // unconditional loads (the row index is clamped into the hyperedge, whose rows hold finite values) + a select: `cond ? load : 0` becomes a
+    // branch around the load
+    const float pl = Ps[ri * 8 + jj], dl = dSs[ri * 8 + jj];
+    const float pij = (i < k) ? pl : 0.f, dsij = (i < k) ? dl : 0.f;
     if (i + 1 < ML) {
       int a = ro0 + (i + 1 < k ? i + 1 : 0) * kLd;
       FB_PIN(a, gk);
@@ -1699,7 +1768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int la = wave * 8 + (lane >> 3);
       const bool acta = la < n_real;
       int ia = 0;
-      if (acta) { ia = tinfo[la]; attn_row8<ML>(Rs, Xs, Xs, Fs, xpad, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
+      if (acta) { ia = tinfo[la]; attn_row8_kv<ML>(Rs, Xs, Fs, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
       __builtin_amdgcn_sched_barrier(0);
       FB_T(2);
       __syncthreads();
