@@ -59,6 +59,37 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
   f32x16 aWn = {0}, aWa = {0};
   float csz = 0.f, csd = 0.f;
 
+  // Register prefetch, one tile ahead: while tile t is computed, the rows of tile t + stride (X, the d x_hat sum, dXs, x0: four float4 per
+  // staged row and thread, the ids and this thread's two attribute pieces) are in flight.  Loads are unconditional on clamped indices and
+  // the masks apply to the values: no branch sits around a load.  (Without the prefetch every tile waited out its HBM round trips --
+  // id -> attribute row even two dependent ones -- with only the CU's other workgroup to cover them: 0.33 of the HBM roof.)
+  float4 pxv[4], pdv[4], psv[4], px0[4], pav[2];
+  int pid = 0;
+  const float4 dxp = *reinterpret_cast<const float4*>(g.dxpad + sc4);        // the shared padding token's d x_hat (fb_unfold2_kernel)
+  const int a_row0 = tid >> 3, a_q = (tid & 7) * 4;                           // attribute pieces: rows a_row0 and a_row0 + 32, columns a_q .. a_q + 3
+  const int a_qc = a_q < g.n_attr ? a_q : 0;
+#define FBW_GLOAD(TILE)                                                                                  \
+  do {                                                                                                   \
+    const int64_t tb__ = (int64_t)(TILE) * 64;                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                \
+      const int64_t t__ = tb__ + srow + 16 * i__;                                                        \
+      const int64_t tc__ = t__ < T ? t__ : (int64_t)T - 1;                                               \
+      pxv[i__] = *reinterpret_cast<const float4*>(g.X + tc__ * 64 + sc4);                                \
+      pdv[i__] = *reinterpret_cast<const float4*>(g.dxh + tc__ * 64 + sc4);                              \
+      psv[i__] = *reinterpret_cast<const float4*>(g.dXs + tc__ * 64 + sc4);                              \
+      px0[i__] = *reinterpret_cast<const float4*>(g.x0 + tc__ * 64 + sc4);                               \
+    }                                                                                                    \
+    {                                                                                                    \
+      const int64_t t__ = tb__ + (tid & 63);                                                             \
+      pid = (int)g.ids[t__ < T ? t__ : (int64_t)T - 1];                                                  \
+    }                                                                                                    \
+    _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__) {                                                \
+      const int64_t t__ = tb__ + a_row0 + 32 * j__;                                                      \
+      const int64_t id__ = g.ids[t__ < T ? t__ : (int64_t)T - 1];                                        \
+      pav[j__] = *reinterpret_cast<const float4*>(g.attr_table + id__ * g.n_attr + a_qc);                \
+    }                                                                                                    \
+  } while (0)
+  if ((int)blockIdx.x < ntiles) FBW_GLOAD(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t t_base = (int64_t)tile * 64;
     __syncthreads();                              // previous tile's GEMMs are done with the working tiles
@@ -69,24 +100,20 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
       const int64_t t = t_base + row;
       const bool valid = t < T;
       const int64_t tc = valid ? t : (int64_t)T - 1;
-      const float4 xv = *reinterpret_cast<const float4*>(g.X + tc * 64 + sc4);
-      float4 d;
-      if (tc < T - 1) {
-        d = *reinterpret_cast<const float4*>(g.dxh + tc * 64 + sc4);
-        for (int hd = 1; hd < g.nslab; ++hd) {
-          const float4 v = *reinterpret_cast<const float4*>(g.dxh + ((int64_t)hd * g.tcap + tc) * 64 + sc4);
-          d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
-        }
-      } else {
-        d = *reinterpret_cast<const float4*>(g.dxpad + sc4);        // the shared padding token (fb_unfold2_kernel)
+      const float4 xv = pxv[i];
+      float4 d = pdv[i];
+      for (int hd = 1; hd < g.nslab; ++hd) {          // per-head slabs (deterministic / row-sparse modes): the other seven, added in order
+        const float4 v = *reinterpret_cast<const float4*>(g.dxh + ((int64_t)hd * g.tcap + tc) * 64 + sc4);
+        d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
       }
+      if (tc >= T - 1) d = dxp;
       const float mean = group_sum16_dpp((xv.x + xv.y) + (xv.z + xv.w)) * (1.f / 64.f);
       const float a0 = xv.x - mean, a1 = xv.y - mean, a2 = xv.z - mean, a3 = xv.w - mean;
       const float rs = __builtin_amdgcn_rsqf(group_sum16_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) * (1.f / 64.f) + kEps);
       const float4 xh = make_float4(a0 * rs, a1 * rs, a2 * rs, a3 * rs);
       const float ma = group_sum16_dpp((d.x + d.y) + (d.z + d.w)) * (1.f / 64.f);
       const float mb = group_sum16_dpp((d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w)) * (1.f / 64.f);
-      const float4 s = *reinterpret_cast<const float4*>(g.dXs + tc * 64 + sc4);
+      const float4 s = psv[i];
       const float m = valid ? 1.f : 0.f;
       float4 z;
       z.x = m * (rs * (d.x - ma - xh.x * mb) + s.x) * (1.f - xv.x * xv.x);
@@ -94,17 +121,18 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
       z.z = m * (rs * (d.z - ma - xh.z * mb) + s.z) * (1.f - xv.z * xv.z);
       z.w = m * (rs * (d.w - ma - xh.w * mb) + s.w) * (1.f - xv.w * xv.w);
       *reinterpret_cast<float4*>(&Zs[row * kLd + sc4]) = z;
-      const float4 x0v = *reinterpret_cast<const float4*>(g.x0 + tc * 64 + sc4);
+      const float4 x0v = px0[i];
       *reinterpret_cast<float4*>(&X0s[row * kLd + sc4]) = make_float4(x0v.x * m, x0v.y * m, x0v.z * m, x0v.w * m);
     }
-    if (tid < 64) ids_s[tid] = (t_base + tid < T) ? (int)g.ids[t_base + tid] : 0;
-    for (int i = tid; i < 64 * (kAttrCols / 4); i += 256) {         // 8 float4 slots per row
-      const int row = i >> 3, q = (i & 7) * 4;
-      const int64_t t = t_base + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < T && q < g.n_attr) v = *reinterpret_cast<const float4*>(g.attr_table + g.ids[t] * g.n_attr + q);
-      *reinterpret_cast<float4*>(&As[row * kLdA + q]) = v;
+    if (tid < 64) ids_s[tid] = (t_base + tid < T) ? pid : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = a_row0 + 32 * j;
+      const bool on = t_base + row < T && a_q < g.n_attr;
+      const float4 v = pav[j];
+      *reinterpret_cast<float4*>(&As[row * kLdA + a_q]) = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (tile + (int)gridDim.x < ntiles) FBW_GLOAD(tile + (int)gridDim.x);      // next tile's rows: in flight during this tile's GEMMs
     __syncthreads();
     // ---- dX0 = dZ0 . Wn  (Wn stored [n][k]: column walk) ----
     {
