@@ -626,3 +626,48 @@ def test_merged_layerwise_batched_head_products_match_separate_gemms_and_four_pr
         for which in (0, 1):
             b = res[which][1][o:o + p.numel()]
             assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
+
+
+def test_trainer_step_with_empty_rows_half_tile_backward():
+    """The Trainer's default d = 64 step (merged heads, half-tile backward, heads' d x_hat through float atomics) on a batch with 300
+    all-padding rows in the middle and k = 1 rows (a half tile then holds more than 31 hyperedges, some with no token at all), against
+    the four-product recompute kernels on 64-row tiles and against the layer-by-layer kernels."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(12)
+    x = _mixed_batch(N, [2, 3, 5], 60, rng)
+    ones = torch.zeros(50, x.shape[1], dtype=x.dtype, device="cuda")
+    ones[:, 0] = torch.randint(1, N + 1, (50,), device="cuda")
+    x = torch.cat([x[:70], torch.zeros(300, x.shape[1], dtype=x.dtype, device="cuda"), ones, x[70:]])
+    y = (torch.rand(len(x), device="cuda") < 0.3).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    res = []
+    for options in ((), ("disable_merged", "disable_qkv_save"), ("disable_fused",)):
+        clf, _ = hip_model(num, 64, "table", 9)
+        clf.train(True)
+        tr = Trainer(clf, base_seed=3)
+        for o in options:
+            _lib.set_option(o, 1)
+        try:
+            logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
+            torch.cuda.synchronize()
+        finally:
+            for o in options:
+                _lib.set_option(o, 0)
+        tr.check_status()
+        res.append((logits.clone(), tr.gflat.clone()))
+    assert float(res[0][0][70:370].abs().max()) == float(res[2][0][70:370].abs().max())      # all-padding rows: the same constant logit
+    for which in (1, 2):
+        assert float((res[0][0] - res[which][0]).abs().max()) <= 2e-5 * max(1.0, float(res[which][0].abs().max()))
+    clf, _ = hip_model(num, 64, "table", 9)
+    rt = clf._runtime()
+    for n, p in clf.named_parameters():
+        o = (p.data_ptr() - rt.flat.data_ptr()) // 4
+        if n == GAUGE or o < 0 or o >= rt.n_flat:
+            continue
+        a = res[2][1][o:o + p.numel()]
+        scale = max(float(a.abs().max()), 1e-6)
+        for which in (0, 1):
+            b = res[which][1][o:o + p.numel()]
+            assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
