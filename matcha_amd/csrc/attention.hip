@@ -473,31 +473,6 @@ int launch_attn_bwd(const float* Q, const float* K, const float* V, const float*
   return MATCHA_OK;
 }
 
-// out[t][f] = sum over the 8 heads of per_head[t][h d + f]  (merged heads, embed_dim >= 128: the attention backward returns dK / dV
-// per head although every head attended the same [T, d] key / value rows)
-__global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ in, int64_t T, int d, float* __restrict__ out, const int32_t* __restrict__ t_dev) {
-  if (t_dev) T = *t_dev;
-  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;       // float4 index into out
-  const int per_row = d / 4;
-  const int64_t t = i4 / per_row;
-  if (t >= T) return;
-  const int f = (int)(i4 - t * per_row) * 4;
-  const float* src = in + t * (int64_t)MATCHA_N_HEAD * d + f;
-  float4 s = *reinterpret_cast<const float4*>(src);
-#pragma unroll
-  for (int h = 1; h < MATCHA_N_HEAD; ++h) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)h * d);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  *reinterpret_cast<float4*>(out + t * d + f) = s;
-}
-int launch_head_sum(const float* per_head, int64_t T, int d, float* out, hipStream_t st, const int32_t* t_dev) {
-  if (T <= 0) return MATCHA_OK;
-  hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)cdiv(T * (d / 4), 256)), dim3(256), 0, st, per_head, T, d, out, t_dev);
-  MATCHA_CHECK_LAUNCH("head_sum_kernel");
-  return MATCHA_OK;
-}
-
 }  // namespace matcha
 
 using namespace matcha;

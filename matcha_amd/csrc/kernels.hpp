@@ -188,7 +188,6 @@ int launch_attn_fwd(const float* Q, const float* K, const float* V, const int32_
 int launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, const int32_t* row_off, int64_t B, int L,
                     int d, float* dQ, float* dK, float* dV, float* slab, hipStream_t st, bool shared_kv = false, float* dKsum = nullptr,
                     float* dVsum = nullptr);
-int launch_head_sum(const float* per_head, int64_t T, int d, float* out, hipStream_t st, const int32_t* t_dev);   // out[t][f] = sum_h per_head[t][h d + f]
 size_t attn_bwd_slab_bytes(int64_t B, int d);
 // attention_wide.hip: the same attention for embed_dim >= 128 with one operand set live at a time (no spills at L = 8, d = 256)
 bool attn_wide_eligible(int d);
