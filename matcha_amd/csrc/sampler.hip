@@ -39,6 +39,49 @@ __device__ __forceinline__ bool rows_equal(const int64_t* __restrict__ a, int La
   return true;
 }
 
+// The same two functions on a row held in REGISTERS (neg_sample_kernel's candidate): every index is a compile-time constant after
+// unrolling, so the array never becomes a scratch-memory object (dynamic indices cost 144 B of scratch per lane and 94 scratch
+// instructions in the first version); the early exits are flags.
+__device__ __forceinline__ uint64_t row_hash_reg(const int64_t (&row)[MATCHA_MAX_L], int L) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  bool live = true;
+#pragma unroll
+  for (int i = 0; i < MATCHA_MAX_L; ++i) {
+    const uint64_t v = (uint64_t)row[i];
+    live = live && i < L && v != 0;
+    uint64_t t = h ^ (v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
+    t *= 0xBF58476D1CE4E5B9ull;
+    t ^= t >> 31;
+    h = live ? t : h;
+  }
+  return h;
+}
+__device__ __forceinline__ bool rows_equal_reg(const int64_t* __restrict__ a, int La, const int64_t (&b)[MATCHA_MAX_L], int Lb) {
+  const int L = La > Lb ? La : Lb;
+  bool decided = false, equal = true;
+#pragma unroll
+  for (int i = 0; i < MATCHA_MAX_L; ++i) {
+    const int64_t va = (i < La) ? a[i < La ? i : 0] : 0, vb = i < Lb ? b[i] : 0;
+    const bool on = !decided && i < L;
+    if (on && va != vb) { decided = true; equal = false; }
+    if (on && va == vb && va == 0) decided = true;
+  }
+  return equal;
+}
+__device__ __forceinline__ bool set_contains_reg(const int32_t* __restrict__ set, const int64_t* __restrict__ edges, int L_set,
+                                                 const int64_t (&row)[MATCHA_MAX_L], int L) {
+  const int64_t cap = reinterpret_cast<const int64_t*>(set)[0];
+  const int32_t* slots = set + kSetHeader;
+  uint64_t pos = row_hash_reg(row, L) & (uint64_t)(cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    const int32_t idx = slots[pos];
+    if (idx < 0) return false;
+    if (rows_equal_reg(edges + (int64_t)idx * L_set, L_set, row, L)) return true;
+    pos = (pos + 1) & (uint64_t)(cap - 1);
+  }
+  return false;
+}
+
 __global__ void hashset_clear_kernel(int32_t* set, int64_t cap) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { reinterpret_cast<int64_t*>(set)[0] = cap; }
@@ -100,51 +143,68 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restri
   int64_t* out = neg + n * L;
   // `while neighbor_check(temp, dict)` with temp == the positive on entry (main.py:390-392): if the positive is
   // not a member (in particular: empty set, the reference's phase 1, main.py:589) the loop never runs.
-  bool resample = (n_set > 0) && (k > 0) && set_contains(set, set_edges, L_set, orig, L);
+  bool resample = (n_set > 0) && (k > 0) && set_contains_reg(set, set_edges, L_set, orig, L);
   bool done = false;
   if (resample) {
     const uint32_t key = rng_key(*seed, kStreamNeg);
     uint32_t mask = 0;
     for (uint32_t a = 0; mask == 0; ++a) mask = rng_u32(key, (uint32_t)n, 0xFFFF0000u + a) & ((1u << k) - 1u);
+    // the chromosome ranges of the positions that may be redrawn do not change between trials: looked up once
+    int64_t cstart[MATCHA_MAX_L], clen[MATCHA_MAX_L];
+#pragma unroll
+    for (int i = 0; i < MATCHA_MAX_L; ++i) {
+      cstart[i] = 0; clen[i] = -1;
+      if (i < k && ((mask >> i) & 1u)) {
+        // a node outside [1, n_nodes] or without a chromosome (node2chrom = -1, the default fill of train.run) cannot be
+        // redrawn: it is kept and the call is flagged (the reference raises KeyError / IndexError at main.py:401-403)
+        const int c = (orig[i] >= 1 && orig[i] <= n_nodes) ? node2chrom[orig[i]] : -1;
+        if (c >= 0 && c < n_chrom) {
+          cstart[i] = chrom_range[2 * c];
+          clen[i] = (int64_t)chrom_range[2 * c + 1] - cstart[i];
+        } else if (status) {
+          atomicOr(status, MATCHA_STATUS_BAD_CHROM);
+        }
+      }
+    }
     for (int trial = 0; trial < kMaxTrials && !done; ++trial) {
+      // unused slots (i >= k) sort behind every node id and are put back to 0 afterwards
+      constexpr int64_t kBig = 0x7FFFFFFFFFFFFFFFll;
 #pragma unroll
       for (int i = 0; i < MATCHA_MAX_L; ++i) {
-        cand[i] = orig[i];
-        if (i < k && ((mask >> i) & 1u)) {
-          // a node outside [1, n_nodes] or without a chromosome (node2chrom = -1, the default fill of train.run) cannot be
-          // redrawn: it is kept and the call is flagged (the reference raises KeyError / IndexError at main.py:401-403)
-          const int c = (orig[i] >= 1 && orig[i] <= n_nodes) ? node2chrom[orig[i]] : -1;
-          if (c >= 0 && c < n_chrom) {
-            const int64_t start = chrom_range[2 * c], end = chrom_range[2 * c + 1];
-            const uint32_t r = rng_u32(key, (uint32_t)n, (uint32_t)(8 * trial + i));
-            cand[i] = start + (int64_t)(((uint64_t)r * (uint64_t)(end - start)) >> 32);
-          } else if (status && trial == 0) {
-            atomicOr(status, MATCHA_STATUS_BAD_CHROM);
-          }
+        cand[i] = i < k ? orig[i] : kBig;
+        if (clen[i] >= 0) {
+          const uint32_t r = rng_u32(key, (uint32_t)n, (uint32_t)(8 * trial + i));
+          cand[i] = cstart[i] + (int64_t)(((uint64_t)r * (uint64_t)clen[i]) >> 32);
         }
       }
-      // sort ascending (k <= 8), then reject duplicates / close neighbours / known hyperedges (main.py:410-421, :392)
-#pragma unroll
-      for (int a = 1; a < MATCHA_MAX_L; ++a) {
-        if (a < k) {
-          const int64_t v = cand[a];
-          int b = a - 1;
-          while (b >= 0 && cand[b] > v) { cand[b + 1] = cand[b]; --b; }
-          cand[b + 1] = v;
-        }
-      }
+      // sort ascending (k <= 8): Batcher's odd-even merge network, 19 compare-exchanges on registers (an insertion sort indexes the array
+      // with run-time values); then reject duplicates / close neighbours / known hyperedges (main.py:410-421, :392)
+#define NS_CE(A, B) do { const int64_t lo__ = cand[A] < cand[B] ? cand[A] : cand[B], hi__ = cand[A] < cand[B] ? cand[B] : cand[A]; cand[A] = lo__; cand[B] = hi__; } while (0)
+      static_assert(MATCHA_MAX_L == 8, "the sorting network below is for 8 slots");
+      NS_CE(0, 1); NS_CE(2, 3); NS_CE(4, 5); NS_CE(6, 7);
+      NS_CE(0, 2); NS_CE(1, 3); NS_CE(4, 6); NS_CE(5, 7);
+      NS_CE(1, 2); NS_CE(5, 6);
+      NS_CE(0, 4); NS_CE(1, 5); NS_CE(2, 6); NS_CE(3, 7);
+      NS_CE(2, 4); NS_CE(3, 5);
+      NS_CE(1, 2); NS_CE(3, 4); NS_CE(5, 6);
+#undef NS_CE
       bool ok = true;
-      for (int a = 0; a + 1 < k; ++a) {
+#pragma unroll
+      for (int a = 0; a + 1 < MATCHA_MAX_L; ++a) {
         const int64_t gap = cand[a + 1] - cand[a];
-        if (gap == 0 || gap <= min_dis) ok = false;
+        if (a + 1 < k && (gap == 0 || gap <= min_dis)) ok = false;
       }
-      if (ok && !set_contains(set, set_edges, L_set, cand, L)) done = true;
+#pragma unroll
+      for (int i = 0; i < MATCHA_MAX_L; ++i) cand[i] = i < k ? cand[i] : 0;
+      if (ok && !set_contains_reg(set, set_edges, L_set, cand, L)) done = true;
     }
     // trials exhausted (tiny chromosome, large min_dis, dense known set): the row is returned equal to its positive and counted;
     // the reference would loop forever (main.py:392)
     if (!done && status) atomicAdd(status + 1, 1);
   }
-  for (int i = 0; i < L; ++i) out[i] = done ? cand[i] : orig[i];
+#pragma unroll
+  for (int i = 0; i < MATCHA_MAX_L; ++i)
+    if (i < L) out[i] = done ? cand[i] : orig[i];
 }
 
 }  // namespace matcha
