@@ -209,6 +209,7 @@ struct FrontFwdArgs {
   const float* Wa; const float* ba; const float* Wn; const float* bn;
   const int32_t* count;
   float* x0; float* X;
+  float* zero_rows;   // [T, 64] rows zeroed next to the X rows (the d x_hat buffer the backward's float atomics add into); null: not asked
 };
 
 __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
@@ -360,7 +361,10 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = srow + 16 * i;
-      if (t_base + row < T) *reinterpret_cast<float4*>(g.X + (t_base + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&Xs[row * kLd + sc4]);
+      if (t_base + row < T) {
+        *reinterpret_cast<float4*>(g.X + (t_base + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&Xs[row * kLd + sc4]);
+        if (g.zero_rows) *reinterpret_cast<float4*>(g.zero_rows + (t_base + row) * 64 + sc4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
 }
@@ -368,10 +372,12 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
 struct FrontReduceArgs {
   const float* slab; int nwg; int n_attr;
   float* dWn; float* dWa; float* dbn; float* dba;
+  int32_t* touched;   // table front end: the two "this group of parameters received a gradient" flags, set here instead of by a launch of their own; null: not asked
 };
 // fixed-order sum over the workgroup slabs (64 outputs x 16 lanes per block), accumulated into the gradient tensors
 __global__ __launch_bounds__(1024) void front_slab_reduce_kernel(FrontReduceArgs a) {
   __shared__ float part[16][64];
+  if (a.touched && blockIdx.x == 0 && threadIdx.x < 2) a.touched[threadIdx.x] = 1;
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
   float s = 0.f;
@@ -409,8 +415,9 @@ int front_grid() {
 }  // namespace
 
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
-                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st) {
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st, float* zero_rows) {
   FrontFwdArgs g;
+  g.zero_rows = zero_rows;
   g.ids = ids; g.table = table; g.dense = dense; g.attr_table = attr_table; g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
   int grid = front_grid() / 2 * 3;                      // three workgroups per CU (44 KB of LDS each)
@@ -419,7 +426,7 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
   // (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
-  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + (x0 ? 512.0 : 256.0)), st);
+  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + (x0 ? 512.0 : 256.0) + (zero_rows ? 256.0 : 0.0)), st);
   hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);
   MATCHA_CHECK_LAUNCH("front_fwd_kernel");
   return MATCHA_OK;
@@ -430,7 +437,7 @@ size_t front_bwd_ws_floats() { return (size_t)1024 * kFrontSlab; }
 
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
-                     matcha_tensors& grads, hipStream_t st) {
+                     matcha_tensors& grads, hipStream_t st, int32_t* touched) {
   FrontBwdArgs g;
   g.X = X; g.dxh = dxh; g.nslab = nslab; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr_table = attr_table; g.n_attr = n_attr;
   g.Wn = p.next_w; g.count = rg.count; g.dX0 = dX0; g.dtable = dtable; g.slab = ws;
@@ -448,6 +455,7 @@ int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, 
   }
   FrontReduceArgs a;
   a.slab = ws; a.nwg = grid; a.n_attr = n_attr; a.dWn = grads.next_w; a.dWa = grads.attr_w; a.dbn = grads.next_b; a.dba = grads.attr_b;
+  a.touched = touched;
   hipLaunchKernelGGL(front_slab_reduce_kernel, dim3((unsigned)cdiv(kFrontSlab, 64)), dim3(1024), 0, st, a);
   MATCHA_CHECK_LAUNCH("front_slab_reduce_kernel");
   return MATCHA_OK;

@@ -57,7 +57,7 @@ size_t ragged_bytes(int64_t B, int L);
 int ragged_tiles_cap(int64_t B, int L);
 int ragged_halves_cap(int64_t B, int L);
 void ragged_carve(int64_t B, int L, char* base, Ragged& r);
-int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st);
+int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st, int level = 2);
 
 struct HeadParams {
   const float *gp, *bp, *g1, *b1, *g2, *b2, *wc, *bc;
@@ -124,7 +124,7 @@ int launch_head_bwd(const int32_t* row_off, const float* H2, const float* X, int
                     const float* y, const float* w, const float* logits, const float* dlogits, float alpha, float* dH2,
                     float* dXs, float* slab, const HeadParams& ghp, hipStream_t st);
 size_t colsum_slab_bytes(int64_t n, int nv, int d);
-int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st);
+int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon = false);   // zero_recon: losses[1..2] = 0 too
 
 // fused_fwd.hip (embed_dim 64)
 size_t fused_fold_floats();
@@ -162,7 +162,7 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool halves);
+                            bool dx_atomic, bool halves, bool dxh_zeroed = false);
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
 constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
 constexpr int kImgRecM = 4096 + 512;               // merged heads: the r rows (r = B_h x_hat + b_h) + the attention probabilities
@@ -175,11 +175,11 @@ const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padd
 // backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel
 bool front_bwd_supported(int d, int n_attr);
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
-                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st);
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st, float* zero_rows = nullptr);
 size_t front_bwd_ws_floats();
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
-                     matcha_tensors& grads, hipStream_t st);
+                     matcha_tensors& grads, hipStream_t st, int32_t* touched = nullptr);
 
 // attention.hip
 // shared_kv (embed_dim >= 128, merged heads): K and V are [T, d] tensors that every head attends (dK / dV still come back per head)

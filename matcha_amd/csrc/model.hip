@@ -133,11 +133,19 @@ static bool save_qkv() { return !options().disable_qkv_save; }
 // it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
 static std::mutex g_qkv_mu;
 static std::unordered_map<const void*, int> g_qkv_saved;     // bit 0: Q/K/V tiles saved; bit 1: the forward ran per HALF tile (fused_fwd32)
-static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false, bool img_half = false) {
+static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false, bool img_half = false, bool dxh_zeroed = false) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
   if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
-  // bit 2: the saved records are the merged heads' r rows; bit 3: one record per HALF tile (fused_bwdh_kernel) instead of per 64-row tile
-  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0) | (img_half ? 8 : 0);
+  // bit 2: the saved records are the merged heads' r rows; bit 3: one record per HALF tile (fused_bwdh_kernel) instead of per 64-row tile;
+  // bit 4: the forward zeroed the d x_hat buffer's rows for the backward's float atomics (consumed by the first backward)
+  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0) | (img_half ? 8 : 0) | (dxh_zeroed ? 16 : 0);
+}
+static bool take_dxh_zeroed(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_qkv_mu);
+  auto it = g_qkv_saved.find(ws);
+  if (it == g_qkv_saved.end() || !(it->second & 16)) return false;
+  it->second &= ~16;
+  return true;
 }
 static int ws_state(const void* ws) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
@@ -414,21 +422,36 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const int32_t* cnt = w.rg.count;
   const int64_t* ids = w.rg.tok_id;
 
-  // CSR plan: real tokens + one shared padding token
-  MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st));
+  // which fused kernels will run on this workspace (decided here: the plan, the front end and the saved records depend on it)
+  const bool fused_path = !force_layerwise && fused_enabled(s) && (opts->forward_only || fused_train_enabled(s));
+  const bool lif = fused_path && loss_in_forward(s, *opts, y, w_bce);      // the tail's backward runs in the forward kernel: nothing saved
+  const bool keep_qkv = !opts->forward_only && save_qkv();
+  const bool fwd32 = !options().disable_fwd32;                     // wave-independent forward (one wavefront per half tile)
+  // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities for fused_bwdh_kernel
+  const bool merged = fwd32 && !options().disable_merged;
+  const bool img_half = merged && !options().disable_bwdh;
+  // CSR plan: real tokens + one shared padding token; tile lists only for the kernels that will read them (the half-tile forward /
+  // backward pair needs neither the 64-row tiles nor the token -> tile map; a backward that recomputes Q/K/V walks 64-row tiles)
+  const int plan_level = !fused_enabled(s) ? 0 : ((fused_path && img_half && (opts->forward_only || keep_qkv)) ? 1 : 2);
+  MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st, plan_level));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
   const bool front = !force_layerwise && fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
+  // table front end: the two reconstruction-loss slots are zero; loss_reduce_kernel writes them when it runs anyway
+  const bool recon_zero_in_loss = s.mode == 0 && recon_out && fused_path && y && w_bce && losses;
+  // the backward that follows a loss-in-forward step adds the heads' d x_hat with float atomics (matcha_backward: dx_atomic): the front-end
+  // kernel zeroes that buffer's rows next to the X rows it writes (a 59 MB memset + a launch less in front of the backward kernel)
+  const bool zero_dxh = front && lif && keep_qkv && img_half && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
-    if (recon_out && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    if (recon_out && !recon_zero_in_loss && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
   } else {
     MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot));
   }
   if (front) {
     // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
     MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, w.rg, Tn,
-                                opts->forward_only ? nullptr : w.x0, w.X, st));     // x0 (pre-activation) is only read by the backward pass
+                                opts->forward_only ? nullptr : w.x0, w.X, st, zero_dxh ? w.dO : nullptr));     // x0 (pre-activation) is only read by the backward pass
   } else {
     MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, p.attr_w,
                                 p.attr_b, w.x0, st, cnt));
@@ -437,21 +460,15 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_TANH; g.bias[0] = p.next_b;
     MATCHA_TRY(launch_gemm_rm(false, g, st));
   }
-  if (!force_layerwise && fused_enabled(s) && (opts->forward_only || fused_train_enabled(s))) {
+  if (fused_path) {
     // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
     // token); every training forward also leaves its Q/K/V tiles and attention probabilities for the fused backward (w.qkv)
-    const bool lif = loss_in_forward(s, *opts, y, w_bce);            // the tail's backward runs in this kernel: nothing saved
     const bool save = !opts->forward_only && !lif;
     MATCHA_TRY(launch_fold_ln(p, w.folded, st));
-    const bool keep_qkv = !opts->forward_only && save_qkv();
-    const bool fwd32 = !options().disable_fwd32;                     // wave-independent forward (one wavefront per half tile)
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
-    // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities for fused_bwdm_kernel
-    const bool merged = fwd32 && !options().disable_merged;
-    const bool img_half = merged && !options().disable_bwdh;
-    note_qkv_saved(ws, keep_qkv, fwd32, merged, img_half);
+    note_qkv_saved(ws, keep_qkv, fwd32, merged, img_half, zero_dxh);
     if (fwd32) {
       if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
       MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
@@ -463,7 +480,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
     }
-    if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st));
+    if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
     }
@@ -638,7 +655,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
     if (merged_bwd)
       MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic,
-                                         fwd_saved_half_records(ws)));
+                                         fwd_saved_half_records(ws), dx_atomic && fwd_saved_half_records(ws) && take_dxh_zeroed(ws)));
     else
       MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
     MATCHA_TRY(encoder_done(*opts, st));
@@ -647,10 +664,9 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
       const bool rows_out = s.mode == 1 || opts->deterministic || opts->sparse_table_grad;     // dX0 rows instead of float atomics
       MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, dx_atomic ? 1 : MATCHA_N_HEAD, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
-                                  rows_out ? w.dX0 : nullptr, rows_out ? nullptr : g_.table, w.front_ws, g_, st));
+                                  rows_out ? w.dX0 : nullptr, rows_out ? nullptr : g_.table, w.front_ws, g_, st, s.mode == 0 ? touched : nullptr));
       if (s.mode == 0) {
-        MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));
-        if (touched) MATCHA_TRY(launch_fill_i32(touched, 2, 1, st));
+        MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));       // (the two `touched` flags were set by front_slab_reduce_kernel)
       } else {
         MATCHA_TRY(adj_backward(s, p, *frozen, *opts, ids, Tn, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st,
                                 w.rg.tok_slot));

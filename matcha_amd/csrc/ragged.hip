@@ -117,13 +117,16 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
       }
     }
   }
+  const int tr = count[1];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const int tr = count[1];
     row_off[B] = tr;
     tok_slot[tr] = (int32_t)(B * L);
     tok_id[tr] = 0;
     tok_pos[tr] = 0;
   }
+  // tok_key of every slot behind the real tokens is 0 (the padding token's included): written here instead of a memset of the whole
+  // array in front of the plan (the real tokens' keys are written above by their owners; nobody else touches slots >= tr)
+  for (int64_t i = tr + (int64_t)blockIdx.x * 256 + threadIdx.x; i < B * L + 1; i += (int64_t)gridDim.x * 256) tok_key[i] = 0;
 }
 
 // Tiles of the fused kernels: runs of whole consecutive hyperedges with at most 63 tokens (+ the shared padding token = 64
@@ -139,9 +142,9 @@ constexpr int kSuperTok = 63 * 32;
 // blockIdx.y = 0: tiles of <= 63 tokens; 1: half tiles of <= 31 tokens (same superblocks, own lists)
 __global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb0, int cap_per_sb1,
                                                        const int32_t* __restrict__ sb_first, int32_t* __restrict__ sb_tiles0,
-                                                       int32_t* __restrict__ sb_cnt0, int32_t* __restrict__ sb_tiles1, int32_t* __restrict__ sb_cnt1) {
+                                                       int32_t* __restrict__ sb_cnt0, int32_t* __restrict__ sb_tiles1, int32_t* __restrict__ sb_cnt1, int y0) {
   const int s = blockIdx.x, lane = threadIdx.x;
-  const bool half = blockIdx.y != 0;
+  const bool half = (int)blockIdx.y + y0 != 0;
   const int kTileTok = half ? kHalfTok : kFullTok;
   const int cap_per_sb = half ? cap_per_sb1 : cap_per_sb0;
   int32_t* sb_tiles = half ? sb_tiles1 : sb_tiles0;
@@ -183,8 +186,9 @@ struct CompactArgs {
   const int32_t* sb_tiles[2]; int32_t* sb_cnt[2]; int cap_per_sb[2]; int ntiles_cap[2]; int32_t* meta[2];
 };
 // blockIdx.x = 0: tiles -> tile_meta, count[2];  1: half tiles -> half_meta, count[3]
-__global__ __launch_bounds__(1024) void tile_compact_kernel(CompactArgs a, int nsb, int32_t* __restrict__ count) {
-  const int which = blockIdx.x;
+__global__ __launch_bounds__(1024) void tile_compact_kernel(CompactArgs a, int nsb, int32_t* __restrict__ count, int x0) {
+  const int which = (int)blockIdx.x + x0;
+  if (x0 != 0 && threadIdx.x == 0) count[2] = 0;       // half tiles only: no 64-row tile list this time
   const int32_t* __restrict__ sb_tiles = a.sb_tiles[which];
   int32_t* __restrict__ sb_cnt = a.sb_cnt[which];
   const int cap_per_sb = a.cap_per_sb[which], ntiles_cap = a.ntiles_cap[which];
@@ -285,8 +289,9 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
   r.tok_tile = (int32_t*)take((size_t)(T + 1) * 4);
 }
 
-int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st) {
-  if (hipMemsetAsync(r.tok_key, 0, (size_t)(B * L + 1) * 4, st) != hipSuccess) { set_error("ragged plan: memset failed"); return MATCHA_EHIP; }
+// level 2: everything; 1: no 64-row tile list and no token -> tile map (the fused kernels that run work on half tiles only); 0: rows and
+// tokens only (no fused kernel will read a tile list)
+int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st, int level) {
   hipLaunchKernelGGL(row_count_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum);
   MATCHA_CHECK_LAUNCH("row_count_kernel");
   hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, r.blk_sum, r.nblk, r.count, r.sb_first, r.nsb, (int32_t)B);
@@ -294,16 +299,20 @@ int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int3
   hipLaunchKernelGGL(row_fill_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum, r.count, r.row_off, r.tok_slot, r.tok_id, r.tok_pos, r.sb_first, kSuperTok,
                      r.tok_key, n_nodes, status);
   MATCHA_CHECK_LAUNCH("row_fill_kernel");
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb, 2), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_hcap, r.sb_first, r.sb_tiles, r.sb_cnt,
-                     r.sb_htiles, r.sb_hcnt);
+  if (level <= 0) return MATCHA_OK;
+  const int first = level >= 2 ? 0 : 1;                // list 0: 64-row tiles, list 1: half tiles
+  hipLaunchKernelGGL(tile_pack_kernel, dim3(r.nsb, 2 - first), dim3(64), 0, st, r.row_off, B, r.nsb, r.sb_cap, r.sb_hcap, r.sb_first, r.sb_tiles, r.sb_cnt,
+                     r.sb_htiles, r.sb_hcnt, first);
   MATCHA_CHECK_LAUNCH("tile_pack_kernel");
   CompactArgs ca;
   ca.sb_tiles[0] = r.sb_tiles; ca.sb_cnt[0] = r.sb_cnt; ca.cap_per_sb[0] = r.sb_cap; ca.ntiles_cap[0] = r.ntiles; ca.meta[0] = r.tile_meta;
   ca.sb_tiles[1] = r.sb_htiles; ca.sb_cnt[1] = r.sb_hcnt; ca.cap_per_sb[1] = r.sb_hcap; ca.ntiles_cap[1] = r.nhalves; ca.meta[1] = r.half_meta;
-  hipLaunchKernelGGL(tile_compact_kernel, dim3(2), dim3(1024), 0, st, ca, r.nsb, r.count);
+  hipLaunchKernelGGL(tile_compact_kernel, dim3(2 - first), dim3(1024), 0, st, ca, r.nsb, r.count, first);
   MATCHA_CHECK_LAUNCH("tile_compact_kernel");
-  hipLaunchKernelGGL(tok_tile_kernel, dim3(r.ntiles), dim3(64), 0, st, r.tile_meta, r.tok_tile);
-  MATCHA_CHECK_LAUNCH("tok_tile_kernel");
+  if (level >= 2) {
+    hipLaunchKernelGGL(tok_tile_kernel, dim3(r.ntiles), dim3(64), 0, st, r.tile_meta, r.tok_tile);
+    MATCHA_CHECK_LAUNCH("tok_tile_kernel");
+  }
   return MATCHA_OK;
 }
 
@@ -328,5 +337,5 @@ extern "C" int matcha_ragged_plan(const int64_t* x, int64_t B, int32_t L, int32_
   view->row_off = r.row_off; view->tok_slot = r.tok_slot; view->tok_id = r.tok_id; view->tok_key = r.tok_key; view->tok_pos = r.tok_pos;
   view->count = r.count; view->tile_meta = r.tile_meta; view->tiles_cap = r.ntiles;
   view->half_meta = r.half_meta; view->halves_cap = r.nhalves; view->tok_tile = r.tok_tile;
-  return launch_ragged_plan(x, B, L, n_nodes, status, r, (hipStream_t)stream);
+  return launch_ragged_plan(x, B, L, n_nodes, status, r, (hipStream_t)stream, 2);
 }

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int32_t* __restrict
 }
 
 // sum of row losses / B in a fixed order (one block): losses[0] = bce
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out, int zero_recon) {
   __shared__ float red[1024];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int64_t i = threadIdx.x;
@@ -593,7 +593,10 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+  if (threadIdx.x == 0) {
+    out[0] = red[0] / (float)B;
+    if (zero_recon) { out[1] = 0.f; out[2] = 0.f; }   // table front end: no reconstruction loss (instead of a memset in front of the forward)
+  }
 }
 
 // dst[v][j] += sum_blk slab[blk][v][j]   (v < nv, j < d), blocks ascending; dst pointers per v
@@ -725,8 +728,8 @@ int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const f
   return MATCHA_OK;
 }
 
-int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, row_loss, B, bce_out);
+int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, row_loss, B, bce_out, zero_recon ? 1 : 0);
   MATCHA_CHECK_LAUNCH("loss_reduce_kernel");
   return MATCHA_OK;
 }
@@ -739,7 +742,7 @@ int launch_head_fwd(const int32_t* row_off, const float* H2, const float* X, int
   DISPATCH_NCH(d, hipLaunchKernelGGL((head_fwd_kernel<NCH>), dim3((unsigned)cdiv(B, 16)), dim3(256), 0, st, row_off, H2, X, B, L, d, hp, y, w, logits, rl));
   MATCHA_CHECK_LAUNCH("head_fwd_kernel");
   if (rl && bce_out) {
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rl, B, bce_out);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rl, B, bce_out, 0);
     MATCHA_CHECK_LAUNCH("loss_reduce_kernel");
   }
   return MATCHA_OK;
