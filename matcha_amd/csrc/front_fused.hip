@@ -209,7 +209,6 @@ struct FrontFwdArgs {
   const float* Wa; const float* ba; const float* Wn; const float* bn;
   const int32_t* count;
   float* x0; float* X;
-  float* zero_rows;   // [T, 64] rows zeroed next to the X rows (the d x_hat buffer the backward's float atomics add into); null: not asked
 };
 
 __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
@@ -361,10 +360,7 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = srow + 16 * i;
-      if (t_base + row < T) {
-        *reinterpret_cast<float4*>(g.X + (t_base + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&Xs[row * kLd + sc4]);
-        if (g.zero_rows) *reinterpret_cast<float4*>(g.zero_rows + (t_base + row) * 64 + sc4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      if (t_base + row < T) *reinterpret_cast<float4*>(g.X + (t_base + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&Xs[row * kLd + sc4]);
     }
   }
 }
@@ -415,9 +411,8 @@ int front_grid() {
 }  // namespace
 
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
-                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st, float* zero_rows) {
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st) {
   FrontFwdArgs g;
-  g.zero_rows = zero_rows;
   g.ids = ids; g.table = table; g.dense = dense; g.attr_table = attr_table; g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
   int grid = front_grid() / 2 * 3;                      // three workgroups per CU (44 KB of LDS each)
@@ -426,7 +421,7 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
   // (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
-  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + (x0 ? 512.0 : 256.0) + (zero_rows ? 256.0 : 0.0)), st);
+  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + (x0 ? 512.0 : 256.0)), st);
   hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);
   MATCHA_CHECK_LAUNCH("front_fwd_kernel");
   return MATCHA_OK;

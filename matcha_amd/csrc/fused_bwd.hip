@@ -2240,9 +2240,9 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
 // merged heads: fused_bwdm_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool halves, bool dxh_zeroed) {
+                            bool dx_atomic, bool halves) {
   const int64_t tcap = B * L + 1;
-  if (dx_atomic && !dxh_zeroed && hipMemsetAsync(dxh, 0, (size_t)tcap * 64 * sizeof(float), st) != hipSuccess) { set_error("fused_bwd_merged: memset failed"); return MATCHA_EHIP; }
+  if (dx_atomic && hipMemsetAsync(dxh, 0, (size_t)tcap * 64 * sizeof(float), st) != hipSuccess) { set_error("fused_bwd_merged: memset failed"); return MATCHA_EHIP; }
   int nchunks = chunks_for(rg.ntiles);
   if (halves) {                                              // two four-wave workgroups per CU
     nchunks = 2 * chunks_for(rg.nhalves);

@@ -162,7 +162,7 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
                      int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool halves, bool dxh_zeroed = false);
+                            bool dx_atomic, bool halves);
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
 constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
 constexpr int kImgRecM = 4096 + 512;               // merged heads: the r rows (r = B_h x_hat + b_h) + the attention probabilities
@@ -175,7 +175,7 @@ const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padd
 // backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel
 bool front_bwd_supported(int d, int n_attr);
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
-                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st, float* zero_rows = nullptr);
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st);
 size_t front_bwd_ws_floats();
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,

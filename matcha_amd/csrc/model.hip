@@ -133,19 +133,11 @@ static bool save_qkv() { return !options().disable_qkv_save; }
 // it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
 static std::mutex g_qkv_mu;
 static std::unordered_map<const void*, int> g_qkv_saved;     // bit 0: Q/K/V tiles saved; bit 1: the forward ran per HALF tile (fused_fwd32)
-static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false, bool img_half = false, bool dxh_zeroed = false) {
+static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false, bool img_half = false) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
   if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
-  // bit 2: the saved records are the merged heads' r rows; bit 3: one record per HALF tile (fused_bwdh_kernel) instead of per 64-row tile;
-  // bit 4: the forward zeroed the d x_hat buffer's rows for the backward's float atomics (consumed by the first backward)
-  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0) | (img_half ? 8 : 0) | (dxh_zeroed ? 16 : 0);
-}
-static bool take_dxh_zeroed(const void* ws) {
-  std::lock_guard<std::mutex> lk(g_qkv_mu);
-  auto it = g_qkv_saved.find(ws);
-  if (it == g_qkv_saved.end() || !(it->second & 16)) return false;
-  it->second &= ~16;
-  return true;
+  // bit 2: the saved records are the merged heads' r rows; bit 3: one record per HALF tile (fused_bwdh_kernel) instead of per 64-row tile
+  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0) | (img_half ? 8 : 0);
 }
 static int ws_state(const void* ws) {
   std::lock_guard<std::mutex> lk(g_qkv_mu);
@@ -439,9 +431,6 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const bool front = !force_layerwise && fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
   // table front end: the two reconstruction-loss slots are zero; loss_reduce_kernel writes them when it runs anyway
   const bool recon_zero_in_loss = s.mode == 0 && recon_out && fused_path && y && w_bce && losses;
-  // the backward that follows a loss-in-forward step adds the heads' d x_hat with float atomics (matcha_backward: dx_atomic): the front-end
-  // kernel zeroes that buffer's rows next to the X rows it writes (a 59 MB memset + a launch less in front of the backward kernel)
-  const bool zero_dxh = front && lif && keep_qkv && img_half && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
     if (recon_out && !recon_zero_in_loss && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
@@ -451,7 +440,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   if (front) {
     // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
     MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, w.rg, Tn,
-                                opts->forward_only ? nullptr : w.x0, w.X, st, zero_dxh ? w.dO : nullptr));     // x0 (pre-activation) is only read by the backward pass
+                                opts->forward_only ? nullptr : w.x0, w.X, st));     // x0 (pre-activation) is only read by the backward pass
   } else {
     MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, p.attr_w,
                                 p.attr_b, w.x0, st, cnt));
@@ -468,7 +457,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
-    note_qkv_saved(ws, keep_qkv, fwd32, merged, img_half, zero_dxh);
+    note_qkv_saved(ws, keep_qkv, fwd32, merged, img_half);
     if (fwd32) {
       if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
       MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
@@ -655,7 +644,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
     if (merged_bwd)
       MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic,
-                                         fwd_saved_half_records(ws), dx_atomic && fwd_saved_half_records(ws) && take_dxh_zeroed(ws)));
+                                         fwd_saved_half_records(ws)));
     else
       MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
     MATCHA_TRY(encoder_done(*opts, st));
