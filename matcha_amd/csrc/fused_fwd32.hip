@@ -218,7 +218,7 @@ struct MergeArgs {
 // grid (4 row slices, 2 matrices, 8 heads): 16 rows of B_h (y = 0; slice 0 also b_h) or of M_h (y = 1; slice 0 of head 0 also bdyn)
 __global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
   __shared__ float As[16 * 65];
-  __shared__ float Bs[64 * 65];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * 68];
   const int slice = blockIdx.x, hd = blockIdx.z, tid = threadIdx.x;
   const float* Wk = a.wk + (int64_t)hd * 4096;
   const bool isB = blockIdx.y == 0;
@@ -227,25 +227,57 @@ __global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
   const int a_rs = isB ? 1 : 512, a_cs = isB ? 64 : 1;
   const float* Bm = (isB ? a.wq : a.wv) + (int64_t)hd * 4096;
   float* out = (isB ? a.B : a.M) + (int64_t)hd * 4096;
-  for (int i = tid; i < 16 * 64; i += 256) As[(i >> 6) * 65 + (i & 63)] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
-  for (int i = tid; i < 64 * 64; i += 256) Bs[(i >> 6) * 65 + (i & 63)] = Bm[i];
-  __syncthreads();
-  for (int o = tid; o < 16 * 64; o += 256) {
-    const int i = o >> 6, j = o & 63;
-    float s = 0.f;
-#pragma unroll 8
-    for (int x = 0; x < 64; ++x) s += As[i * 65 + x] * Bs[x * 65 + j];
-    out[(16 * slice + i) * 64 + j] = s;
+  if (isB) {               // A(i, x) = W'k[x][16 slice + i]: walk W'k's rows (16 consecutive floats per x) instead of its columns
+    for (int i = tid; i < 16 * 64; i += 256) As[(i & 15) * 65 + (i >> 4)] = A[(int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)];
+  } else {
+    for (int i = tid; i < 16 * 64; i += 256) As[(i >> 6) * 65 + (i & 63)] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
   }
-  if (slice == 0 && tid < 64) {
+  {
+    // the 64 x 64 right operand: four float4 per thread, all in flight before the first LDS store (one scalar load per trip serialised
+    // sixteen global round trips)
+    float4 bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bv[u] = reinterpret_cast<const float4*>(Bm)[tid + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = (tid + 256 * u) * 4;
+      *reinterpret_cast<float4*>(&Bs[(f >> 6) * 68 + (f & 63)]) = bv[u];
+    }
+  }
+  __syncthreads();
+  {
+    // 16 x 64 outputs = one 16 x 16 MFMA tile per wavefront, 16 steps of v_mfma_f32_16x16x4_f32 over the contraction index (the scalar
+    // loop this replaces read two LDS words per multiply-add: 18 us for sixteen 64^3 products)
+    const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[c16 * 65 + 4 * kk + kq], Bs[(4 * kk + kq) * 68 + 16 * wave + c16], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[(16 * slice + 4 * kq + reg) * 64 + 16 * wave + c16] = acc[reg];
+  }
+  if (slice == 0) {
+    // the two bias vectors: four lanes per output, float4 reads, a fixed xor tree (one thread per output walked 512 terms alone: it was
+    // the longest path of the kernel)
+    const int o = tid >> 2, part = tid & 3;
     if (isB) {
       float s = 0.f;
-      for (int m = 0; m < 64; ++m) s += Wk[m * 64 + tid] * a.cq[hd * 64 + m];
-      a.bvec[hd * 64 + tid] = s;
+      for (int m = 16 * part; m < 16 * part + 16; ++m) s += Wk[m * 64 + o] * a.cq[hd * 64 + m];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+      if (part == 0) a.bvec[hd * 64 + o] = s;
     } else if (hd == 0) {
-      float s = a.fc1_b[tid];
-      for (int m = 0; m < 512; ++m) s += a.fc1_w[tid * 512 + m] * a.cv[m];
-      a.bdyn[tid] = s;
+      const float4* wrow = reinterpret_cast<const float4*>(a.fc1_w + o * 512 + 128 * part);
+      const float4* cvp = reinterpret_cast<const float4*>(a.cv + 128 * part);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+      for (int m = 0; m < 32; m += 2) {
+        const float4 w0 = wrow[m], c0 = cvp[m], w1 = wrow[m + 1], c1 = cvp[m + 1];
+        s0 += (w0.x * c0.x + w0.y * c0.y) + (w0.z * c0.z + w0.w * c0.w);
+        s1 += (w1.x * c1.x + w1.y * c1.y) + (w1.z * c1.z + w1.w * c1.w);
+      }
+      float s = s0 + s1;
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+      if (part == 0) a.bdyn[o] = a.fc1_b[o] + s;
     }
   }
 }
