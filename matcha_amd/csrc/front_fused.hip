@@ -377,8 +377,16 @@ __global__ __launch_bounds__(1024) void front_slab_reduce_kernel(FrontReduceArgs
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
   float s = 0.f;
-  if (i < kFrontSlab)
-    for (int b = q; b < a.nwg; b += 16) s += a.slab[(int64_t)b * kFrontSlab + i];
+  if (i < kFrontSlab) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four slabs in flight per thread (one at a time was a chain of nwg / 16 round trips)
+    int b = q;
+    for (; b + 48 < a.nwg; b += 64) {
+      s0 += a.slab[(int64_t)b * kFrontSlab + i]; s1 += a.slab[(int64_t)(b + 16) * kFrontSlab + i];
+      s2 += a.slab[(int64_t)(b + 32) * kFrontSlab + i]; s3 += a.slab[(int64_t)(b + 48) * kFrontSlab + i];
+    }
+    for (; b < a.nwg; b += 16) s0 += a.slab[(int64_t)b * kFrontSlab + i];
+    s = (s0 + s1) + (s2 + s3);
+  }
   part[q][o] = s;
   __syncthreads();
   if (q == 0 && i < kFrontSlab) {

@@ -1949,28 +1949,44 @@ __global__ __launch_bounds__(256) void fbm_reduce_kernel(ChainArgs a) {
   const int head = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= kWgSlabM) return;
   const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlabM + i;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   int c = 0;
-  for (; c + 3 < a.nchunks; c += 4) {
+  for (; c + 7 < a.nchunks; c += 8) {                  // eight chunk slabs in flight per thread
     s0 += base[(int64_t)c * kWgSlabM]; s1 += base[(int64_t)(c + 1) * kWgSlabM]; s2 += base[(int64_t)(c + 2) * kWgSlabM]; s3 += base[(int64_t)(c + 3) * kWgSlabM];
+    s4 += base[(int64_t)(c + 4) * kWgSlabM]; s5 += base[(int64_t)(c + 5) * kWgSlabM]; s6 += base[(int64_t)(c + 6) * kWgSlabM]; s7 += base[(int64_t)(c + 7) * kWgSlabM];
   }
   for (; c < a.nchunks; ++c) s0 += base[(int64_t)c * kWgSlabM];
-  a.red[(int64_t)head * kWgSlabM + i] = (s0 + s1) + (s2 + s3);
+  a.red[(int64_t)head * kWgSlabM + i] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
 }
 // out[i][j] (16 rows of a 64 x 64 product per block) = sum_x A(i, x) B(x, j) [+ u[i] v[j]] with strided operands staged through LDS
 __device__ __forceinline__ void mm64_slice(const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
                                            const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out, int slice,
                                            float* __restrict__ As, float* __restrict__ Bs) {
   const int tid = threadIdx.x;
-  for (int i = tid; i < 16 * 64; i += 256) As[(i >> 6) * 65 + (i & 63)] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
-  for (int i = tid; i < 64 * 64; i += 256) Bs[(i >> 6) * 65 + (i & 63)] = B[(int64_t)(i >> 6) * b_rs + (int64_t)(i & 63) * b_cs];
+  {
+    // every load of the two operand tiles in flight before the first LDS store (strided operands: scalar loads)
+    float av[4], bv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int i = tid + 256 * t; av[t] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs]; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const int i = tid + 256 * t; bv[t] = B[(int64_t)(i >> 6) * b_rs + (int64_t)(i & 63) * b_cs]; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int i = tid + 256 * t; As[(i >> 6) * 65 + (i & 63)] = av[t]; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const int i = tid + 256 * t; Bs[(i >> 6) * 65 + (i & 63)] = bv[t]; }
+  }
   __syncthreads();
-  for (int o = tid; o < 16 * 64; o += 256) {
-    const int i = o >> 6, j = o & 63;
-    float s = u ? u[16 * slice + i] * v[j] : 0.f;
-#pragma unroll 8
-    for (int x = 0; x < 64; ++x) s += As[i * 65 + x] * Bs[x * 65 + j];
-    out[(16 * slice + i) * 64 + j] = s;
+  // 16 x 64 outputs = one 16 x 16 tile per wavefront, 16 steps of v_mfma_f32_16x16x4_f32 over the contraction index
+  const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = MFMA16(As[c16 * 65 + 4 * kk + kq], Bs[(4 * kk + kq) * 65 + 16 * wave + c16], acc);
+  const int j = 16 * wave + c16;
+  const float vj = u ? v[j] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i = 4 * kq + reg;
+    out[(16 * slice + i) * 64 + j] = acc[reg] + (u ? u[16 * slice + i] * vj : 0.f);
   }
 }
 // grid (4 row slices, 4 jobs, 8 heads): the four matrix gradients of a head in fused_bwd8_kernel's slab format; slice 0 also the vectors
@@ -1994,8 +2010,13 @@ __global__ __launch_bounds__(256) void fbm_chain_kernel(ChainArgs a) {
     mm64_slice(dM, 64, 1, Wv, 1, 64, dbdyn, a.cv + head * 64, out + 3 * 4096, slice, As, Bs);
   }
   if (slice == 0 && job == 0 && tid < 64) {
-    float s = 0.f, t = 0.f;
-    for (int x = 0; x < 64; ++x) { s += Wk[tid * 64 + x] * db[x]; t += Wf[x * 512 + tid] * dbdyn[x]; }
+    float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+#pragma unroll 8
+    for (int x = 0; x < 64; x += 2) {
+      s0 += Wk[tid * 64 + x] * db[x]; s1 += Wk[tid * 64 + x + 1] * db[x + 1];
+      t0 += Wf[x * 512 + tid] * dbdyn[x]; t1 += Wf[(x + 1) * 512 + tid] * dbdyn[x + 1];
+    }
+    const float s = s0 + s1, t = t0 + t1;
     out[kVecOff + tid] = s;                          // dcq[m] = sum_a W'k[m][a] db[a]
     out[kVecOff + 64 + tid] = 0.f;                   // dck: the K bias only shifts all scores of a query (no gradient)
     out[kVecOff + 128 + tid] = t;                    // dcv[m] = sum_n Wf[n][m] dbdyn[n]

@@ -227,10 +227,20 @@ __global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
   const int a_rs = isB ? 1 : 512, a_cs = isB ? 64 : 1;
   const float* Bm = (isB ? a.wq : a.wv) + (int64_t)hd * 4096;
   float* out = (isB ? a.B : a.M) + (int64_t)hd * 4096;
-  if (isB) {               // A(i, x) = W'k[x][16 slice + i]: walk W'k's rows (16 consecutive floats per x) instead of its columns
-    for (int i = tid; i < 16 * 64; i += 256) As[(i & 15) * 65 + (i >> 4)] = A[(int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)];
-  } else {
-    for (int i = tid; i < 16 * 64; i += 256) As[(i >> 6) * 65 + (i & 63)] = A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
+  {
+    // the 16 x 64 left operand, its four loads per thread in flight together.  B_h: A(i, x) = W'k[x][16 slice + i] -- walk W'k's rows
+    // (16 consecutive floats per x) instead of its columns
+    float av[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tid + 256 * t;
+      av[t] = isB ? A[(int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)] : A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tid + 256 * t;
+      As[isB ? (i & 15) * 65 + (i >> 4) : (i >> 6) * 65 + (i & 63)] = av[t];
+    }
   }
   {
     // the 64 x 64 right operand: four float4 per thread, all in flight before the first LDS store (one scalar load per trip serialised

@@ -225,24 +225,30 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(CompactArgs a, int n
   int32_t* __restrict__ sb_cnt = a.sb_cnt[which];
   const int cap_per_sb = a.cap_per_sb[which], ntiles_cap = a.ntiles_cap[which];
   int32_t* __restrict__ meta = a.meta[which];
-  __shared__ int buf[1024];
+  __shared__ int wtot[16];
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int base = 0; base < nsb; base += 1024) {
     const int i = base + threadIdx.x;
     const int c = i < nsb ? sb_cnt[i] : 0;
-    buf[threadIdx.x] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {               // Hillis-Steele inclusive scan
-      const int v = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
-      __syncthreads();
-      buf[threadIdx.x] += v;
-      __syncthreads();
+    // inclusive scan inside each wavefront (six shuffle steps), then the sixteen wave totals (a Hillis-Steele pass over LDS took
+    // twenty barriers per 1024 counts)
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
     }
-    if (i < nsb) sb_cnt[i] = carry + buf[threadIdx.x] - c;
+    if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 1023) carry += buf[1023];
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) { const int v = wtot[w2]; if (w2 < wave) wbase += v; tot += v; }
+    if (i < nsb) sb_cnt[i] = carry + wbase + incl - c;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += tot;
     __syncthreads();
   }
   const int total = carry < ntiles_cap ? carry : ntiles_cap;
@@ -250,10 +256,19 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(CompactArgs a, int n
   __syncthreads();                                     // sb_cnt (now offsets) written by this block: visible after the barrier
   const int4* src = reinterpret_cast<const int4*>(sb_tiles);
   int4* dst = reinterpret_cast<int4*>(meta);
-  for (int i = threadIdx.x; i < nsb * cap_per_sb; i += 1024) {
-    const int s = i / cap_per_sb, j = i - s * cap_per_sb;
-    const int lo = sb_cnt[s], hi = (s + 1 < nsb) ? sb_cnt[s + 1] : total;
-    if (lo + j < hi && lo + j < ntiles_cap) dst[lo + j] = src[i];
+  // one wavefront per superblock: its (few) tiles move as consecutive int4 (a flat loop over nsb * cap_per_sb slots spent a division and two
+  // dependent loads per slot, most of them empty)
+  __shared__ int offs[1025];                          // the offsets of up to 1024 superblocks: one parallel round of loads instead of two
+  const bool staged = nsb <= 1024;                     // dependent ones per superblock and wavefront
+  if (staged) {
+    if ((int)threadIdx.x < nsb) offs[threadIdx.x] = sb_cnt[threadIdx.x];
+    if (threadIdx.x == 0) offs[nsb] = total;
+    __syncthreads();
+  }
+  for (int s = wave; s < nsb; s += 16) {
+    const int lo = staged ? offs[s] : sb_cnt[s], hi = staged ? offs[s + 1] : ((s + 1 < nsb) ? sb_cnt[s + 1] : total);
+    for (int j = lane; lo + j < hi && j < cap_per_sb; j += 64)
+      if (lo + j < ntiles_cap) dst[lo + j] = src[(int64_t)s * cap_per_sb + j];
   }
   for (int i = total + threadIdx.x; i < ntiles_cap + 2; i += 1024) dst[i] = make_int4(0, 0, 0, 0);
 }

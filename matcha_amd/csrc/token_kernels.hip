@@ -582,19 +582,29 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int32_t* __restrict
 
 // sum of row losses / B in a fixed order (one block): losses[0] = bce
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out, int zero_recon) {
-  __shared__ float red[1024];
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  __shared__ float red[16];
+  // fixed order: thread t sums rows t, t + 1024, ... (eight loads in flight), xor tree inside the wavefront, the sixteen wavefronts in order
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+  const int64_t B4 = ((uintptr_t)row_loss % 16 == 0) ? B / 4 : 0;           // float4 part (the workspace buffer is 256-byte aligned)
+  const float4* r4 = reinterpret_cast<const float4*>(row_loss);
   int64_t i = threadIdx.x;
-  for (; i + 3072 < B; i += 4096) { a0 += row_loss[i]; a1 += row_loss[i + 1024]; a2 += row_loss[i + 2048]; a3 += row_loss[i + 3072]; }
-  for (; i < B; i += 1024) a0 += row_loss[i];
-  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  for (; i + 3072 < B4; i += 4096) {
+    const float4 v0 = r4[i], v1 = r4[i + 1024], v2 = r4[i + 2048], v3 = r4[i + 3072];
+    a0 += v0.x + v0.y; a1 += v0.z + v0.w; a2 += v1.x + v1.y; a3 += v1.z + v1.w;
+    a4 += v2.x + v2.y; a5 += v2.z + v2.w; a6 += v3.x + v3.y; a7 += v3.z + v3.w;
   }
+  for (; i < B4; i += 1024) { const float4 v = r4[i]; a0 += v.x + v.y; a1 += v.z + v.w; }
+  for (int64_t j = 4 * B4 + threadIdx.x; j < B; j += 1024) a2 += row_loss[j];
+  float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = red[0] / (float)B;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t / (float)B;
     if (zero_recon) { out[1] = 0.f; out[2] = 0.f; }   // table front end: no reconstruction loss (instead of a memset in front of the forward)
   }
 }
