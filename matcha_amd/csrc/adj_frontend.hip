@@ -25,6 +25,35 @@ constexpr int kSortTok = 1024;   // tokens per workgroup in the counting sort
 constexpr int kMaxChrom = 63;     // buckets = chromosomes + 1 (padding)
 constexpr int kLdA = 68;
 
+// Four consecutive floats of a row of n floats that starts at an arbitrary float offset (feature rows of a chromosome: n_c floats each).
+// gfx950 serves a global_load_dwordx4 on a 4-byte-aligned address (tools/ubench/unaligned_x4.hip: correct, same cost as four dword loads
+// when bandwidth-bound), and one such load per lane keeps 4x the bytes in flight of the scalar staging it replaces.  A window that would
+// run past the row's end is read from the row's last four floats and shifted (row4_fix); columns >= n come back as 0.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f4u row4_load(const float* __restrict__ row, int col0, int n) {
+  if (n >= 4) {
+    const int start = col0 < n - 4 ? col0 : n - 4;
+    return *reinterpret_cast<const f4u*>(row + start);
+  }
+  f4u v;
+  v.x = row[0]; v.y = row[n > 1 ? 1 : 0]; v.z = row[n > 2 ? 2 : 0]; v.w = 0.f;       // n in 1..3: the whole row
+  return v;
+}
+__device__ __forceinline__ void row4_fix(const f4u& raw, int col0, int n, float (&e)[4]) {
+  e[0] = raw.x; e[1] = raw.y; e[2] = raw.z; e[3] = raw.w;
+  int sh = n >= 4 ? (col0 < n - 4 ? 0 : col0 - (n - 4)) : col0;                          // floats the window was moved back by
+  if (sh >= 4) { e[0] = e[1] = e[2] = e[3] = 0.f; return; }
+  if (sh == 1) { e[0] = e[1]; e[1] = e[2]; e[2] = e[3]; e[3] = 0.f; }
+  else if (sh == 2) { e[0] = e[2]; e[1] = e[3]; e[2] = 0.f; e[3] = 0.f; }
+  else if (sh == 3) { e[0] = e[3]; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+  if (n < 4) {                                                                           // short rows: zero what lies behind the end
+    if (col0 + 0 >= n) e[0] = 0.f;
+    if (col0 + 1 >= n) e[1] = 0.f;
+    if (col0 + 2 >= n) e[2] = 0.f;
+    if (col0 + 3 >= n) e[3] = 0.f;
+  }
+}
+
 struct AdjWs {
   int32_t *order, *other_map, *seg, *counts /* [0]=m (other tokens), [1]=non-pad tokens */, *hist, *base;
   float *Hs, *TH, *rec, *dTH, *dZ, *lossslab;
@@ -229,38 +258,43 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
     for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
     for (int kc = 0; kc < n_c; kc += 64) {
       __syncthreads();
-      // stage A: wave w gathers rows w, w+4, ...; a wave-instruction reads 64 consecutive floats of one feature row
-      const int kk = kc + lane;
-      const int kcl = kk < n_c ? kk : n_c - 1;
-      const float kmask = kk < n_c ? 1.f : 0.f;
-      for (int i0 = 0; i0 < 32; i0 += 8) {            // 8 rows' loads in flight before the first is consumed
-        float fv[8];
+      // stage A: wave w gathers rows w, w+4, ...; a lane reads four consecutive floats, a wave-instruction 64 floats of each of FOUR rows,
+      // eight instructions (the wave's 32 rows) in flight before the first is consumed
+      const int sub = lane >> 4, c4 = (lane & 15) * 4, col0 = kc + c4;
+      {
+        f4u raw[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) fv[u] = g.feats[rowoff[wave + 4 * (i0 + u)] + kcl];
+        for (int u = 0; u < 8; ++u) raw[u] = row4_load(g.feats + rowoff[wave + 4 * (4 * u + sub)], col0, n_c);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int rr = wave + 4 * (i0 + u);
-          float v = fv[u] * kmask;
+          const int rr = wave + 4 * (4 * u + sub);
+          float e[4];
+          row4_fix(raw[u], col0, n_c, e);
           if (drop) {
             int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
             if (g.slot_map) slot = g.slot_map[slot];
-            v = (rng_u32(key, (uint32_t)slot, (uint32_t)kk) >= thr) ? v * keep_scale : 0.f;   // counter = (token slot, column)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              e[j] = (rng_u32(key, (uint32_t)slot, (uint32_t)(col0 + j)) >= thr) ? e[j] * keep_scale : 0.f;   // counter = (token slot, column)
           }
-          As[rr * kLdA + lane] = v;
+          *reinterpret_cast<float4*>(&As[rr * kLdA + c4]) = make_float4(e[0], e[1], e[2], e[3]);
         }
       }
-      for (int j0 = wave; j0 < 32 * NT; j0 += 32) {   // weight rows: 8 loads in flight
-        float wv[8];
+      // weight rows [d][n_c]: the same windows
+      for (int j0 = wave; j0 < 32 * NT; j0 += 32) {
+        f4u raw[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + 4 * u;
+        for (int u = 0; u < 2; ++u) {
+          const int j = j0 + 4 * (4 * u + sub);
           const int jc = j < g.d ? j : g.d - 1;
-          wv[u] = W0[(int64_t)jc * n_c + kcl];
+          raw[u] = row4_load(W0 + (int64_t)jc * n_c, col0, n_c);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + 4 * u;
-          if (j < 32 * NT) Bs[j * kLdA + lane] = (j < g.d) ? wv[u] * kmask : 0.f;
+        for (int u = 0; u < 2; ++u) {
+          const int j = j0 + 4 * (4 * u + sub);
+          float e[4];
+          row4_fix(raw[u], col0, n_c, e);
+          if (j < 32 * NT) *reinterpret_cast<float4*>(&Bs[j * kLdA + c4]) = (j < g.d) ? make_float4(e[0], e[1], e[2], e[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       __syncthreads();
@@ -359,31 +393,39 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
         if (MODE == 1) rowoff[tid] = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
       }
       __syncthreads();
-      // a wave-instruction reads 64 consecutive floats of one row; 8 rows' loads are issued before the first is consumed
-      // (one row per trip left every trip waiting out a full global-memory round trip: 32 serialised latencies per step)
-      for (int i0 = 0; i0 < 32; i0 += 8) {
-        float av[8], bv[8];
+      // a lane reads four consecutive floats, a wave-instruction 64 floats of each of FOUR rows; the wave's 32 rows = 8 instructions per
+      // operand, all issued before the first is consumed (one float per lane and 8 rows in flight ran at a third of this)
+      {
+        const int sub = lane >> 4, c4 = (lane & 15) * 4;
+        const int acol0 = mo0 + c4, bcol0 = no0 + c4;
+        f4u ra[8], rb[8];
         int sl[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int rr = wave + 4 * (i0 + u);
+          const int rr = wave + 4 * (4 * u + sub);
           const int slot = rowslot[rr];
           sl[u] = slot;
           const int slc = slot >= 0 ? slot : 0;
           const int64_t p = p0 + rr < p_hi ? p0 + rr : p_hi - 1;
           const int64_t arow = MODE == 0 ? (int64_t)slc : p;
-          av[u] = g.A[arow * g.d + acolc];
-          bv[u] = MODE == 0 ? g.Bd[p * g.d + bcolc] : g.feats[rowoff[rr] + bcolc];
+          ra[u] = row4_load(g.A + arow * g.d, acol0, g.d);
+          rb[u] = MODE == 0 ? row4_load(g.Bd + p * g.d, bcol0, ncols) : row4_load(g.feats + rowoff[rr], bcol0, ncols);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int rr = wave + 4 * (i0 + u);
+          const int rr = wave + 4 * (4 * u + sub);
           const float rowm = sl[u] >= 0 ? 1.f : 0.f;
           const int slc = sl[u] >= 0 ? sl[u] : 0;
-          float b = bv[u];
-          if (drop) b = (rng_u32(key, (uint32_t)(g.slot_map ? g.slot_map[slc] : slc), (uint32_t)bcol) >= thr) ? b * keep_scale : 0.f;
-          As[rr * kLdA + lane] = av[u] * (amask * rowm);
-          Bs[rr * kLdA + lane] = b * (bmask * rowm);
+          float ea[4], eb[4];
+          row4_fix(ra[u], acol0, g.d, ea);
+          row4_fix(rb[u], bcol0, ncols, eb);
+          if (drop) {
+            const uint32_t slot = (uint32_t)(g.slot_map ? g.slot_map[slc] : slc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) eb[j] = (rng_u32(key, slot, (uint32_t)(bcol0 + j)) >= thr) ? eb[j] * keep_scale : 0.f;
+          }
+          *reinterpret_cast<float4*>(&As[rr * kLdA + c4]) = make_float4(ea[0] * rowm, ea[1] * rowm, ea[2] * rowm, ea[3] * rowm);
+          *reinterpret_cast<float4*>(&Bs[rr * kLdA + c4]) = make_float4(eb[0] * rowm, eb[1] * rowm, eb[2] * rowm, eb[3] * rowm);
         }
       }
       __syncthreads();
