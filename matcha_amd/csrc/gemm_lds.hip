@@ -42,7 +42,7 @@ struct StageRegs {
 // B tile in LDS: NT: [n = 64][k = BK] (stride BK + 4);  NN (B_KN): [k = BK][n = 64] (stride 68)
 
 template <bool B_KN, int FLAGS, int BK>
-__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_per_block) {
+__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_per_block, int group_parallel) {
   constexpr int LDK = BK + 4;                        // row stride of the k-major tiles (A, and B in NT mode)
   constexpr int F4 = BK / 4;                         // float4 per k-row segment
   constexpr int RPP = 256 / F4;                      // rows staged per pass (16 or 32)
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int z = blockIdx.z;
+  // group_parallel (grouped mode, few row tiles): blockIdx.z = the group this workgroup serves; a row tile that several groups cut is
+  // handled by several workgroups side by side instead of one workgroup walking the groups in turn
+  const int z = group_parallel ? 0 : (int)blockIdx.z;
   const float* __restrict__ A = g.A[z];
   float* __restrict__ C = g.C[z];
   const int64_t M = g.m_dev ? (int64_t)(*g.m_dev) : g.M;
@@ -96,6 +98,11 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
     while (c_lo < g.n_groups && g.seg[c_lo + 1] <= m0) ++c_lo;
     c_hi = c_lo;
     while (c_hi < g.n_groups && g.seg[c_hi + 1] < m_end) ++c_hi;
+    if (group_parallel) {
+      const int gsel = (int)blockIdx.z;
+      if (gsel < c_lo || gsel > c_hi) return;            // the whole workgroup: no barrier has been reached
+      c_lo = c_hi = gsel;
+    }
   }
   bool a_resident = false;
   for (int grp = c_lo; grp <= c_hi; ++grp) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g, int n_tiles_p
 }
 
 template <bool B_KN, int FLAGS, int BK>
-static void launch_bk(const GemmArgs& g, dim3 grid, int ntpb, hipStream_t st) {
+static void launch_bk(const GemmArgs& g, dim3 grid, int ntpb, hipStream_t st, int gpar) {
   auto kfn = gemm_lds_kernel<B_KN, FLAGS, BK>;
   const size_t b_sz = B_KN ? (size_t)BK * kLd : (size_t)kBN * (BK + 4);
   const size_t lds_bytes = ((size_t)(g.K > BK ? 2 : 1) * kBM * (BK + 4) + 2 * b_sz) * sizeof(float);
@@ -268,12 +275,12 @@ static void launch_bk(const GemmArgs& g, dim3 grid, int ntpb, hipStream_t st) {
       configured = true;
     }
   }
-  hipLaunchKernelGGL(kfn, grid, dim3(256), lds_bytes, st, g, ntpb);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds_bytes, st, g, ntpb, gpar);
 }
 template <bool B_KN, int FLAGS>
-static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, size_t, hipStream_t st) {
-  if (g.K > kBK) launch_bk<B_KN, FLAGS, 32>(g, grid, ntpb, st);      // several k chunks: 32 deep, two workgroups per CU
-  else launch_bk<B_KN, FLAGS, 64>(g, grid, ntpb, st);                // K <= 64: the activation tile stays resident
+static void launch_one(const GemmArgs& g, dim3 grid, int ntpb, size_t, hipStream_t st, int gpar = 0) {
+  if (g.K > kBK) launch_bk<B_KN, FLAGS, 32>(g, grid, ntpb, st, gpar);      // several k chunks: 32 deep, two workgroups per CU
+  else launch_bk<B_KN, FLAGS, 64>(g, grid, ntpb, st, gpar);                // K <= 64: the activation tile stays resident
 }
 
 int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
@@ -292,31 +299,37 @@ int launch_gemm_rm(bool b_kn, const GemmArgs& g, hipStream_t st) {
   // K <= 64: one workgroup keeps its activation tile in LDS and walks up to 8 column tiles
   int ntpb = 1;
   if (g.K <= kBK) { ntpb = tiles_n < 8 ? tiles_n : 8; }
+  const int64_t tiles_m = cdiv(g.M, kBM);
+  // few row tiles (the reference's own 384-row batch: 11): parallelism before reuse -- one column tile per workgroup, and in grouped mode
+  // one workgroup per (row tile, group) instead of one per row tile walking its groups (each pass is a global -> LDS -> MFMA -> store
+  // round trip of ~10 us)
+  if (tiles_m * cdiv(tiles_n, ntpb) < 256) ntpb = 1;
+  const int gpar = (g.seg && g.batch == 1 && g.n_groups > 1 && tiles_m * g.n_groups <= 4096) ? 1 : 0;
   const size_t lds_bytes = (size_t)((g.K > kBK ? 2 : 1) * kBM + 2 * kBN) * kLd * sizeof(float);
-  dim3 grid((unsigned)cdiv(tiles_n, ntpb), (unsigned)cdiv(g.M, kBM), (unsigned)g.batch);
+  dim3 grid((unsigned)cdiv(tiles_n, ntpb), (unsigned)tiles_m, (unsigned)(gpar ? g.n_groups : g.batch));
   ProfScope ps(b_kn ? MATCHA_PROF_GEMM_NN : MATCHA_PROF_GEMM_NT, 2.0 * (double)g.M * (double)g.N * (double)g.K * g.batch, st);
   const int F = g.flags;
   constexpr int B_ = MATCHA_EPI_BIAS, T_ = MATCHA_EPI_TANH, R_ = MATCHA_EPI_RESIDUAL, D_ = MATCHA_EPI_DROPOUT, M_ = MATCHA_EPI_ROWMASK,
                 G_ = MATCHA_EPI_DTANH;
   if (!b_kn) {
     switch (F) {
-      case 0: launch_one<false, 0>(g, grid, ntpb, lds_bytes, st); break;
-      case B_: launch_one<false, B_>(g, grid, ntpb, lds_bytes, st); break;
-      case B_ | T_: launch_one<false, B_ | T_>(g, grid, ntpb, lds_bytes, st); break;
-      case B_ | T_ | D_: launch_one<false, B_ | T_ | D_>(g, grid, ntpb, lds_bytes, st); break;
-      case B_ | M_: launch_one<false, B_ | M_>(g, grid, ntpb, lds_bytes, st); break;
-      case B_ | M_ | D_: launch_one<false, B_ | M_ | D_>(g, grid, ntpb, lds_bytes, st); break;
-      case B_ | R_: launch_one<false, B_ | R_>(g, grid, ntpb, lds_bytes, st); break;
-      default: launch_one<false, -1>(g, grid, ntpb, lds_bytes, st); break;
+      case 0: launch_one<false, 0>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case B_: launch_one<false, B_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case B_ | T_: launch_one<false, B_ | T_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case B_ | T_ | D_: launch_one<false, B_ | T_ | D_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case B_ | M_: launch_one<false, B_ | M_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case B_ | M_ | D_: launch_one<false, B_ | M_ | D_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case B_ | R_: launch_one<false, B_ | R_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      default: launch_one<false, -1>(g, grid, ntpb, lds_bytes, st, gpar); break;
     }
   } else {
     switch (F) {
-      case 0: launch_one<true, 0>(g, grid, ntpb, lds_bytes, st); break;
-      case G_: launch_one<true, G_>(g, grid, ntpb, lds_bytes, st); break;
-      case G_ | D_: launch_one<true, G_ | D_>(g, grid, ntpb, lds_bytes, st); break;
-      case R_ | M_: launch_one<true, R_ | M_>(g, grid, ntpb, lds_bytes, st); break;
-      case R_ | M_ | D_: launch_one<true, R_ | M_ | D_>(g, grid, ntpb, lds_bytes, st); break;
-      default: launch_one<true, -1>(g, grid, ntpb, lds_bytes, st); break;
+      case 0: launch_one<true, 0>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case G_: launch_one<true, G_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case G_ | D_: launch_one<true, G_ | D_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case R_ | M_: launch_one<true, R_ | M_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      case R_ | M_ | D_: launch_one<true, R_ | M_ | D_>(g, grid, ntpb, lds_bytes, st, gpar); break;
+      default: launch_one<true, -1>(g, grid, ntpb, lds_bytes, st, gpar); break;
     }
   }
   MATCHA_CHECK_LAUNCH("gemm_lds_kernel");

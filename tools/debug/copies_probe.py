@@ -25,7 +25,7 @@ y = torch.cat([torch.ones(P, device=dev), torch.zeros(B - P, device=dev)])
 w = torch.ones(B, device=dev)
 cursor = torch.zeros(1, dtype=torch.long, device=dev)
 ar = torch.arange(P, device=dev)
-clf = bench.make_model("table", 64, num, dev)
+clf = bench.make_model(os.environ.get("FRONT", "table"), 64, num, dev)
 clf.train()
 tr = Trainer(clf, lr=1e-3, base_seed=9)
 M = shard.shape[0]
