@@ -529,6 +529,9 @@ def main():
                             ("reference_batch_384_rows", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="table")),
                             # the same launch-bound step replayed from ONE hipGraph (Trainer.capture path: nothing in the step allocates or synchronises)
                             ("reference_batch_384_rows_hipgraph", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="table", graph=True)),
+                            # the reference's own set-up (main.py:609-613 builds MultipleEmbedding = the adj front end; 96 positives x (1 + 3) rows per step;
+                            # 80 ms per such step on 8 CPU cores)
+                            ("reference_batch_384_rows_adj", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="adj")),
                             ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table")),
                             ("configs4_c5_1M_nodes_d256", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=16384, front_end="table",
                                                                 edges=10_000_000)),
