@@ -256,48 +256,50 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+    // contraction in chunks of 64 feature columns, software-pipelined: the loads of chunk kc + 64 (8 feature-row windows and 2 NT weight-row
+    // windows per lane) are in flight while the MFMAs of chunk kc run.  A lane reads four consecutive floats, a wave-instruction 64 floats of
+    // each of FOUR rows; the wave's 32 rows are 8 instructions.
+    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+    f4u rawa[8], raww[2 * NT];
+#define ENC_GLOAD(KC)                                                                                    \
+  do {                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) rawa[u] = row4_load(g.feats + rowoff[wave + 4 * (4 * u + sub)], (KC) + c4, n_c); \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                    \
+        const int j = wave + 32 * t + 4 * (4 * u + sub);                                                 \
+        raww[2 * t + u] = row4_load(W0 + (int64_t)(j < g.d ? j : g.d - 1) * n_c, (KC) + c4, n_c);        \
+      }                                                                                                  \
+  } while (0)
+    __syncthreads();                                  // rowoff / rowslot of this row step are in LDS
+    ENC_GLOAD(0);
     for (int kc = 0; kc < n_c; kc += 64) {
-      __syncthreads();
-      // stage A: wave w gathers rows w, w+4, ...; a lane reads four consecutive floats, a wave-instruction 64 floats of each of FOUR rows,
-      // eight instructions (the wave's 32 rows) in flight before the first is consumed
-      const int sub = lane >> 4, c4 = (lane & 15) * 4, col0 = kc + c4;
-      {
-        f4u raw[8];
+      const int col0 = kc + c4;
+      __syncthreads();                                // the previous chunk's MFMAs are done with the tiles
 #pragma unroll
-        for (int u = 0; u < 8; ++u) raw[u] = row4_load(g.feats + rowoff[wave + 4 * (4 * u + sub)], col0, n_c);
+      for (int u = 0; u < 8; ++u) {
+        const int rr = wave + 4 * (4 * u + sub);
+        float e[4];
+        row4_fix(rawa[u], col0, n_c, e);
+        if (drop) {
+          int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
+          if (g.slot_map) slot = g.slot_map[slot];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = wave + 4 * (4 * u + sub);
-          float e[4];
-          row4_fix(raw[u], col0, n_c, e);
-          if (drop) {
-            int slot = rowslot[rr] < 0 ? 0 : rowslot[rr];
-            if (g.slot_map) slot = g.slot_map[slot];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              e[j] = (rng_u32(key, (uint32_t)slot, (uint32_t)(col0 + j)) >= thr) ? e[j] * keep_scale : 0.f;   // counter = (token slot, column)
-          }
-          *reinterpret_cast<float4*>(&As[rr * kLdA + c4]) = make_float4(e[0], e[1], e[2], e[3]);
+          for (int j = 0; j < 4; ++j)
+            e[j] = (rng_u32(key, (uint32_t)slot, (uint32_t)(col0 + j)) >= thr) ? e[j] * keep_scale : 0.f;   // counter = (token slot, column)
         }
+        *reinterpret_cast<float4*>(&As[rr * kLdA + c4]) = make_float4(e[0], e[1], e[2], e[3]);
       }
-      // weight rows [d][n_c]: the same windows
-      for (int j0 = wave; j0 < 32 * NT; j0 += 32) {
-        f4u raw[2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int j = j0 + 4 * (4 * u + sub);
-          const int jc = j < g.d ? j : g.d - 1;
-          raw[u] = row4_load(W0 + (int64_t)jc * n_c, col0, n_c);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = j0 + 4 * (4 * u + sub);
+          const int j = wave + 32 * t + 4 * (4 * u + sub);
           float e[4];
-          row4_fix(raw[u], col0, n_c, e);
-          if (j < 32 * NT) *reinterpret_cast<float4*>(&Bs[j * kLdA + c4]) = (j < g.d) ? make_float4(e[0], e[1], e[2], e[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          row4_fix(raww[2 * t + u], col0, n_c, e);
+          *reinterpret_cast<float4*>(&Bs[j * kLdA + c4]) = (j < g.d) ? make_float4(e[0], e[1], e[2], e[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-      }
       __syncthreads();
+      if (kc + 64 < n_c) ENC_GLOAD(kc + 64);          // in flight during this chunk's MFMAs
       const float* arow = &As[(32 * wave + r) * kLdA + 4 * h];
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
         }
       }
     }
+#undef ENC_GLOAD
     const int64_t mrow0 = m0 + 32 * wave + 4 * h;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -355,44 +358,60 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                              // [128][kLdA]
   float* Bs = lds + 128 * kLdA;                 // [128][kLdA]
-  __shared__ int64_t rowoff[128];               // MODE 1: element offset of the feature row;  MODE 0: unused
-  __shared__ int rowslot[128];                  // token slot of the sorted row, -1 = past the range
+  __shared__ int64_t rowoff2[2][128];           // MODE 1: element offset of the feature row;  MODE 0: unused.  Two sets: the next step's
+  __shared__ int rowslot2[2][128];              // token slot of the sorted row, -1 = past the range        indices are fetched during this step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int mo0 = blockIdx.x * 64;             // output row tile (j)
   const int no0 = blockIdx.y * 64;             // output column tile (k or feature column)
-  // blockIdx.z = chromosome * splits + split: the chromosomes run in parallel (a small batch used to walk all of them
-  // serially inside two workgroups), each cut into `splits` equal row ranges (g.rows_per_block carries `splits`)
-  const int splits = g.rows_per_block;
+  // blockIdx.z = a window of g.rows_per_block consecutive SORTED rows (a multiple of 128), whatever chromosomes it touches: one pass of the
+  // loop below per chromosome in the window, each with its own accumulators and atomics.  (Equal shares of every chromosome -- the first
+  // version -- gave the workgroups of chromosome 1 five times the rows of chromosome 21's and the kernel the duration of the longest.)
+  const int64_t win_lo = (int64_t)blockIdx.z * g.rows_per_block;
+  const int64_t win_hi = win_lo + g.rows_per_block;
   const bool drop = MODE == 1 && g.p_drop > 0.f;
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
   if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
   const int acol = mo0 + lane, acolc = acol < g.d ? acol : g.d - 1;
   const float amask = acol < g.d ? 1.f : 0.f;
-  {
-    const int c = blockIdx.z / splits, sp = blockIdx.z - c * splits;
+  if (win_lo >= g.seg[g.C]) return;
+  for (int c = 0; c < g.C; ++c) {
     const int64_t c_lo = g.seg[c], c_hi = g.seg[c + 1];
-    const int64_t per = ((c_hi - c_lo + splits - 1) / splits + 127) / 128 * 128;      // whole 128-row steps per split
-    const int64_t p_lo = c_lo + sp * per;
-    const int64_t p_hi = p_lo + per < c_hi ? p_lo + per : c_hi;
-    if (p_lo >= p_hi) return;
+    if (c_hi <= win_lo) continue;
+    if (c_lo >= win_hi) break;
+    const int64_t p_lo = c_lo > win_lo ? c_lo : win_lo;
+    const int64_t p_hi = c_hi < win_hi ? c_hi : win_hi;
+    if (p_lo >= p_hi) continue;
     const int lo = g.bounds[c], n_c = g.bounds[c + 1] - g.bounds[c];
     const int ncols = MODE == 0 ? g.d : n_c;
-    if (no0 >= ncols) return;
+    if (no0 >= ncols) continue;
+    __syncthreads();                            // the previous chromosome's last step is done with the tiles and the index sets
     const int bcol = no0 + lane, bcolc = bcol < ncols ? bcol : ncols - 1;
     const float bmask = bcol < ncols ? 1.f : 0.f;
     f32x16 acc = {0};
+    // index pipeline: sorted row -> token slot -> node id -> feature-row offset are two dependent global round trips; the indices of step
+    // p0 + 128 are fetched while step p0 stages and multiplies (set `cur ^ 1`), so only the first step waits for them
+    auto fetch_idx = [&](int64_t q0, int& slot_out, int64_t& off_out) {
+      const int64_t p = q0 + tid;
+      const bool in = p < p_hi;
+      const int slot = g.order[in ? p : p_hi - 1];
+      slot_out = in ? slot : -1;
+      off_out = MODE == 1 ? g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c : 0;
+    };
+    int cur = 0;
+    if (tid < 128) {
+      int sl0; int64_t of0;
+      fetch_idx(p_lo, sl0, of0);
+      rowslot2[0][tid] = sl0; rowoff2[0][tid] = of0;
+    }
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += 128) {
-      __syncthreads();                          // previous step's MFMAs are done with the tiles and the index arrays
-      if (tid < 128) {
-        const int64_t p = p0 + tid;
-        const bool in = p < p_hi;
-        const int slot = g.order[in ? p : p_hi - 1];
-        rowslot[tid] = in ? slot : -1;
-        if (MODE == 1) rowoff[tid] = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
-      }
-      __syncthreads();
+      __syncthreads();                          // previous step's MFMAs are done with the tiles; this step's index set is complete
+      const int* rowslot = rowslot2[cur];
+      const int64_t* rowoff = rowoff2[cur];
+      int nsl = -1; int64_t nof = 0;
+      const bool more = p0 + 128 < p_hi;
+      if (more && tid < 128) fetch_idx(p0 + 128, nsl, nof);
       // a lane reads four consecutive floats, a wave-instruction 64 floats of each of FOUR rows; the wave's 32 rows = 8 instructions per
       // operand, all issued before the first is consumed (one float per lane and 8 rows in flight ran at a third of this)
       {
@@ -434,6 +453,8 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
         const int t = 2 * m + h;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[t * kLdA + 32 * wr + r], Bs[t * kLdA + 32 * wc + r], acc, 0, 0, 0);
       }
+      if (more && tid < 128) { rowslot2[cur ^ 1][tid] = nsl; rowoff2[cur ^ 1][tid] = nof; }
+      cur ^= 1;
     }
     float* out = MODE == 0 ? g.out + (int64_t)c * g.d * g.d : g.out + (int64_t)g.d * lo;
     const int col = no0 + 32 * wc + r;
@@ -643,10 +664,12 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     MATCHA_CHECK_LAUNCH("adj_recon_dnode_kernel");
   }
   // ---- encoder ----
-  int splits = (int)cdiv(T, (int64_t)C * 1024);      // ~1024 rows per workgroup at an even spread of the tokens over the chromosomes
-  if (splits < 1) splits = 1;
-  const int rpb = splits;
-  const unsigned zblocks = (unsigned)(C * splits);
+  // windows of sorted rows (whole 128-row steps): ~320 windows of up to 1024 rows at large batches (every window ends in 64 x 64 float atomics per
+  // column tile onto a small gradient array: more, smaller windows lose to their contention), one step per window at small ones
+  int steps_per_win = (int)(T / (128 * 320));
+  steps_per_win = steps_per_win < 1 ? 1 : (steps_per_win > 8 ? 8 : steps_per_win);
+  const int rpb = 128 * steps_per_win;
+  const unsigned zblocks = (unsigned)cdiv(T, (int64_t)rpb);
   {
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));

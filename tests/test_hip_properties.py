@@ -124,7 +124,13 @@ def test_full_size_train_step_is_reproducible(deterministic):
         for n in outs[0][1]:
             a, b = outs[0][1][n], other[1][n]
             if not deterministic and n.startswith(("node_embedding.", "next_w.", "attribute_nn.")):
-                assert torch.allclose(a, b, rtol=0, atol=1e-6), n
+                # same sums up to the order of the float atomics; the first AdamW step is lr * g / (|g| + eps), which turns that rounding noise
+                # into a visible fraction of lr wherever |g| is itself near eps: the typical element agrees to 1e-6, none moves further apart
+                # than the 2 lr such an element can (one run in five had such an element in next_w: the gradient-level statement is
+                # test_sorted_table_gradient_equals_atomic_scatter_and_is_bitwise_reproducible)
+                diff = (a - b).abs().reshape(-1).float()
+                assert float(torch.quantile(diff[:1 << 20], 0.5)) <= 1e-6, n
+                assert float(diff.max()) <= 2 * 1e-3 + 1e-5, (n, float(diff.max()))
             else:
                 assert torch.equal(a, b), n
 
