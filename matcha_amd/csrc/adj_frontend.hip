@@ -344,6 +344,7 @@ struct AdjTnArgs {
   const float* feats;
   float* out;                // MODE 0: adj_w1 grads [C,d,d];  MODE 1: adj_w0 grads (chromosome c at d*bounds[c], row stride n_c)
   int C, d, rows_per_block;
+  int chrom_parallel;
   const uint64_t* seed;
   float p_drop;
   const int32_t* slot_map;
@@ -367,7 +368,10 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
   // blockIdx.z = a window of g.rows_per_block consecutive SORTED rows (a multiple of 128), whatever chromosomes it touches: one pass of the
   // loop below per chromosome in the window, each with its own accumulators and atomics.  (Equal shares of every chromosome -- the first
   // version -- gave the workgroups of chromosome 1 five times the rows of chromosome 21's and the kernel the duration of the longest.)
-  const int64_t win_lo = (int64_t)blockIdx.z * g.rows_per_block;
+  // (Small batches, g.chrom_parallel: blockIdx.z = window * C + chromosome -- the few chromosomes of a window side by side, not in turn.)
+  const int zwin = g.chrom_parallel ? (int)blockIdx.z / g.C : (int)blockIdx.z;
+  const int csel = g.chrom_parallel ? (int)blockIdx.z - zwin * g.C : -1;
+  const int64_t win_lo = (int64_t)zwin * g.rows_per_block;
   const int64_t win_hi = win_lo + g.rows_per_block;
   const bool drop = MODE == 1 && g.p_drop > 0.f;
   uint32_t key = 0, thr = 0;
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
   const int acol = mo0 + lane, acolc = acol < g.d ? acol : g.d - 1;
   const float amask = acol < g.d ? 1.f : 0.f;
   if (win_lo >= g.seg[g.C]) return;
-  for (int c = 0; c < g.C; ++c) {
+  for (int c = csel >= 0 ? csel : 0; c < (csel >= 0 ? csel + 1 : g.C); ++c) {
     const int64_t c_lo = g.seg[c], c_hi = g.seg[c + 1];
     if (c_hi <= win_lo) continue;
     if (c_lo >= win_hi) break;
@@ -669,12 +673,14 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
   int steps_per_win = (int)(T / (128 * 320));
   steps_per_win = steps_per_win < 1 ? 1 : (steps_per_win > 8 ? 8 : steps_per_win);
   const int rpb = 128 * steps_per_win;
-  const unsigned zblocks = (unsigned)cdiv(T, (int64_t)rpb);
+  const int64_t nwin = cdiv(T, (int64_t)rpb);
+  const int cpar = nwin * C <= 2048 ? 1 : 0;         // few windows: one workgroup per (window, chromosome)
+  const unsigned zblocks = (unsigned)(cpar ? nwin * C : nwin);
   {
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));
     a.A = dnode; a.Bd = w.Hs; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
-    a.out = g_.adj_w1; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = 0.f;
+    a.out = g_.adj_w1; a.C = C; a.d = d; a.rows_per_block = rpb; a.chrom_parallel = cpar; a.seed = o.seed; a.p_drop = 0.f;
     auto k0 = adj_tn_kernel<0>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAdjTnLds) != hipSuccess) {
       set_error("adj_tn_kernel: cannot raise the dynamic LDS limit"); return MATCHA_EHIP;
@@ -696,7 +702,7 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));
     a.A = w.dZ; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
-    a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
+    a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.chrom_parallel = cpar; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
     auto k1 = adj_tn_kernel<1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAdjTnLds) != hipSuccess) {
       set_error("adj_tn_kernel: cannot raise the dynamic LDS limit"); return MATCHA_EHIP;
