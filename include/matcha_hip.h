@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MATCHA_ABI_VERSION 5
+#define MATCHA_ABI_VERSION 6
 
 #define MATCHA_OK 0
 #define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
@@ -151,6 +151,19 @@ typedef struct matcha_frozen {
   const int64_t* feat_off;   /* [C+1] element offsets into feats (device)                                 */
   const float* inter;        /* adj: [N, N] z-scored inter-chromosome matrix (Modules.py:146-154)         */
   const int32_t* bounds_host;/* [C+1] same as bounds, HOST pointer                                         */
+  /* ---- ABI 6 (all zero = the layouts above) ---- */
+  int32_t feat_row_pad;      /* adj: 0 = the rows of chromosome i are n_i floats, back to back; P > 0 (a multiple of 4) = every row is
+                                padded with zeros to a multiple of P floats, `feats` is 16-byte aligned and every feat_off[i] a
+                                multiple of 4 -- aligned 16-byte loads of feature rows; the fused embed_dim-64 kernels
+                                (csrc/adj_fused.hip) require P = 64, other values run the layer-by-layer kernels               */
+  int32_t attr_mode;         /* 0 = attribute rows are read from attr_table; 1 = the table has the structure main.py:497-512 builds
+                                (one-hot chromosome || bin index inside the chromosome / attr_scale, row 0 zeros) and is NOT read:
+                                a token's row is rebuilt from its node id, attr_bounds and attr_scale (one random row per token
+                                instead of two; the caller has verified the structure bit for bit, attr_table may be NULL)     */
+  int32_t attr_ld;           /* attr_mode 0: row stride of attr_table in floats (0 = n_attr); 32 = rows padded to one 128-byte
+                                fetch unit                                                                                       */
+  float attr_scale;          /* attr_mode 1: num[0] of main.py:503                                                               */
+  const int32_t* attr_bounds;/* attr_mode 1: device int32 [n_attr] = 0, n_0, n_0+n_1, ..., N                                      */
 } matcha_frozen;
 
 /* Per-call options of the fused step. */

@@ -355,11 +355,17 @@ class _Runtime:
         if self.mode == 1:
             feats = [e.embedding.detach().to(device=dev, dtype=torch.float32).contiguous() for e in ne.embeddings]
             offs = np.zeros(self.n_chrom + 1, dtype=np.int64)
+            # every feature row padded with zeros to a multiple of 64 floats (matcha_frozen.feat_row_pad): the gather-GEMMs read
+            # aligned 16-byte pieces and a 64-column K chunk never needs a tail mask
+            pad = _lib.FEAT_ROW_PAD
             for i, f in enumerate(feats):
-                if tuple(f.shape) != (self.bounds_list[i + 1] - self.bounds_list[i],) * 2:
+                n_i = self.bounds_list[i + 1] - self.bounds_list[i]
+                if tuple(f.shape) != (n_i, n_i):
                     raise ValueError("adj mode expects square [n_i, n_i] feature matrices (main.py:571-577)")
-                offs[i + 1] = offs[i] + f.numel()
+                feats[i] = torch.nn.functional.pad(f, (0, (n_i + pad - 1) // pad * pad - n_i))
+                offs[i + 1] = offs[i] + feats[i].numel()
             self.feat_pack = torch.cat([f.reshape(-1) for f in feats])
+            self.frozen.feat_row_pad = pad
             self.feat_off_host = offs
             self.inter = ne.inter_initial.embedding.detach().to(device=dev, dtype=torch.float32).contiguous()
             self.bounds_dev = torch.tensor(self.bounds_list, dtype=torch.int32, device=dev)

@@ -40,7 +40,8 @@ class Tensors(C.Structure):
 
 class Frozen(C.Structure):
     _fields_ = [("attr_table", _fp), ("bounds", _fp), ("feats", _fp), ("feat_off", _fp), ("inter", _fp),
-                ("bounds_host", _fp)]
+                ("bounds_host", _fp), ("feat_row_pad", C.c_int32), ("attr_mode", C.c_int32), ("attr_ld", C.c_int32),
+                ("attr_scale", C.c_float), ("attr_bounds", _fp)]
 
 
 class StepOpts(C.Structure):
@@ -108,7 +109,8 @@ SIGNATURES = {
     "matcha_zscore_rows": (C.c_int, [_fp, _I64, _I64, _fp]),
 }
 
-ABI_VERSION = 5             # MATCHA_ABI_VERSION of include/matcha_hip.h
+FEAT_ROW_PAD = 64           # adj front end: feature rows padded to this many floats (matcha_frozen.feat_row_pad)
+ABI_VERSION = 6             # MATCHA_ABI_VERSION of include/matcha_hip.h
 
 _lib = None
 

@@ -15,52 +15,14 @@
 // segments); they are the only non-bitwise-reproducible sums of the adj path.
 #include <string.h>
 
-#include "kernels.hpp"
+#include "adj_common.hpp"
 
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSortTok = 1024;   // tokens per workgroup in the counting sort
-constexpr int kMaxChrom = 63;     // buckets = chromosomes + 1 (padding)
 constexpr int kLdA = 68;
-
-// Four consecutive floats of a row of n floats that starts at an arbitrary float offset (feature rows of a chromosome: n_c floats each).
-// gfx950 serves a global_load_dwordx4 on a 4-byte-aligned address (tools/ubench/unaligned_x4.hip: correct, same cost as four dword loads
-// when bandwidth-bound), and one such load per lane keeps 4x the bytes in flight of the scalar staging it replaces.  A window that would
-// run past the row's end is read from the row's last four floats and shifted (row4_fix); columns >= n come back as 0.
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ f4u row4_load(const float* __restrict__ row, int col0, int n) {
-  if (n >= 4) {
-    const int start = col0 < n - 4 ? col0 : n - 4;
-    return *reinterpret_cast<const f4u*>(row + start);
-  }
-  f4u v;
-  v.x = row[0]; v.y = row[n > 1 ? 1 : 0]; v.z = row[n > 2 ? 2 : 0]; v.w = 0.f;       // n in 1..3: the whole row
-  return v;
-}
-__device__ __forceinline__ void row4_fix(const f4u& raw, int col0, int n, float (&e)[4]) {
-  e[0] = raw.x; e[1] = raw.y; e[2] = raw.z; e[3] = raw.w;
-  int sh = n >= 4 ? (col0 < n - 4 ? 0 : col0 - (n - 4)) : col0;                          // floats the window was moved back by
-  if (sh >= 4) { e[0] = e[1] = e[2] = e[3] = 0.f; return; }
-  if (sh == 1) { e[0] = e[1]; e[1] = e[2]; e[2] = e[3]; e[3] = 0.f; }
-  else if (sh == 2) { e[0] = e[2]; e[1] = e[3]; e[2] = 0.f; e[3] = 0.f; }
-  else if (sh == 3) { e[0] = e[3]; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
-  if (n < 4) {                                                                           // short rows: zero what lies behind the end
-    if (col0 + 0 >= n) e[0] = 0.f;
-    if (col0 + 1 >= n) e[1] = 0.f;
-    if (col0 + 2 >= n) e[2] = 0.f;
-    if (col0 + 3 >= n) e[3] = 0.f;
-  }
-}
-
-struct AdjWs {
-  int32_t *order, *other_map, *seg, *counts /* [0]=m (other tokens), [1]=non-pad tokens */, *hist, *base;
-  float *Hs, *TH, *rec, *dTH, *dZ, *lossslab;
-  int nblk;
-  int64_t nr_pad;
-  size_t total;
-};
 
 static size_t adj_carve(const matcha_shape& s, int64_t T, char* base, AdjWs& w) {
   size_t off = 0;
@@ -84,6 +46,7 @@ static size_t adj_carve(const matcha_shape& s, int64_t T, char* base, AdjWs& w) 
   w.dTH = (float*)take((size_t)T * s.d * 4);
   w.dZ = (float*)take((size_t)T * s.d * 4);
   w.lossslab = (float*)take((size_t)(cdiv(T, 64) + 8) * 4);
+  w.rgrad = (float*)take((size_t)w.nr_pad * (s.d + 1) * 4);
   w.total = off;
   return off;
 }
@@ -216,6 +179,7 @@ struct AdjEncArgs {
   float* Hs;
   int64_t T;
   int C, d;
+  int feat_pad;                // matcha_frozen.feat_row_pad
   int splits;                  // workgroups per chromosome (grid = C * splits); a workgroup takes every splits-th 128-row step
   const uint64_t* seed;
   float p_drop;
@@ -250,7 +214,7 @@ __global__ __launch_bounds__(256) void adj_encode_fwd_kernel(AdjEncArgs g) {
       const bool in = p >= row_lo && p < row_hi;
       const int64_t pc = in ? p : row_lo;                         // out-of-range rows alias a valid row (never stored)
       const int slot = g.order[pc];
-      rowoff[tid] = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c;
+      rowoff[tid] = g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)feat_ld(n_c, g.feat_pad);
       rowslot[tid] = in ? slot : -1;
     }
     f32x16 acc[NT];
@@ -344,7 +308,7 @@ struct AdjTnArgs {
   const float* feats;
   float* out;                // MODE 0: adj_w1 grads [C,d,d];  MODE 1: adj_w0 grads (chromosome c at d*bounds[c], row stride n_c)
   int C, d, rows_per_block;
-  int chrom_parallel;
+  int chrom_parallel, feat_pad;
   const uint64_t* seed;
   float p_drop;
   const int32_t* slot_map;
@@ -401,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void adj_tn_kernel(AdjTnArgs g) {
       const bool in = p < p_hi;
       const int slot = g.order[in ? p : p_hi - 1];
       slot_out = in ? slot : -1;
-      off_out = MODE == 1 ? g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)n_c : 0;
+      off_out = MODE == 1 ? g.feat_off[c] + (g.x[slot] - lo - 1) * (int64_t)feat_ld(n_c, g.feat_pad) : 0;
     };
     int cur = 0;
     if (tid < 128) {
@@ -567,8 +531,11 @@ static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int6
   return MATCHA_OK;
 }
 
+// fused_x0 / fused_X (embed_dim 64, adj_fused_eligible): the attribute path and next_w run in the same kernel and the encoder's input rows come
+// back instead of node_out; `save` = a backward pass (adj_backward with fused = true) will follow on this workspace
 int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* x, int64_t T,
-                float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* t_dev, const int32_t* slot_map) {
+                float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* t_dev, const int32_t* slot_map,
+                float* fused_x0, float* fused_X, bool save, bool fused_node) {
   MATCHA_TRY(check_adj(s, p, f));
   MATCHA_CHECK_ARG(ws && ((uintptr_t)ws) % 256 == 0, "adj_forward: workspace missing or misaligned");
   AdjWs w;
@@ -577,13 +544,19 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
   const int C = s.n_chrom, d = s.d;
   const int r = (recon_out && o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
   MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, t_dev, st));
+  // fused_node: a node-rows-only call that no backward pass follows (matcha_node_embeddings) may take the fused kernel too
+  if (adj_fused_eligible(s, f) && (fused_X || (fused_node && node_out && !recon_out))) {
+    MATCHA_CHECK_ARG(!(o.training != 0 && o.p_drop_adj > 0.f) || o.seed, "adj_forward: dropout needs a seed");
+    return adj_fused_forward(s, p, f, o, x, T, w, r, save, fused_X ? nullptr : node_out, fused_x0, fused_X, recon_out, st, slot_map);
+  }
+  MATCHA_CHECK_ARG(!fused_X, "adj_forward: the fused front end was asked for a shape it does not cover");
   const bool train = o.training != 0 && o.p_drop_adj > 0.f;
   MATCHA_CHECK_ARG(!train || o.seed, "adj_forward: dropout needs a seed");
   // layer 1: gather-GEMM + tanh -> Hs (sorted rows)
   {
     AdjEncArgs a;
     a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats; a.w0 = p.adj_w0;
-    a.Hs = w.Hs; a.T = T; a.C = C; a.d = d; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
+    a.Hs = w.Hs; a.T = T; a.C = C; a.d = d; a.feat_pad = f.feat_row_pad; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
     const int nt = (int)cdiv(d, 32);
     a.splits = (int)cdiv(T, (int64_t)C * 128);
     if (a.splits < 1) a.splits = 1;
@@ -635,7 +608,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
 
 int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* x, int64_t T,
                  float* dnode, const float* drecon, matcha_tensors& g_, int32_t* touched, void* ws, size_t ws_bytes, void* gemm_ws,
-                 size_t gemm_ws_bytes, hipStream_t st, const int32_t* slot_map) {
+                 size_t gemm_ws_bytes, hipStream_t st, const int32_t* slot_map, bool fused) {
   MATCHA_TRY(check_adj(s, p, f));
   AdjWs w;
   const size_t need = adj_carve(s, T, (char*)ws, w);
@@ -648,6 +621,7 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     hipLaunchKernelGGL(adj_flags_kernel, dim3(1), dim3(64), 0, st, w.seg, w.counts, C, r, touched);
     MATCHA_CHECK_LAUNCH("adj_flags_kernel");
   }
+  if (fused) return adj_fused_backward(s, p, f, o, x, T, w, r, dnode, drecon, g_, st, slot_map);
   // ---- recon branch: d loss / d rec = g * 200/(m n_r) * (rec - target) ----
   if (r >= 0 && (drecon || o.beta != 0.f)) {
     MATCHA_CHECK_ARG(g_.recon_w && g_.recon_b && f.bounds_host, "adj_backward: recon gradient buffers missing");
@@ -680,7 +654,7 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));
     a.A = dnode; a.Bd = w.Hs; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
-    a.out = g_.adj_w1; a.C = C; a.d = d; a.rows_per_block = rpb; a.chrom_parallel = cpar; a.seed = o.seed; a.p_drop = 0.f;
+    a.out = g_.adj_w1; a.C = C; a.d = d; a.feat_pad = f.feat_row_pad; a.rows_per_block = rpb; a.chrom_parallel = cpar; a.seed = o.seed; a.p_drop = 0.f;
     auto k0 = adj_tn_kernel<0>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAdjTnLds) != hipSuccess) {
       set_error("adj_tn_kernel: cannot raise the dynamic LDS limit"); return MATCHA_EHIP;
@@ -702,7 +676,7 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
     AdjTnArgs a;
     memset(&a, 0, sizeof(a));
     a.A = w.dZ; a.x = x; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats;
-    a.out = g_.adj_w0; a.C = C; a.d = d; a.rows_per_block = rpb; a.chrom_parallel = cpar; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
+    a.out = g_.adj_w0; a.C = C; a.d = d; a.feat_pad = f.feat_row_pad; a.rows_per_block = rpb; a.chrom_parallel = cpar; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
     auto k1 = adj_tn_kernel<1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAdjTnLds) != hipSuccess) {
       set_error("adj_tn_kernel: cannot raise the dynamic LDS limit"); return MATCHA_EHIP;

@@ -50,11 +50,13 @@ void prof_record(bool start, double work, hipStream_t st) {
 // adj_frontend.hip
 int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
                 const int64_t* x, int64_t T, float* node_out, float* recon_out, void* ws, size_t ws_bytes, hipStream_t st,
-                const int32_t* t_dev, const int32_t* slot_map);
+                const int32_t* t_dev, const int32_t* slot_map, float* fused_x0 = nullptr, float* fused_X = nullptr, bool save = false,
+                bool fused_node = false);
 int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o,
                  const int64_t* x, int64_t T, float* dnode, const float* drecon, matcha_tensors& g, int32_t* touched,
-                 void* ws, size_t ws_bytes, void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st, const int32_t* slot_map);
+                 void* ws, size_t ws_bytes, void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st, const int32_t* slot_map, bool fused = false);
 size_t adj_workspace_bytes(const matcha_shape& s, int64_t T);
+bool adj_fused_eligible(const matcha_shape& s, const matcha_frozen& f);     // adj_fused.hip
 
 struct Workspace {
   Ragged rg;
@@ -431,13 +433,20 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const bool front = !force_layerwise && fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
   // table front end: the two reconstruction-loss slots are zero; loss_reduce_kernel writes them when it runs anyway
   const bool recon_zero_in_loss = s.mode == 0 && recon_out && fused_path && y && w_bce && losses;
+  // adj front end at embed_dim 64: gather-GEMM, W1, attribute path and next_w in ONE kernel over the chromosome-sorted rows (adj_fused.hip)
+  const bool adj_fused = front && fused_path && s.mode == 1 && adj_fused_eligible(s, *frozen);
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
     if (recon_out && !recon_zero_in_loss && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+  } else if (adj_fused) {
+    MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, nullptr, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot,
+                           opts->forward_only ? nullptr : w.x0, w.X, !opts->forward_only));
   } else {
     MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot));
   }
-  if (front) {
+  if (adj_fused) {
+    // x0 and X are already there
+  } else if (front) {
     // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
     MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, w.rg, Tn,
                                 opts->forward_only ? nullptr : w.x0, w.X, st));     // x0 (pre-activation) is only read by the backward pass
@@ -658,7 +667,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
         MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));       // (the two `touched` flags were set by front_slab_reduce_kernel)
       } else {
         MATCHA_TRY(adj_backward(s, p, *frozen, *opts, ids, Tn, w.dX0, drecon, g_, touched, w.adj_ws, w.adj_ws_bytes, w.gemm_ws, w.gemm_ws_bytes, st,
-                                w.rg.tok_slot));
+                                w.rg.tok_slot, adj_fused_eligible(s, *frozen)));
       }
       return MATCHA_OK;
     }
@@ -747,5 +756,5 @@ extern "C" int matcha_node_embeddings(const matcha_shape* shp, const matcha_tens
   memset(&o, 0, sizeof(o));
   o.random_chrom = -1;   // no reconstruction branch
   MATCHA_CHECK_ARG(ws && ws_bytes >= adj_workspace_bytes(*shp, T), "matcha_node_embeddings: adj mode needs a workspace of matcha_workspace_bytes()");
-  return adj_forward(*shp, *params, *frozen, o, ids, T, rows, nullptr, ws, ws_bytes, st, nullptr, nullptr);
+  return adj_forward(*shp, *params, *frozen, o, ids, T, rows, nullptr, ws, ws_bytes, st, nullptr, nullptr, nullptr, nullptr, false, true);
 }

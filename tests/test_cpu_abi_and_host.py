@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libmatcha_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding missing for {name}"
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.matcha_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.matcha_abi_version() == _lib.ABI_VERSION == 6
     assert lib.matcha_device_count() >= 0
 
 
