@@ -77,49 +77,61 @@ struct AdjFwdArgs {
 };
 
 // HEAD: also run the attribute path + next_w (x0, X); without it the kernel stops at the node rows (get_node_embeddings).
-// Three workgroups per CU (52 KB of LDS, <= 168 registers): the kernel is a chain of short dependent phases -- row indices -> feature rows
-// -> four products with a barrier between them -- and what hides their latency is the other workgroups of the CU.  For that the weights
-// of the three small products are fetched after the gather-GEMM (not held through it) and the attribute rows never get a tile: under
-// attr_mode 1 a lane builds its MFMA fragments from (chromosome column, coordinate), under attr_mode 0 it reads them from the table.
+// The kernel is a chain of short dependent phases -- row indices -> feature rows -> four products with a barrier between them (22 us for
+// one workgroup alone) -- and what hides that latency is the other workgroups of the CU: FOUR of them (two LDS tiles = 35 KB, <= 128
+// registers).  For that the tiles are reused as soon as they are dead, the weights of the small products are fetched a phase before
+// their use (not held through the gather-GEMM) and the attribute rows never get a tile: under attr_mode 1 a lane builds its MFMA
+// fragments from (chromosome column, coordinate), under attr_mode 0 it reads them from the table.
 template <bool HEAD>
-__global__ __launch_bounds__(256, 3) void adj_fused_fwd_kernel(AdjFwdArgs g) {
+__global__ __launch_bounds__(256, 4) void adj_fused_fwd_kernel(AdjFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* T0 = lds;                                // GEMM 1 A tile (feature chunk), then node -> x0
-  float* T1 = lds + kTile;                        // GEMM 1 B tile (W0 chunk), then TH
-  float* T2 = lds + 2 * kTile;                    // Hs, then X
+  float* T0 = lds;                                // GEMM 1 A tile (feature chunk), then Hs, then node -> x0
+  float* T1 = lds + kTile;                        // GEMM 1 B tile (W0 chunk), then TH, then X
   __shared__ int64_t rowoff[64];                  // element offset of the gathered feature row
   __shared__ int rowtok[64];                      // token index of the sorted row, -1 = past the item's rows
   __shared__ uint32_t rowh[64];                   // dropout: lowbias32(slot ^ key) of the row
   __shared__ int rowcol[64];                      // attr_mode 1: chromosome column of the row's attribute row (-1: all zeros)
   __shared__ float rowcoord[64];
   __shared__ int rowid[64];
+  __shared__ int abounds[64];                     // attr_mode 1: the chromosome bounds (searched per row)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+  // independent loads first: the attribute bounds, the seed
+  if (HEAD && g.attr.mode == 1 && tid >= 64 && tid < 64 + g.attr.n_attr) abounds[tid - 64] = g.attr.bounds[tid - 64];
+  const bool drop_on = g.p_drop > 0.f;
+  uint64_t seedv = 0;
+  if (drop_on) seedv = *g.seed;
   int c, p0, nrows;
   if (!find_item64(g.seg, g.C + 1, blockIdx.x, c, p0, nrows)) return;
   const bool pad = c >= g.C;                      // the padding bucket: node row = 0 (Modules.py:178)
-  const int lo = pad ? 0 : g.bounds[c], n_c = pad ? 0 : g.bounds[c + 1] - lo;
+  const int cc_ = pad ? 0 : c;
+  // one round trip: the chromosome's bounds and feature offset, this thread's sorted row; then the row's node id
+  const int lo_raw = g.bounds[cc_], hi_raw = g.bounds[cc_ + 1];
+  const int64_t foff = g.feat_off[cc_];
+  int tok = 0;
+  if (tid < 64) tok = g.order[p0 + (tid < nrows ? tid : 0)];
+  const int lo = pad ? 0 : lo_raw, n_c = pad ? 0 : hi_raw - lo_raw;
   const int ldf = feat_ld(n_c, g.feat_pad);
-  const bool drop = g.p_drop > 0.f && !pad;
+  const bool drop = drop_on && !pad;
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
-  if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
+  if (drop) { key = rng_key(seedv, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
+  float4 w1f[8];                                  // W1_c as B fragments of the second product
   if (tid < 64) {
-    const bool in = tid < nrows;
-    const int tok = g.order[p0 + (in ? tid : 0)];
     const int64_t id = g.ids[tok];
-    rowtok[tid] = in ? tok : -1;
+    const int slot = g.slot_map ? g.slot_map[tok] : tok;
+    rowtok[tid] = tid < nrows ? tok : -1;
     rowid[tid] = (int)id;
-    rowoff[tid] = pad ? 0 : g.feat_off[c] + (id - lo - 1) * (int64_t)ldf;
-    rowh[tid] = lowbias32((uint32_t)(g.slot_map ? g.slot_map[tok] : tok) ^ key);
-    if (HEAD && g.attr.mode == 1) {
-      int col; float coord;
-      attr_decode(g.attr, g.attr.bounds, (int)id, col, coord);
-      rowcol[tid] = col; rowcoord[tid] = coord;
-    }
+    rowoff[tid] = pad ? 0 : foff + (id - lo - 1) * (int64_t)ldf;
+    rowh[tid] = lowbias32((uint32_t)slot ^ key);
   }
-  __syncthreads();                                // the row tables are in LDS
+  __syncthreads();                                // the row tables (and the attribute bounds) are in LDS
+  if (HEAD && g.attr.mode == 1 && tid < 64) {
+    int col; float coord;
+    attr_decode(g.attr, abounds, rowid[tid], col, coord);
+    rowcol[tid] = col; rowcoord[tid] = coord;     // read after the next barrier at the earliest
+  }
   const int col = 32 * wc + r;
   f32x16 acc = {0};
   if (!pad) {
@@ -168,29 +180,30 @@ __global__ __launch_bounds__(256, 3) void adj_fused_fwd_kernel(AdjFwdArgs g) {
       }
     }
 #undef AFF_GLOAD
-    // W1_c as B fragments: in flight during the tanh epilogue and the barrier
-    float4 w1f[8];
-    const float* W1 = g.w1 + (int64_t)c * 4096;
+    {                                             // in flight during the barrier, the tanh epilogue and the Hs rows' way out
+      const float* W1 = g.w1 + (int64_t)c * 4096;
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) w1f[cc] = *reinterpret_cast<const float4*>(W1 + (32 * wc + r) * 64 + 8 * cc + 4 * h);
+      for (int cc = 0; cc < 8; ++cc) w1f[cc] = *reinterpret_cast<const float4*>(W1 + (32 * wc + r) * 64 + 8 * cc + 4 * h);
+    }
+    __syncthreads();                              // every wave is done with the last chunk: T0 takes Hs
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      T2[row * kLd + col] = fast_tanh(acc[reg]);
+      T0[row * kLd + col] = fast_tanh(acc[reg]);
     }
-    __syncthreads();                              // Hs tile complete (and every wave is done with T0 / T1)
+    __syncthreads();                              // Hs tile complete
     if (g.Hs) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = srow + 16 * i;
-        if (row < nrows) *reinterpret_cast<float4*>(g.Hs + (int64_t)(p0 + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&T2[row * kLd + sc4]);
+        if (row < nrows) *reinterpret_cast<float4*>(g.Hs + (int64_t)(p0 + row) * 64 + sc4) = *reinterpret_cast<const float4*>(&T0[row * kLd + sc4]);
       }
     }
     // ---- GEMM 2: node = Hs . W1_c^T ----
     acc = (f32x16){0};
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const float4 a = *reinterpret_cast<const float4*>(&T2[(32 * wr + r) * kLd + 8 * cc + 4 * h]);
+      const float4 a = *reinterpret_cast<const float4*>(&T0[(32 * wr + r) * kLd + 8 * cc + 4 * h]);
       const float4 b = w1f[cc];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(256, 3) void adj_fused_fwd_kernel(AdjFwdArgs g) {
     }
     bav = g.ba[32 * wc + r]; bnv = g.bn[32 * wc + r];
   }
+  __syncthreads();                                // every wave is done reading Hs from T0 (pad bucket: the tiles were never used)
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void adj_fused_fwd_kernel(AdjFwdArgs g) {
     const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     T0[row * kLd + col] += acc[reg] + bav;        // in place: this lane owns the element
   }
-  __syncthreads();
+  __syncthreads();                                // x0 complete; the TH rows have left T1
   if (g.x0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -277,13 +291,13 @@ __global__ __launch_bounds__(256, 3) void adj_fused_fwd_kernel(AdjFwdArgs g) {
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    T2[row * kLd + col] = fast_tanh(acc[reg] + bnv);
+    T1[row * kLd + col] = fast_tanh(acc[reg] + bnv);
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = srow + 16 * i;
-    if (row < nrows) *reinterpret_cast<float4*>(g.X + (int64_t)rowtok[row] * 64 + sc4) = *reinterpret_cast<const float4*>(&T2[row * kLd + sc4]);
+    if (row < nrows) *reinterpret_cast<float4*>(g.X + (int64_t)rowtok[row] * 64 + sc4) = *reinterpret_cast<const float4*>(&T1[row * kLd + sc4]);
   }
 }
 
@@ -760,7 +774,7 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
   a.Hs = save ? w.Hs : nullptr; a.TH = recon ? w.TH : nullptr; a.node = node_out; a.x0 = x0; a.X = X; a.C = C;
   a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
   const unsigned grid = (unsigned)(cdiv(T, 64) + C + 1);
-  const size_t lds = (size_t)3 * kTile * sizeof(float);
+  const size_t lds = (size_t)2 * kTile * sizeof(float);
   {
     ProfScope ps(MATCHA_PROF_ADJ_ENCODE, 0.0, st);
     if (X) {
@@ -828,6 +842,7 @@ int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const mat
   const int64_t steps = cdiv(T, 64);
   int spi = (int)(steps / 640);
   spi = spi < 1 ? 1 : (spi > 16 ? 16 : spi);
+  if (options().tune > 0) spi = options().tune;
   a.steps_per_item = spi;
   const unsigned grid = (unsigned)(cdiv(steps, spi) + C);
   const size_t lds = (size_t)4 * kTile * sizeof(float);

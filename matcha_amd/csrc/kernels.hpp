@@ -109,6 +109,7 @@ struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
   int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic, disable_bwdh, disable_bmm_heads;
   int debug_nan, fused_dbg, fwd_lds_pad;
+  int tune;       // development: a free integer read by whatever kernel is being tuned (0 = defaults)
 };
 Options& options();
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
