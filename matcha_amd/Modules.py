@@ -269,6 +269,52 @@ def _gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     return out.view(*ids.shape, d)
 
 
+ATTR_COMPUTE = True     # tests flip these two to reach the other attribute-row paths with the same model
+ATTR_PAD = True
+
+
+def _attr_structure(table: torch.Tensor):
+    """(bounds, scale) when ``table`` [N+1, A] is what get_attributes (main.py:497-512) builds -- row 0 zeros; row id: a one-hot
+    chromosome column c(id) in the first A-1 columns, the chromosomes' ids forming consecutive ranges in column order, and a last
+    column float32(id - 1 - first id of the chromosome) / float32(scale) -- checked for EVERY row, bit for bit; None otherwise.
+    bounds = [0, n_0, n_0 + n_1, ..., N] (A entries), scale = num[0]."""
+    if table.dim() != 2 or table.shape[1] < 2 or table.shape[1] > 64 or table.shape[0] < 2:
+        return None
+    A = table.shape[1]
+    if bool((table[0] != 0).any()):
+        return None
+    body = table[1:]
+    hot = body[:, :A - 1]
+    if not bool(((hot == 0) | (hot == 1)).all()) or not bool((hot.sum(1) == 1).all()):
+        return None
+    col = hot.argmax(1)
+    step = col[1:] - col[:-1]
+    if bool((step < 0).any()):
+        return None
+    counts = torch.bincount(col, minlength=A - 1).cpu().tolist()
+    bounds = [0]
+    for c in counts:
+        bounds.append(bounds[-1] + int(c))
+    lo = torch.tensor(bounds[:-1], dtype=torch.int64, device=table.device)[col]
+    j = torch.arange(body.shape[0], device=table.device, dtype=torch.int64) - lo          # bin index inside its chromosome
+    coord = body[:, A - 1]
+    nz = torch.nonzero(j > 0)
+    if nz.numel() == 0:
+        scale = 1.0
+    else:
+        i0 = int(nz[0])
+        c0 = float(coord[i0])
+        if c0 <= 0:
+            return None
+        scale = float(round(float(j[i0]) / c0))
+        if scale < 1:
+            return None
+    want = j.to(torch.float32) / torch.tensor(scale, dtype=torch.float32, device=table.device)   # IEEE float32 division, like numpy's
+    if not bool((want == coord).all()):
+        return None
+    return bounds, scale
+
+
 class _Runtime:
     """Flat storage for the LIVE parameters (one buffer -> one AdamW launch, one all-reduce bucket) plus the
     ctypes descriptors handed to the C ABI.  Rebuilt whenever a parameter's storage moved (``.to()``,
@@ -352,6 +398,24 @@ class _Runtime:
         self._keep = [self.attr_table]
         self.frozen = _lib.Frozen()
         self.frozen.attr_table = self.attr_table.data_ptr()
+        # attribute rows: when the table has the structure main.py:497-512 builds (one-hot chromosome || bin index / num[0]) the kernels
+        # rebuild a token's row from its node id instead of gathering it (attr_mode 1: one random row per token); any other
+        # table is read as rows padded to 32 floats = one 128-byte fetch unit (a 96-byte row straddles two units three times out of four)
+        st = _attr_structure(self.attr_table) if ATTR_COMPUTE else None
+        self.attr_mode = 0
+        if st is not None:
+            bounds, scale = st
+            self.attr_bounds = torch.tensor(bounds, dtype=torch.int32, device=dev)
+            self.frozen.attr_mode, self.frozen.attr_scale = 1, float(scale)
+            self.frozen.attr_bounds = self.attr_bounds.data_ptr()
+            self.attr_mode = 1
+            self._keep.append(self.attr_bounds)
+        # (the table stays available under attr_mode 1: the fused embed_dim-64 front end keeps gathering its rows -- attr_src.hpp --
+        # and the layer-by-layer attribute_nn backward reads them as the B operand of its weight-gradient product)
+        if self.n_attr < 32 and ATTR_PAD:
+            self.attr_table = torch.nn.functional.pad(self.attr_table, (0, 32 - self.n_attr)).contiguous()
+            self._keep[0] = self.attr_table
+            self.frozen.attr_table, self.frozen.attr_ld = self.attr_table.data_ptr(), 32
         if self.mode == 1:
             feats = [e.embedding.detach().to(device=dev, dtype=torch.float32).contiguous() for e in ne.embeddings]
             offs = np.zeros(self.n_chrom + 1, dtype=np.int64)

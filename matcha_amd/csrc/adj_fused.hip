@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256, 4) void adj_fused_fwd_kernel(AdjFwdArgs g) {
   if (HEAD && g.attr.mode == 1 && tid < 64) {
     int col; float coord;
     attr_decode(g.attr, abounds, rowid[tid], col, coord);
-    rowcol[tid] = col; rowcoord[tid] = coord;     // read after the next barrier at the earliest
+    rowcol[tid] = col; rowcoord[tid] = coord;     // read after the gather-GEMM's barriers ...
   }
+  if (HEAD && pad) __syncthreads();               // ... which the padding bucket does not run
   const int col = 32 * wc + r;
   f32x16 acc = {0};
   if (!pad) {

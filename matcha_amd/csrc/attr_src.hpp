@@ -24,6 +24,13 @@ static inline AttrSrc attr_src(const matcha_frozen& f, int n_attr) {
   a.ld = f.attr_ld > 0 ? f.attr_ld : n_attr; a.scale = f.attr_scale;
   return a;
 }
+// for the kernels that keep gathering rows when a table is there (front_fused.hip: its row pieces are loaded by eight threads per row,
+// a per-thread rebuild would repeat the search eight times; measured slower than the padded 128-byte rows it replaces)
+static inline AttrSrc attr_src_table_first(const matcha_frozen& f, int n_attr) {
+  AttrSrc a = attr_src(f, n_attr);
+  if (f.attr_table) a.mode = 0;
+  return a;
+}
 static inline int check_attr(const matcha_frozen& f, int n_attr) {
   if (f.attr_mode == 0) {
     MATCHA_CHECK_ARG(f.attr_table, "attribute table missing (attr_mode 0)");

@@ -15,6 +15,7 @@
 // 8 partials (2 KB), X, dXs, x0 (768 B), the id and its attribute row, and dZ0 / dX0 never reach HBM (table mode).
 // Persistent workgroups walk 64-token tiles; next_w stays in LDS, the two weight gradients in MFMA accumulators; one slab
 // per workgroup, summed in a fixed order by front_slab_reduce_kernel.  LDS 78 KB -> two workgroups per CU.
+#include "attr_src.hpp"
 #include "kernels.hpp"
 
 namespace matcha {
@@ -32,7 +33,7 @@ constexpr float kEps = 1e-5f;
 
 struct FrontBwdArgs {
   const float* X; const float* dxh; int nslab; int64_t tcap; const float* dxpad; const float* dXs; const float* x0;
-  const int64_t* ids; const float* attr_table; int n_attr;
+  const int64_t* ids; AttrSrc attr; int n_attr;
   const float* Wn;                                // next_w [64][64] ([out][in])
   const int32_t* count;                           // {Tr + 1, Tr, tiles}
   float* dX0;                                     // adj front end: [Tn, 64] output; table front end: null
@@ -48,6 +49,9 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
   float* Ds = lds + 3 * kTile;                    // dX0
   float* As = lds + 4 * kTile;                    // attribute rows [64][kLdA]
   int* ids_s = reinterpret_cast<int*>(As + 64 * kLdA);   // [64] node id of each row (0: padding / past the end)
+  __shared__ int abounds[64];                     // attr_mode 1: chromosome bounds (attribute rows are rebuilt from the node id)
+  if (g.attr.mode == 1 && threadIdx.x < g.attr.n_attr) abounds[threadIdx.x] = g.attr.bounds[threadIdx.x];
+  if (g.attr.mode == 1) __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
@@ -86,7 +90,14 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
     _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__) {                                                \
       const int64_t t__ = tb__ + a_row0 + 32 * j__;                                                      \
       const int64_t id__ = g.ids[t__ < T ? t__ : (int64_t)T - 1];                                        \
-      pav[j__] = *reinterpret_cast<const float4*>(g.attr_table + id__ * g.n_attr + a_qc);                \
+      if (g.attr.mode == 1) {                                                                            \
+        int cl__; float cd__;                                                                            \
+        attr_decode(g.attr, abounds, (int)id__, cl__, cd__);                                             \
+        pav[j__] = make_float4(attr_elem(a_qc, cl__, cd__, g.n_attr), attr_elem(a_qc + 1, cl__, cd__, g.n_attr),  \
+                               attr_elem(a_qc + 2, cl__, cd__, g.n_attr), attr_elem(a_qc + 3, cl__, cd__, g.n_attr)); \
+      } else {                                                                                           \
+        pav[j__] = *reinterpret_cast<const float4*>(g.attr.table + id__ * g.attr.ld + a_qc);             \
+      }                                                                                                  \
     }                                                                                                    \
   } while (0)
   if ((int)blockIdx.x < ntiles) FBW_GLOAD(blockIdx.x);
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
 
 struct FrontFwdArgs {
   const int64_t* ids; const float* table; const float* dense;       // node rows: table[id] (table front end) or dense[t] (adj)
-  const float* attr_table; int n_attr;
+  AttrSrc attr; int n_attr;
   const float* Wa; const float* ba; const float* Wn; const float* bn;
   const int32_t* count;
   float* x0; float* X;
@@ -218,6 +229,9 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   float* Es = lds;                                // node rows, then x0 in place
   float* As = lds + kTile;                        // attribute rows [64][kLdA]
   float* Xs = As + 64 * kLdA;                     // X tile on its way out
+  __shared__ int abounds[64];                     // attr_mode 1: chromosome bounds (attribute rows are rebuilt from the node id: ONE random
+  if (g.attr.mode == 1 && threadIdx.x < g.attr.n_attr) abounds[threadIdx.x] = g.attr.bounds[threadIdx.x];   // row per token)
+  if (g.attr.mode == 1) __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
@@ -267,7 +281,15 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
       pe[i__] = *reinterpret_cast<const float4*>(src__ + sc4);                                           \
     }                                                                                                    \
     _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__) {                                                \
-      const float4 v__ = *reinterpret_cast<const float4*>(g.attr_table + id_a[j__] * g.n_attr + aqc);     \
+      float4 v__;                                                                                        \
+      if (g.attr.mode == 1) {                                                                            \
+        int cl__; float cd__;                                                                            \
+        attr_decode(g.attr, abounds, (int)id_a[j__], cl__, cd__);                                        \
+        v__ = make_float4(attr_elem(aqc, cl__, cd__, g.n_attr), attr_elem(aqc + 1, cl__, cd__, g.n_attr), \
+                          attr_elem(aqc + 2, cl__, cd__, g.n_attr), attr_elem(aqc + 3, cl__, cd__, g.n_attr)); \
+      } else {                                                                                           \
+        v__ = *reinterpret_cast<const float4*>(g.attr.table + id_a[j__] * g.attr.ld + aqc);              \
+      }                                                                                                  \
       pa[j__] = make_float4(v__.x * amask, v__.y * amask, v__.z * amask, v__.w * amask);                 \
     }                                                                                                    \
   } while (0)
@@ -418,18 +440,19 @@ int front_grid() {
 
 }  // namespace
 
-int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
+int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const matcha_frozen& f, int n_attr,
                      const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st) {
+  MATCHA_TRY(check_attr(f, n_attr));
   FrontFwdArgs g;
-  g.ids = ids; g.table = table; g.dense = dense; g.attr_table = attr_table; g.n_attr = n_attr;
+  g.ids = ids; g.table = table; g.dense = dense; g.attr = attr_src_table_first(f, n_attr); g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
   int grid = front_grid() / 2 * 3;                      // three workgroups per CU (44 KB of LDS each)
   const int64_t max_tiles = cdiv(tcap, 64);
   if (grid > max_tiles) grid = (int)max_tiles;
   const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
-  // algorithmic bytes per token: id 8 + node row 256 + attribute row read; x0 and X rows written
-  // (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
-  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + 4.0 * n_attr + (x0 ? 512.0 : 256.0)), st);
+  // algorithmic bytes per token: id 8 + node row 256 + attribute row read (attr_mode 1: rebuilt from the id, nothing read); x0 and X rows
+  // written (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
+  ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + (g.attr.mode == 1 ? 0.0 : 4.0 * n_attr) + (x0 ? 512.0 : 256.0)), st);
   hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);
   MATCHA_CHECK_LAUNCH("front_fwd_kernel");
   return MATCHA_OK;
@@ -439,20 +462,21 @@ bool front_bwd_supported(int d, int n_attr) { return d == 64 && n_attr >= 4 && n
 size_t front_bwd_ws_floats() { return (size_t)1024 * kFrontSlab; }
 
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
-                     const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
+                     const int64_t* ids, const matcha_frozen& f, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
                      matcha_tensors& grads, hipStream_t st, int32_t* touched) {
+  MATCHA_TRY(check_attr(f, n_attr));
   FrontBwdArgs g;
-  g.X = X; g.dxh = dxh; g.nslab = nslab; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr_table = attr_table; g.n_attr = n_attr;
+  g.X = X; g.dxh = dxh; g.nslab = nslab; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr = attr_src_table_first(f, n_attr); g.n_attr = n_attr;
   g.Wn = p.next_w; g.count = rg.count; g.dX0 = dX0; g.dtable = dtable; g.slab = ws;
   int grid = front_grid();
   const int64_t max_tiles = cdiv(tcap, 64);
   if (grid > max_tiles) grid = (int)max_tiles;
   const size_t lds = ((size_t)4 * kTile + 64 * kLdA + 64) * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(front_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(front_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   {
     // algorithmic bytes per token: the d x_hat partials (8 per-head slabs, or 1 when the heads were added with atomics) + X + dXs + x0, id,
     // attribute row; table mode adds 256 B of atomics
-    ProfScope ps(MATCHA_PROF_FRONT_BWD, (double)tcap * ((3.0 + nslab) * 256.0 + 8.0 + 4.0 * n_attr + 256.0), st);
+    ProfScope ps(MATCHA_PROF_FRONT_BWD, (double)tcap * ((3.0 + nslab) * 256.0 + 8.0 + (g.attr.mode == 1 ? 0.0 : 4.0 * n_attr) + 256.0), st);
     hipLaunchKernelGGL(front_bwd_kernel, dim3(grid), dim3(256), lds, st, g);
     MATCHA_CHECK_LAUNCH("front_bwd_kernel");
   }

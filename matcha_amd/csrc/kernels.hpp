@@ -92,7 +92,7 @@ int launch_gemm_tn_wide(const float* A, const float* B, int64_t M, int64_t N, in
                         size_t ws_bytes, const int32_t* r_dev, int* P_out, int64_t* slab_stride_out, hipStream_t st);
 
 // token_kernels.hip
-int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
+int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const matcha_frozen& f,
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev = nullptr);
 int launch_embed_scatter(const int64_t* x, int64_t T, int d, const float* dx0, float* dtable, hipStream_t st, const int32_t* t_dev = nullptr);
 int launch_gather_rows(const int64_t* ids, int64_t T, int d, const float* table, int64_t n_nodes, float* rows, int32_t* status, hipStream_t st);
@@ -175,11 +175,11 @@ const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padd
 // backward = LayerNorm backward of the summed d x_hat partials, next_w and attribute_nn
 // backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel
 bool front_bwd_supported(int d, int n_attr);
-int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const float* attr_table, int n_attr,
+int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const matcha_frozen& f, int n_attr,
                      const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st);
 size_t front_bwd_ws_floats();
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
-                     const int64_t* ids, const float* attr_table, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
+                     const int64_t* ids, const matcha_frozen& f, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
                      matcha_tensors& grads, hipStream_t st, int32_t* touched = nullptr);
 
 // attention.hip

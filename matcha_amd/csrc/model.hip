@@ -409,7 +409,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const bool train = opts->training != 0;
   MATCHA_CHECK_ARG(!train || opts->seed || (opts->p_drop_adj <= 0 && opts->p_drop_fc1 <= 0 && opts->p_drop_pff <= 0),
                    "matcha_forward: training with dropout needs opts->seed");
-  MATCHA_CHECK_ARG(frozen->attr_table && p.attr_w && p.attr_b && p.next_w && p.next_b && p.w_q && p.w_k && p.w_v && p.fc1_w &&
+  MATCHA_CHECK_ARG((frozen->attr_table || frozen->attr_mode == 1) && p.attr_w && p.attr_b && p.next_w && p.next_b && p.w_q && p.w_k && p.w_v && p.fc1_w &&
                        p.fc1_b && p.pff0_w && p.pff0_b && p.pff1_w && p.pff1_b && p.pff_ln_g && p.pff_ln_b && p.ln1_g && p.ln1_b &&
                        p.ln2_g && p.ln2_b && p.cls_w && p.cls_b && p.ln_q_g && p.ln_q_b && p.ln_k_g && p.ln_k_b && p.ln_v_g && p.ln_v_b,
                    "matcha_forward: a parameter pointer is null");
@@ -448,10 +448,10 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // x0 and X are already there
   } else if (front) {
     // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
-    MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, w.rg, Tn,
+    MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, *frozen, s.n_attr, w.rg, Tn,
                                 opts->forward_only ? nullptr : w.x0, w.X, st));     // x0 (pre-activation) is only read by the backward pass
   } else {
-    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, frozen->attr_table, s.n_attr, p.attr_w,
+    MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, *frozen, s.n_attr, p.attr_w,
                                 p.attr_b, w.x0, st, cnt));
     // X = tanh(next_w(x0))   (Modules.py:270)
     GemmArgs g = gemm1(w, w.x0, p.next_w, w.X, Tn, d, d, false);
@@ -661,7 +661,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
       if (s.mode == 0) MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");
       const bool rows_out = s.mode == 1 || opts->deterministic || opts->sparse_table_grad;     // dX0 rows instead of float atomics
-      MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, dx_atomic ? 1 : MATCHA_N_HEAD, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, frozen->attr_table, s.n_attr, w.rg,
+      MATCHA_TRY(launch_front_bwd(p, w.X, w.dO, dx_atomic ? 1 : MATCHA_N_HEAD, Tn, fused_bwd_dxpad(w.fb_ws), w.dXs, w.x0, ids, *frozen, s.n_attr, w.rg,
                                   rows_out ? w.dX0 : nullptr, rows_out ? nullptr : g_.table, w.front_ws, g_, st, s.mode == 0 ? touched : nullptr));
       if (s.mode == 0) {
         MATCHA_TRY(table_gradient(s, *opts, w, Tn, g_, st));       // (the two `touched` flags were set by front_slab_reduce_kernel)
@@ -725,8 +725,9 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
   // attribute_nn: dWa += dX0^T attr_table[id] ; dba += colsum(dX0)
-  MATCHA_TRY(launch_gemm_tn(w.dX0, frozen->attr_table, g_.attr_w, g_.attr_b, d, s.n_attr, Tn, d, s.n_attr, ids, true, w.gemm_ws,
-                            w.gemm_ws_bytes, st, cnt));
+  MATCHA_CHECK_ARG(frozen->attr_table, "matcha_backward: the layer-by-layer attribute_nn backward gathers attr_table rows (also under attr_mode 1)");
+  MATCHA_TRY(launch_gemm_tn(w.dX0, frozen->attr_table, g_.attr_w, g_.attr_b, d, s.n_attr, Tn, d, frozen->attr_ld > 0 ? frozen->attr_ld : s.n_attr, ids, true,
+                            w.gemm_ws, w.gemm_ws_bytes, st, cnt));
   // node embedding
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(g_.table, "matcha_backward: table mode without a table gradient buffer");

@@ -5,6 +5,9 @@
 // Layout: activations are [T = B*L tokens, d] fp32 row-major; a token row is handled by a group of 16
 // adjacent lanes, each owning float4 chunks j = 4*s + 64*c (s = lane & 15), so one wave-instruction reads
 // four whole rows (4 x 256 B at d = 64) and every row statistic is a 4-step xor-shuffle reduction.
+#include <string.h>
+
+#include "attr_src.hpp"
 #include "kernels.hpp"
 
 namespace matcha {
@@ -163,10 +166,13 @@ __device__ __forceinline__ void block_colsum_store(Row (&part)[NV], int d, float
 template <int NCH>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ x, int64_t T, int d,
                                                         const float* __restrict__ table, const float* __restrict__ dense,
-                                                        const float* __restrict__ attr_table, int n_attr,
+                                                        AttrSrc attr, int n_attr,
                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
                                                         float* __restrict__ x0, int tok_per_blk, const int32_t* __restrict__ t_dev) {
   if (t_dev) T = *t_dev;                                // ragged layout: the token count lives on the device
+  const float* __restrict__ attr_table = attr.table;
+  __shared__ int abounds[64];                           // attr_mode 1: chromosome bounds (the attribute row is rebuilt from the node id)
+  if (attr.mode == 1 && threadIdx.x < n_attr) abounds[threadIdx.x] = attr.bounds[threadIdx.x];
   // attribute_nn.weight [d, n_attr] is staged TRANSPOSED in LDS ([n_attr][d]) once per workgroup, so that the 16
   // lanes of a token read consecutive float4s (conflict-free; the 16 token groups broadcast) instead of each
   // lane walking a strided column of the weight in global memory.
@@ -205,15 +211,38 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     if (table) { load_row<NCH>(table + ca * d, s, d, ea); load_row<NCH>(table + cb * d, s, d, eb); }
     else if (dense) { load_row<NCH>(dense + ta * d, s, d, ea); load_row<NCH>(dense + (hb ? tb : ta) * d, s, d, eb); }
     else { zero_row<NCH>(ea); zero_row<NCH>(eb); }
-    const float* arow_a = attr_table + ca * n_attr;
-    const float* arow_b = attr_table + cb * n_attr;
+    Row oa = bias, ob = bias;
+    if (attr.mode == 1) {
+      // one-hot chromosome || coordinate: the product has two non-zero terms, W[:, chromosome] and coordinate * W[:, n_attr - 1], added in
+      // column order like the general loop below (whose other terms are exact zeros): bit-identical to it, and no second random row
+      int cla, clb; float cda, cdb;
+      attr_decode(attr, abounds, (int)ca, cla, cda);
+      attr_decode(attr, abounds, (int)cb, clb, cdb);
+      const float ona = cla >= 0 ? 1.f : 0.f, onb = clb >= 0 ? 1.f : 0.f;
+      const float* wca = wt + (cla >= 0 ? cla : 0) * d;
+      const float* wcb = wt + (clb >= 0 ? clb : 0) * d;
+      const float* wl = wt + (n_attr - 1) * d;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int j = 4 * s + 64 * c;
+        if (j < d) {
+          const float4 wa4 = *reinterpret_cast<const float4*>(wca + j), wb4 = *reinterpret_cast<const float4*>(wcb + j);
+          const float4 wl4 = *reinterpret_cast<const float4*>(wl + j);
+          oa.v[c].x += ona * wa4.x; oa.v[c].y += ona * wa4.y; oa.v[c].z += ona * wa4.z; oa.v[c].w += ona * wa4.w;
+          ob.v[c].x += onb * wb4.x; ob.v[c].y += onb * wb4.y; ob.v[c].z += onb * wb4.z; ob.v[c].w += onb * wb4.w;
+          oa.v[c].x += cda * wl4.x; oa.v[c].y += cda * wl4.y; oa.v[c].z += cda * wl4.z; oa.v[c].w += cda * wl4.w;
+          ob.v[c].x += cdb * wl4.x; ob.v[c].y += cdb * wl4.y; ob.v[c].z += cdb * wl4.z; ob.v[c].w += cdb * wl4.w;
+        }
+      }
+    } else {
+    const float* arow_a = attr_table + ca * attr.ld;
+    const float* arow_b = attr_table + cb * attr.ld;
     float ava[2], avb[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       ava[q] = (16 * q + s < n_attr) ? arow_a[16 * q + s] : 0.f;      // 16 attribute values per coalesced load
       avb[q] = (16 * q + s < n_attr) ? arow_b[16 * q + s] : 0.f;
     }
-    Row oa = bias, ob = bias;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int base = 16 * q;
@@ -248,6 +277,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
           }
         }
       }
+    }
     }
     acc_row<NCH>(oa, ea);
     store_row<NCH>(x0 + ta * d, s, d, oa);
@@ -647,15 +677,17 @@ static inline int nch_of(int d) { return d <= 64 ? 1 : (d <= 128 ? 2 : 4); }
     default: { constexpr int NCH = 4; CALL; } break; \
   }
 
-int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const float* attr_table,
+int launch_embed_fwd(const int64_t* x, int64_t T, int d, const float* table, const float* dense, const matcha_frozen& f,
                      int n_attr, const float* Wa, const float* ba, float* x0, hipStream_t st, const int32_t* t_dev) {
   if (T <= 0) return MATCHA_OK;
+  MATCHA_TRY(check_attr(f, n_attr));
+  const AttrSrc attr = attr_src(f, n_attr);
   const int tok_per_blk = T >= 256 * 1024 ? 256 : (T >= 64 * 1024 ? 128 : (T >= 16 * 1024 ? 64 : 16));
   dim3 grid((unsigned)cdiv(T, tok_per_blk));
   const size_t lds = (size_t)n_attr * d * sizeof(float);
-  // algorithmic bytes per token: index 8 + embedding row 4d + attribute row 4*n_attr read, x0 row 4d written
-  ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)T * (8.0 + 4.0 * d + 4.0 * n_attr + 4.0 * d), st);
-  DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), lds, st, x, T, d, table, dense, attr_table, n_attr, Wa, ba, x0, tok_per_blk, t_dev));
+  // algorithmic bytes per token: index 8 + embedding row 4d + attribute row 4*n_attr read (attr_mode 1: nothing), x0 row 4d written
+  ProfScope ps(MATCHA_PROF_EMBED_FWD, (double)T * (8.0 + 4.0 * d + (attr.mode == 1 ? 0.0 : 4.0 * n_attr) + 4.0 * d), st);
+  DISPATCH_NCH(d, hipLaunchKernelGGL((embed_fwd_kernel<NCH>), grid, dim3(256), lds, st, x, T, d, table, dense, attr, n_attr, Wa, ba, x0, tok_per_blk, t_dev));
   MATCHA_CHECK_LAUNCH("embed_fwd_kernel");
   return MATCHA_OK;
 }
@@ -790,7 +822,10 @@ extern "C" int matcha_embed_fwd(const int64_t* x, int64_t T, int32_t d, const fl
                                 float* x0, matcha_stream_t stream) {
   MATCHA_CHECK_ARG(x && attr_table && attr_w && attr_b && x0, "matcha_embed_fwd: null pointer");
   MATCHA_CHECK_ARG(d % 4 == 0 && d > 0 && d <= 256, "matcha_embed_fwd: d=%d must be a multiple of 4, <= 256", d);
-  return launch_embed_fwd(x, T, d, table, dense, attr_table, n_attr, attr_w, attr_b, x0, (hipStream_t)stream, nullptr);
+  matcha_frozen f;
+  memset(&f, 0, sizeof(f));
+  f.attr_table = attr_table;                      // op-level entry point: plain [N+1, n_attr] rows
+  return launch_embed_fwd(x, T, d, table, dense, f, n_attr, attr_w, attr_b, x0, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int matcha_embed_scatter_bwd(const int64_t* x, int64_t T, int32_t d, const float* dx0, float* dtable,

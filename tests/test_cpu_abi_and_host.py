@@ -167,3 +167,31 @@ def test_rng_spec_is_stable():
     m = R.dropout_mask(7, R.STREAM_DROP_PFF, 0.4, 2000, 16)
     assert set(np.unique(m).tolist()) == {0.0, np.float32(1.0) / (np.float32(1.0) - np.float32(0.4))}
     assert abs(float((m == 0).mean()) - 0.4) < 0.02
+
+
+def test_attribute_structure_detection_is_exact():
+    """matcha_amd.Modules._attr_structure: get_attributes' table (main.py:497-512) is recognised with its bounds and scale; anything
+    else -- a wrong coordinate by one ulp, two ones in a row, chromosomes out of order, a non-zero padding row -- is refused, so the
+    kernels only ever rebuild rows that equal the table's bit for bit."""
+    import torch
+    from matcha_amd import synth
+    from matcha_amd.Modules import _attr_structure
+    from oracle import hypersagnn as O
+    for name in ("tiny", "c1", "c23", "hg38_1mb"):
+        num = synth.LAYOUTS[name]
+        bounds, scale = _attr_structure(torch.from_numpy(O.attribute_table(num)))
+        assert bounds == [0] + list(np.cumsum(num)) and scale == float(num[0])
+    base = O.attribute_table(synth.LAYOUTS["c23"])
+    for edit in ("ulp", "two_ones", "pad_row", "order", "dense"):
+        t = base.copy()
+        if edit == "ulp":
+            t[9, -1] = np.nextafter(t[9, -1], np.float32(2.0))
+        elif edit == "two_ones":
+            t[4, 3] = 1.0
+        elif edit == "pad_row":
+            t[0, 0] = 1.0
+        elif edit == "order":
+            t[[1, 140]] = t[[140, 1]]
+        else:
+            t = np.random.default_rng(0).normal(size=t.shape).astype(np.float32)
+        assert _attr_structure(torch.from_numpy(t)) is None, edit
