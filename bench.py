@@ -44,7 +44,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA peak (no xf
 # MFMA-bound kernel classes.  The fused kernels count ALGORITHMIC GEMM flops only: fused_fwd 4 projections per
 # head + the two pff GEMMs; fused_bwd 8 GEMMs per head (dO, dWfc1, 3 dW', 3 d x_hat terms) -- the Q/K/V recompute of the
 # backward kernel and the O(k) attention arithmetic are not counted.
-GEMM_CLASSES = ("gemm_nt", "gemm_nn", "gemm_tn", "fused_fwd", "fused_bwd")
+GEMM_CLASSES = ("gemm_nt", "gemm_nn", "gemm_tn", "fused_fwd", "fused_bwd", "adj_encode", "adj_recon", "adj_bwd")
 # Merged heads (embed_dim 64, round 3): with d_k = d_v = d_model the four per-head products of the reference collapse into two in the
 # forward (r = B_h x, dyn += M_h z) and eight into four in the backward.  `achieved` stays what the contract asks for -- the reference
 # formulation's ALGORITHMIC flops over the kernel's time -- and `executed_fraction` says what share of them the matrix cores really
@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each; ms_per_step / value are the MEDIAN window "
+                                                             "(min and max are reported beside it)")
     ap.add_argument("--rows", type=int, default=65536, help="rows (positives+negatives) per GPU per step")
     ap.add_argument("--front-end", choices=["table", "adj"], default="table")
     ap.add_argument("--layout", default="hg38_1mb", help="hg38_1mb | hg38_100kb | c1 | c5 (matcha_amd/synth.py LAYOUTS)")
@@ -148,7 +150,7 @@ class Dist:
 
 
 def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof="auto", graph=False, edges_per_k=100000, edges=0,
-                 table_exchange="auto", model_only=True, deterministic=False, zipf=False):
+                 table_exchange="auto", model_only=True, deterministic=False, zipf=False, windows=1):
     """Build the workload on the device, run `warmup` untimed + `steps` timed steps, return the measurements."""
     from matcha_amd.engine import Trainer
     from matcha_amd.sampler import HyperedgeSet, NegativeSampler
@@ -256,12 +258,23 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
 
     if prof_cls != "none":
         lib.matcha_profile_select(_lib.PROF[prof_cls])
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # `windows` timed windows of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both sides; the line
+    # reports the median window (run-to-run noise of one 36 ms window exceeded the differences being resolved), min and max beside it
+    win = []
+    for _ in range(max(1, windows)):
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t[0])
+        win.append(dt)
+    elapsed = float(np.median(win))
+    steps_timed = steps * len(win)
     roof = None
     if prof_cls != "none":
         ms, n, wk = C.c_double(), C.c_int64(), C.c_double()
@@ -277,19 +290,23 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             if prof_cls in GEMM_CLASSES:
                 ach = wk.value / (ms.value * 1e-3) / 1e12
                 roof = dict(bound="mfma", kernel=prof_cls, achieved=round(ach, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches_per_step=n.value / steps,
+                            frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches_per_step=n.value / steps_timed,
                             avg_launch_ms=round(per_launch_ms, 5), work_per_launch=wk.value / n.value)
                 ex = executed_fraction(lib, prof_cls, dim)
+                # frac = the contract's figure (SURVEY d4's ALGORITHMIC flops of the reference formulation / time / peak);
+                # frac_executed = the flops the kernel really issues / time / peak (merged heads execute half of the reference's
+                # products) -- the number the hardware bounds; mfma_util_pmc = the matrix pipe's busy share from the PMC pass
+                roof["executed_fraction"] = round(ex, 4)
+                roof["executed_tflops"] = round(ach * ex, 3)
+                roof["frac_executed"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
+                roof["mfma_util_pmc"] = None
                 if ex < 1.0:
-                    roof["executed_fraction"] = round(ex, 4)
-                    roof["executed_tflops"] = round(ach * ex, 3)
-                    roof["executed_frac_of_peak"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
-                    roof["note"] = ("achieved = the reference formulation's algorithmic flops / time; merged heads execute "
-                                    "executed_fraction of them (DESIGN.md §4.1)")
+                    roof["note"] = ("frac = the reference formulation's algorithmic flops / time / peak; merged heads execute "
+                                    "executed_fraction of them: frac_executed is what the silicon does (DESIGN.md §4.1)")
             else:
                 ach = wk.value / (ms.value * 1e-3) / 1e9
                 roof = dict(bound="hbm", kernel=prof_cls, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches_per_step=n.value / steps,
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches_per_step=n.value / steps_timed,
                             avg_launch_ms=round(per_launch_ms, 5), work_per_launch=wk.value / n.value)
     if roof is not None:
         # HBM bytes per launch from committed PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -304,6 +321,12 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
                     if c:
                         roof["traffic"] = round(c["hbm_bytes_per_launch"], 1)
                         roof["traffic_source"] = os.path.basename(f)
+                    mf = os.path.join(os.path.dirname(f), os.path.basename(f).replace("pmc_traffic", "pmc_mfma"))
+                    if "mfma_util_pmc" in roof and os.path.exists(mf):
+                        with open(mf) as fh2:
+                            mm = json.load(fh2)
+                        if mm.get("csrc_sha16") == csrc_sha16():
+                            roof["mfma_util_pmc"] = mm.get("classes", {}).get(prof_cls, {}).get("mfma_util")
                     break
             except (OSError, ValueError, KeyError):
                 pass
@@ -319,10 +342,6 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             trainer.step(x, y, w, alpha=1.0, beta=0.001, random_chrom=0)
         dist.barrier()
         model_only_ms = (time.perf_counter() - t1) / k2 * 1e3
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t[0])
     trainer.check_status()
     exhausted = sampler.check_status()
     losses = trainer.losses.cpu().tolist()
@@ -344,7 +363,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
         else:
             ach = work / (ms_step * 1e-3) / 1e9
             roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
-    out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, roof=roof, roof_all=roof_all, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
+    out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, windows=win, roof=roof, roof_all=roof_all, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
                pool=pool, wts=None if pool is None else wts, num=num, known_edges=workload_edges, sparse_exchange=bool(trainer._sparse),
                exhausted_negatives=exhausted, comm_bytes=dict(trainer.comm_bytes), overlap=bool(trainer._side is not None and trainer._overlap()))
     del trainer, clf, sampler, hset, pool_all
@@ -402,14 +421,34 @@ def gather_roofline(device):
     return out
 
 
+def visible_gpus() -> int:
+    """Number of GPUs a child would see, WITHOUT a HIP / HSA call in this process (torch.cuda.device_count() falls back to
+    hipGetDeviceCount on ROCm builds without amdsmi, which opens the GPU): the KFD topology lists one node per agent, GPUs are the nodes
+    with SIMDs; *_VISIBLE_DEVICES narrows it."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(f) as fh:
+                for line in fh:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` (N > 1) outside a torch.distributed.run launch: start the N ranks ourselves -- one process per GPU
     over RCCL, exactly the command the driver would have used -- as a CHILD process, before anything in this process has touched
-    the GPU (no HIP call, no torch.cuda.is_available(); counting devices does not initialise it), and hand its exit code back.
+    the GPU (no HIP call, no torch.cuda.is_available(); the devices are counted from the KFD topology, visible_gpus), and hand its exit code back.
     Rank 0's JSON line reaches stdout through the inherited descriptor.  Never falls back to one rank."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_gpus()
     if n_dev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to report a {args.gpus}-GPU line", file=sys.stderr)
         return 3
@@ -455,12 +494,25 @@ def front_gather_roofline(device):
         torch.cuda.synchronize(device)
         tokens = B * L + 1
         t = ms.value * 1e-3 / max(n.value, 1)
-        read = tokens * (8.0 + 4.0 * d + 4.0 * n_attr)
+        # attribute rows: embed_fwd rebuilds them from the node id when the table has get_attributes' structure (attr_mode 1: ONE random
+        # row per token); front_fwd keeps reading them, as rows padded to one 128-byte fetch unit (csrc/attr_src.hpp)
+        attr_read = 0 if (cls == "embed_fwd" and clf._runtime().attr_mode == 1) else 4 * n_attr
+        read = tokens * (8.0 + 4.0 * d + attr_read)
         written = tokens * 4.0 * d
-        out.append(dict(table=name, d=d, tokens_per_launch=tokens, resident="hbm", bound="hbm", kernel=cls, avg_launch_ms=round(t * 1e3, 4),
-                        achieved=round(read / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(read / t / 1e9 / HBM_PEAK_GBS, 4),
-                        read_bytes_per_token=8 + 4 * d + 4 * n_attr, written_bytes_per_token=4 * d,
-                        read_plus_write_gbs=round((read + written) / t / 1e9, 1)))
+        rec = dict(table=name, d=d, tokens_per_launch=tokens, resident="hbm", bound="hbm", kernel=cls, avg_launch_ms=round(t * 1e3, 4),
+                   achieved=round(read / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(read / t / 1e9 / HBM_PEAK_GBS, 4),
+                   read_bytes_per_token=8 + 4 * d + attr_read, written_bytes_per_token=4 * d,
+                   read_plus_write_gbs=round((read + written) / t / 1e9, 1),
+                   # the kernel moves as many bytes out as in: the measured copy ceiling (6.29 TB/s read + write) is its HBM bound,
+                   # i.e. frac <= ~0.39-0.40 whatever the access pattern
+                   copy_frac=round((read + written) / t / 1e9 / HBM_COPY_GBS, 4))
+        if cls == "front_fwd":
+            # ... and it is not a pure gather: attribute_nn (K = 32) and next_w (K = 64) run on the gathered tile, 2 x 64 x 96 flop per
+            # token = 24 flop per byte moved, the machine's own balance (157 TFLOP/s : 6.3 TB/s): both roofs bind at once
+            fl = tokens * 2.0 * 64 * (32 + 64)
+            rec["mfma_tflops"] = round(fl / t / 1e12, 2)
+            rec["mfma_frac"] = round(fl / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        out.append(rec)
         del clf, x
         gc.collect()
         torch.cuda.empty_cache()
@@ -489,7 +541,7 @@ def main():
 
     m = run_workload(dist, layout=args.layout, dim=args.dim, ks=ks, rows=args.rows, front_end=args.front_end, steps=args.steps,
                      warmup=args.warmup, prof=args.prof, graph=args.graph, edges_per_k=args.edges_per_k, edges=args.edges,
-                     table_exchange=args.table_exchange, deterministic=args.deterministic, zipf=args.zipf)
+                     table_exchange=args.table_exchange, deterministic=args.deterministic, zipf=args.zipf, windows=args.windows)
     B, P, L, N = m["B"], m["P"], m["L"], m["N"]
     elapsed = m["elapsed"]
     result = {
@@ -498,6 +550,9 @@ def main():
         "unit": "hyperedges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "timed_windows": {"n": len(m["windows"]), "steps_each": args.steps, "statistic": "median",
+                          "ms_per_step_min": round(min(m["windows"]) / args.steps * 1e3, 4),
+                          "ms_per_step_max": round(max(m["windows"]) / args.steps * 1e3, 4)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.layout} bins (N={N}), k in {{{args.ks}}} mixed-k zero-padded to L={L}, embed_dim={args.dim}, "
@@ -525,7 +580,7 @@ def main():
         if default_run:
             extras = {}
             for key, kw in (("deterministic_embedding_backward", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="table", deterministic=True)),
-                            ("adj_front_end_configs2", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="adj")),
+                            ("adj_front_end_configs2", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=65536, front_end="adj", prof="auto")),
                             ("reference_batch_384_rows", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="table")),
                             # the same launch-bound step replayed from ONE hipGraph (Trainer.capture path: nothing in the step allocates or synchronises)
                             ("reference_batch_384_rows_hipgraph", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="table", graph=True)),
@@ -533,15 +588,31 @@ def main():
                             # 80 ms per such step on 8 CPU cores)
                             ("reference_batch_384_rows_adj", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="adj")),
                             ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table")),
+                            # BASELINE configs[4] at its FULL size: 1 M nodes, 100 M known hyperedges (generated, hashed and CSR-sharded on the
+                            # device), k in {2..8}, d = 256.  kernel classes on: the HBM-bound part of this step is the dense AdamW over
+                            # the 1 M x 256 table + the gather + the scatter (hbm_bound_share)
                             ("configs4_c5_1M_nodes_d256", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=16384, front_end="table",
-                                                                edges=10_000_000)),
-                            # the same with Zipf(1.0) node ids: the cached regime of the gather and the contended one of the scatter
+                                                                edges=100_000_000, prof="auto")),
+                            # a small batch on the same table: the encoder shrinks with the rows, the 7.2 GB AdamW stream over the table
+                            # does not -- the configuration in which config 5 IS the HBM-bound stress its name promises
+                            ("configs4_c5_2048_rows", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=2048, front_end="table",
+                                                            edges=10_000_000, prof="auto")),
+                            # Zipf(1.0) node ids: the cached regime of the gather and the contended one of the scatter
                             ("configs4_c5_zipf_ids", dict(layout="c5", dim=256, ks=[2, 3, 4, 5, 6, 7, 8], rows=16384, front_end="table",
                                                            edges=10_000_000, zipf=True))):
-                e = run_workload(dist, steps=8, warmup=3, prof="none", model_only=False, **kw)
+                kw = dict(kw)
+                kw.setdefault("prof", "none")
+                e = run_workload(dist, steps=8, warmup=3, model_only=False, windows=3, **kw)
                 extras[key] = {"hyperedges_per_s": round(e["B"] * 8 / e["elapsed"], 1), "ms_per_step": round(e["elapsed"] / 8 * 1e3, 4),
-                               "rows_per_step": e["B"], "known_hyperedges": e["known_edges"], "steps": 8,
+                               "rows_per_step": e["B"], "known_hyperedges": e["known_edges"], "steps": 8, "windows": 3,
                                "exhausted_negatives": e["exhausted_negatives"]}
+                if e["class_ms"]:
+                    top = sorted(e["class_ms"].items(), key=lambda kv: -kv[1])[:6]
+                    extras[key]["kernel_class_ms_per_step"] = {k: round(v, 4) for k, v in top}
+                    hb = sum(e["class_ms"].get(k, 0.0) for k in ("adamw", "embed_fwd", "embed_scatter", "front_fwd", "front_bwd"))
+                    extras[key]["hbm_bound_share"] = round(hb / (e["elapsed"] / 8 * 1e3), 4)
+                    extras[key]["roofline_by_kernel_class"] = {k: v for k, v in e["roof_all"].items() if k in ("adamw", "embed_fwd", "embed_scatter",
+                                                                                                            "adj_encode", "adj_recon", "adj_bwd")}
             result["extra_points"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline and m["pool"] is not None:
         result["cpu_baseline"] = cpu_baseline(args, m["num"], ks, L, m["pool"], m["wts"], 3)
@@ -554,9 +625,8 @@ def main():
 def cpu_baseline(args, num, ks, L, pool, wts, neg_num):
     """The reference's step on the host cores, via the oracle port (oracle/ is the checker/baseline only):
     python negative sampling + PyTorch-CPU forward/backward/AdamW at the reference's own batch (96 positives + 288
-    negatives, main.py:527-528) and at a large batch, bounded to ~args.cpu_seconds in total.  Run with every host core
-    (torch.set_num_threads(os.cpu_count())) AND with 8 threads (the survey's timing configuration: a 256-thread
-    intra-op pool on [384, 64]-sized operands is slower than a handful of threads); `value` is the faster of the two."""
+    negatives, main.py:527-528) and at a large batch, bounded to ~args.cpu_seconds in total (and at least 20 timed steps per point at
+    the reference's batch).  Thread sweep 8 / 16 / 32 / 64 (torch.set_num_threads); `value` is the fastest point, `cores` its threads."""
     from oracle import hypersagnn as O
     from oracle import sampler as OS
     attr = attribute_table(num)
@@ -570,7 +640,9 @@ def cpu_baseline(args, num, ks, L, pool, wts, neg_num):
     known = {tuple(int(v) for v in r if v) for r in pool}             # the FULL known set, as the device sampler sees it
     n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
     n_cpu = os.cpu_count() or 1
-    thread_cfgs = sorted({n_cpu, min(8, n_cpu)}, reverse=True)
+    # thread sweep (a 256-thread intra-op pool on [384, 64]-sized operands is pure oversubscription: 22 rows/s in round 3's one-step
+    # sample -- dropped): 8 / 16 / 32 / 64 threads where the host has them, >= 20 steps each at the reference's batch
+    thread_cfgs = sorted({t for t in (8, 16, 32, 64) if t <= n_cpu} or {n_cpu})
     best, notes, best_cores = 0.0, [], n_cpu
     budget = args.cpu_seconds / (2 * len(thread_cfgs))
     for cores in thread_cfgs:
@@ -578,9 +650,9 @@ def cpu_baseline(args, num, ks, L, pool, wts, neg_num):
         P_ = {k: torch.from_numpy(np.array(v)).requires_grad_(not k.startswith("attribute_dict")) for k, v in sd.items()}
         opt = O.AdamWRef()
         rng = np.random.default_rng(5)
-        for pos_n, label in ((96, "B=384 (reference batch)"), (2048, "B=8192")):
+        for pos_n, label, min_steps in ((96, "B=384 (reference batch)", 21), (2048, "B=8192", 4)):
             t_spent, rows, steps = 0.0, 0, 0
-            while t_spent < budget and steps < 200:
+            while (t_spent < budget or steps < min_steps) and steps < 200:
                 sel = rng.integers(0, len(pool), size=pos_n)
                 t0 = time.perf_counter()
                 neg = OS.sample_negatives(pool[sel], known, n2c, cr, neg_num, 0, seed=steps)

@@ -67,6 +67,10 @@ int matcha_device_count(void);
 #define MATCHA_PROF_FUSED_BWD 17
 #define MATCHA_PROF_FRONT_FWD 18   /* gather + attribute_nn + next_w + tanh (front_fused.hip) */
 #define MATCHA_PROF_FRONT_BWD 19   /* LayerNorm backward of the d x_hat partials + next_w / attribute_nn backward + scatter */
+#define MATCHA_PROF_ADJ_RECON 20   /* adj front end: reconstruction branch, forward (+ its backward in a training forward); FLOP       */
+#define MATCHA_PROF_ADJ_BWD 21     /* adj front end: encoder backward (dW1, dZ, dW0); FLOP.  MATCHA_PROF_ADJ_ENCODE (14) = the fused
+                                      forward (gather-GEMM, W1, attribute path, next_w); FLOP.  The adj classes count the EXPECTED work
+                                      of uniformly drawn node ids: a token's feature row has sum_i n_i^2 / N columns on average         */
 int matcha_profile_select(int32_t kernel_class);
 int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
 

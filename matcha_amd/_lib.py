@@ -18,7 +18,8 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_TANH, EPI_DROPOUT, EPI_ROWMASK, EPI_RESIDUAL, EPI_DTANH, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
 PROF = dict(gemm_nt=1, gemm_nn=2, gemm_tn=3, attn_fwd=4, attn_bwd=5, embed_fwd=6, embed_scatter=7, ln3_fwd=8, ln3_bwd=9,
-            head_fwd=10, head_bwd=11, adamw=12, neg_sample=13, adj_encode=14, gather_rows=15, fused_fwd=16, fused_bwd=17, front_fwd=18, front_bwd=19)
+            head_fwd=10, head_bwd=11, adamw=12, neg_sample=13, adj_encode=14, gather_rows=15, fused_fwd=16, fused_bwd=17, front_fwd=18, front_bwd=19,
+            adj_recon=20, adj_bwd=21)
 
 _fp = C.c_void_p  # device pointers travel as void*
 

@@ -776,8 +776,14 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
   a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
   const unsigned grid = (unsigned)(cdiv(T, 64) + C + 1);
   const size_t lds = (size_t)2 * kTile * sizeof(float);
+  // expected feature columns of a uniformly drawn token (2 n_i d + 2 d^2 flop per token; + the attribute path and next_w here)
+  double e_nc = 0.0;
+  if (f.bounds_host && f.bounds_host[C] > 0) {
+    for (int i = 0; i < C; ++i) { const double n_i = f.bounds_host[i + 1] - f.bounds_host[i]; e_nc += n_i * n_i; }
+    e_nc /= (double)f.bounds_host[C];
+  }
   {
-    ProfScope ps(MATCHA_PROF_ADJ_ENCODE, 0.0, st);
+    ProfScope ps(MATCHA_PROF_ADJ_ENCODE, (double)T * (2.0 * e_nc * 64 + 2.0 * 4096 + (X ? 2.0 * s.n_attr * 64 + 2.0 * 4096 : 0.0)), st);
     if (X) {
       MATCHA_TRY(check_attr(f, s.n_attr));
       auto k = adj_fused_fwd_kernel<true>;
@@ -805,6 +811,8 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
   int rgrid = (int)cdiv(T, 64);
   if (rgrid > 512) rgrid = 512;
   const size_t rlds = (size_t)3 * kTile * sizeof(float);
+  // 2 d n_r flop per token outside chromosome r, three times that with the branch's backward in the same pass
+  ProfScope ps(MATCHA_PROF_ADJ_RECON, (double)T * (1.0 - (double)n_r / (double)s.n_nodes) * 2.0 * 64 * n_r * (save ? 3.0 : 1.0), st);
   if (save) {
     if (hipMemsetAsync(w.rgrad, 0, (size_t)w.nr_pad * 65 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
     auto k = adj_recon_kernel<true>;
@@ -849,6 +857,12 @@ int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const mat
   const size_t lds = (size_t)4 * kTile * sizeof(float);
   auto k = adj_fused_bwd_kernel;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  double e_nc = 0.0;
+  if (f.bounds_host && f.bounds_host[C] > 0) {
+    for (int i = 0; i < C; ++i) { const double n_i = f.bounds_host[i + 1] - f.bounds_host[i]; e_nc += n_i * n_i; }
+    e_nc /= (double)f.bounds_host[C];
+  }
+  ProfScope ps(MATCHA_PROF_ADJ_BWD, (double)T * (2.0 * e_nc * 64 + 4.0 * 4096), st);      // dW0 (2 n_c d) + dW1 + dZ (2 d^2 each) per token
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
   MATCHA_CHECK_LAUNCH("adj_fused_bwd_kernel");
   return MATCHA_OK;

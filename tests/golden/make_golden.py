@@ -221,6 +221,75 @@ def g3_train(M, name, num, d, mode, seed, alpha, beta, tag, n_steps=10, full=Tru
     print("G3", name, tag, "bce0", out["bce0"], "recon0", out["recon0"], "none", len(out["grad_none"]))
 
 
+def g3_grads(M, name, num, d, mode, seed, rows_per_k=48):
+    """Round 4: ELEMENT-wise step-0 gradients at a layout too large for a full ten-step fixture (hg38 1 Mb: N = 3067, 23 chromosomes):
+    every element of every front-end tensor (table / per-chromosome encoders / recon head / attribute_nn / next_w) and of the small
+    encoder tensors, every 8th element of the four [8d, d] matrices (their full form is pinned at the c23 layout)."""
+    clf, attr, feats, inter_z, sd = build_ref(M, num, d, mode, seed)
+    C, N = len(num), int(np.sum(num))
+    set_dropout(clf, 0.0)
+    clf.train()
+    out = {}
+    chrom = predraw_chroms(C, 1, 4321)
+    out["chroms"] = np.asarray(chrom, dtype=np.int64)
+    x, y, w = synth.make_batch(np.random.default_rng(seed + 5), N, [2, 3, 4, 5], rows_per_k)
+    out["x0"], out["y0"], out["w0"] = x, y, w
+    pred, recon = clf(torch.from_numpy(x), return_recon=True)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.from_numpy(y), weight=torch.from_numpy(w))
+    (bce * 1.0 + recon * 0.001).backward()
+    out["bce0"], out["recon0"], out["logits0"] = bce.detach().numpy().copy(), recon.detach().numpy().copy(), pred.detach().numpy().copy()
+    none = []
+    for n_, p in clf.named_parameters():
+        if p.grad is None:
+            none.append(n_)
+            continue
+        gnp = p.grad.numpy()
+        if n_.endswith(("w_qs.weight", "w_ks.weight", "w_vs.weight", "fc1.weight")) and "encode1" in n_:
+            out["grad0s8/" + n_] = gnp.reshape(-1)[::8].copy()
+        else:
+            out["grad0/" + n_] = gnp.copy()
+    out["grad_none"] = np.asarray(none)
+    np.savez_compressed(os.path.join(HERE, f"g3g_{name}.npz"), **out)
+    print("G3g", name, "bce0", out["bce0"], "recon0", out["recon0"], "tensors", len(out) - 8)
+
+
+def g3_long(M, name, num, d, mode, seed, n_steps=50):
+    """Round 4: a 50-step free-running trajectory (dropout off, torch.optim.AdamW): batches, logits of every step, the final
+    embeddings.npy.  No parameters (the ten-step fixtures hold those)."""
+    clf, attr, feats, inter_z, sd = build_ref(M, num, d, mode, seed)
+    C, N = len(num), int(np.sum(num))
+    set_dropout(clf, 0.0)
+    clf.train()
+    opt = torch.optim.AdamW(list(clf.parameters()), lr=1e-3, amsgrad=False)
+    glb = dict(num_list=torch.as_tensor(np.cumsum(num)), batch_size=96, device=torch.device("cpu"), np=np, torch=torch, math=math)
+    main_functions({"save_embeddings"}, glb)
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="matcha_gold_")
+    os.makedirs(os.path.join(tmp, "run"))
+    os.chdir(os.path.join(tmp, "run"))
+    try:
+        chroms = predraw_chroms(C, n_steps, 1234)
+        out["chroms"] = np.asarray(chroms, dtype=np.int64)
+        brng = np.random.default_rng(seed + 3)
+        for step in range(n_steps):
+            x, y, w = synth.make_batch(brng, N, [2, 3, 4, 5] if step % 2 == 0 else [3], 24 if step % 2 == 0 else 96)
+            out[f"x{step}"], out[f"y{step}"], out[f"w{step}"] = x.astype(np.int16), y, w
+            pred, recon = clf(torch.from_numpy(x), return_recon=True)
+            bce = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.from_numpy(y), weight=torch.from_numpy(w))
+            loss = bce * 1.0 + recon * 0.001
+            opt.zero_grad()
+            loss.backward()
+            out[f"logits{step}"] = pred.detach().numpy().copy()
+            opt.step()
+        np.random.seed(99)
+        out["emb_after"] = glb["save_embeddings"](clf, True)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, f"g3long_{name}.npz"), **out)
+    print("G3long", name, "steps", n_steps)
+
+
 def g1_g5(M):
     """G1 reference-initialised state_dict (tiny); G5 preprocessing pins; reference-pickled model2load."""
     num = synth.LAYOUTS["tiny"]
@@ -568,9 +637,19 @@ def g9_process(M, U):
     print("G9", "N =", N, "clusters kept", len(edge_list), "pixels", len(bin1), {k: out[k].shape for k in ("intra_balanced", "corr_0")})
 
 
+def round4(M):
+    g3_grads(M, "hg38_table_d64", synth.LAYOUTS["hg38_1mb"], 64, "table", 46)
+    g3_grads(M, "hg38_adj_d64", synth.LAYOUTS["hg38_1mb"], 64, "adj", 47)
+    g3_long(M, "c23_table_d64", synth.LAYOUTS["c23"], 64, "table", 48)
+    g3_long(M, "c23_adj_d64", synth.LAYOUTS["c23"], 64, "adj", 49)
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
+    if "--round4" in sys.argv:       # only the fixtures round 4 added (the others are unchanged)
+        round4(M)
+        return
     g1_g5(M)
     g2_eval(M, "tiny_adj", synth.LAYOUTS["tiny"], 16, "adj", 21)
     g2_eval(M, "tiny_table", synth.LAYOUTS["tiny"], 16, "table", 22)
@@ -592,6 +671,7 @@ def main():
     g7_kmers(M, U)
     g8_positives(M, U)
     g9_process(M, U)
+    round4(M)
 
 
 if __name__ == "__main__":

@@ -50,3 +50,32 @@ def logit_err(a, b, floor=0.05):
     b = np.asarray(b, dtype=np.float64).reshape(-1)
     den = np.maximum(np.abs(b), floor * (np.abs(b).max() + 1e-30))
     return float((np.abs(a - b) / den).max())
+
+
+def oracle_self_noise(name, layout, d, mode, seed, alpha, beta, tag, n_steps, perm_seed=0):
+    """The oracle's own fp32 noise floor on a G3 fixture: the recorded batches are replayed through the oracle with the ROWS of every
+    batch permuted -- the same mathematics, another summation order in every reduction over rows -- and compared with the golden
+    (reference) values exactly like the HIP path is.  Returns (per-step element-wise logit error, {tensor: max |param - golden| after
+    the last step}).  AdamW turns the rounding noise of gradient elements near its eps into visible fractions of lr, so from step 1 on
+    this floor -- not the forward tolerance -- is what a correct implementation can be held to (tests/test_hip_model.py)."""
+    g = gold(f"g3_{name}_{tag}.npz")
+    num = synth.LAYOUTS[layout]
+    P, fe, _ = oracle_state(num, d, mode, seed, requires_grad=True)
+    opt = O.AdamWRef()
+    rng = np.random.default_rng(perm_seed)
+    errs = []
+    for step in range(n_steps):
+        x, y, w = (g[f"{n}{step}"] for n in "xyw")
+        perm = rng.permutation(len(x))
+        xt, yt, wt = (torch.from_numpy(np.ascontiguousarray(a[perm])) for a in (x, y, w))
+        loss, bce, recon, logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, alpha, beta, random_chrom=int(g["chroms"][step]))
+        back = np.empty_like(logits.numpy())
+        back[perm] = logits.numpy()
+        errs.append(logit_err(back, g[f"logits{step}"]))
+        opt.step(P, grads)
+    pn = {}
+    for key in g.files:
+        if key.startswith(f"param{n_steps - 1}/"):
+            n = key.split("/", 1)[1]
+            pn[n] = float(np.abs(P[n].detach().numpy() - g[key]).max())
+    return errs, pn

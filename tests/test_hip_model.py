@@ -167,12 +167,16 @@ def _train_g3(name, layout, d, seed, alpha, beta, tag, n_steps, full, use_fused,
             if step == 0:
                 _check_grads(g, {n: p.grad for n, p in clf.named_parameters()}, none_ref, full)
             opt.step()
-        # Step 0 is pure forward parity: TOL element-wise on the logits.  Later steps sit behind AdamW updates, whose g / (|g| + eps)
-        # turns the rounding noise of near-zero gradient elements into visible fractions of lr -- in the reference too: the oracle run
-        # on these batches with the rows of each batch permuted (same mathematics, other fp32 summation order) differs from itself by
-        # 1 - 3e-5 at steps 1..9 (tools/debug/g3_steps.py), the HIP path (step-0 gradients within 1e-6 of the golden ones, every
-        # tensor) by 0.3 - 1.2e-4 on the n_attr = 24 fixture whichever kernels run (fused, four-wave forward, layer by layer).  So:
-        # logits of later steps element-wise within 2 TOL, and the north-star quantity -- the output PROBABILITY -- within TOL always.
+        # Step 0 is pure forward parity: TOL element-wise on the logits.  Later steps sit behind AdamW updates, and AdamW's first step
+        # is lr * g / (|g| + eps): a weight whose true gradient is ~1e-9 moves by whatever fraction of lr the implementation's rounding
+        # noise there dictates.  Measured against an fp64 run of the oracle (the exact trajectory, tools/debug/g3_f64_steps.py): on the
+        # n_attr = 24 table fixture ONE element of fc1.weight lands 0.11 lr away from exact in the HIP path (0.009 lr in the reference's
+        # own fp32 run), every other parameter of every tensor stays within 0.005 lr for all ten steps, and that single weight moves the
+        # later logits by 0.6 - 1.8e-4 -- with the merged heads, the four-product heads and the layer-by-layer kernels alike
+        # (tools/debug/g3_noise.py: 1.8 / 1.0 / 1.2e-4; with libm's tanh instead of the one-v_exp one 0.7 / 1.3 / 1.2e-4: it is the
+        # luck of one near-zero element, not a property of a formulation).  What this trajectory test can therefore hold the later
+        # steps to is 2 TOL on the logits and TOL on the north-star quantity, the output PROBABILITY; the kernels themselves are held
+        # to TOL at EVERY step, with the evolved weights, by test_teacher_forced_steps_match_oracle_at_every_step below.
         lg_np, lg_ref = logits.detach().cpu().numpy(), g[f"logits{step}"]
         assert logit_err(lg_np, lg_ref) < (TOL if step == 0 else 2 * TOL), step
         pr, pr_ref = 1.0 / (1.0 + np.exp(-lg_np.astype(np.float64))), 1.0 / (1.0 + np.exp(-lg_ref.astype(np.float64)))
@@ -228,9 +232,78 @@ def test_g3_training_hg38_table_d64(use_fused):
     _train_g3("hg38_table_d64", "hg38_1mb", 64, 41, 1.0, 0.001, "phase2", 3, False, use_fused)
 
 
+D64_FULL = [("c1_table_d64", "c1", 43, "table"), ("c23_table_d64", "c23", 44, "table"), ("c23_adj_d64", "c23", 45, "adj")]
+
+
+@pytest.mark.parametrize("variant", ["merged", "four_product"])
+@pytest.mark.parametrize("name,layout,seed,mode", D64_FULL)
+def test_teacher_forced_steps_match_oracle_at_every_step(name, layout, seed, mode, variant):
+    """Ten AdamW steps on the golden batches with the HIP path as the teacher: BEFORE every step the oracle takes over the HIP
+    path's current parameters (fp32, bit for bit), so both compute the same function of the same weights, and logits, losses and
+    every gradient element must agree to TOL at every step -- kernels on evolved weights, free of the eps-regime noise AdamW adds
+    to a free-running trajectory (see _train_g3).  Both head formulations are held to the same bar."""
+    from matcha_amd.engine import Trainer
+    g = gold(f"g3_{name}_phase2.npz")
+    num = synth.LAYOUTS[layout]
+    if variant == "four_product":
+        _lib.set_option("disable_merged", 1)
+    try:
+        clf, _ = hip_model(num, 64, mode, seed)
+        for m in clf.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        clf.train()
+        tr = Trainer(clf, lr=1e-3)
+        P, fe, _ = oracle_state(num, 64, mode, seed, requires_grad=True)
+        worst_lg, worst_g = 0.0, 0.0
+        for step in range(10):
+            x, y, w = (torch.from_numpy(g[f"{n}{step}"]) for n in "xyw")
+            rc = int(g["chroms"][step])
+            with torch.no_grad():
+                for n, p in clf.named_parameters():
+                    if n in P and P[n].requires_grad:
+                        P[n].copy_(p.detach().cpu())
+            loss, bce, recon, lg_ref, g_ref = O.loss_and_grads(P, fe, x, y, w, 1.0, 0.001, random_chrom=rc)
+            lg = tr.forward_backward(x.cuda().contiguous(), y.reshape(-1).cuda().contiguous(), w.reshape(-1).cuda().contiguous(), 1.0, 0.001, rc)
+            torch.cuda.synchronize()
+            e = logit_err(lg.cpu().numpy(), lg_ref.numpy())
+            worst_lg = max(worst_lg, e)
+            assert e < TOL, (step, e)
+            assert abs(float(tr.losses[0]) - float(bce)) < TOL * max(1.0, abs(float(bce))), step
+            assert abs(float(tr.losses[1]) - float(recon[0])) < TOL * max(1.0, abs(float(recon[0]))), step
+            for n, v in _trainer_grads(tr, clf).items():
+                ref = g_ref.get(n)
+                if n == GAUGE or n.startswith("attribute_dict"):
+                    continue
+                assert (v is None) == (ref is None), (step, n)
+                if v is None:
+                    continue
+                ge = float((v.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3)
+                worst_g = max(worst_g, ge)
+                assert ge <= TOL, (step, n, ge)
+            tr.all_reduce()
+            tr.optimizer_step()
+        print(f"teacher-forced {name} {variant}: worst logit err {worst_lg:.1e}, worst gradient err {worst_g:.1e}")
+    finally:
+        _lib.set_option("disable_merged", 0)
+
+
+@pytest.mark.parametrize("variant", ["merged", "four_product"])
+@pytest.mark.parametrize("name,layout,seed,mode", [("c23_table_d64", "c23", 44, "table")])
+def test_g3_training_d64_full_both_head_formulations(name, layout, seed, mode, variant):
+    """The free-running golden trajectory on the fixture with the largest later-step deviation, with the merged heads and with the
+    reference's four products per head: the same gates hold for both (the 2 TOL gate of the later steps must not be
+    what lets one formulation pass)."""
+    if variant == "four_product":
+        _lib.set_option("disable_merged", 1)
+    try:
+        _train_g3(name, layout, 64, seed, 1.0, 0.001, "phase2", 10, True, True, mode=mode)
+    finally:
+        _lib.set_option("disable_merged", 0)
+
+
 @pytest.mark.parametrize("use_fused", [False, True])
-@pytest.mark.parametrize("name,layout,seed,mode", [("c1_table_d64", "c1", 43, "table"), ("c23_table_d64", "c23", 44, "table"),
-                                                   ("c23_adj_d64", "c23", 45, "adj")])
+@pytest.mark.parametrize("name,layout,seed,mode", D64_FULL)
 def test_g3_training_d64_full(name, layout, seed, mode, use_fused):
     """The bench's own kernel configuration (embed_dim 64: fused forward with the loss inside, saved-Q/K/V fused backward, fused
     front end, fused AdamW) against FULL reference fixtures: every gradient element of step 0 and every parameter after 1 and
@@ -342,3 +415,72 @@ def test_second_backward_through_one_forward_is_refused():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second backward"):
         loss.backward()
+
+
+@pytest.mark.parametrize("name,mode,seed", [("hg38_table_d64", "table", 46), ("hg38_adj_d64", "adj", 47)])
+def test_g3g_elementwise_gradients_at_the_hg38_layout(name, mode, seed):
+    """Round 4 fixture g3g_*: every gradient element of the front-end tensors (3068 x 64 table; 23 per-chromosome encoders, the
+    recon head of the drawn chromosome; attribute_nn with n_attr = 24; next_w) and of the small encoder tensors, every 8th element
+    of the four [8d, d] matrices, at the true hg38 1 Mb layout -- the fused Trainer path (the bench's kernels) against the reference."""
+    from matcha_amd.engine import Trainer
+    g = gold(f"g3g_{name}.npz")
+    clf, _ = hip_model(synth.LAYOUTS["hg38_1mb"], 64, mode, seed)
+    for m in clf.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    clf.train()
+    tr = Trainer(clf, lr=1e-3)
+    x, y, w = (torch.from_numpy(g[f"{n}0"]).cuda() for n in "xyw")
+    logits = tr.forward_backward(x.contiguous(), y.reshape(-1).contiguous(), w.reshape(-1).contiguous(), 1.0, 0.001, int(g["chroms"][0]))
+    torch.cuda.synchronize()
+    assert logit_err(logits.cpu().numpy(), g["logits0"]) < TOL
+    assert abs(float(tr.losses[0]) - float(g["bce0"])) < TOL * max(1.0, abs(float(g["bce0"])))
+    assert abs(float(tr.losses[1]) - float(g["recon0"][0])) < TOL * max(1.0, abs(float(g["recon0"][0])))
+    grads = _trainer_grads(tr, clf)
+    assert {n for n, v in grads.items() if v is None} - {"attribute_dict_embedding.weight"} == set(g["grad_none"].tolist()) - {"attribute_dict_embedding.weight"}
+    checked = 0
+    for n, v in grads.items():
+        if v is None or n == GAUGE:
+            continue
+        if ("grad0/" + n) in g.files:
+            ref, got = g["grad0/" + n], v.cpu().numpy()
+        else:
+            ref, got = g["grad0s8/" + n], v.cpu().numpy().reshape(-1)[::8]
+        assert np.abs(got - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+        checked += 1
+    assert checked >= 25
+
+
+@pytest.mark.parametrize("name,mode,seed", [("c23_table_d64", "table", 48), ("c23_adj_d64", "adj", 49)])
+def test_g3long_fifty_step_trajectory(name, mode, seed):
+    """Round 4 fixture g3long_*: fifty free-running AdamW steps (dropout off) against the reference's: the output PROBABILITY of every
+    step within TOL (north_star's quantity), the final embeddings.npy within TOL; the logits themselves carry the eps-regime noise of
+    AdamW discussed in _train_g3 and are held to 2 TOL over the fifty steps."""
+    from matcha_amd.engine import Trainer
+    g = gold(f"g3long_{name}.npz")
+    num = synth.LAYOUTS["c23"]
+    clf, _ = hip_model(num, 64, mode, seed)
+    for m in clf.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    clf.train()
+    tr = Trainer(clf, lr=1e-3)
+    worst_p, worst_l = 0.0, 0.0
+    for step in range(50):
+        x = torch.from_numpy(g[f"x{step}"].astype(np.int64)).cuda()
+        y, w = (torch.from_numpy(g[f"{n}{step}"]).cuda() for n in "yw")
+        logits = tr.step(x.contiguous(), y.reshape(-1).contiguous(), w.reshape(-1).contiguous(), 1.0, 0.001, int(g["chroms"][step]))[2]
+        lg_np, lg_ref = logits.detach().cpu().numpy().reshape(-1, 1), g[f"logits{step}"]
+        pr, pr_ref = 1.0 / (1.0 + np.exp(-lg_np.astype(np.float64))), 1.0 / (1.0 + np.exp(-lg_ref.astype(np.float64)))
+        worst_p = max(worst_p, float(np.abs(pr - pr_ref).max() / pr_ref.max()))
+        worst_l = max(worst_l, logit_err(lg_np, lg_ref))
+        assert np.abs(pr - pr_ref).max() <= TOL * pr_ref.max(), step
+        assert logit_err(lg_np, lg_ref) < 2 * TOL, step
+    clf.eval()
+    np.random.seed(99)
+    N = int(np.sum(num))
+    with torch.no_grad():
+        emb = clf.get_node_embeddings(torch.arange(1, N + 1).view(-1, 1))[:, 0, :].cpu().numpy()
+    ref = g["emb_after"]
+    print(f"fifty steps {name}: worst probability err {worst_p:.1e}, worst logit err {worst_l:.1e}, embeddings {np.abs(emb - ref).max() / max(1.0, np.abs(ref).max()):.1e}")
+    assert np.abs(emb - ref).max() <= TOL * max(1.0, np.abs(ref).max())
