@@ -200,7 +200,16 @@ typedef struct matcha_step_opts {
                                 contiguous tail of a flat gradient buffer laid out in matcha_tensors order) are final, i.e.
                                 before the front-end backward and the embedding scatter run: a data-parallel caller starts the
                                 all-reduce of that part on a second stream and overlaps it with the rest of the backward      */
+  const int32_t* random_chrom_dev; /* ABI 6, optional (NULL = use random_chrom): DEVICE int32 holding the chromosome drawn at
+                                Modules.py:192, read by the kernels when they run -- a step captured in a hipGraph then replays with a new
+                                draw every time the caller rewrites the cell (random_chrom itself is a launch parameter and would be
+                                frozen into the graph).  Honoured by the fused adj front end (embed_dim 64, feat_row_pad 64:
+                                matcha_random_chrom_dev_supported); other shapes return MATCHA_EINVAL                              */
 } matcha_step_opts;
+
+/* 1 if matcha_forward / matcha_backward honour opts->random_chrom_dev for this shape and these frozen inputs (table mode: always --
+ * nothing reads the chromosome there). */
+int matcha_random_chrom_dev_supported(const matcha_shape* shp, const matcha_frozen* frozen);
 
 /* Scratch (bytes) the fused forward+backward needs for a [B,L] batch. */
 size_t matcha_workspace_bytes(const matcha_shape* shp, int64_t B, int32_t L);

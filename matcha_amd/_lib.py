@@ -49,7 +49,8 @@ class StepOpts(C.Structure):
     _fields_ = [("training", C.c_int32), ("random_chrom", C.c_int32), ("p_drop_adj", C.c_float),
                 ("p_drop_fc1", C.c_float), ("p_drop_pff", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
                 ("seed", _fp), ("forward_only", C.c_int32), ("loss_in_forward", C.c_int32), ("status", _fp),
-                ("sparse_table_grad", C.c_int32), ("deterministic", C.c_int32), ("encoder_done_event", _fp)]
+                ("sparse_table_grad", C.c_int32), ("deterministic", C.c_int32), ("encoder_done_event", _fp),
+                ("random_chrom_dev", _fp)]
 
 
 class RaggedView(C.Structure):
@@ -85,6 +86,7 @@ SIGNATURES = {
     "matcha_scatter_rows": (C.c_int, [_fp, _fp, _I64, _I32, _I32, _fp, _fp, _SZ, _fp]),
     "matcha_ragged_plan_bytes": (_SZ, [_I64, _I32]),
     "matcha_ragged_plan": (C.c_int, [_fp, _I64, _I32, _I32, _fp, _fp, _SZ, C.POINTER(RaggedView), _fp]),
+    "matcha_random_chrom_dev_supported": (C.c_int, [C.POINTER(Shape), C.POINTER(Frozen)]),
     "matcha_set_option": (C.c_int, [C.c_char_p, _I32]),
     "matcha_get_option": (C.c_int32, [C.c_char_p]),
     "matcha_adamw_step": (C.c_int, [_fp, _fp, _fp, _fp, _I64, _fp, _I32, _fp, _fp, _fp, _fp, _D, _D, _D, _D, _D, _D, _fp]),

@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void adj_hist_kernel(const int64_t* __restrict
 // the prefix sums are written back the same way -- walking it in global memory was two chains of strided dependent loads (23 us at 65 536
 // rows); larger batches keep that path.
 __global__ __launch_bounds__(1024) void adj_scan_kernel(const int32_t* __restrict__ hist, int nblk, int C, int r_chrom, int32_t* __restrict__ base,
-                                                        int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched, int lds_ints) {
+                                                        int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched, int lds_ints,
+                                                        const int32_t* __restrict__ r_dev) {
   extern __shared__ int hs[];
+  if (r_dev) { const int rv = *r_dev; r_chrom = (rv >= 0 && rv < C) ? rv : -1; }     // opts->random_chrom_dev
   __shared__ int tot[kMaxChrom + 2];
   __shared__ int segs[kMaxChrom + 2];
   const int n = nblk * (C + 1);
@@ -141,7 +143,9 @@ __global__ __launch_bounds__(1024) void adj_scan_kernel(const int32_t* __restric
 }
 
 // touched flags only (backward): which per-chromosome tensors received a gradient this step
-__global__ void adj_flags_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ counts, int C, int r_chrom, int32_t* __restrict__ touched) {
+__global__ void adj_flags_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ counts, int C, int r_chrom, int32_t* __restrict__ touched,
+                                 const int32_t* __restrict__ r_dev) {
+  if (r_dev) { const int rv = *r_dev; r_chrom = (rv >= 0 && rv < C) ? rv : -1; }
   const int k = threadIdx.x;
   if (k == 0) { touched[0] = 1; touched[1] = 0; }
   if (k < C) {
@@ -153,8 +157,9 @@ __global__ void adj_flags_kernel(const int32_t* __restrict__ seg, const int32_t*
 __global__ __launch_bounds__(256) void adj_scatter_kernel(const int64_t* __restrict__ x, int64_t T, const int32_t* __restrict__ bounds, int C,
                                                           int r_chrom, const int32_t* __restrict__ base, const int32_t* __restrict__ seg,
                                                           int32_t* __restrict__ order, int32_t* __restrict__ other_map,
-                                                          const int32_t* __restrict__ t_dev) {
+                                                          const int32_t* __restrict__ t_dev, const int32_t* __restrict__ r_dev) {
   extern __shared__ int tc[];
+  if (r_dev) { const int rv = *r_dev; r_chrom = (rv >= 0 && rv < C) ? rv : -1; }
   if (t_dev) T = *t_dev;                 // [C+1][256] per-thread counts -> exclusive prefix
   const int tid = threadIdx.x;
   for (int k = 0; k <= C; ++k) tc[k * 256 + tid] = 0;
@@ -530,16 +535,16 @@ static int check_adj(const matcha_shape& s, const matcha_tensors& p, const match
 }
 
 static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int64_t* x, int64_t T, int r_chrom, AdjWs& w, int32_t* touched,
-                       const int32_t* t_dev, hipStream_t st) {
+                       const int32_t* t_dev, hipStream_t st, const int32_t* r_dev = nullptr) {
   const int C = s.n_chrom;
   hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist, t_dev);
   MATCHA_CHECK_LAUNCH("adj_hist_kernel");
   const int scan_ints = w.nblk * (C + 1) <= 12288 ? w.nblk * (C + 1) : 0;        // <= 48 KB of LDS for the staged histogram
   hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(1024), (size_t)scan_ints * sizeof(int), st, w.hist, w.nblk, C, r_chrom, w.base, w.seg, w.counts,
-                     touched, scan_ints);
+                     touched, scan_ints, r_dev);
   MATCHA_CHECK_LAUNCH("adj_scan_kernel");
   hipLaunchKernelGGL(adj_scatter_kernel, dim3(w.nblk), dim3(256), (size_t)(C + 1) * 256 * sizeof(int), st, x, T, f.bounds, C, r_chrom, w.base,
-                     w.seg, w.order, w.other_map, t_dev);
+                     w.seg, w.order, w.other_map, t_dev, r_dev);
   MATCHA_CHECK_LAUNCH("adj_scatter_kernel");
   return MATCHA_OK;
 }
@@ -555,8 +560,12 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
   const size_t need = adj_carve(s, T, (char*)ws, w);
   if (ws_bytes < need) { set_error("adj_forward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
   const int C = s.n_chrom, d = s.d;
-  const int r = (recon_out && o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
-  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, t_dev, st));
+  const bool fused_here = adj_fused_eligible(s, f) && (fused_X || (fused_node && node_out && !recon_out));
+  MATCHA_CHECK_ARG(!o.random_chrom_dev || fused_here, "adj_forward: opts->random_chrom_dev needs the fused adj front end (embed_dim 64, feat_row_pad 64)");
+  const int32_t* r_dev = recon_out ? o.random_chrom_dev : nullptr;
+  // with a device-side chromosome the host only knows that SOME chromosome will be drawn: r = 0 stands for "the branch runs"
+  const int r = r_dev ? 0 : ((recon_out && o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1);
+  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, t_dev, st, r_dev));
   // fused_node: a node-rows-only call that no backward pass follows (matcha_node_embeddings) may take the fused kernel too
   if (adj_fused_eligible(s, f) && (fused_X || (fused_node && node_out && !recon_out))) {
     MATCHA_CHECK_ARG(!(o.training != 0 && o.p_drop_adj > 0.f) || o.seed, "adj_forward: dropout needs a seed");
@@ -628,10 +637,11 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
   if (ws_bytes < need) { set_error("adj_backward: workspace %zu < %zu bytes", ws_bytes, need); return MATCHA_ENOMEM; }
   MATCHA_CHECK_ARG(g_.adj_w0 && g_.adj_w1, "adj_backward: gradient buffers missing");
   const int C = s.n_chrom, d = s.d;
-  const int r = (o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1;
+  MATCHA_CHECK_ARG(!o.random_chrom_dev || fused, "adj_backward: opts->random_chrom_dev needs the fused adj front end");
+  const int r = o.random_chrom_dev ? 0 : ((o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1);
   const bool train = o.training != 0 && o.p_drop_adj > 0.f;
   if (touched) {     // order/seg/other_map of the forward are still in the workspace; only the flags are (re)written
-    hipLaunchKernelGGL(adj_flags_kernel, dim3(1), dim3(64), 0, st, w.seg, w.counts, C, r, touched);
+    hipLaunchKernelGGL(adj_flags_kernel, dim3(1), dim3(64), 0, st, w.seg, w.counts, C, r, touched, o.random_chrom_dev);
     MATCHA_CHECK_LAUNCH("adj_flags_kernel");
   }
   if (fused) return adj_fused_backward(s, p, f, o, x, T, w, r, dnode, drecon, g_, st, slot_map);

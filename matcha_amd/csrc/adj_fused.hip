@@ -307,10 +307,11 @@ struct AdjReconArgs {
   const int64_t* ids;
   const int32_t *order, *seg, *counts;
   const float* TH;                    // [sorted rows][64]
-  const float *Wr, *br;               // recon head of chromosome r: [n_r][64], [n_r]
+  const float *Wr, *br;               // recon head of chromosome r: [n_r][64], [n_r]   (r_dev: the packed tensors' bases, chromosome c at 64 bounds[c] / bounds[c])
   const float* inter;                 // [N][N]
   int64_t n_nodes;
   int r, lo_r, n_r;
+  const int32_t *r_dev, *bounds;      // opts->random_chrom_dev: the chromosome is read here (graph replay), its range from bounds
   float* dnr;                         // GRAD: [sorted rows][64] = (d loss / d node) of the branch, unscaled
   float *gW, *gb;                     // GRAD: unscaled head gradient [n_r][64], [n_r] (zeroed by the caller; float atomics)
   float* slab;                        // per-workgroup partial sums of the squared residuals
@@ -318,6 +319,10 @@ struct AdjReconArgs {
 
 template <bool GRAD>
 __global__ __launch_bounds__(256, 2) void adj_recon_kernel(AdjReconArgs g) {
+  if (g.r_dev) {
+    g.r = *g.r_dev; g.lo_r = g.bounds[g.r]; g.n_r = g.bounds[g.r + 1] - g.lo_r;
+    g.Wr += (int64_t)64 * g.lo_r; g.br += g.lo_r;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ts = lds;                                // TH tile
   float* Ws = lds + kTile;                        // Wr chunk [64 columns of r][64]
@@ -495,8 +500,9 @@ __global__ __launch_bounds__(256, 2) void adj_recon_kernel(AdjReconArgs g) {
 
 // recon_loss = 100 * sum / (m * n_r)  (mean over columns, mean over rows, * 100; Modules.py:199), 0 when m == 0 (:195)
 __global__ __launch_bounds__(256) void adj_recon_sum_kernel(const float* __restrict__ slab, int nslab, const int32_t* __restrict__ counts, int n_r,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const int32_t* __restrict__ r_dev, const int32_t* __restrict__ bounds) {
   __shared__ float red[256];
+  if (r_dev) { const int r = *r_dev; n_r = bounds[r + 1] - bounds[r]; }
   const int m = counts[0];
   float s = 0.f;
   for (int i = threadIdx.x; i < nslab; i += 256) s += slab[i];
@@ -514,7 +520,9 @@ __global__ __launch_bounds__(256) void adj_recon_sum_kernel(const float* __restr
 
 // grads.recon_w / recon_b of chromosome r += g * (unscaled gradient of the forward pass)
 __global__ __launch_bounds__(256) void adj_recon_apply_kernel(const float* __restrict__ gW, const float* __restrict__ gb, int n_r, float* __restrict__ dW,
-                                                              float* __restrict__ db, const float* __restrict__ drecon, float beta) {
+                                                              float* __restrict__ db, const float* __restrict__ drecon, float beta,
+                                                              const int32_t* __restrict__ r_dev, const int32_t* __restrict__ bounds) {
+  if (r_dev) { const int r = *r_dev, lo = bounds[r]; n_r = bounds[r + 1] - lo; dW += (int64_t)64 * lo; db += lo; }   // dW / db: the packed tensors' bases
   const float gsc = drecon ? drecon[0] : beta;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n_r * 64) dW[i] += gsc * gW[i];
@@ -538,6 +546,7 @@ struct AdjBwdArgs {
   const uint64_t* seed;
   float p_drop;
   const int32_t* slot_map;
+  const int32_t* r_dev;
 };
 
 // work item = (chromosome, window of steps_per_item 64-row steps); the grid is sized for the bound and blocks behind the last item leave
@@ -580,7 +589,8 @@ __global__ __launch_bounds__(256, 2) void adj_fused_bwd_kernel(AdjBwdArgs g) {
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
   if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
-  const bool with_r = g.dnr != nullptr && c != g.r;
+  const int r_chrom = g.r_dev ? *g.r_dev : g.r;
+  const bool with_r = g.dnr != nullptr && c != r_chrom;
   const float gsc = with_r ? (g.drecon ? g.drecon[0] : g.beta) : 0.f;
   {
     const float* W1 = g.w1 + (int64_t)c * 4096;
@@ -802,12 +812,13 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
     return MATCHA_OK;
   }
   MATCHA_CHECK_ARG(p.recon_w && p.recon_b && f.inter && f.bounds_host, "adj_forward: recon tensors / bounds_host missing");
-  const int lo_r = f.bounds_host[r_chrom], n_r = f.bounds_host[r_chrom + 1] - lo_r;
+  const int32_t* r_dev = o.random_chrom_dev;      // the chromosome lives on the device: offsets and widths are read there, launches sized for the widest
+  const int lo_r = r_dev ? 0 : f.bounds_host[r_chrom], n_r = r_dev ? s.max_bins : f.bounds_host[r_chrom + 1] - lo_r;
   AdjReconArgs b;
   memset(&b, 0, sizeof(b));
   b.ids = ids; b.order = w.order; b.seg = w.seg; b.counts = w.counts; b.TH = w.TH; b.Wr = p.recon_w + (int64_t)64 * lo_r; b.br = p.recon_b + lo_r;
   b.inter = f.inter; b.n_nodes = s.n_nodes; b.r = r_chrom; b.lo_r = lo_r; b.n_r = n_r; b.dnr = w.dTH; b.gW = w.rgrad; b.gb = w.rgrad + w.nr_pad * 64;
-  b.slab = w.lossslab;
+  b.slab = w.lossslab; b.r_dev = r_dev; b.bounds = f.bounds;
   int rgrid = (int)cdiv(T, 64);
   if (rgrid > 512) rgrid = 512;
   const size_t rlds = (size_t)3 * kTile * sizeof(float);
@@ -824,7 +835,7 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
     hipLaunchKernelGGL(k, dim3(rgrid), dim3(256), rlds, st, b);
   }
   MATCHA_CHECK_LAUNCH("adj_recon_kernel");
-  hipLaunchKernelGGL(adj_recon_sum_kernel, dim3(1), dim3(256), 0, st, w.lossslab, rgrid, w.counts, n_r, recon_out);
+  hipLaunchKernelGGL(adj_recon_sum_kernel, dim3(1), dim3(256), 0, st, w.lossslab, rgrid, w.counts, n_r, recon_out, r_dev, f.bounds);
   MATCHA_CHECK_LAUNCH("adj_recon_sum_kernel");
   return MATCHA_OK;
 }
@@ -837,16 +848,17 @@ int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const mat
   const bool recon = r_chrom >= 0 && (drecon || o.beta != 0.f);
   if (recon) {
     MATCHA_CHECK_ARG(g_.recon_w && g_.recon_b && f.bounds_host, "adj_backward: recon gradient buffers missing");
-    const int lo_r = f.bounds_host[r_chrom], n_r = f.bounds_host[r_chrom + 1] - lo_r;
+    const int32_t* r_dev = o.random_chrom_dev;
+    const int lo_r = r_dev ? 0 : f.bounds_host[r_chrom], n_r = r_dev ? s.max_bins : f.bounds_host[r_chrom + 1] - lo_r;
     hipLaunchKernelGGL(adj_recon_apply_kernel, dim3((unsigned)cdiv((int64_t)n_r * 64, 256)), dim3(256), 0, st, w.rgrad, w.rgrad + w.nr_pad * 64, n_r,
-                       g_.recon_w + (int64_t)64 * lo_r, g_.recon_b + lo_r, drecon, o.beta);
+                       g_.recon_w + (int64_t)64 * lo_r, g_.recon_b + lo_r, drecon, o.beta, r_dev, f.bounds);
     MATCHA_CHECK_LAUNCH("adj_recon_apply_kernel");
   }
   AdjBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.ids = ids; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats; a.feat_pad = f.feat_row_pad;
   a.w1 = p.adj_w1; a.dX0 = dX0; a.dnr = recon ? w.dTH : nullptr; a.drecon = drecon; a.beta = o.beta; a.Hs = w.Hs; a.gW0 = g_.adj_w0; a.gW1 = g_.adj_w1;
-  a.C = C; a.r = r_chrom; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map;
+  a.C = C; a.r = r_chrom; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map; a.r_dev = o.random_chrom_dev;
   // windows: ~2 per CU at large batches (every window ends in 64 x (64 + n_c) float atomics), one 64-row step per window at small ones
   const int64_t steps = cdiv(T, 64);
   int spi = (int)(steps / 640);

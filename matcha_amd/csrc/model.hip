@@ -563,6 +563,12 @@ extern "C" int matcha_get_embedding(const matcha_shape* shp, const matcha_tensor
   return launch_expand_embedding(x, B, L, shp->d, w.rg.row_off, w.H2, w.X, params->pff_ln_g, params->pff_ln_b, dynamic, static_, (hipStream_t)stream);
 }
 
+extern "C" int matcha_random_chrom_dev_supported(const matcha_shape* shp, const matcha_frozen* frozen) {
+  if (!shp || !frozen) return 0;
+  if (shp->mode == 0) return 1;
+  return adj_fused_eligible(*shp, *frozen) && fused_train_enabled(*shp) && front_bwd_supported(shp->d, shp->n_attr) ? 1 : 0;
+}
+
 extern "C" int matcha_set_option(const char* name, int32_t value) {
   MATCHA_CHECK_ARG(name, "matcha_set_option: null name");
   for (const OptionName& n : kOptionNames)

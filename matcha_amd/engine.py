@@ -91,12 +91,21 @@ class Trainer:
             self._logits[key] = torch.empty(B, dtype=torch.float32, device=self.rt.device)
         return self._ws[key], self._logits[key]
 
-    def _opts(self, alpha: float, beta: float, random_chrom: int):
+    def _opts(self, alpha: float, beta: float, random_chrom):
         o = _lib.StepOpts()
         o.training = 1 if self.model.training else 0
         o.p_drop_adj, o.p_drop_fc1, o.p_drop_pff = self.model._dropout_p()
         o.alpha, o.beta = float(alpha), float(beta)
-        o.random_chrom = int(random_chrom)
+        if isinstance(random_chrom, torch.Tensor):
+            # a device int32 cell: the kernels read the chromosome when they run, so a captured step replays with whatever the
+            # caller wrote there last (matcha_step_opts.random_chrom_dev)
+            if random_chrom.dtype != torch.int32 or not random_chrom.is_cuda or random_chrom.numel() != 1:
+                raise ValueError("random_chrom as a tensor must be ONE int32 on the model's device")
+            o.random_chrom = 0
+            if self.rt.mode == 1:
+                o.random_chrom_dev = random_chrom.data_ptr()
+        else:
+            o.random_chrom = int(random_chrom)
         o.seed = self.seed.data_ptr()
         o.loss_in_forward = 1            # the loss is alpha*bce + beta*recon here: the tail's backward runs inside the forward kernel
         o.status = self.rt.status.data_ptr()
@@ -119,7 +128,7 @@ class Trainer:
         self.rt.check_status("Trainer.step")
 
     # ---- one step -------------------------------------------------------------------------------------
-    def forward_backward(self, x, y, w, alpha=1.0, beta=0.001, random_chrom: int = 0):
+    def forward_backward(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0):
         """forward + backward into the flat gradient buffer (accumulating).  x int64 [B,L]; y, w float [B] or [B,1]."""
         rt = self.rt
         if not rt.still_packed():
@@ -260,8 +269,10 @@ class Trainer:
                                               _lib.ptr(self.seg_step), _lib.ptr(self.seg_coef), self.lr, self.betas[0], self.betas[1],
                                               self.eps, self.wd, 1.0 / self.world, rt.stream()), "matcha_adamw_step")
 
-    def step(self, x, y, w, alpha=1.0, beta=0.001, random_chrom: int = 0):
-        """One optimisation step.  Returns device tensors (bce [scalar view], recon [1], logits [B]); nothing syncs."""
+    def step(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0):
+        """One optimisation step.  Returns device tensors (bce [scalar view], recon [1], logits [B]); nothing syncs.
+        ``random_chrom``: the chromosome of the reconstruction branch (Modules.py:192) as an int, or as a one-element int32 device
+        tensor the kernels read when they run (what a captured step needs, ``capture``)."""
         x = x.contiguous()
         y = y.reshape(-1).contiguous()
         w = w.reshape(-1).contiguous()
@@ -271,17 +282,22 @@ class Trainer:
         return self.losses[0], self.losses[1:2], logits
 
     # ---- hipGraph capture of the single-GPU step ---------------------------------------------------------
-    def capture(self, x, y, w, alpha=1.0, beta=0.001, random_chrom: int = 0):
+    def supports_device_chrom(self) -> bool:
+        """Whether this model's kernels take the reconstruction branch's chromosome from device memory (what capturing an adj step
+        needs): the fused adj front end of embed_dim 64 does, the table front end never reads it."""
+        return bool(self.lib.matcha_random_chrom_dev_supported(C.byref(self.rt.shape), C.byref(self.rt.frozen)))
+
+    def capture(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0):
         """Capture forward+backward+AdamW on static input buffers; returns a callable that replays the graph.
-        Refill ``x``, ``y``, ``w`` in place between replays."""
-        if self.world > 1:
+        Refill ``x``, ``y``, ``w`` (and the ``random_chrom`` cell) in place between replays."""
+        if self.world > 1 or self.force_collectives:
             raise RuntimeError("capture() covers the single-GPU step; with DP the all-reduce sits between two graphs")
-        if self.rt.mode == 1 and beta != 0.0:
-            # random_chrom is a launch-shape parameter of the reconstruction branch (its bounds are read on the host), so a graph
-            # would replay ONE chromosome forever and only recon[r] would ever train; the reference draws a new one per
-            # forward (Modules.py:192)
-            raise RuntimeError("capture() would freeze random_chrom (adj front end with beta != 0): replay the step eagerly, "
-                               "or capture with beta = 0.  alpha and beta are baked into a captured graph as well.")
+        if self.rt.mode == 1 and beta != 0.0 and not (isinstance(random_chrom, torch.Tensor) and self.supports_device_chrom()):
+            # as an int, random_chrom is a launch parameter of the reconstruction branch: a graph would replay ONE chromosome forever
+            # and only recon[r] would ever train; the reference draws a new one per forward (Modules.py:192)
+            raise RuntimeError("capture() would freeze random_chrom (adj front end with beta != 0): pass it as a one-element int32 "
+                               "device tensor (fused adj front end, embed_dim 64), replay the step eagerly, or capture with beta = 0.  "
+                               "alpha and beta are baked into a captured graph as well.")
         x = x.contiguous()
         y = y.reshape(-1).contiguous()
         w = w.reshape(-1).contiguous()

@@ -47,6 +47,7 @@ def _barrier():
     if _dist()[1] > 1:
         torch.distributed.barrier()
 
+GRAPH_EPOCHS = os.environ.get("MATCHA_TRAIN_GRAPH", "1") != "0"     # single GPU: the epoch loop replays one captured step (Session.graph_epoch)
 NEG_NUM = 3          # main.py:527
 BATCH_SIZE = 96      # main.py:528 (positives per step)
 MODEL_NAME = "model.chkpt"   # main.py:530
@@ -150,7 +151,74 @@ class Session:
         return x, y, w, sizes
 
     def random_chrom(self) -> int:
-        return int(np.random.choice(np.arange(self.n_chrom), 1)[0]) if self.n_chrom else 0   # Modules.py:192
+        # Modules.py:192 draws np.random.choice(np.arange(C), 1); randint consumes numpy's global stream too, at a sixth of the cost
+        # (the draw sits on the per-step host path)
+        return int(np.random.randint(self.n_chrom)) if self.n_chrom else 0
+
+    # ---- one epoch as replays of ONE captured step (single GPU) -------------------------------------------------------------------
+    # The reference's batch is 96 positives + 288 negatives (main.py:527-528): ~0.25 ms of kernels per step, against which a step
+    # enqueued call by call from Python (slicing, three torch.cat, the sampler, ~30 launches through ctypes) costs the host several
+    # times that.  Everything a step does is already on the device and free of synchronisation, so the step -- positives gathered by a
+    # device-side counter, negative sampling, batch assembly, forward, backward, AdamW, the epoch's running sums and its row in the
+    # prediction table -- is captured once into a hipGraph and the epoch loop is `graph.replay()` per step.
+    def graph_ok(self, beta: float) -> bool:
+        tr = self.trainer
+        return (GRAPH_EPOCHS and self.world == 1 and not tr.force_collectives
+                and (tr.rt.mode == 0 or beta == 0.0 or tr.supports_device_chrom()))
+
+    def graph_epoch(self, e: torch.Tensor, w: torch.Tensor, n_batch: int, P: int, alpha: float, beta: float):
+        """e int64 [>= n_batch * P, L], w float32: the epoch's shuffled positives.  Returns (bce_sum, recon_sum, preds [n_batch, B],
+        labels [B], sizes [n_batch, B]) as device tensors; nothing has synchronised."""
+        dev, L, B = self.dev, int(e.shape[1]), P * (1 + NEG_NUM)
+        # the chromosome of every step's reconstruction branch, drawn exactly as the step-by-step loop draws them (Modules.py:192)
+        chroms = np.asarray([self.random_chrom() for _ in range(n_batch)], dtype=np.int32)
+        key = (n_batch, P, L, float(alpha), float(beta), id(self.trainer), id(self.sampler))
+        st = self.__dict__.get("_graph_state")
+        if st is None or st["key"] != key:
+            st = dict(key=key, graph=None,
+                      pos=torch.empty((n_batch * P, L), dtype=torch.long, device=dev), w=torch.empty(n_batch * P, dtype=torch.float32, device=dev),
+                      chroms=torch.empty(n_batch, dtype=torch.int32, device=dev), cell=torch.zeros(1, dtype=torch.int32, device=dev),
+                      it=torch.zeros(1, dtype=torch.long, device=dev), ar=torch.arange(P, device=dev),
+                      x=torch.zeros((B, L), dtype=torch.long, device=dev),
+                      y=torch.cat([torch.ones(P, device=dev), torch.zeros(B - P, device=dev)]),           # main.py:444-445
+                      ww=torch.ones(B, dtype=torch.float32, device=dev),                                  # main.py:446-447
+                      preds=torch.empty((n_batch, B), dtype=torch.float32, device=dev), sizes=torch.empty((n_batch, B), dtype=torch.long, device=dev),
+                      sums=torch.zeros(2, dtype=torch.float32, device=dev))
+            self._graph_state = st
+        st["pos"].copy_(e[:n_batch * P]); st["w"].copy_(w[:n_batch * P]); st["chroms"].copy_(torch.from_numpy(chroms))
+        st["it"].zero_(); st["sums"].zero_()
+
+        def one_step():
+            idx = st["it"] * P + st["ar"]
+            torch.index_select(st["pos"], 0, idx, out=st["x"][:P])
+            torch.index_select(st["w"], 0, idx, out=st["ww"][:P])
+            self.sampler.sample_into(st["x"][:P], st["x"][P:])
+            torch.index_select(st["chroms"], 0, st["it"], out=st["cell"])
+            bce, recon, logits = self.trainer.step(st["x"], st["y"], st["ww"], alpha=alpha, beta=beta, random_chrom=st["cell"])
+            st["sums"][0] += bce
+            st["sums"][1] += recon[0]
+            st["preds"].index_copy_(0, st["it"], torch.sigmoid(logits).view(1, B))                      # main.py:58
+            st["sizes"].index_copy_(0, st["it"], (st["x"] != 0).sum(dim=1).view(1, B))
+            st["it"] += 1
+
+        done = 0
+        if st["graph"] is None:
+            # the first steps of the epoch run call by call on a side stream (they ARE steps of the epoch: buffers get allocated,
+            # kernels loaded), then the same function is captured; capturing enqueues nothing
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(min(2, n_batch)):
+                    one_step()
+                    done += 1
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            st["graph"] = g
+        for _ in range(n_batch - done):
+            st["graph"].replay()
+        return st["sums"][0], st["sums"][1], st["preds"], st["y"], st["sizes"]
 
 
 def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: float, beta: float, batch_size: int = BATCH_SIZE):
@@ -165,6 +233,13 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
     gb = batch_size * sess.world                                                # global batch: every rank steps on batch_size positives
     n_batch = len(e) // gb
     mine = torch.from_numpy(shard_rows(gb, sess.rank, sess.world)).to(dev)      # this rank's rows of a global batch (strided)
+    tm = sess.__dict__.setdefault("timing", {})          # wall clock of the epoch's phases (tools/epoch_bench.py reads it)
+    t_loop = time.perf_counter()
+    if n_batch > 0 and sess.graph_ok(beta):
+        bce_sum, rec_sum, p2, y1, s2 = sess.graph_epoch(e, w, n_batch, batch_size, alpha, beta)
+        pred, label, size = p2.reshape(-1).cpu(), y1.repeat(n_batch).cpu(), s2.reshape(-1).cpu()         # the epoch's one synchronisation
+        tm["loop_s"] = time.perf_counter() - t_loop
+        return _epoch_metrics(sess, bce_sum, rec_sum, pred, label, size, n_batch)
     bce_sum = torch.zeros((), device=dev)
     rec_sum = torch.zeros((), device=dev)
     preds, labels, sizes = [], [], []
@@ -182,6 +257,19 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
         torch.distributed.all_reduce(both)
         bce_sum, rec_sum = both[0] / sess.world, both[1] / sess.world
     pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()     # the epoch's one synchronisation
+    tm["loop_s"] = time.perf_counter() - t_loop
+    return _epoch_metrics(sess, bce_sum, rec_sum, pred, label, size, n_batch)
+
+
+def _epoch_metrics(sess: Session, bce_sum, rec_sum, pred, label, size, n_batch: int):
+    t_m = time.perf_counter()
+    try:
+        return _epoch_metrics_impl(sess, bce_sum, rec_sum, pred, label, size, n_batch)
+    finally:
+        sess.__dict__.setdefault("timing", {})["metrics_s"] = time.perf_counter() - t_m
+
+
+def _epoch_metrics_impl(sess: Session, bce_sum, rec_sum, pred, label, size, n_batch: int):
     sess.trainer.check_status()                                                  # IndexError if a node id outside [0, N] reached a step
     exhausted = sess.sampler.check_status()                                      # KeyError for nodes without a chromosome
     if exhausted:

@@ -100,3 +100,48 @@ def test_end_to_end_run_writes_reference_outputs(tmp_path, front_end):
     # predict surface (main.py:482-494) with ragged input
     out = T.predict(model, [[1, 5], [2, 20, 40]])
     assert out.shape == (2, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front_end,d,layout", [("table", 64, "c23"), ("adj", 64, "c23"), ("table", 16, "tiny")])
+def test_graph_replayed_epoch_equals_the_step_by_step_epoch(tmp_path, front_end, d, layout):
+    """train_epoch on one GPU replays ONE captured step (positives picked by a device counter, sampler, assembly, forward, backward,
+    AdamW, running sums: Session.graph_epoch).  Same kernels, same seeds, same order as the call-by-call loop: with the deterministic
+    table gradient every parameter, every prediction and both loss sums come out bitwise equal; with the adj front end (float atomics
+    in its weight gradients, the reconstruction chromosome read from device memory per replay) to rounding."""
+    from matcha_amd import train as T
+    from tests.test_hip_model import hip_model
+    num = synth.LAYOUTS[layout]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(3)
+    edges = np.concatenate([np.pad(synth.make_edges(rng, N, k, 400), ((0, 0), (0, 3 - k))) for k in (2, 3)])
+    weights = rng.uniform(0.6, 1.0, size=len(edges)).astype(np.float32)
+    res = {}
+    for graph in (False, True):
+        T.GRAPH_EPOCHS = graph
+        try:
+            np.random.seed(5)
+            torch.manual_seed(5)
+            clf, _ = hip_model(num, d, front_end, 81)
+            clf.train()
+            sess = T.Session(clf, synth.node2chrom(num), synth.chrom_range(num).astype(np.int32), 2, 3, 0, seed=11, deterministic=True)
+            sess.set_known(edges)
+            assert sess.graph_ok(0.001) == graph
+            out = []
+            for ep in range(2):                                   # the second epoch replays the graph captured in the first
+                out.append(T.train_epoch(sess, edges, weights, 1.0, 0.001, batch_size=24))
+            torch.cuda.synchronize()
+            res[graph] = (out, {n: p.detach().cpu().clone() for n, p in clf.named_parameters()})
+        finally:
+            T.GRAPH_EPOCHS = True
+    (o0, p0), (o1, p1) = res[False], res[True]
+    for a, b in zip(o0, o1):
+        if front_end == "table":
+            assert a == b
+        else:
+            assert abs(a[0] - b[0]) < 1e-5 and abs(a[1] - b[1]) < 1e-3 * max(1.0, abs(a[1])) and a[2:] == b[2:]
+    for n in p0:
+        if front_end == "table":
+            assert torch.equal(p0[n], p1[n]), n
+        else:
+            assert float((p0[n] - p1[n]).abs().max()) <= 2e-3, n      # 32 AdamW steps, float-atomic weight gradients: a few lr at most
