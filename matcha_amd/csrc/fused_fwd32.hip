@@ -676,271 +676,147 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // =========================== tail: pff_n1, LayerNorms, classifier (all in registers) ===========================
   }
   if (F32_ABL & 8) { if (dyn.lo[0] == 12345.f) g.logits[0] = dyn.hi[3]; return; }
-  // the tail's seven parameter vectors -> TV [7][64]: gp bp g1 b1 g2 b2 wc  (the biases of fc1 / conv0 / conv1 come with the weight stream)
-  __syncthreads();                                    // the last head's P V reads of TV are done
-  for (int i4 = lane; i4 < 112; i4 += 64) {
-    const int v = i4 >> 4;
-    const float* src = (v == 0 ? g.hp.gp : v == 1 ? g.hp.bp : v == 2 ? g.hp.g1 : v == 3 ? g.hp.b1 : v == 4 ? g.hp.g2 : v == 5 ? g.hp.b2 : g.hp.wc) + 4 * (i4 & 15);
-    *reinterpret_cast<f32x4*>(TV + 4 * i4) = *reinterpret_cast<const f32x4*>(src);
-  }
-  float* T1 = TK;
-  float* T2 = TV;
-  float* myrow = krow;
-  const float* tpar = T2 + 4 * h;                     // this lane's feature offset inside a 64-float vector
-  uint32_t keep1 = 0, keep2 = 0;
-  FL y;
-  {
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const int f = 32 * (e >> 4) + 8 * ((e >> 2) & 3) + (e & 3);     // + 4 h
-      float v = e < 16 ? dyn.lo[e] : dyn.hi[e - 16];
-      const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow1) >= thr1;
-      keep1 |= kp ? (1u << e) : 0u;
-      v = (kp && real) ? v * ks1 : 0.f;               // the padding token's row is masked (Modules.py:614)
-      if (e < 16) y.lo[e] = v; else y.hi[e - 16] = v;
-    }
-    if (g.Y && r <= n) fl_store_global(g.Y + tok * 64 + 4 * h, y);
-  }
-  FL h1 = fl_zero();
-  W32_CHAIN(h1, y, true);                             // conv0 (+ bias)
-  {
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const int f = 32 * (e >> 4) + 8 * ((e >> 2) & 3) + (e & 3);
-      float v = fast_tanh(e < 16 ? h1.lo[e] : h1.hi[e - 16]);
-      const bool kp = lowbias32((uint32_t)(f + 4 * h) ^ hrow2) >= thr2;
-      keep2 |= kp ? (1u << e) : 0u;
-      v = kp ? v * ks2 : 0.f;
-      if (e < 16) h1.lo[e] = v; else h1.hi[e - 16] = v;
-    }
-    if (g.H1 && r <= n) fl_store_global(g.H1 + tok * 64 + 4 * h, h1);
-  }
-  FL h2 = y;                                          // residual as the accumulator's initial value
-  W32_CHAIN(h2, h1, false);                           // conv1 (+ bias); the window is primed again before the backward GEMMs
-  if (g.H2 && r <= n) fl_store_global(g.H2 + tok * 64 + 4 * h, h2);
-  FF_T(7);
-  __syncthreads();                                    // the parameter vectors in T2 are visible
-  // ---- out_t = sum_f (LN1(LN_pff(H2)) - LN2(X))_f^2 wc_f + bc ----
-  float mh, rh, mu, ru;
-  fl_stats(h2, mh, rh);
-  FL u;                                               // LN_pff output (before layer_norm1)
-  {
-    const FL Gp = fl_vec(tpar + 0 * 64), Bp = fl_vec(tpar + 1 * 64);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { u.lo[e] = (h2.lo[e] - mh) * rh * Gp.lo[e] + Bp.lo[e]; u.hi[e] = (h2.hi[e] - mh) * rh * Gp.hi[e] + Bp.hi[e]; }
-  }
-  fl_stats(u, mu, ru);
-  FL df;                                              // dynamic - static
-  {
-    const FL G1 = fl_vec(tpar + 2 * 64), B1 = fl_vec(tpar + 3 * 64);
-    const FL G2 = fl_vec(tpar + 4 * 64), B2 = fl_vec(tpar + 5 * 64);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      df.lo[e] = ((u.lo[e] - mu) * ru * G1.lo[e] + B1.lo[e]) - (xh.lo[e] * G2.lo[e] + B2.lo[e]);
-      df.hi[e] = ((u.hi[e] - mu) * ru * G1.hi[e] + B1.hi[e]) - (xh.hi[e] * G2.hi[e] + B2.hi[e]);
-    }
-  }
-  {
-    const FL Wc = fl_vec(tpar + 6 * 64);
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { s0 += df.lo[e] * df.lo[e] * Wc.lo[e]; s1 += df.hi[e] * df.hi[e] * Wc.hi[e]; }
-    const float o = xhalf_sum(s0 + s1) + g.hp.bc[0];
-    if (h == 0) outs[r] = real ? o : 0.f;
-  }
-  __syncthreads();
-  // ---- per-hyperedge masked mean -> logit (+ BCE term, + its gradient) ----
-  for (int e = lane; e < n_h; e += 64) {
-    const int64_t b = b0 + e;
-    int lo = he_lo, kk = he_k;
-    float yb = he_y, wb = he_w;
-    if (e >= 64) {                                    // beyond the prefetched 64 (many all-padding rows in one half tile)
-      lo = g.row_off[b] - t0; kk = g.row_off[b + 1] - g.row_off[b];
-      if (g.row_loss) { yb = g.y[b]; wb = g.w[b]; }
-    }
-    float tot = 0.f;
-    for (int i = 0; i < kk; ++i) tot += outs[lo + i];
-    const float z = tot / ((float)kk + 1e-15f);
-    g.logits[b] = z;
-    if (g.row_loss) g.row_loss[b] = wb * (fmaxf(z, 0.f) - z * yb + log1pf(expf(-fabsf(z))));
-    if (g.ddyn0) {                                    // main.py:56 backward: d bce / d z = w (sigmoid(z) - y) / B  (x alpha, main.py:166)
-      const float dz = g.alpha_over_B * wb * (1.f / (1.f + expf(-z)) - yb);
-      const float dout = dz / ((float)kk + 1e-15f);
-      for (int i = 0; i < kk; ++i) douts[lo + i] = dout;
-    }
-  }
-  FF_T(8);
-  if (!g.ddyn0 || (F32_ABL & 4)) return;
-
-  // =========================== backward of the tail and of pff_n1 (Modules.py:290-311, :353-376) ===========================
-  __syncthreads();
-  const float dout = real ? douts[r] : 0.f;
-  float* tsl = g.tslab + (int64_t)blockIdx.x * kTailSlab32;
-  // cross-token sums of a per-token FL quantity: through T1 as [token][feature], one lane per feature column
-#define F32_COLSUM(V, SLOT)                                                                              \
-  do {                                                                                                   \
-    __syncthreads();                                                                                     \
-    fl_store(myrow, V);                                                                                  \
-    __syncthreads();                                                                                     \
-    float c0__ = 0.f, c1__ = 0.f, c2__ = 0.f, c3__ = 0.f;                                                \
-    _Pragma("unroll") for (int t__ = 0; t__ < 32; t__ += 4) {                                            \
-      c0__ += T1[t__ * kLdH + lane]; c1__ += T1[(t__ + 1) * kLdH + lane];                                \
-      c2__ += T1[(t__ + 2) * kLdH + lane]; c3__ += T1[(t__ + 3) * kLdH + lane];                          \
-    }                                                                                                    \
-    cs_last = (c0__ + c1__) + (c2__ + c3__);                                                             \
-    tsl[kTailVec32 + (SLOT) * 64 + lane] = cs_last;                                                      \
-  } while (0)
-  float cs_last = 0.f, db1 = 0.f;
-  FL dh2;
-  {
-    // d(dynamic) = 2 df wc dout;  d(static) = - d(dynamic)
-    FL ddn;
-    {
-      const FL Wc = fl_vec(tpar + 6 * 64);
-      FL aw;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        aw.lo[e] = df.lo[e] * df.lo[e] * dout; aw.hi[e] = df.hi[e] * df.hi[e] * dout;
-        ddn.lo[e] = 2.f * df.lo[e] * Wc.lo[e] * dout; ddn.hi[e] = 2.f * df.hi[e] * Wc.hi[e] * dout;
-      }
-      F32_COLSUM(aw, 6);                              // d wc
-    }
-    // layer_norm2 (static branch) -> gradient into X; its affine gradients
-    {
-      const FL G2 = fl_vec(tpar + 4 * 64);
-      FL t;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { t.lo[e] = -ddn.lo[e] * xh.lo[e]; t.hi[e] = -ddn.hi[e] * xh.hi[e]; }
-      F32_COLSUM(t, 4);                               // d g2
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { t.lo[e] = -ddn.lo[e] * G2.lo[e]; t.hi[e] = -ddn.hi[e] * G2.hi[e]; }      // d x_hat
-      const float a = xhalf_sum(fl_sum(t)) * (1.f / 64.f), b = xhalf_sum(fl_dot(t, xh)) * (1.f / 64.f);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { t.lo[e] = rx * (t.lo[e] - a - xh.lo[e] * b); t.hi[e] = rx * (t.hi[e] - a - xh.hi[e] * b); }
-      if (r <= n) fl_store_global(g.dXs + tok * 64 + 4 * h, t);      // the padding token's row is zero (dout = 0)
-    }
-    // layer_norm1 (dynamic branch)
-    FL uh;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { uh.lo[e] = (u.lo[e] - mu) * ru; uh.hi[e] = (u.hi[e] - mu) * ru; }
-    {
-      FL t;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { t.lo[e] = ddn.lo[e] * uh.lo[e]; t.hi[e] = ddn.hi[e] * uh.hi[e]; }
-      F32_COLSUM(t, 2);                               // d g1
-      F32_COLSUM(ddn, 3);                             // d b1   (d b2 = - d b1: written below)
-      db1 = cs_last;
-    }
-    FL du;
-    {
-      const FL G1 = fl_vec(tpar + 2 * 64);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { du.lo[e] = ddn.lo[e] * G1.lo[e]; du.hi[e] = ddn.hi[e] * G1.hi[e]; }
-      const float a = xhalf_sum(fl_sum(du)) * (1.f / 64.f), b = xhalf_sum(fl_dot(du, uh)) * (1.f / 64.f);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { du.lo[e] = ru * (du.lo[e] - a - uh.lo[e] * b); du.hi[e] = ru * (du.hi[e] - a - uh.hi[e] * b); }
-    }
-    // pff_n1.layer_norm
-    FL hh;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { hh.lo[e] = (h2.lo[e] - mh) * rh; hh.hi[e] = (h2.hi[e] - mh) * rh; }
-    {
-      FL t;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { t.lo[e] = du.lo[e] * hh.lo[e]; t.hi[e] = du.hi[e] * hh.hi[e]; }
-      F32_COLSUM(t, 0);                               // d gp
-      F32_COLSUM(du, 1);                              // d bp
-    }
-    {
-      const FL Gp = fl_vec(tpar + 0 * 64);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { dh2.lo[e] = du.lo[e] * Gp.lo[e]; dh2.hi[e] = du.hi[e] * Gp.hi[e]; }
-      const float a = xhalf_sum(fl_sum(dh2)) * (1.f / 64.f), b = xhalf_sum(fl_dot(dh2, hh)) * (1.f / 64.f);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { dh2.lo[e] = rh * (dh2.lo[e] - a - hh.lo[e] * b); dh2.hi[e] = rh * (dh2.hi[e] - a - hh.hi[e] * b); }
-    }
-  }
-  // d b2 = - d b1;  d bc = sum of dout over the tokens
-  {
-    tsl[kTailVec32 + 5 * 64 + lane] = -db1;
-    float sd = (h == 0) ? dout : 0.f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o, 64);
-    if (lane == 0) tsl[kTailVec32 + 9 * 64] = sd;
-  }
-  // the weight stream resumes at conv1^T (the window was not refilled across the end of conv1)
-  FF_T(9);
-  W32_PRIME();
-  // ---- conv1: dW1[n][k] = sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2 ----
-  __syncthreads();
-  fl_store(myrow, dh2);                               // T1 = dH2 [token][feature] (rows past the tokens are zero: dout = 0)
-  fl_store(T2 + r * kLdH + 4 * h, h1);                // T2 = H1 (the parameter vectors are dead)
-  __syncthreads();
-#define F32_TN(A_T, B_T, SLAB, CS_SLOT)                                                                  \
-  do {                                                                                                   \
-    float cs__[2];                                                                                       \
-    _Pragma("unroll") for (int wr__ = 0; wr__ < 2; ++wr__) {                                             \
-      f32x16 a0__ = {0}, a1__ = {0};                                                                     \
-      float s__ = 0.f;                                                                                   \
-      _Pragma("unroll 8") for (int m__ = 0; m__ < 16; ++m__) {                                           \
-        const int t__ = 2 * m__ + h;                                                                     \
-        const float ga__ = (A_T)[t__ * kLdH + 32 * wr__ + r];                                            \
-        s__ += ga__;                                                                                     \
-        a0__ = MFMA32(ga__, (B_T)[t__ * kLdH + r], a0__);                                                \
-        a1__ = MFMA32(ga__, (B_T)[t__ * kLdH + 32 + r], a1__);                                           \
-      }                                                                                                  \
-      cs__[wr__] = xhalf_sum(s__);                                                                       \
-      f32x4* s0__ = reinterpret_cast<f32x4*>(SLAB) + ((0 * 2 + wr__) * 64 + lane) * 4;                   \
-      f32x4* s1__ = reinterpret_cast<f32x4*>(SLAB) + ((1 * 2 + wr__) * 64 + lane) * 4;                   \
-      _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__) {                                              \
-        s0__[q__] = (f32x4){a0__[4 * q__], a0__[4 * q__ + 1], a0__[4 * q__ + 2], a0__[4 * q__ + 3]};     \
-        s1__[q__] = (f32x4){a1__[4 * q__], a1__[4 * q__ + 1], a1__[4 * q__ + 2], a1__[4 * q__ + 3]};     \
-      }                                                                                                  \
-    }                                                                                                    \
-    tsl[kTailVec32 + (CS_SLOT) * 64 + lane] = h == 0 ? cs__[0] : cs__[1];                                \
-  } while (0)
-  F32_TN(T1, T2, tsl, 7);
-  FF_T(10);
-  // ---- dZ1^T = W1^T . dH2^T, x dropout mask x tanh' ----
-  FL dz = fl_zero();
-  W32_CHAIN(dz, dh2, true);
-  {
-    const float unscale = drop2 ? 1.f - g.p_pff : 1.f;
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const float hval = (e < 16 ? h1.lo[e] : h1.hi[e - 16]) * unscale;       // tanh value (0 where dropped)
-      float v = e < 16 ? dz.lo[e] : dz.hi[e - 16];
-      if (drop2) v = ((keep2 >> e) & 1u) ? v * ks2 : 0.f;
-      v *= 1.f - hval * hval;
-      if (e < 16) dz.lo[e] = v; else dz.hi[e - 16] = v;
-    }
-  }
-  // ---- conv0: dW0[n][k] = sum_t dZ1[t][n] Y[t][k];  d b0 = column sums of dZ1 ----
-  __syncthreads();                                    // the column walks over dH2 and H1 are done
-  fl_store(T2 + r * kLdH + 4 * h, dz);
-  fl_store(myrow, y);
-  __syncthreads();
-  FF_T(11);
-  F32_TN(T2, T1, tsl + 4096, 8);
-  FF_T(12);
-  // ---- d dyn^T = (W0^T . dZ1^T + dH2^T) x dropout mask x row mask ----
-  FL dd = dh2;                                        // residual: H2 = conv1(H1) + Y
-  W32_CHAIN(dd, dz, false);
-#pragma unroll
-  for (int e = 0; e < 32; ++e) {
-    float v = e < 16 ? dd.lo[e] : dd.hi[e - 16];
-    if (drop1) v = ((keep1 >> e) & 1u) ? v * ks1 : 0.f;
-    v = real ? v : 0.f;
-    if (e < 16) dd.lo[e] = v; else dd.hi[e - 16] = v;
-  }
-  if (r <= n) fl_store_global(g.ddyn0 + tok * 64 + 4 * h, dd);     // the padding token's row: zeros (every half tile writes the same)
-  FF_T(13);
+#define F32_TAIL_SYNC() __syncthreads()
+#include "fused_fwd32_tail.hpp"
+#undef F32_TAIL_SYNC
 #ifdef FF_TIMING
   if (blockIdx.x == 2000 && lane == 0)
     printf("fused_fwd32 wave 2000 us: setup %.1f prologue K0 Q0 %.1f | 8 heads: V+scores %.1f K'+PV %.1f Q' %.1f fc1 %.1f | pff fwd %.1f ln+logit %.1f | ln-bwd+colsums %.1f dW1 %.1f dZ1 %.1f dW0 %.1f ddyn %.1f\n",
            tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[7] * 0.01, tph[8] * 0.01, tph[9] * 0.01,
            tph[10] * 0.01, tph[11] * 0.01, tph[12] * 0.01, tph[13] * 0.01);
 #endif
+}
+
+// ---- the same forward for SMALL batches: eight wavefronts per half tile, one per head ---------------------------------------------------
+// fused_fwd32_kernel gives a half tile to ONE wavefront, which walks the eight heads in turn: 78 us of latency whatever the batch.  At the
+// reference's own batch (96 + 288 rows, main.py:527-528: ~45 half tiles on 256 CUs) that chain IS the kernel's duration.  Here a workgroup
+// of eight wavefronts takes the half tile: every wavefront normalises the rows (redundantly: 32 in-lane adds), wavefront hd computes
+// r = B_hd x_hat + b_hd, the attention of head hd on the shared x_hat tile and its dyn contribution M_hd z, the eight partial dyn tiles
+// are summed in head order by wavefront 0, which runs the tail alone (the same text: fused_fwd32_tail.hpp).  Merged heads only; the saved
+// records, the slab of parameter-gradient partials and every output are exactly the single-wave kernel's, so the backward kernels do not
+// know which forward ran.  The heads' partial products are summed as eight separately rounded tiles instead of one MFMA accumulation
+// chain: logits differ from the single-wave kernel by ~1e-7 relative (tests/test_hip_properties.py).
+template <int ML>
+__global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
+  constexpr bool MG = true;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#undef FF_T
+#define FF_T(i) do { } while (0)
+  float* TK = lds;                       // the x_hat rows (keys = values of every head); tail: product tiles
+  float* TV = lds + kHT;                 // tail: parameter vectors, H1, dZ1
+  float* outs = lds + 2 * kHT;
+  float* douts = outs + 32;
+  float* Pd = lds + 2 * kHT + 64;        // [8][32][kLdH] the heads' dyn contributions
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int hd = threadIdx.x >> 6;       // this wavefront's head
+
+  const int4 meta = reinterpret_cast<const int4*>(g.half_meta)[blockIdx.x];
+  const int t0 = meta.x, n = meta.y, b0 = meta.z, n_h = meta.w;
+  if (n_h <= 0) return;
+  const int tok_pad = g.count[1];
+  const float inv_temp = 0.125f;
+  const bool real = r < n;
+  const int64_t tok = real ? (int64_t)(t0 + r) : (int64_t)tok_pad;
+
+  // weight stream of THIS head: R_hd sits at matrix 0 (hd = 0) or 2 hd - 1, M_hd at 2 hd + 2 (hd < 7) or 15 (fold_frag_kernel's merged order)
+  const f32x4* wp = g.wfrag + (int64_t)(hd == 0 ? 0 : 2 * hd - 1) * kFragF4 + lane;
+  f32x4 W_[F32_WIN];
+  W32_PRIME();
+
+  FL xh = fl_load(g.X + tok * 64 + 4 * h);
+  int pos = 0, k = 0;
+  if (real) {
+    const int tp = g.tok_pos[tok];
+    pos = tp & 255; k = tp >> 8;
+  }
+  const int li0 = r - pos;
+  uint32_t thr1 = 0, thr2 = 0, hrow1 = 0, hrow2 = 0;
+  float ks1 = 1.f, ks2 = 1.f;
+  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
+  if (drop1 || drop2) {
+    const uint32_t slot = (uint32_t)g.tok_slot[tok];
+    const uint64_t seed = *g.seed;
+    hrow1 = lowbias32(slot ^ rng_key(seed, kStreamDropFc1));
+    hrow2 = lowbias32(slot ^ rng_key(seed, kStreamDropPff));
+    if (drop1) { thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
+    if (drop2) { thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
+  }
+  int he_lo = 0, he_k = 0;
+  float he_y = 0.f, he_w = 0.f;
+  if (lane < n_h) {
+    he_lo = g.row_off[b0 + lane];
+    he_k = g.row_off[b0 + lane + 1] - he_lo;
+    he_lo -= t0;
+    if (g.row_loss) { he_y = g.y[b0 + lane]; he_w = g.w[b0 + lane]; }
+  }
+  float rx;
+  {
+    float mean;
+    fl_stats(xh, mean, rx);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { xh.lo[e] = (xh.lo[e] - mean) * rx; xh.hi[e] = (xh.hi[e] - mean) * rx; }
+  }
+  const int kRec = kImgRecH;
+  float* img_tok = nullptr;
+  float* pimg_tok = nullptr;
+  if (g.qkv && real) {                   // half-tile records (fused_bwdh_kernel): as in fused_fwd32_kernel with img_half
+    float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
+    img_tok = base + (32 * h + r) * 4;
+    pimg_tok = base + 2048 + r * 8;
+  }
+  const int n_pad = g.L - k;
+  const float padf = (float)n_pad;
+  const bool hpad = n_pad > 0;
+  int ro[ML + 1];
+#pragma unroll
+  for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLdH + 4 * h;
+  ro[ML] = n * kLdH + 4 * h;
+  float* krow = TK + r * kLdH + 4 * h;
+  float p[ML + 1];
+  float sc_part = 0.f;
+
+  if (hd == 0) fl_store(krow, xh);
+  FL q = fl_zero(), o = fl_zero();
+  W32_CHAIN(q, xh, false);                            // r_hd = B_hd x_hat + b_hd
+  F32_IMG_STORE(q, hd, 0);
+  wp = g.wfrag + (int64_t)(hd < 7 ? 2 * hd + 2 : 15) * kFragF4 + lane;
+  W32_PRIME();                                        // M_hd: in flight during the attention
+  __syncthreads();                                    // x_hat rows visible
+  F32_STAGE18(F32_MG_ONLY);                           // scores, softmax, probabilities out, z = P x_hat
+  F32_MG_PIECE(36); F32_MG_PIECE(37);
+  {
+    FL dynp = fl_zero();
+    W32_CHAIN(dynp, o, false);                        // M_hd z (+ the merged bias with head 0)
+    fl_store(Pd + hd * kHT + r * kLdH + 4 * h, dynp);
+  }
+  __syncthreads();
+  if (hd != 0) return;                                // wavefront 0 alone from here: no workgroup barrier below
+  FL dyn = fl_load(Pd + r * kLdH + 4 * h);
+#pragma unroll 1
+  for (int j = 1; j < MATCHA_N_HEAD; ++j) {
+    const FL t = fl_load(Pd + j * kHT + r * kLdH + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dyn.lo[e] += t.lo[e]; dyn.hi[e] += t.hi[e]; }
+  }
+  wp = g.wfrag + (int64_t)16 * kFragF4 + lane;      // conv0, conv1, conv1^T, conv0^T follow the heads in the merged stream
+  W32_PRIME();
+  // one wavefront: its LDS accesses execute in order, a compiler fence is all an ordering point needs
+#define F32_TAIL_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#include "fused_fwd32_tail.hpp"
+#undef F32_TAIL_SYNC
+}
+
+static int fwd32h_max_halves() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    n = 2 * cus;
+  }
+  return n;
 }
 
 size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragF4 * 4; }
@@ -997,6 +873,24 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
   // algorithmic flops per token: 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
   ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);
   const int ml = L <= 2 ? 2 : (L <= 6 ? L : 8);
+  // small batches (at most two half tiles per CU even at the bound): the heads side by side in eight wavefronts per half tile
+  if (merged && (img_half || !qkv) && rg.nhalves <= fwd32h_max_halves() && !options().disable_fwd32h) {
+    const size_t ldsh = ((size_t)10 * kHT + 64) * sizeof(float);
+    auto launchh = [&](auto kfn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
+      hipLaunchKernelGGL(kfn, dim3(rg.nhalves), dim3(512), ldsh, st, g);
+    };
+    switch (ml) {
+      case 2: launchh(fused_fwd32h_kernel<2>); break;
+      case 3: launchh(fused_fwd32h_kernel<3>); break;
+      case 4: launchh(fused_fwd32h_kernel<4>); break;
+      case 5: launchh(fused_fwd32h_kernel<5>); break;
+      case 6: launchh(fused_fwd32h_kernel<6>); break;
+      default: launchh(fused_fwd32h_kernel<8>); break;
+    }
+    MATCHA_CHECK_LAUNCH("fused_fwd32h_kernel");
+    return MATCHA_OK;
+  }
   if (merged) {
     switch (ml) {
       case 2: launch(fused_fwd32_kernel<2, true>); break;

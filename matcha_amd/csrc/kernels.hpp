@@ -108,6 +108,7 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
   int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic, disable_bwdh, disable_bmm_heads;
+  int disable_fwd32h;     // small batches: one wavefront per half tile (fused_fwd32_kernel) instead of eight, one per head
   int debug_nan, fused_dbg, fwd_lds_pad;
   int tune;       // development: a free integer read by whatever kernel is being tuned (0 = defaults)
 };

@@ -100,7 +100,8 @@ static const OptionName kOptionNames[] = {
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
     {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32}, {"disable_merged", &Options::disable_merged},
     {"disable_dx_atomic", &Options::disable_dx_atomic}, {"disable_bwdh", &Options::disable_bwdh}, {"disable_bmm_heads", &Options::disable_bmm_heads},
-    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune}};
+    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune},
+    {"disable_fwd32h", &Options::disable_fwd32h}};
 Options& options() {
   static Options o = [] {
     Options v;

@@ -65,8 +65,9 @@ def test_full_size_properties_table():
         # (2) rows are independent: permuting the batch permutes the logits (same batch width L)
         perm = torch.randperm(len(x), device="cuda")
         assert torch.allclose(clf(x[perm]), base[perm], rtol=0, atol=1e-6)
-        # (3) a subset evaluated alone at the same width gives the same logits
-        assert torch.allclose(clf(x[:1000]), base[:1000], rtol=0, atol=1e-6)
+        # (3) a subset evaluated alone at the same width gives the same logits (1000 rows run the head-parallel small-batch forward,
+        # which sums the heads' contributions as eight rounded tiles: equal to rounding, not bitwise)
+        assert torch.allclose(clf(x[:1000]), base[:1000], rtol=0, atol=2e-6 * max(1.0, float(base.abs().max())))
         # (4) node order inside a hyperedge does not matter (real nodes permuted, pads kept last)
         xs = x[:4096].clone()
         k = (xs != 0).sum(1)
@@ -418,13 +419,16 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
         clf, _ = hip_model(num, 64, mode, 41)
         clf.train(True)
         tr = Trainer(clf, base_seed=8)
-        for o in options:
+        # (this test is about the BACKWARD kernels: the single-wave forward in every case, so that "same formulation" means bitwise equal
+        # logits -- small batches would otherwise take the head-parallel forward wherever the records allow it, which rounds differently;
+        # test_head_parallel_small_batch_forward_matches_the_single_wave_forward compares the two forwards)
+        for o in options + ("disable_fwd32h",):
             _lib.set_option(o, 1)
         try:
             logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
             torch.cuda.synchronize()
         finally:
-            for o in options:
+            for o in options + ("disable_fwd32h",):
                 _lib.set_option(o, 0)
         res.append((logits.clone(), tr.gflat.clone()))
     # the forward pass computes the same thing whatever the backward will be: bitwise within a formulation, to rounding across them
@@ -609,13 +613,16 @@ def test_merged_layerwise_batched_head_products_match_separate_gemms_and_four_pr
         clf, _ = hip_model(num, d, "table", 23)
         clf.train(True)
         tr = Trainer(clf, base_seed=4)
-        for o in options:
+        # (this test is about the BACKWARD kernels: the single-wave forward in every case, so that "same formulation" means bitwise equal
+        # logits -- small batches would otherwise take the head-parallel forward wherever the records allow it, which rounds differently;
+        # test_head_parallel_small_batch_forward_matches_the_single_wave_forward compares the two forwards)
+        for o in options + ("disable_fwd32h",):
             _lib.set_option(o, 1)
         try:
             logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=1)
             torch.cuda.synchronize()
         finally:
-            for o in options:
+            for o in options + ("disable_fwd32h",):
                 _lib.set_option(o, 0)
         res.append((logits.clone(), tr.gflat.clone()))
     scale_l = max(1.0, float(res[2][0].abs().max()))
@@ -677,3 +684,42 @@ def test_trainer_step_with_empty_rows_half_tile_backward():
         for which in (0, 1):
             b = res[which][1][o:o + p.numel()]
             assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+def test_head_parallel_small_batch_forward_matches_the_single_wave_forward(mode):
+    """fused_fwd32h_kernel (eight wavefronts per half tile, one per head: what batches of up to two half tiles per CU run) against
+    fused_fwd32_kernel (one wavefront walks the eight heads) on the same batch: the heads' dyn contributions are summed as eight
+    rounded tiles instead of one MFMA accumulation chain, nothing else differs -- logits within 2e-6 of their scale, every gradient
+    within 2e-6 of its tensor's scale, training (dropout on: the same masks) and inference."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(_big_batch(N, 384, rng)).cuda()
+    y = (torch.rand(len(x), device="cuda") < 0.25).float()
+    w = torch.ones(len(x), device="cuda")
+    out = {}
+    for name, flag in (("heads", 0), ("single", 1)):
+        _lib.set_option("disable_fwd32h", flag)
+        try:
+            clf, _ = hip_model(num, 64, mode, 9)
+            clf.train()
+            tr = Trainer(clf, lr=1e-3, base_seed=5, deterministic=True)
+            lg = tr.forward_backward(x, y, w, 1.0, 0.001, 2).clone()
+            torch.cuda.synchronize()
+            g = tr.gflat.clone()
+            clf.eval()
+            with torch.no_grad():
+                ev = clf(x).clone()
+            out[name] = (lg, g, ev, tr)
+        finally:
+            _lib.set_option("disable_fwd32h", 0)
+    a, b = out["heads"], out["single"]
+    assert not torch.equal(a[0], b[0]) or not torch.equal(a[2], b[2])        # the two kernels really ran (they round differently)
+    assert float((a[0] - b[0]).abs().max()) <= 2e-6 * max(1.0, float(b[0].abs().max()))
+    assert float((a[2] - b[2]).abs().max()) <= 2e-6 * max(1.0, float(b[2].abs().max()))
+    rt = a[3].rt
+    for p_, o in zip(rt.live, rt.seg_off_list[:-1]):
+        ga, gb = a[1][o:o + p_.numel()], b[1][o:o + p_.numel()]
+        assert float((ga - gb).abs().max()) <= 2e-6 * max(float(gb.abs().max()), 1e-3)

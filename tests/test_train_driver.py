@@ -144,4 +144,8 @@ def test_graph_replayed_epoch_equals_the_step_by_step_epoch(tmp_path, front_end,
         if front_end == "table":
             assert torch.equal(p0[n], p1[n]), n
         else:
-            assert float((p0[n] - p1[n]).abs().max()) <= 2e-3, n      # 32 AdamW steps, float-atomic weight gradients: a few lr at most
+            # 32 AdamW steps on float-atomic weight gradients: the recon heads' gradients (x beta = 1e-3) sit in AdamW's eps regime,
+            # where the order of the atomics decides the sign of a step -- a few lr for single elements, nothing for the bulk
+            diff = (p0[n] - p1[n]).abs().reshape(-1)
+            assert float(diff.max()) <= 1e-2, n
+            assert float(torch.quantile(diff, 0.9)) <= 2e-4, n
