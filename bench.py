@@ -115,7 +115,7 @@ def make_model(front_end, dim, num, device):
 def executed_fraction(lib, kernel_class, dim):
     """Share of a kernel class's algorithmic GEMM flops that the merged-heads kernels execute (1.0 for everything else)."""
     if dim == 64 and kernel_class in EXECUTED_FRACTION_MERGED and lib.matcha_get_option(b"disable_merged") == 0 \
-            and lib.matcha_get_option(b"disable_fwd32") == 0 and lib.matcha_get_option(b"disable_fused") == 0:
+            and lib.matcha_get_option(b"disable_fused") == 0:
         return EXECUTED_FRACTION_MERGED[kernel_class]
     return 1.0
 

@@ -85,8 +85,11 @@ __global__ __launch_bounds__(256) void adj_hist_kernel(const int64_t* __restrict
 // rows); larger batches keep that path.
 __global__ __launch_bounds__(1024) void adj_scan_kernel(const int32_t* __restrict__ hist, int nblk, int C, int r_chrom, int32_t* __restrict__ base,
                                                         int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched, int lds_ints,
-                                                        const int32_t* __restrict__ r_dev) {
+                                                        const int32_t* __restrict__ r_dev, float* __restrict__ zero_buf, int zero_n) {
   extern __shared__ int hs[];
+  // the fused reconstruction kernel's gradient scratch, zeroed here instead of by a memset in front of it (one launch less; and a memset
+  // NODE of a captured step was seen to run unordered with its consumer -- tools/debug/graph_vs_eager2.py)
+  for (int i = threadIdx.x; i < zero_n; i += 1024) zero_buf[i] = 0.f;
   if (r_dev) { const int rv = *r_dev; r_chrom = (rv >= 0 && rv < C) ? rv : -1; }     // opts->random_chrom_dev
   __shared__ int tot[kMaxChrom + 2];
   __shared__ int segs[kMaxChrom + 2];
@@ -535,13 +538,13 @@ static int check_adj(const matcha_shape& s, const matcha_tensors& p, const match
 }
 
 static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int64_t* x, int64_t T, int r_chrom, AdjWs& w, int32_t* touched,
-                       const int32_t* t_dev, hipStream_t st, const int32_t* r_dev = nullptr) {
+                       const int32_t* t_dev, hipStream_t st, const int32_t* r_dev = nullptr, bool zero_rgrad = false) {
   const int C = s.n_chrom;
   hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist, t_dev);
   MATCHA_CHECK_LAUNCH("adj_hist_kernel");
   const int scan_ints = w.nblk * (C + 1) <= 12288 ? w.nblk * (C + 1) : 0;        // <= 48 KB of LDS for the staged histogram
   hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(1024), (size_t)scan_ints * sizeof(int), st, w.hist, w.nblk, C, r_chrom, w.base, w.seg, w.counts,
-                     touched, scan_ints, r_dev);
+                     touched, scan_ints, r_dev, zero_rgrad ? w.rgrad : nullptr, zero_rgrad ? (int)(w.nr_pad * (s.d + 1)) : 0);
   MATCHA_CHECK_LAUNCH("adj_scan_kernel");
   hipLaunchKernelGGL(adj_scatter_kernel, dim3(w.nblk), dim3(256), (size_t)(C + 1) * 256 * sizeof(int), st, x, T, f.bounds, C, r_chrom, w.base,
                      w.seg, w.order, w.other_map, t_dev, r_dev);
@@ -565,7 +568,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
   const int32_t* r_dev = recon_out ? o.random_chrom_dev : nullptr;
   // with a device-side chromosome the host only knows that SOME chromosome will be drawn: r = 0 stands for "the branch runs"
   const int r = r_dev ? 0 : ((recon_out && o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1);
-  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, t_dev, st, r_dev));
+  MATCHA_TRY(sort_tokens(s, f, x, T, r, w, nullptr, t_dev, st, r_dev, fused_here && save && recon_out && r >= 0));
   // fused_node: a node-rows-only call that no backward pass follows (matcha_node_embeddings) may take the fused kernel too
   if (adj_fused_eligible(s, f) && (fused_X || (fused_node && node_out && !recon_out))) {
     MATCHA_CHECK_ARG(!(o.training != 0 && o.p_drop_adj > 0.f) || o.seed, "adj_forward: dropout needs a seed");
@@ -591,7 +594,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
     MATCHA_CHECK_LAUNCH("adj_encode_fwd_kernel");
   }
   // layer 2: node[order[p]] = Hs[p] . W1_c^T ; padding slots stay 0 (Modules.py:178)
-  if (hipMemsetAsync(node_out, 0, (size_t)T * d * sizeof(float), st) != hipSuccess) { set_error("memset(node) failed"); return MATCHA_EHIP; }
+  MATCHA_TRY(zero_async(node_out, (size_t)T * d * sizeof(float), st));
   {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -603,7 +606,7 @@ int adj_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_fro
   }
   if (!recon_out) return MATCHA_OK;
   if (r < 0) {
-    if (hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    MATCHA_TRY(zero_async(recon_out, 2 * sizeof(float), st));
     return MATCHA_OK;
   }
   // recon branch (Modules.py:192-199)

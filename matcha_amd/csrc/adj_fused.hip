@@ -808,7 +808,7 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
   }
   if (!recon_out) return MATCHA_OK;
   if (r_chrom < 0) {
-    if (hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    MATCHA_TRY(zero_async(recon_out, 2 * sizeof(float), st));
     return MATCHA_OK;
   }
   MATCHA_CHECK_ARG(p.recon_w && p.recon_b && f.inter && f.bounds_host, "adj_forward: recon tensors / bounds_host missing");
@@ -824,8 +824,7 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
   const size_t rlds = (size_t)3 * kTile * sizeof(float);
   // 2 d n_r flop per token outside chromosome r, three times that with the branch's backward in the same pass
   ProfScope ps(MATCHA_PROF_ADJ_RECON, (double)T * (1.0 - (double)n_r / (double)s.n_nodes) * 2.0 * 64 * n_r * (save ? 3.0 : 1.0), st);
-  if (save) {
-    if (hipMemsetAsync(w.rgrad, 0, (size_t)w.nr_pad * 65 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+  if (save) {                                     // (w.rgrad was zeroed by the sort's scan kernel)
     auto k = adj_recon_kernel<true>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
     hipLaunchKernelGGL(k, dim3(rgrid), dim3(256), rlds, st, b);

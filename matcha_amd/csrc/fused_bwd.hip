@@ -138,15 +138,6 @@ __device__ __forceinline__ void proj_store_T(float* __restrict__ Ts, const float
   for (int gq = 0; gq < 4; ++gq)
     *reinterpret_cast<float4*>(&Ts[(32 * wr + r) * kLd + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
 }
-__device__ __forceinline__ void quad_store(float* __restrict__ Ts, const f32x16& acc, const float* __restrict__ bias, int wr, int wc, int r, int h) {
-  const int col = 32 * wc + r;
-  const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    Ts[row * kLd + col] = acc[reg] + bv;
-  }
-}
 
 __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rstd) {
   const float s = group_sum<16>((v.x + v.y) + (v.z + v.w));
@@ -326,81 +317,6 @@ __device__ __forceinline__ void attn_col_fb(const float* __restrict__ Qs, const 
 // in flight.  (sched_barrier alone does not do it: instruction selection has already placed the unchained LDS loads of all rows
 // ahead of the arithmetic when the machine scheduler sees the fence.)
 #define FB_PIN(addr, x) asm volatile("" : "+v"(addr), "+v"((x).a), "+v"((x).b), "+v"((x).c), "+v"((x).d))
-template <int ML>
-__device__ __forceinline__ void attn_row8(const float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs,
-                                          const float* __restrict__ Fs, const float* __restrict__ kpad, const float* __restrict__ vpad,
-                                          const float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0, int k, int n_pad, int sub,
-                                          float inv_temp, V8& o, V8& gq, V8& accK, V8& accV) {
-  const float padf = (float)n_pad;
-  const bool hp = n_pad > 0;
-  float p[ML], ds[ML], pp, dsp;
-  {
-    const float4 pa = *reinterpret_cast<const float4*>(&Ps[li * 8]), pb = *reinterpret_cast<const float4*>(&Ps[li * 8 + 4]);
-    const float w[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-#pragma unroll
-    for (int j = 0; j < ML; ++j) p[j] = (j < k) ? w[j] : 0.f;
-    pp = hp ? w[7] : 0.f;
-  }
-  const float ppf = padf * pp;
-  const int ro0 = li0 * kLd + 8 * sub;                   // key / value row j (clamped to the hyperedge): ro0 + min(j, k - 1) rows
-  {
-    const V8 go = ld8(&Fs[li * kLd + 8 * sub]);
-    const V8 vp = ld8(vpad + 8 * sub);
-    o = scale8(ppf, vp);
-    dsp = group_sum8_dpp(dot8(go, vp));
-    float sig = ppf * dsp;
-    V8 vn = ld8(&Vs[ro0]), vn2 = ld8(&Vs[ro0 + (1 < k ? 1 : 0) * kLd]);      // two rows in flight
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-      const V8 v = vn;
-      vn = vn2;
-      if (j + 2 < ML) {
-        int a = ro0 + (j + 2 < k ? j + 2 : 0) * kLd;
-        FB_PIN(a, o);
-        vn2 = ld8(&Vs[a]);
-      }
-      axpy8(o, p[j], v);
-      const float d = group_sum8_dpp(dot8(go, v));
-      ds[j] = d;
-      sig += p[j] * d;
-    }
-#pragma unroll
-    for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
-    dsp = pp * (dsp - sig) * inv_temp;
-    axpy8(accV, ppf, go);
-  }
-  const float dspf = padf * dsp;
-  {
-    const V8 kp = ld8(kpad + 8 * sub);
-    gq = scale8(dspf, kp);
-    int a0 = ro0;
-    FB_PIN(a0, o);                                     // the K pass starts after the V pass is done with its rows
-    V8 kn = ld8(&Ks[a0]), kn2 = ld8(&Ks[a0 + (1 < k ? 1 : 0) * kLd]);
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-      const V8 kk = kn;
-      kn = kn2;
-      if (j + 2 < ML) {
-        int a = ro0 + (j + 2 < k ? j + 2 : 0) * kLd;
-        FB_PIN(a, gq);
-        kn2 = ld8(&Ks[a]);
-      }
-      axpy8(gq, ds[j], kk);
-    }
-  }
-  {
-    int a = li * kLd + 8 * sub;
-    FB_PIN(a, gq);
-    const V8 q = ld8(&Qs[a]);
-    axpy8(accK, dspf, q);
-  }
-  if (sub == 1) {                                          // row i of dS for the column phase (P is in Ps already)
-    float* dst = dSs + li * 8;
-    *reinterpret_cast<float4*>(dst) = make_float4(ds[0], ds[1 % ML], ML > 2 ? ds[2 % ML] : 0.f, ML > 3 ? ds[3 % ML] : 0.f);
-    if (ML > 4) *reinterpret_cast<float4*>(dst + 4) = make_float4(ds[4 % ML], ML > 5 ? ds[5 % ML] : 0.f, ML > 6 ? ds[6 % ML] : 0.f, ML > 7 ? ds[7 % ML] : 0.f);
-  }
-}
-
 // Keys = values (merged heads: both are the x_hat rows, kpad = vpad = the padding token's x_hat): ONE pass over the rows.  With the weights
 // w_j = p_ij (w_pad = n_pad p_i,pad) and d_j = dz_i . x_j:   z_i = sum_j w_j x_j,   sig = sum_j w_j d_j,   A = sum_j (w_j d_j) x_j, and
 //   d r_i = sum_j dS_ij x_j = (A - sig z_i) / temp        (dS_ij = w_j (d_j - sig) / temp; the sums include the padding term),
@@ -616,37 +532,16 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
     *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
   } while (0)
-  // Q, K, V tiles of the forward pass: reloaded thread for thread (the register image proj_store_T of fused_fwd.hip wrote)
-  // instead of recomputed -- 1.4 GB per 65 536-row step through an HBM that is otherwise idle, against 96 MFMAs per wave and tile
-  const bool img = g.qkv != nullptr;
-  f32x4 qi0, qi1, qi2, qi3, ki0, ki1, ki2, ki3, vi0, vi1, vi2, vi3, pn = {0.f, 0.f, 0.f, 0.f};
-  const int img_lane = ((wr * 2 + wc) * 4) * 64 + lane;
-#define FB_QKV_GLOAD(TILE)                                                                               \
-  do {                                                                                                   \
-    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.qkv + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * kImgRec);  \
-    const f32x4* b__ = r__ + img_lane;                                                                   \
-    if (tid < 128) pn = __builtin_nontemporal_load(r__ + 3072 + tid);                                    \
-    qi0 = __builtin_nontemporal_load(b__); qi1 = __builtin_nontemporal_load(b__ + 64);                   \
-    qi2 = __builtin_nontemporal_load(b__ + 128); qi3 = __builtin_nontemporal_load(b__ + 192);            \
-    ki0 = __builtin_nontemporal_load(b__ + 1024); ki1 = __builtin_nontemporal_load(b__ + 1088);          \
-    ki2 = __builtin_nontemporal_load(b__ + 1152); ki3 = __builtin_nontemporal_load(b__ + 1216);          \
-    vi0 = __builtin_nontemporal_load(b__ + 2048); vi1 = __builtin_nontemporal_load(b__ + 2112);          \
-    vi2 = __builtin_nontemporal_load(b__ + 2176); vi3 = __builtin_nontemporal_load(b__ + 2240);          \
-  } while (0)
-#define FB_IMG_STAGE(TS, R0, R1, R2, R3)                                                                 \
-  do {                                                                                                   \
-    f32x4* d__ = reinterpret_cast<f32x4*>(&(TS)[(32 * wr + r) * kLd + 32 * wc + 4 * h]);                 \
-    d__[0] = R0; d__[2] = R1; d__[4] = R2; d__[6] = R3;                                                  \
-  } while (0)
+  // (round 4: this kernel is the reference variant -- it always recomputes Q, K, V and the softmax; the saved-tile modes of rounds 2-3 went
+  // with the eight-wave kernel they fed)
+  constexpr bool img = false;
   FB_ROWS_GLOAD(mc);
-  if (img && tile_lo < tile_hi) FB_QKV_GLOAD(tile_lo);
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
     const int t0 = mc.x, n_real = mc.y;
     if (n_real <= 0) {                                // no token starts in this window (all-padding rows only)
       FB_ROWS_GLOAD(mn);
-      if (img && tile + 1 < tile_hi) FB_QKV_GLOAD(tile + 1);
       mc = mn; mn = mnn;
       continue;
     }
@@ -655,12 +550,6 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
     // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the token -> hyperedge map ----
     FB_ROW_STAGE(0); FB_ROW_STAGE(1); FB_ROW_STAGE(2); FB_ROW_STAGE(3);
     if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
-    if (img) {
-      FB_IMG_STAGE(Qs, qi0, qi1, qi2, qi3);
-      FB_IMG_STAGE(Ks, ki0, ki1, ki2, ki3);
-      FB_IMG_STAGE(Vs, vi0, vi1, vi2, vi3);
-      if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;          // rows of P: the row phase starts from them
-    }
     __syncthreads();
     FB_T(0);
     // ---- recompute Q, K, V when the forward pass did not leave them (one accumulator at a time: fusing the three loops
@@ -766,7 +655,6 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
       }
     }
     FB_T(5);
-    if (img && tile + 1 < tile_hi) FB_QKV_GLOAD(tile + 1);     // next tile's Q, K, V: in flight during the weight-gradient GEMMs
     // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
     if (!(g.dbg & 4)) {
       // 8 trips of 4 contraction steps (8 tokens); the operands of trip i + 1 are fetched before the 16 MFMAs of trip i.
@@ -867,383 +755,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
   if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
 }
 
-// ---- the same walk with EIGHT wavefronts: two per SIMD -------------------------------------------------------------------
-// fused_bwd_kernel runs one wavefront per SIMD (157 KB of LDS, > 256 registers per lane), so nothing hides its LDS / global
-// latency and barrier skew: 6.9 us of MFMA + 2.9 us of VALU issue per (tile, head) take 13.9 us.  Here the SAME tiles in LDS are
-// worked on by 512 threads: wave (quad, hf) with quad = the old (wr, wc) output quadrant; waves w and w + 4 share a SIMD.
-//   token-side products (dO, d x_hat): v_mfma_f32_16x16x4_f32, wave (quad, hf) owns feature columns 32 wc + 16 hf .. + 16 of its
-//     quadrant's 32 token rows (two 16 x 16 tiles) -- half the MFMAs per wave, an 8-register accumulator
-//   weight gradients: v_mfma_f32_32x32x2_f32 as before, the 64-token contraction split by hf (tokens 32 hf .. 32 hf + 31); each half
-//     keeps its own four accumulators for the whole walk and writes its own slab (fb_unfold_kernel sums 2 x nchunks slabs)
-//   attention: one token per 8-lane group in ONE pass (64 groups), half the live state per lane
-// Requires the Q/K/V images of the training forward (no recompute path).
-#ifndef FB8_ABL
-#define FB8_ABL 0
-#endif
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
-
-template <int ML>
-__global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef FB_TIMING
-  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = wall_clock64();
-#endif
-  float* Wq = lds;
-  float* Xs = lds + 3 * kTile;        // x_hat (rows >= n_real are zero)
-  float* Ds = lds + 4 * kTile;        // dDyn  (rows >= n_real are zero)
-  float* Qs = lds + 5 * kTile;        // Q -> dQ
-  float* Ks = lds + 6 * kTile;        // K -> dK
-  float* Vs = lds + 7 * kTile;        // V -> dV
-  float* Fs = lds + 8 * kTile;        // dO -> O
-  float* sm = lds + 9 * kTile;
-  int* tinfo = reinterpret_cast<int*>(sm);
-  float* cb = sm + 64;
-  float* kpad = cb + 192;
-  float* vpad = kpad + 64;
-  float* xpad = vpad + 64;
-  float* Ps = xpad + 64;
-  float* dSs = Ps + 512;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int quad = wave & 3, hf = wave >> 2;
-  const int r = lane & 31, h = lane >> 5;              // 32x32x2 fragments (weight gradients)
-  const int wr = quad & 1, wc = quad >> 1;
-  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x4 fragments (token-side products)
-  const int fb = 32 * wc + 16 * hf;                    // this wave's 16 feature columns there
-  const int srow = tid >> 4, sc4 = (tid & 15) * 4;     // staging: 32 rows x 16 lanes (float4)
-  const int sub = lane & 7;
-
-  int head, chunk;
-  if ((g.nchunks & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    head = j & 7;
-    chunk = (j >> 3) * 8 + xcd;
-  } else {
-    head = blockIdx.x & 7;
-    chunk = blockIdx.x >> 3;
-  }
-  const int tr = g.count[1];
-  int ntr = g.count[2];
-  if (ntr > g.ntiles) ntr = g.ntiles;
-  const int per = (ntr + g.nchunks - 1) / g.nchunks;
-  const int tile_lo = chunk * per;
-  const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
-  const float inv_temp = 0.125f;
-
-  // ---- resident weights ----
-  const int64_t wofs = (int64_t)head * 64 * 64;
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const float* src = (m == 0 ? g.wq : (m == 1 ? g.wk : g.wv)) + wofs;
-    const float4 t0 = *reinterpret_cast<const float4*>(src + (int64_t)srow * 64 + sc4);
-    const float4 t1 = *reinterpret_cast<const float4*>(src + (int64_t)(srow + 32) * 64 + sc4);
-    *reinterpret_cast<float4*>(&Wq[m * kTile + srow * kLd + sc4]) = t0;
-    *reinterpret_cast<float4*>(&Wq[m * kTile + (srow + 32) * kLd + sc4]) = t1;
-  }
-  if (tid < 192) cb[tid] = (tid < 64 ? g.cq : (tid < 128 ? g.ck : g.cv))[head * 64 + (tid & 63)];
-  if (tid < 16) {
-    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
-    float m, rs;
-    ln_row16(xv, m, rs);
-    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
-  }
-  __syncthreads();
-  if (tid < 128) {
-    const int n = tid & 63;
-    const float* W = Wq + (tid < 64 ? 1 : 2) * kTile;
-    float s = 0.f;
-    for (int k = 0; k < 64; ++k) s += xpad[k] * W[n * kLd + k];
-    (tid < 64 ? kpad : vpad)[n] = s + cb[64 + (tid >> 6) * 64 + n];
-  }
-
-  // weight-gradient accumulators: rows n = 32 wr + 16 mt + 4 kq + reg, column k = fb + c16 of dW'q, dW'k, dW'v, dWfc1 (two 16 x 16 tiles each)
-  f32x4 aq0 = {0.f, 0.f, 0.f, 0.f}, aq1 = aq0, ak0 = aq0, ak1 = aq0, av0 = aq0, av1 = aq0, af0 = aq0, af1 = aq0;
-  V8 accK = zero8(), accV = zero8();
-  f2 cs2 = {0.f, 0.f};              // column sums (bias gradients) of ONE of {dDyn, dQ, dK, dV} -- tile 4 + u, u = 2 wc + hf -- columns 32 wr + c16 and + 16
-
-  const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
-  const int4 mzero = make_int4(0, 0, 0, 0);
-  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
-  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
-  float4 xn0, xn1, dn0, dn1;
-  int tpn = 0;
-#define FB8_ROW_GLOAD(I, M)                                                                              \
-  do {                                                                                                   \
-    const int row__ = srow + 32 * (I);                                                                   \
-    const int64_t tok__ = (M).x + (row__ < (M).y ? row__ : ((M).y > 0 ? (M).y - 1 : 0));                 \
-    xn##I = *reinterpret_cast<const float4*>(g.X + tok__ * 64 + sc4);                                    \
-    dn##I = *reinterpret_cast<const float4*>(g.dDyn + tok__ * 64 + sc4);                                 \
-  } while (0)
-#define FB8_ROWS_GLOAD(M)                                                                                \
-  do {                                                                                                   \
-    FB8_ROW_GLOAD(0, M); FB8_ROW_GLOAD(1, M);                                                            \
-    if (tid < 64) tpn = g.tok_pos[(M).x + (tid < (M).y ? tid : ((M).y > 0 ? (M).y - 1 : 0))];           \
-  } while (0)
-#define FB8_ROW_STAGE(I)                                                                                 \
-  do {                                                                                                   \
-    const int row__ = srow + 32 * (I);                                                                   \
-    const float msk__ = row__ < n_real ? 1.f : 0.f;                                                      \
-    const float4 xv__ = xn##I, dv__ = dn##I;                                                             \
-    const float mean__ = group_sum16_dpp((xv__.x + xv__.y) + (xv__.z + xv__.w)) * (1.f / 64.f);          \
-    const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
-    const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
-    const float rs__ = msk__ * __builtin_amdgcn_rsqf(q__ * (1.f / 64.f) + kEpsLn);                       \
-    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
-    const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
-    *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
-  } while (0)
-  // Q, K, V register images of the forward pass (fused_fwd.hip, proj_store_T: [quadrant][gq][lane] float4): this wave takes the
-  // two feature groups gq = 2 hf, 2 hf + 1 of its quadrant
-  f32x4 qi0, qi1, ki0, ki1, vi0, vi1, pn = {0.f, 0.f, 0.f, 0.f};
-  const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
-#define FB8_QKV_GLOAD(TILE)                                                                              \
-  do {                                                                                                   \
-    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.qkv + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * kImgRec);  \
-    const f32x4* b__ = r__ + img_lane;                                                                   \
-    if (tid < 128) pn = __builtin_nontemporal_load(r__ + 3072 + tid);                                    \
-    qi0 = __builtin_nontemporal_load(b__); qi1 = __builtin_nontemporal_load(b__ + 64);                   \
-    ki0 = __builtin_nontemporal_load(b__ + 1024); ki1 = __builtin_nontemporal_load(b__ + 1088);          \
-    vi0 = __builtin_nontemporal_load(b__ + 2048); vi1 = __builtin_nontemporal_load(b__ + 2112);          \
-  } while (0)
-#define FB8_IMG_STAGE(TS, R0, R1)                                                                        \
-  do {                                                                                                   \
-    f32x4* d__ = reinterpret_cast<f32x4*>(&(TS)[(32 * wr + r) * kLd + 32 * wc + 4 * h]);                 \
-    d__[4 * hf] = R0; d__[4 * hf + 2] = R1;                                                              \
-  } while (0)
-  // A fragments (16 feature rows x 64 k) of the head's fc1 block for dO^T = Wfc1[:, head block]^T . dDyn^T, held for the whole walk
-  // (measured: re-reading them per tile from L2, at the top of the tile or as a prefetch during the weight-gradient GEMMs, is 2 - 6 % slower)
-  float fcb[16];
-#define FB8_FC_GLOAD(P)                                                                                  \
-  do {                                                                                                   \
-    _Pragma("unroll") for (int c__ = 0; c__ < 4; ++c__)                                                  \
-      _Pragma("unroll") for (int x__ = 0; x__ < 4; ++x__) fcb[4 * c__ + x__] = (P)[(16 * c__ + x__) * 512]; \
-  } while (0)
-  FB8_ROWS_GLOAD(mc);
-  if (tile_lo < tile_hi) FB8_QKV_GLOAD(tile_lo);
-  FB8_FC_GLOAD(g.fc1_w + (int64_t)(4 * kq) * 512 + head * 64 + fb + c16);
-
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
-    const int t0 = mc.x, n_real = mc.y;
-    if (n_real <= 0) {
-      FB8_ROWS_GLOAD(mn);
-      if (tile + 1 < tile_hi) FB8_QKV_GLOAD(tile + 1);
-      mc = mn; mn = mnn;
-      continue;
-    }
-    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
-    FB_T(7);
-    // Every per-lane index below is re-derived from an opaque copy of the thread id: left to itself the compiler hoists some fifty
-    // loop-invariant LDS / global addresses out of the tile loop and then spills them (256 registers per lane here).
-    int tid_ = tid;
-    asm volatile("" : "+v"(tid_));
-    const int lane = tid_ & 63, wave = tid_ >> 6;
-    const int quad = wave & 3, hf = wave >> 2;
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = quad & 1, wc = quad >> 1;
-    const int c16 = lane & 15, kq = lane >> 4;
-    const int fb = 32 * wc + 16 * hf;
-    const int srow = tid_ >> 4, sc4 = (tid_ & 15) * 4;
-    const int sub = lane & 7;
-    const float* fcp = g.fc1_w + (int64_t)(4 * kq) * 512 + head * 64 + fb + c16;
-    const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
-    FB8_ROW_STAGE(0); FB8_ROW_STAGE(1);
-    if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
-    FB8_IMG_STAGE(Qs, qi0, qi1);
-    FB8_IMG_STAGE(Ks, ki0, ki1);
-    FB8_IMG_STAGE(Vs, vi0, vi1);
-    if (tid < 128) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
-    __syncthreads();
-    FB_T(0);
-    // ---- dO^T = Wfc1[:, head block]^T . dDyn^T: lane (c16, kq) ends with token 32 wr + c16 (+ 16) and features fb + 4 kq + {0..3} ----
-    {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      const float* dp = Ds + (32 * wr + c16) * kLd + 4 * kq;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 b0 = *reinterpret_cast<const float4*>(dp + 16 * c), b1 = *reinterpret_cast<const float4*>(dp + 16 * kLd + 16 * c);
-        acc0 = MFMA16(fcb[4 * c + 0], b0.x, acc0); acc1 = MFMA16(fcb[4 * c + 0], b1.x, acc1);
-        acc0 = MFMA16(fcb[4 * c + 1], b0.y, acc0); acc1 = MFMA16(fcb[4 * c + 1], b1.y, acc1);
-        acc0 = MFMA16(fcb[4 * c + 2], b0.z, acc0); acc1 = MFMA16(fcb[4 * c + 2], b1.z, acc1);
-        acc0 = MFMA16(fcb[4 * c + 3], b0.w, acc0); acc1 = MFMA16(fcb[4 * c + 3], b1.w, acc1);
-      }
-      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + c16) * kLd + fb + 4 * kq]) = acc0;
-      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]) = acc1;
-    }
-    __syncthreads();
-    FB_T(1);
-    // ---- attention forward + backward: 8 lanes per token, all 64 tokens in one pass ----
-    {
-      V8 o0, q0, k0, v0;
-      const int la = wave * 8 + (lane >> 3);
-      const bool acta = la < n_real && !(FB8_ABL & 1);
-      int ia = 0;
-      if (acta) { ia = tinfo[la]; attn_row8<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      FB_T(2);
-      // dK / dV replace K / V right away: the column phase reads only Q and dO rows of other tokens (K and V were last read in the
-      // row phase, before the barrier above); dQ and O wait for the barrier below
-      if (acta) {
-        attn_col8<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
-        st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
-      } else {                                        // rows past the tile's tokens: zero, the weight-gradient GEMMs run over all 64 rows
-        ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
-      }
-      __syncthreads();
-      FB_T(3);
-      if (acta) {
-        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0);
-      } else {
-        ZR8(&Qs[la * kLd + 8 * sub]);
-      }
-    }
-    __syncthreads();
-    FB_T(4);
-    FB8_ROWS_GLOAD(mn);                               // next tile's rows: in flight during the GEMMs below
-    if (!(FB8_ABL & 8))
-    // ---- this head's share of d x_hat^T = W'q^T dQ^T + W'k^T dK^T + W'v^T dV^T: 12 steps of 16 contraction indices ----
-    {
-      f32x4 dx0 = {0.f, 0.f, 0.f, 0.f}, dx1 = dx0;
-      const float* arow = Qs + (32 * wr + c16) * kLd + 4 * kq;
-      const float* wcol = Wq + (4 * kq) * kLd + fb + c16;
-      float4 a00, a01, a10, a11;
-      float w00, w01, w02, w03, w10, w11, w12, w13;
-#define FB8_DX_LOAD(A0, A1, W, S)                                                                        \
-  do {                                                                                                   \
-    constexpr int m__ = (S) / 4, c__ = (S) % 4;                                                          \
-    const float* ap__ = arow + m__ * kTile + 16 * c__;                                                   \
-    const float* wp__ = wcol + m__ * kTile + (16 * c__) * kLd;                                           \
-    A0 = *reinterpret_cast<const float4*>(ap__); A1 = *reinterpret_cast<const float4*>(ap__ + 16 * kLd); \
-    W##0 = wp__[0]; W##1 = wp__[kLd]; W##2 = wp__[2 * kLd]; W##3 = wp__[3 * kLd];                        \
-  } while (0)
-#define FB8_DX_MMA(A0, A1, W)                                                                            \
-  do {                                                                                                   \
-    dx0 = MFMA16(W##0, A0.x, dx0); dx1 = MFMA16(W##0, A1.x, dx1);                                        \
-    dx0 = MFMA16(W##1, A0.y, dx0); dx1 = MFMA16(W##1, A1.y, dx1);                                        \
-    dx0 = MFMA16(W##2, A0.z, dx0); dx1 = MFMA16(W##2, A1.z, dx1);                                        \
-    dx0 = MFMA16(W##3, A0.w, dx0); dx1 = MFMA16(W##3, A1.w, dx1);                                        \
-  } while (0)
-#define FB8_DX_PAIR(S)                                                                                   \
-  do {                                                                                                   \
-    FB8_DX_LOAD(a10, a11, w1, (S) + 1);                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FB8_DX_MMA(a00, a01, w0);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if ((S) + 2 < 12) FB8_DX_LOAD(a00, a01, w0, ((S) + 2 < 12 ? (S) + 2 : 0));                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FB8_DX_MMA(a10, a11, w1);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  } while (0)
-      FB8_DX_LOAD(a00, a01, w0, 0);
-      FB8_DX_PAIR(0); FB8_DX_PAIR(2); FB8_DX_PAIR(4); FB8_DX_PAIR(6); FB8_DX_PAIR(8); FB8_DX_PAIR(10);
-      float* out = g.dxh + ((int64_t)head * g.tcap + t0 + 32 * wr + c16) * 64 + fb + 4 * kq;
-      if (32 * wr + c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
-      if (32 * wr + 16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
-    }
-    FB_T(5);
-    if (tile + 1 < tile_hi) FB8_QKV_GLOAD(tile + 1);     // next tile's Q, K, V: in flight during the weight-gradient GEMMs
-    // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k], 16 steps of 4 tokens; lane group kq takes token 16 c + 4 kq + x in
-    //      step (c, x) (rows 4 apart = 16 banks apart: the two lane groups of a half-wave do not collide) ----
-    if (!(FB8_ABL & 4)) {
-      const float* pq = Qs + (4 * kq) * kLd + 32 * wr + c16;      // Qs, Ks, Vs are consecutive tiles; columns n and n + 16 as one ds_read2
-      const float* pd = Ds + (4 * kq) * kLd + 32 * wr + c16;
-      const float* px = Xs + (4 * kq) * kLd + fb + c16;
-      const float* po = Fs + (4 * kq) * kLd + fb + c16;
-      const float* pc = pd + (2 * wc + hf) * kTile;             // this wave's share of the column sums: its own extra operand read (the four
-                                                                // waves of a row half split the four matrices instead of all summing all four)
-      f2 qa, ka, va, da, qb, kb, vb, db, ca, cb;
-      float xa, oa, xb, ob;
-#define FB8_TN_LOAD(S, ST)                                                                               \
-  do {                                                                                                   \
-    constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
-    q##S = (f2){pq[o__], pq[o__ + 16]}; k##S = (f2){pq[kTile + o__], pq[kTile + o__ + 16]};              \
-    v##S = (f2){pq[2 * kTile + o__], pq[2 * kTile + o__ + 16]}; d##S = (f2){pd[o__], pd[o__ + 16]};      \
-    x##S = px[o__]; o##S = po[o__]; c##S = (f2){pc[o__], pc[o__ + 16]};                                  \
-  } while (0)
-#define FB8_TN_MMA(S)                                                                                    \
-  do {                                                                                                   \
-    cs2 += c##S;                                                                                         \
-    aq0 = MFMA16(q##S.x, x##S, aq0); aq1 = MFMA16(q##S.y, x##S, aq1);                                    \
-    ak0 = MFMA16(k##S.x, x##S, ak0); ak1 = MFMA16(k##S.y, x##S, ak1);                                    \
-    av0 = MFMA16(v##S.x, x##S, av0); av1 = MFMA16(v##S.y, x##S, av1);                                    \
-    af0 = MFMA16(d##S.x, o##S, af0); af1 = MFMA16(d##S.y, o##S, af1);                                    \
-  } while (0)
-#define FB8_TN_PAIR(ST)                                                                                  \
-  do {                                                                                                   \
-    FB8_TN_LOAD(b, (ST) + 1);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FB8_TN_MMA(a);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if ((ST) + 2 < 16) FB8_TN_LOAD(a, ((ST) + 2 < 16 ? (ST) + 2 : 0));                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FB8_TN_MMA(b);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  } while (0)
-      FB8_TN_LOAD(a, 0);
-      FB8_TN_PAIR(0); FB8_TN_PAIR(2); FB8_TN_PAIR(4); FB8_TN_PAIR(6); FB8_TN_PAIR(8); FB8_TN_PAIR(10); FB8_TN_PAIR(12); FB8_TN_PAIR(14);
-    }
-    FB_T(6);
-    mc = mn; mn = mnn;
-  }
-
-  // ---- workgroup slab ----
-  __syncthreads();
-#ifdef FB_TIMING
-  if (blockIdx.x == 0 && (tid == 0 || tid == 256))
-    printf("fused_bwd8 wg0 wave %d us: stage %.1f dO %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (tiles %d)\n", tid >> 6,
-           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
-#endif
-  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
-  {
-    const int col = fb + c16;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = 32 * wr + 4 * kq + reg;
-      slab[0 * 4096 + row * 64 + col] = aq0[reg]; slab[0 * 4096 + (row + 16) * 64 + col] = aq1[reg];
-      slab[1 * 4096 + row * 64 + col] = ak0[reg]; slab[1 * 4096 + (row + 16) * 64 + col] = ak1[reg];
-      slab[2 * 4096 + row * 64 + col] = av0[reg]; slab[2 * 4096 + (row + 16) * 64 + col] = av1[reg];
-      slab[3 * 4096 + row * 64 + col] = af0[reg]; slab[3 * 4096 + (row + 16) * 64 + col] = af1[reg];
-    }
-  }
-  // column sums: lane (c16, kq) covered tokens 16 c + 4 kq + x of matrix u = 2 wc + hf for columns 32 wr + c16 (.x) and + 16 (.y); the four
-  // lane groups are added in a fixed xor order
-  float* red = Xs;                      // [3][64]: dcq dck dcv
-  float* red2 = Ds;                     // [64] fc1 bias gradient (column sums of dDyn)
-  {
-    float a = cs2.x, b = cs2.y;
-    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-    const int u = 2 * wc + hf;
-    if (kq == 0) {
-      float* dst = u == 0 ? red2 : red + (u - 1) * 64;
-      dst[32 * wr + c16] = a; dst[32 * wr + 16 + c16] = b;
-    }
-  }
-  // dK_pad / dV_pad: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 8 waves in order
-  float* redp = Xs + 3 * 64;            // [8][2][64]
-  const float accp[16] = {accK.a.x, accK.a.y, accK.b.x, accK.b.y, accK.c.x, accK.c.y, accK.d.x, accK.d.y,
-                          accV.a.x, accV.a.y, accV.b.x, accV.b.y, accV.c.x, accV.c.y, accV.d.x, accV.d.y};
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float v = accp[i];
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 8) redp[(wave * 2 + (i >> 3)) * 64 + 8 * lane + (i & 7)] = v;
-  }
-  __syncthreads();
-  if (tid < 192) slab[kVecOff + tid] = red[tid];
-  if (tid < 128) {
-    const int vec = tid >> 6, f = tid & 63;
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += redp[(w * 2 + vec) * 64 + f];
-    slab[kVecOff + 192 + tid] = t;
-  }
-  if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
-}
 
 // ---- merged heads (round 3): the backward of  r = B_h x + b_h,  s_ij = r_i . x_j,  z_i = sum_j p_ij x_j,  dyn += M_h z  ---------------
 // (fused_fwd32.hip, MG = true).  Per (tile, head) FOUR 64 x 64 products instead of eight:  dZ = dDyn M_h;  d x_hat = dR B_h + (the
@@ -1254,338 +766,6 @@ __global__ __launch_bounds__(512) void fused_bwd8_kernel(FusedBwdArgs g) {
 // chain rule from (dB_h, db_h, dM_h, d bdyn) to the folded projections, and the LayerNorm un-folding runs as before.
 constexpr int kWgSlabM = 2 * 4096 + 4 * 64;     // dB_h dM_h | db_h (column sums of dR), d bdyn (column sums of dDyn), dxpad, spare
 constexpr int kVecOffM = 2 * 4096;
-struct FusedBwdMArgs {
-  const float* X; const float* dDyn; const int32_t* count; const int32_t* tile_meta; const int32_t* tok_pos;
-  int L; int ntiles; int nchunks;
-  const float* mB; const float* mM;               // merged matrices [8][64][64] (launch_merge_heads)
-  float* dxh; int64_t tcap;
-  int dx_atomic;                                   // 1: every head adds into ONE [tcap][64] buffer with float atomics (zeroed by the launcher); 0: one slab per head
-  float* wslab;                                    // [8][nchunks][kWgSlabM]
-  const float* rimg;                               // [ntiles][8][kImgRecM]: r rows (register images) + attention probabilities of the forward
-};
-
-template <int ML>
-__global__ __launch_bounds__(512) void fused_bwdm_kernel(FusedBwdMArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Wb = lds;                    // B_h [a][b], resident
-  // two sets {x_hat, dDyn, r -> dR} (+ probabilities, token info): the NEXT tile is staged into the other set at the end of a tile, so
-  // the walk has no staging phase (and one barrier less) on its critical path.  Ds, Rs consecutive: the column sums pick one by offset
-  float* set0 = lds + 1 * kTile;
-  float* Fs = lds + 7 * kTile;        // dZ -> Z
-  float* Gs = lds + 8 * kTile;        // attention's gradient into the x_hat rows (keys + values)
-  float* sm = lds + 9 * kTile;
-  float* xpad = sm;
-  float* dSs = xpad + 64;
-  float* Ps0 = dSs + 512;             // [2][512]
-  int* tinfo0 = reinterpret_cast<int*>(Ps0 + 1024);   // [2][64]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int quad = wave & 3, hf = wave >> 2;
-  const int wr = quad & 1, wc = quad >> 1;
-  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x4 fragments
-  const int fb = 32 * wc + 16 * hf;                    // this wave's 16 feature columns
-  const int srow = tid >> 4, sc4 = (tid & 15) * 4;     // staging: 32 rows x 16 lanes (float4)
-  const int sub = lane & 7;
-
-  int head, chunk;
-  if ((g.nchunks & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    head = j & 7;
-    chunk = (j >> 3) * 8 + xcd;
-  } else {
-    head = blockIdx.x & 7;
-    chunk = blockIdx.x >> 3;
-  }
-  const int tr = g.count[1];
-  int ntr = g.count[2];
-  if (ntr > g.ntiles) ntr = g.ntiles;
-  const int per = (ntr + g.nchunks - 1) / g.nchunks;
-  const int tile_lo = chunk * per;
-  const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
-  const float inv_temp = 0.125f;
-#ifdef FB_TIMING
-  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = wall_clock64();
-#endif
-
-  // ---- resident B_h, the padding token's x_hat ----
-  {
-    const float* src = g.mB + (int64_t)head * 4096;
-    const float4 t0 = *reinterpret_cast<const float4*>(src + (int64_t)srow * 64 + sc4);
-    const float4 t1 = *reinterpret_cast<const float4*>(src + (int64_t)(srow + 32) * 64 + sc4);
-    *reinterpret_cast<float4*>(&Wb[srow * kLd + sc4]) = t0;
-    *reinterpret_cast<float4*>(&Wb[(srow + 32) * kLd + sc4]) = t1;
-  }
-  if (tid < 16) {
-    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
-    float m, rs;
-    ln_row16(xv, m, rs);
-    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
-  }
-
-  // weight-gradient accumulators: rows n = 32 wr + 16 mt + 4 kq + reg, column k = fb + c16 of dB_h and dM_h (two 16 x 16 tiles each)
-  f32x4 ab0 = {0.f, 0.f, 0.f, 0.f}, ab1 = ab0, am0 = ab0, am1 = ab0;
-  V8 accK = zero8(), accV = zero8();                  // the padding token's gradient as a key (sum dS_i,pad r_i) and as a value (sum p_i,pad dz_i)
-  f2 cs2 = {0.f, 0.f};                                // column sums of dDyn (waves with 2 wc + hf even) or of dR (odd): columns 32 wr + c16 and + 16
-
-  const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
-  const int4 mzero = make_int4(0, 0, 0, 0);
-  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
-  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
-  float4 xn0, xn1, dn0, dn1;
-  int tpn = 0;
-  f32x4 ri0, ri1, pn = {0.f, 0.f, 0.f, 0.f};
-#define FBM_RIMG_GLOAD(TILE)                                                                             \
-  do {                                                                                                   \
-    const f32x4* r__ = reinterpret_cast<const f32x4*>(g.rimg + ((int64_t)(TILE) * MATCHA_N_HEAD + head) * kImgRecM);  \
-    const f32x4* b__ = r__ + img_lane;                                                                   \
-    if (tid < 128) pn = __builtin_nontemporal_load(r__ + 1024 + tid);                                    \
-    ri0 = __builtin_nontemporal_load(b__); ri1 = __builtin_nontemporal_load(b__ + 64);                   \
-  } while (0)
-  // A fragments (16 feature rows x 64 k) of M_h for dZ^T = M_h^T . dDyn^T, held for the whole walk
-  float fcb[16];
-  {
-    const int r = lane & 31, h = lane >> 5;
-    (void)r; (void)h;
-    const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
-    FB8_ROWS_GLOAD(mc);
-    if (tile_lo < tile_hi) FBM_RIMG_GLOAD(tile_lo);
-    const float* mp = g.mM + (int64_t)head * 4096 + (4 * kq) * 64 + fb + c16;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) fcb[4 * c + x] = mp[(16 * c + x) * 64];
-  }
-
-#define FBM_STAGE(PAR, META)                                                                             \
-  do {                                                                                                   \
-    float* Xs = set0 + 3 * (PAR) * kTile;                                                                \
-    float* Ds = Xs + kTile;                                                                              \
-    float* Rs = Ds + kTile;                                                                              \
-    const int n_real = (META).y;                                                                         \
-    const int r = lane & 31, h = lane >> 5;                                                              \
-    FB8_ROW_STAGE(0); FB8_ROW_STAGE(1);                                                                  \
-    if (tid < 64) tinfo0[64 * (PAR) + tid] = tid < n_real ? ((tid - (tpn & 255)) | (tpn & ~255)) : 0;     \
-    FB8_IMG_STAGE(Rs, ri0, ri1);                                                                         \
-    if (tid < 128) reinterpret_cast<f32x4*>(Ps0 + 512 * (PAR))[tid] = pn;                                \
-  } while (0)
-  int par = 0;
-  if (tile_lo < tile_hi) FBM_STAGE(0, mc);
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
-    const int t0 = mc.x, n_real = mc.y;
-    float* Xs = set0 + 3 * par * kTile;
-    float* Ds = Xs + kTile;
-    float* Rs = Ds + kTile;
-    const float* Ps = Ps0 + 512 * par;
-    const int* tinfo = tinfo0 + 64 * par;
-    __syncthreads();                                  // this tile's set is staged; the previous tile's GEMMs are done with Fs / Gs and with the other set
-    FB_T(7);
-    // per-lane indices re-derived from an opaque copy of the thread id (see fused_bwd8_kernel: loop-invariant addresses are hoisted and spilled otherwise)
-    int tid_ = tid;
-    asm volatile("" : "+v"(tid_));
-    const int lane = tid_ & 63, wave = tid_ >> 6;
-    const int quad = wave & 3, hf = wave >> 2;
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = quad & 1, wc = quad >> 1;
-    const int c16 = lane & 15, kq = lane >> 4;
-    const int fb = 32 * wc + 16 * hf;
-    const int srow = tid_ >> 4, sc4 = (tid_ & 15) * 4;
-    const int sub = lane & 7;
-    const int img_lane = ((wr * 2 + wc) * 4 + 2 * hf) * 64 + lane;
-    (void)r; (void)h; (void)srow; (void)sc4;
-    // ---- dZ^T = M_h^T . dDyn^T: lane (c16, kq) ends with token 32 wr + c16 (+ 16) and features fb + 4 kq + {0..3} ----
-    {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      const float* dp = Ds + (32 * wr + c16) * kLd + 4 * kq;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 b0 = *reinterpret_cast<const float4*>(dp + 16 * c), b1 = *reinterpret_cast<const float4*>(dp + 16 * kLd + 16 * c);
-        acc0 = MFMA16(fcb[4 * c + 0], b0.x, acc0); acc1 = MFMA16(fcb[4 * c + 0], b1.x, acc1);
-        acc0 = MFMA16(fcb[4 * c + 1], b0.y, acc0); acc1 = MFMA16(fcb[4 * c + 1], b1.y, acc1);
-        acc0 = MFMA16(fcb[4 * c + 2], b0.z, acc0); acc1 = MFMA16(fcb[4 * c + 2], b1.z, acc1);
-        acc0 = MFMA16(fcb[4 * c + 3], b0.w, acc0); acc1 = MFMA16(fcb[4 * c + 3], b1.w, acc1);
-      }
-      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + c16) * kLd + fb + 4 * kq]) = acc0;
-      *reinterpret_cast<f32x4*>(&Fs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]) = acc1;
-    }
-    FB_T(1);
-    __syncthreads();
-    FB_T(7);
-    // ---- attention forward + backward in x_hat space: 8 lanes per token, all 64 tokens in one pass ----
-    {
-      V8 o0, q0, k0, v0;
-      const int la = wave * 8 + (lane >> 3);
-      const bool acta = la < n_real;
-      int ia = 0;
-      if (acta) { ia = tinfo[la]; attn_row8<ML>(Rs, Xs, Xs, Fs, xpad, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
-      __builtin_amdgcn_sched_barrier(0);
-      FB_T(2);
-      __syncthreads();
-      FB_T(7);
-      if (acta) {
-        attn_col8<ML>(Rs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
-        k0.a += v0.a; k0.b += v0.b; k0.c += v0.c; k0.d += v0.d;      // the row is key AND value: d x_hat_j = sum_i dS_ij r_i + p_ij dz_i
-        st8(&Gs[la * kLd + 8 * sub], k0);
-      } else {
-        ZR8(&Gs[la * kLd + 8 * sub]);
-      }
-      FB_T(3);
-      __syncthreads();                                // every column phase is done with the r and dZ rows
-      FB_T(7);
-      if (acta) {
-        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Rs[la * kLd + 8 * sub], q0);
-      } else {
-        ZR8(&Rs[la * kLd + 8 * sub]);
-      }
-    }
-    FB_T(4);
-    __syncthreads();
-    FB_T(7);
-    FB8_ROWS_GLOAD(mn);                               // next tile's rows: in flight during the GEMMs below
-    // ---- this head's share of d x_hat = dR B_h + Gs: 4 steps of 16 contraction indices ----
-    if (g.dx_atomic) {
-      // rows = tokens 4 kq + reg (+ 16), columns = features fb + c16: one atomic instruction covers 4 token rows x 64 contiguous bytes.  The
-      // eight heads of a chunk run on the same XCD at about the same time: the adds meet in that L2, and d x_hat leaves it once
-      const float* gp = Gs + (32 * wr + 4 * kq) * kLd + fb + c16;
-      f32x4 dx0 = {gp[0], gp[kLd], gp[2 * kLd], gp[3 * kLd]};
-      f32x4 dx1 = {gp[16 * kLd], gp[17 * kLd], gp[18 * kLd], gp[19 * kLd]};
-      const float* arow = Rs + (32 * wr + c16) * kLd + 4 * kq;
-      const float* wcol = Wb + (4 * kq) * kLd + fb + c16;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
-        const float* wp = wcol + (16 * c) * kLd;
-        const float w0 = wp[0], w1 = wp[kLd], w2 = wp[2 * kLd], w3 = wp[3 * kLd];
-        dx0 = MFMA16(a0.x, w0, dx0); dx1 = MFMA16(a1.x, w0, dx1);
-        dx0 = MFMA16(a0.y, w1, dx0); dx1 = MFMA16(a1.y, w1, dx1);
-        dx0 = MFMA16(a0.z, w2, dx0); dx1 = MFMA16(a1.z, w2, dx1);
-        dx0 = MFMA16(a0.w, w3, dx0); dx1 = MFMA16(a1.w, w3, dx1);
-      }
-      float* out = g.dxh + ((int64_t)t0 + 32 * wr + 4 * kq) * 64 + fb + c16;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        if (32 * wr + 4 * kq + reg < n_real) unsafeAtomicAdd(out + reg * 64, dx0[reg]);
-        if (32 * wr + 16 + 4 * kq + reg < n_real) unsafeAtomicAdd(out + (16 + reg) * 64, dx1[reg]);
-      }
-    } else {
-      f32x4 dx0 = *reinterpret_cast<const f32x4*>(&Gs[(32 * wr + c16) * kLd + fb + 4 * kq]);
-      f32x4 dx1 = *reinterpret_cast<const f32x4*>(&Gs[(32 * wr + 16 + c16) * kLd + fb + 4 * kq]);
-      const float* arow = Rs + (32 * wr + c16) * kLd + 4 * kq;
-      const float* wcol = Wb + (4 * kq) * kLd + fb + c16;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
-        const float* wp = wcol + (16 * c) * kLd;
-        const float w0 = wp[0], w1 = wp[kLd], w2 = wp[2 * kLd], w3 = wp[3 * kLd];
-        dx0 = MFMA16(w0, a0.x, dx0); dx1 = MFMA16(w0, a1.x, dx1);
-        dx0 = MFMA16(w1, a0.y, dx0); dx1 = MFMA16(w1, a1.y, dx1);
-        dx0 = MFMA16(w2, a0.z, dx0); dx1 = MFMA16(w2, a1.z, dx1);
-        dx0 = MFMA16(w3, a0.w, dx0); dx1 = MFMA16(w3, a1.w, dx1);
-      }
-      float* out = g.dxh + ((int64_t)head * g.tcap + t0 + 32 * wr + c16) * 64 + fb + 4 * kq;
-      if (32 * wr + c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
-      if (32 * wr + 16 + c16 < n_real) *reinterpret_cast<f32x4*>(out + 16 * 64) = dx1;
-    }
-    FB_T(5);
-    if (tile + 1 < tile_hi) FBM_RIMG_GLOAD(tile + 1);     // next tile's r rows and probabilities: in flight during the weight-gradient GEMMs
-    // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]; 16 steps of 4 tokens ----
-    {
-      const float* pr = Rs + (4 * kq) * kLd + 32 * wr + c16;
-      const float* pd = Ds + (4 * kq) * kLd + 32 * wr + c16;
-      const float* px = Xs + (4 * kq) * kLd + fb + c16;
-      const float* pz = Fs + (4 * kq) * kLd + fb + c16;
-      const float* pc = pd + ((2 * wc + hf) & 1) * kTile;       // column sums: dDyn for even 2 wc + hf, dR for odd (Rs follows Ds)
-      f2 ra, da, ca, rb, db, cb;
-      float xa, za, xb, zb;
-#define FBM_TN_LOAD(S, ST)                                                                               \
-  do {                                                                                                   \
-    constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
-    r##S = (f2){pr[o__], pr[o__ + 16]}; d##S = (f2){pd[o__], pd[o__ + 16]};                              \
-    x##S = px[o__]; z##S = pz[o__]; c##S = (f2){pc[o__], pc[o__ + 16]};                                  \
-  } while (0)
-#define FBM_TN_MMA(S)                                                                                    \
-  do {                                                                                                   \
-    cs2 += c##S;                                                                                         \
-    ab0 = MFMA16(r##S.x, x##S, ab0); ab1 = MFMA16(r##S.y, x##S, ab1);                                    \
-    am0 = MFMA16(d##S.x, z##S, am0); am1 = MFMA16(d##S.y, z##S, am1);                                    \
-  } while (0)
-#define FBM_TN_PAIR(ST)                                                                                  \
-  do {                                                                                                   \
-    FBM_TN_LOAD(b, (ST) + 1);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FBM_TN_MMA(a);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if ((ST) + 2 < 16) FBM_TN_LOAD(a, ((ST) + 2 < 16 ? (ST) + 2 : 0));                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FBM_TN_MMA(b);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  } while (0)
-      FBM_TN_LOAD(a, 0);
-      FBM_TN_PAIR(0); FBM_TN_PAIR(2); FBM_TN_PAIR(4); FBM_TN_PAIR(6); FBM_TN_PAIR(8); FBM_TN_PAIR(10); FBM_TN_PAIR(12); FBM_TN_PAIR(14);
-    }
-    FB_T(6);
-    // ---- the next tile -> the other set (its rows and images were fetched during this tile) ----
-    if (tile + 1 < tile_hi) FBM_STAGE(par ^ 1, mn);
-    FB_T(0);
-    par ^= 1;
-    mc = mn; mn = mnn;
-  }
-
-  // ---- workgroup slab ----
-  __syncthreads();
-#ifdef FB_TIMING
-  if (blockIdx.x == 0 && (tid == 0 || tid == 256))
-    printf("fused_bwdm wg0 wave %d us: stage %.1f dZ %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (tiles %d)\n", tid >> 6,
-           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
-#endif
-  float* Xs = set0;
-  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlabM;
-  {
-    const int col = fb + c16;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = 32 * wr + 4 * kq + reg;
-      slab[0 * 4096 + row * 64 + col] = ab0[reg]; slab[0 * 4096 + (row + 16) * 64 + col] = ab1[reg];
-      slab[1 * 4096 + row * 64 + col] = am0[reg]; slab[1 * 4096 + (row + 16) * 64 + col] = am1[reg];
-    }
-  }
-  // column sums: lane (c16, kq) covered tokens 16 c + 4 kq + x for columns 32 wr + c16 (.x) and + 16 (.y); the four lane groups are added in
-  // a fixed xor order; two of the four waves of a row half computed the same sum (one writes)
-  float* red = Xs;                      // [2][64]: d bdyn (column sums of dDyn), db_h (column sums of dR)
-  {
-    float a = cs2.x, b = cs2.y;
-    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-    const int u = 2 * wc + hf;
-    if (kq == 0 && u < 2) {
-      float* dst = red + u * 64;
-      dst[32 * wr + c16] = a; dst[32 * wr + 16 + c16] = b;
-    }
-  }
-  // d x_hat of the padding token: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 8 waves in order
-  float* redp = Xs + 2 * 64;            // [8][64]
-  const float accp[8] = {accK.a.x + accV.a.x, accK.a.y + accV.a.y, accK.b.x + accV.b.x, accK.b.y + accV.b.y,
-                         accK.c.x + accV.c.x, accK.c.y + accV.c.y, accK.d.x + accV.d.x, accK.d.y + accV.d.y};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float v = accp[i];
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 8) redp[wave * 64 + 8 * lane + i] = v;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    slab[kVecOffM + 64 + tid] = red[tid];            // d bdyn partial
-    slab[kVecOffM + tid] = red[64 + tid];             // db_h partial
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += redp[w * 64 + tid];
-    slab[kVecOffM + 128 + tid] = t;                   // dxpad partial
-  }
-}
-
 // ---- merged heads on HALF tiles: the same four products per (rows, head) as fused_bwdm_kernel, on the forward's own half tiles ----
 // (whole hyperedges, <= 31 tokens: ragged.hip half_meta), FOUR wavefronts per workgroup and TWO workgroups per CU.  fused_bwdm_kernel's
 // eight wavefronts walk one tile in lock step: GEMM phases (MFMA) and the attention phases (latency-bound VALU + LDS, a sixth of the
@@ -2188,10 +1368,10 @@ size_t fused_bwd_ws_floats(int64_t B, int L) {
 }
 
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
-                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv) {
+                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st) {
+  // the REFERENCE formulation (option disable_merged): four products per head, Q / K / V and the softmax recomputed from X -- the A/B
+  // against which the merged kernels are tested; four wavefronts per workgroup on 64-row tiles
   const int64_t tcap = B * L + 1;
-  // eight wavefronts per workgroup (fused_bwd8_kernel) when the forward pass left its Q/K/V tiles
-  const bool eight = qkv != nullptr && !options().disable_bwd8;
   int nchunks = chunks_for(rg.ntiles);
   float* wslab = ws;
   float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
@@ -2202,33 +1382,22 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
     g.X = X; g.dDyn = dDyn; g.row_off = rg.row_off; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
     g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
     g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
-    g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.qkv = qkv;
+    g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.qkv = nullptr;
     g.dbg = options().fused_dbg;
     const size_t lds = ((size_t)9 * kTile + 64 + 192 + 3 * 64 + 2 * 512) * sizeof(float);
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(eight ? 512 : 256), lds, st, g);
+      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
     };
     // algorithmic flops: 8 heads x 8 GEMMs (dO, dWfc1, 3 dW', 3 d x_hat terms) of 2*64*64 per token; the Q/K/V recompute is not counted
     ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
-    if (eight) {
-      switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
-        case 2: launch(fused_bwd8_kernel<2>); break;
-        case 3: launch(fused_bwd8_kernel<3>); break;
-        case 4: launch(fused_bwd8_kernel<4>); break;
-        case 5: launch(fused_bwd8_kernel<5>); break;
-        case 6: launch(fused_bwd8_kernel<6>); break;
-        default: launch(fused_bwd8_kernel<8>); break;
-      }
-    } else {
-      switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
-        case 2: launch(fused_bwd_kernel<2>); break;
-        case 3: launch(fused_bwd_kernel<3>); break;
-        case 4: launch(fused_bwd_kernel<4>); break;
-        case 5: launch(fused_bwd_kernel<5>); break;
-        case 6: launch(fused_bwd_kernel<6>); break;
-        default: launch(fused_bwd_kernel<8>); break;
-      }
+    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+      case 2: launch(fused_bwd_kernel<2>); break;
+      case 3: launch(fused_bwd_kernel<3>); break;
+      case 4: launch(fused_bwd_kernel<4>); break;
+      case 5: launch(fused_bwd_kernel<5>); break;
+      case 6: launch(fused_bwd_kernel<6>); break;
+      default: launch(fused_bwd_kernel<8>); break;
     }
     MATCHA_CHECK_LAUNCH("fused_bwd_kernel");
   }
@@ -2258,25 +1427,22 @@ int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* 
   return MATCHA_OK;
 }
 
-// merged heads: fused_bwdm_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
+// merged heads: fused_bwdh_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool halves) {
+                            bool dx_atomic) {
   const int64_t tcap = B * L + 1;
-  if (dx_atomic && hipMemsetAsync(dxh, 0, (size_t)tcap * 64 * sizeof(float), st) != hipSuccess) { set_error("fused_bwd_merged: memset failed"); return MATCHA_EHIP; }
-  int nchunks = chunks_for(rg.ntiles);
-  if (halves) {                                              // two four-wave workgroups per CU
-    nchunks = 2 * chunks_for(rg.nhalves);
-    if (nchunks > kMaxChunks) nchunks = kMaxChunks;
-    if (nchunks > rg.nhalves) nchunks = rg.nhalves > 0 ? rg.nhalves : 1;
-  }
+  if (dx_atomic) MATCHA_TRY(zero_async(dxh, (size_t)tcap * 64 * sizeof(float), st));
+  int nchunks = 2 * chunks_for(rg.nhalves);                  // two four-wave workgroups per CU
+  if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+  if (nchunks > rg.nhalves) nchunks = rg.nhalves > 0 ? rg.nhalves : 1;
   float* wslab = ws;                                                         // [8][nchunks][kWgSlabM]
-  float* chain = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlabM;         // [8][kWgSlab]  (both inside the eight-product kernel's slab area)
+  float* chain = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlabM;         // [8][kWgSlab]  (both inside the four-product kernel's slab area)
   float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
   float* dxpad = part + 32 * 3 * 3 * 64;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   const MergedView mv = merged_view(merged);
-  if (halves) {
+  {
     FusedBwdHArgs g;
     g.X = X; g.dDyn = dDyn; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.L = L; g.nhalves = rg.nhalves; g.nchunks = nchunks;
     g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
@@ -2296,26 +1462,6 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
       default: launch(fused_bwdh_kernel<8>); break;
     }
     MATCHA_CHECK_LAUNCH("fused_bwdh_kernel");
-  } else {
-    FusedBwdMArgs g;
-    g.X = X; g.dDyn = dDyn; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
-    g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
-    const size_t lds = ((size_t)9 * kTile + 64 + 512 + 2 * 512 + 2 * 64) * sizeof(float);
-    auto launch = [&](auto kfn) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(512), lds, st, g);
-    };
-    // algorithmic flops: the reference's formulation -- 8 heads x 8 GEMMs of 2*64*64 per token; this kernel EXECUTES half of them
-    ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
-    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
-      case 2: launch(fused_bwdm_kernel<2>); break;
-      case 3: launch(fused_bwdm_kernel<3>); break;
-      case 4: launch(fused_bwdm_kernel<4>); break;
-      case 5: launch(fused_bwdm_kernel<5>); break;
-      case 6: launch(fused_bwdm_kernel<6>); break;
-      default: launch(fused_bwdm_kernel<8>); break;
-    }
-    MATCHA_CHECK_LAUNCH("fused_bwdm_kernel");
   }
   {
     ChainArgs c;

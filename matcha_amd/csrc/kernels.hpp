@@ -106,14 +106,19 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
-  int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward, disable_qkv_save;
-  int disable_wide_gemm, disable_bwd8, disable_fwd32, disable_merged, disable_dx_atomic, disable_bwdh, disable_bmm_heads;
+  int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward;
+  int disable_merged;     // the reference formulation of the heads (four products per head, recompute backward): the A/B variant
   int disable_fwd32h;     // small batches: one wavefront per half tile (fused_fwd32_kernel) instead of eight, one per head
+  int disable_wide_gemm, disable_bmm_heads;
   int debug_nan, fused_dbg, fwd_lds_pad;
   int tune;       // development: a free integer read by whatever kernel is being tuned (0 = defaults)
 };
 Options& options();
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
+// Zero `bytes` bytes (a multiple of 4, 4-byte aligned) with a KERNEL.  The library does not use hipMemsetAsync on paths that callers capture
+// into hipGraphs: a small memset NODE of a captured training step was observed to run unordered with the kernel node that consumes the
+// buffer (wrong reconstruction-head gradients in replayed steps only; tools/debug/graph_vs_eager2.py), kernel nodes keep stream order.
+int zero_async(void* p, size_t bytes, hipStream_t st);
 int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const float* bq, const float* gk, const float* bk,
                    const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st,
                    const int32_t* t_dev = nullptr);
@@ -128,15 +133,9 @@ int launch_head_bwd(const int32_t* row_off, const float* H2, const float* X, int
 size_t colsum_slab_bytes(int64_t n, int nv, int d);
 int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon = false);   // zero_recon: losses[1..2] = 0 too
 
-// fused_fwd.hip (embed_dim 64)
+// fused_aux.hip (embed_dim 64): per-step weight folding, reduction of the training forward's parameter-gradient slabs
 size_t fused_fold_floats();
 int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st);
-// With ddyn0 != null (and y, w given) the kernel also runs the backward of the classifier tail and of pff_n1 for
-// loss = alpha * bce: it writes ddyn0 / dXs and per-tile partials of the 12 parameter gradients into tslab
-// (launch_tail_reduce accumulates them into the gradient tensors).
-int launch_fused_fwd(const matcha_tensors& p, const float* folded, const float* X, const Ragged& rg, int64_t B, int L, const float* y, const float* w,
-                     float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                     hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr);
 size_t fused_tail_slab_floats(int64_t B, int L);
 size_t fused_tail_partial_floats();
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial);
@@ -161,10 +160,10 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)
 size_t fused_bwd_ws_floats(int64_t B, int L);
 int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
-                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* qkv = nullptr);
+                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool halves);
+                            bool dx_atomic);
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
 constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
 constexpr int kImgRecM = 4096 + 512;               // merged heads: the r rows (r = B_h x_hat + b_h) + the attention probabilities

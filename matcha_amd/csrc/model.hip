@@ -82,26 +82,25 @@ struct Workspace {
 
 // A/B switches for tests and profiling (include/matcha_hip.h, matcha_set_option): ONE process-wide struct whose initial values
 // come from the environment (MATCHA_DISABLE_FUSED, ...) when it is first touched; no entry point calls getenv per call.
-//   disable_fused            layer-by-layer kernels everywhere
-//   disable_fused_train      fused kernel only for no-grad forwards; training runs layer by layer
-//   disable_fused_front      front end (gather + attribute_nn + next_w; its backward) as separate kernels
+//   disable_fused            layer-by-layer kernels everywhere (the d != 64 path, at embed_dim 64 too)
+//   disable_fused_train      fused kernels only for no-grad forwards; training runs layer by layer
+//   disable_fused_front      front end (gather + attribute_nn + next_w; its backward; the fused adj kernels) as separate kernels
 //   disable_loss_in_forward  the tail's backward as separate kernels even when opts->loss_in_forward is set
-//   disable_qkv_save         the fused backward recomputes the Q/K/V projections instead of reloading the tiles the training
-//                            forward saved (6 KB per token and head-tile of workspace and HBM traffic against 27 % of its MFMAs)
-//   disable_fwd32            the four-wave tile forward (fused_fwd.hip) instead of the wave-independent one (fused_fwd32.hip)
-//   disable_bwdh             merged backward on 64-row tiles with eight wavefronts (fused_bwdm_kernel) instead of half tiles with four (fused_bwdh_kernel)
-//   disable_bmm_heads        merged layer-wise path (embed_dim >= 128): the per-head weight products as 48 separate GEMM launches instead of two batched ones
-//   disable_dx_atomic        merged backward: one d x_hat slab per head (summed by the front-end backward) instead of float atomics into one buffer
-//   disable_bwd8             the fused backward with four wavefronts per workgroup (fused_bwd_kernel) instead of eight (fused_bwd8_kernel)
+//   disable_merged           the REFERENCE formulation of the heads: four products per head forward (fused_fwd32_kernel<ML, false>), eight
+//                            backward with Q / K / V recomputed (fused_bwd_kernel) instead of the merged two / four -- the one variant
+//                            kept for A/B since round 4 (the four-wave forward, the eight-wave and 64-row-tile backward kernels and
+//                            their switches disable_fwd32 / disable_bwd8 / disable_bwdh / disable_qkv_save / disable_dx_atomic are gone:
+//                            what the last one selected is what opts->deterministic / sparse_table_grad select)
+//   disable_fwd32h           small batches: one wavefront per half tile instead of eight (one per head)
+//   disable_bmm_heads        merged layer-wise path (embed_dim >= 128): the per-head weight products as 48 separate GEMM launches
 //   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
 struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
-    {"disable_qkv_save", &Options::disable_qkv_save}, {"disable_fwd32", &Options::disable_fwd32}, {"disable_merged", &Options::disable_merged},
-    {"disable_dx_atomic", &Options::disable_dx_atomic}, {"disable_bwdh", &Options::disable_bwdh}, {"disable_bmm_heads", &Options::disable_bmm_heads},
-    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"disable_bwd8", &Options::disable_bwd8}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}, {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune},
-    {"disable_fwd32h", &Options::disable_fwd32h}};
+    {"disable_merged", &Options::disable_merged}, {"disable_fwd32h", &Options::disable_fwd32h}, {"disable_bmm_heads", &Options::disable_bmm_heads},
+    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg},
+    {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune}};
 Options& options() {
   static Options o = [] {
     Options v;
@@ -129,28 +128,29 @@ static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s)
 static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
   return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && !options().disable_loss_in_forward;
 }
-static bool save_qkv() { return !options().disable_qkv_save; }
-// Whether the forward that last ran on a workspace left its Q/K/V tiles there.  matcha_backward keys off THIS record, not off the
-// option: flipping disable_qkv_save between a forward and its backward (two separate calls on the autograd path) would otherwise
-// make the eight-wave backward consume tiles nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so
-// it cannot live in device memory without a synchronisation); bounded, guarded by a mutex.
-static std::mutex g_qkv_mu;
-static std::unordered_map<const void*, int> g_qkv_saved;     // bit 0: Q/K/V tiles saved; bit 1: the forward ran per HALF tile (fused_fwd32)
-static void note_qkv_saved(const void* ws, bool saved, bool halves, bool merged = false, bool img_half = false) {
-  std::lock_guard<std::mutex> lk(g_qkv_mu);
-  if (g_qkv_saved.size() > 4096) g_qkv_saved.clear();
-  // bit 2: the saved records are the merged heads' r rows; bit 3: one record per HALF tile (fused_bwdh_kernel) instead of per 64-row tile
-  g_qkv_saved[ws] = (saved ? 1 : 0) | (halves ? 2 : 0) | (merged ? 4 : 0) | (img_half ? 8 : 0);
+// Which formulation the forward that last ran on a workspace used.  matcha_backward keys off THIS record, not off the option: flipping
+// disable_merged between a forward and its backward (two separate calls on the autograd path) would otherwise make the merged backward
+// consume records nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so it cannot live in device memory
+// without a synchronisation); bounded, evicted oldest-first, guarded by a mutex.  A backward on a workspace WITHOUT a record is refused.
+static std::mutex g_fwd_mu;
+static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward
+static uint64_t g_fwd_clock = 0;
+static void note_forward(const void* ws, bool merged, bool fused) {
+  std::lock_guard<std::mutex> lk(g_fwd_mu);
+  if (g_fwd_state.size() >= 4096 && g_fwd_state.find(ws) == g_fwd_state.end()) {
+    auto old = g_fwd_state.begin();
+    for (auto it = g_fwd_state.begin(); it != g_fwd_state.end(); ++it)
+      if (it->second.second < old->second.second) old = it;
+    g_fwd_state.erase(old);
+  }
+  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0), ++g_fwd_clock);
 }
-static int ws_state(const void* ws) {
-  std::lock_guard<std::mutex> lk(g_qkv_mu);
-  auto it = g_qkv_saved.find(ws);
-  return it != g_qkv_saved.end() ? it->second : 0;
+static int ws_state(const void* ws) {       // -1: no forward on record for this workspace
+  std::lock_guard<std::mutex> lk(g_fwd_mu);
+  auto it = g_fwd_state.find(ws);
+  return it != g_fwd_state.end() ? it->second.first : -1;
 }
-static bool qkv_saved(const void* ws) { return (ws_state(ws) & 1) != 0; }
-static bool fwd_ran_halves(const void* ws) { return (ws_state(ws) & 2) != 0; }
-static bool fwd_ran_merged(const void* ws) { return (ws_state(ws) & 4) != 0; }
-static bool fwd_saved_half_records(const void* ws) { return (ws_state(ws) & 8) != 0; }
+static bool fwd_ran_merged(const void* ws) { return ws_state(ws) > 0 && (ws_state(ws) & 1) != 0; }
 
 // B_all[h d + a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b];   M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]   (16 small GEMMs)
 static int merged_weights(const matcha_shape& s, const matcha_tensors& p, Workspace& w, hipStream_t st) {
@@ -420,14 +420,13 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   // which fused kernels will run on this workspace (decided here: the plan, the front end and the saved records depend on it)
   const bool fused_path = !force_layerwise && fused_enabled(s) && (opts->forward_only || fused_train_enabled(s));
   const bool lif = fused_path && loss_in_forward(s, *opts, y, w_bce);      // the tail's backward runs in the forward kernel: nothing saved
-  const bool keep_qkv = !opts->forward_only && save_qkv();
-  const bool fwd32 = !options().disable_fwd32;                     // wave-independent forward (one wavefront per half tile)
-  // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities for fused_bwdh_kernel
-  const bool merged = fwd32 && !options().disable_merged;
-  const bool img_half = merged && !options().disable_bwdh;
+  // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities per (half tile, head) for
+  // fused_bwdh_kernel.  disable_merged: the reference's four products, nothing saved, the backward recomputes (fused_bwd_kernel).
+  const bool merged = !options().disable_merged;
+  const bool keep_qkv = !opts->forward_only && merged;
   // CSR plan: real tokens + one shared padding token; tile lists only for the kernels that will read them (the half-tile forward /
-  // backward pair needs neither the 64-row tiles nor the token -> tile map; a backward that recomputes Q/K/V walks 64-row tiles)
-  const int plan_level = !fused_enabled(s) ? 0 : ((fused_path && img_half && (opts->forward_only || keep_qkv)) ? 1 : 2);
+  // backward pair needs neither the 64-row tiles nor the token -> tile map; the recompute backward walks 64-row tiles)
+  const int plan_level = !fused_enabled(s) ? 0 : ((fused_path && (opts->forward_only || merged)) ? 1 : 2);
   MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st, plan_level));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
@@ -438,7 +437,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const bool adj_fused = front && fused_path && s.mode == 1 && adj_fused_eligible(s, *frozen);
   if (s.mode == 0) {
     MATCHA_CHECK_ARG(p.table, "matcha_forward: table mode without table");
-    if (recon_out && !recon_zero_in_loss && hipMemsetAsync(recon_out, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return MATCHA_EHIP; }
+    if (recon_out && !recon_zero_in_loss) MATCHA_TRY(zero_async(recon_out, 2 * sizeof(float), st));
   } else if (adj_fused) {
     MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, nullptr, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot,
                            opts->forward_only ? nullptr : w.x0, w.X, !opts->forward_only));
@@ -467,18 +466,12 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
-    note_qkv_saved(ws, keep_qkv, fwd32, merged, img_half);
-    if (fwd32) {
-      if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
-      MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
-      MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
-                                    lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                    lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr, merged, img_half));
-    } else {
-      MATCHA_TRY(launch_fused_fwd(p, w.folded, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
+    note_forward(ws, merged, true);
+    if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
+    MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
+    MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr));
-    }
+                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr, merged, merged));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -490,7 +483,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
   MATCHA_TRY(launch_ln3_fwd(w.X, Tn, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st, cnt));
   const bool mlw = merged_layerwise(s);
-  note_qkv_saved(ws, false, false, mlw);             // the backward pass on this workspace must use the same formulation
+  note_forward(ws, mlw, false);                      // the backward pass on this workspace must use the same formulation
   if (mlw) {
     MATCHA_TRY(merged_weights(s, p, w, st));
     GemmArgs g = gemm1(w, w.qin, w.lwB, w.Q, Tn, hd, d, false);                 // r = qin B_all^T  (in Q's buffer)
@@ -624,9 +617,10 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
 
   const bool lif = loss_in_forward(s, *opts, y, w_bce);
   MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
+  MATCHA_CHECK_ARG(ws_state(ws) >= 0, "matcha_backward: no matcha_forward on record for this workspace (one backward per forward, same ws pointer)");
   if (lif) {
     // ddyn0 and dXs were produced by matcha_forward; only the per-tile parameter-gradient partials remain to be summed
-    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, fwd_ran_halves(ws), w.tpart));
+    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart));       // one slab per half tile (fused_fwd32.hip)
   } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
@@ -656,13 +650,12 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // merged kernel: the eight heads add their d x_hat into ONE buffer with float atomics (they meet in L2; the per-head slabs are 8 x 256 B
     // per token written and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs
     // and their fixed summation order
-    const bool merged_bwd = qkv_saved(ws) && fwd_ran_merged(ws);
-    const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad && !options().disable_dx_atomic;
+    const bool merged_bwd = fwd_ran_merged(ws);
+    const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad;
     if (merged_bwd)
-      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic,
-                                         fwd_saved_half_records(ws)));
+      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic));
     else
-      MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, qkv_saved(ws) ? w.qkv : nullptr));
+      MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st));
     MATCHA_TRY(encoder_done(*opts, st));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
@@ -682,9 +675,8 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   if (fwd_ran_merged(ws)) {
     // merged heads: dM_all = ddyn0^T Z ; d fc1_b += colsum ; dZ = ddyn0 M_all   (the scratch gradients start from zero: the TN GEMM
     // accumulates C and the column sums alike, and fc1_b's gradient must accumulate)
-    if (hipMemsetAsync(w.lwdM, 0, (size_t)hd * d * sizeof(float), st) != hipSuccess || hipMemsetAsync(w.lwdB, 0, (size_t)hd * d * sizeof(float), st) != hipSuccess) {
-      set_error("matcha_backward: memset failed"); return MATCHA_EHIP;
-    }
+    MATCHA_TRY(zero_async(w.lwdM, (size_t)hd * d * sizeof(float), st));
+    MATCHA_TRY(zero_async(w.lwdB, (size_t)hd * d * sizeof(float), st));
     MATCHA_TRY(launch_gemm_tn(w.ddyn0, w.O, w.lwdM, g_.fc1_b, d, hd, Tn, d, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));
     {
       GemmArgs g = gemm1(w, w.ddyn0, w.lwM, w.dO, Tn, hd, d, true);

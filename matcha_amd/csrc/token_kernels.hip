@@ -719,6 +719,23 @@ int launch_expand_embedding(const int64_t* x, int64_t B, int L, int d, const int
   return MATCHA_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n && (reinterpret_cast<uintptr_t>(p + i4) & 15) == 0) {
+    *reinterpret_cast<float4*>(p + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int64_t i = i4; i < n && i < i4 + 4; ++i) p[i] = 0.f;
+  }
+}
+int zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return MATCHA_OK;
+  MATCHA_CHECK_ARG(p && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, "zero_async: unaligned buffer");
+  const int64_t n = (int64_t)(bytes / 4);
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, (float*)p, n);
+  MATCHA_CHECK_LAUNCH("zero_f32_kernel");
+  return MATCHA_OK;
+}
+
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
   if (n <= 0) return MATCHA_OK;
   hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, p, n, v);

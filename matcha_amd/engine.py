@@ -15,6 +15,7 @@ batch because the loss is a mean over rows (main.py:56).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -88,6 +89,8 @@ class Trainer:
         key = (B, L)
         if key not in self._ws:
             self._ws[key] = self.rt.workspace(B, L)
+            if os.environ.get("MATCHA_POISON_WS"):       # development: a read of workspace bytes nobody wrote shows up as NaN / garbage
+                self._ws[key].fill_(0xFF if os.environ["MATCHA_POISON_WS"] == "nan" else 0x5B)
             self._logits[key] = torch.empty(B, dtype=torch.float32, device=self.rt.device)
         return self._ws[key], self._logits[key]
 

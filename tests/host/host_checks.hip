@@ -183,8 +183,8 @@ static void check_entry_point_errors() {
 static void check_options() {
   CHECK(matcha_get_option("disable_fused") == 0 && matcha_get_option("no_such_option") == -1 && matcha_get_option(nullptr) == -1);
   CHECK(matcha_set_option("no_such_option", 1) == MATCHA_EINVAL && matcha_set_option(nullptr, 1) == MATCHA_EINVAL);
-  CHECK(matcha_set_option("disable_qkv_save", 1) == MATCHA_OK && matcha_get_option("disable_qkv_save") == 1);
-  CHECK(matcha_set_option("disable_qkv_save", 0) == MATCHA_OK && matcha_get_option("disable_qkv_save") == 0);
+  CHECK(matcha_set_option("disable_merged", 1) == MATCHA_OK && matcha_get_option("disable_merged") == 1);
+  CHECK(matcha_set_option("disable_merged", 0) == MATCHA_OK && matcha_get_option("disable_merged") == 0);
   // MATCHA_FUSED_DBG=3 was exported by the test before this process started: the environment is read once, at first use
   CHECK(matcha_get_option("fused_dbg") == 3);
   matcha_shape s = shape(64, 24, 3067, 0, 0, 0);

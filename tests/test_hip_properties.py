@@ -397,15 +397,13 @@ def test_fused_front_end_matches_separate_kernels(mode):
 @pytest.mark.parametrize("mode", ["table", "adj"])
 @pytest.mark.parametrize("ks", [[2, 3, 4, 5], [8, 3], [2], [3], [2, 4], [6, 3]])
 def test_saved_tiles_backward_matches_recompute(mode, ks):
-    """d = 64 training step, every backward kernel on the same weights, dropout seed and batch.  Four-product heads (option
-    disable_merged, the reference's formulation: Q, K, V, fc1 per head): (0) the four-wave kernel recomputing Q/K/V and the softmax
-    (disable_qkv_save), (1) the eight-wave kernel fed by the tiles and probabilities the training forward saved (fused_bwd8_kernel),
-    (2) the four-wave kernel fed by the same saved tiles (disable_bwd8).  Merged heads (the default: B_h = W'k^T W'q, M_h = Wfc1_h
-    W'v -- two products per head forward, four backward): (3) fused_bwdh_kernel (four wavefronts per half tile, heads summed with float
-    atomics) fed by the r rows and probabilities of the merged forward, (4) the merged forward in front of the recompute kernel
-    (disable_qkv_save), (5) fused_bwdm_kernel (eight wavefronts per 64-row tile: disable_bwdh), (6) fused_bwdh_kernel with one d x_hat
-    slab per head (disable_dx_atomic).  Batch widths L = 2, 3, 4, 5, 6, 8 cover every template instance.  The workspace keeps its size
-    in all cases, so one Trainer per case."""
+    """d = 64 training step, every backward kernel on the same weights, dropout seed and batch.  (0) the REFERENCE formulation (option
+    disable_merged: Q, K, V, fc1 per head; fused_bwd_kernel recomputes Q / K / V and the softmax from X) against the merged heads
+    (the default: B_h = W'k^T W'q, M_h = Wfc1_h W'v -- two products per head forward, four backward; fused_bwdh_kernel on the
+    forward's half tiles, fed by the r rows and probabilities the training forward saved): (1) the heads' d x_hat summed with float
+    atomics, (2) one d x_hat slab per head, summed in a fixed order (Trainer(deterministic=True)).  Batch widths L = 2, 3, 4, 5, 6, 8
+    cover every template instance.  (Rounds 2-3 carried four more variants -- an eight-wave four-product kernel on saved Q / K / V
+    tiles, the merged kernel on 64-row tiles ...: pruned in round 4, DESIGN.md.)"""
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS["hg38_1mb"]
     N = int(np.sum(num))
@@ -414,11 +412,10 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
     y = (torch.rand(len(x), device="cuda") < 0.3).float()
     w = torch.rand(len(x), device="cuda") + 0.5
     res = []
-    for options in (("disable_merged", "disable_qkv_save"), ("disable_merged",), ("disable_merged", "disable_bwd8"), (), ("disable_qkv_save",),
-                    ("disable_bwdh",), ("disable_dx_atomic",)):
+    for options, det in ((("disable_merged",), False), ((), False), ((), True)):
         clf, _ = hip_model(num, 64, mode, 41)
         clf.train(True)
-        tr = Trainer(clf, base_seed=8)
+        tr = Trainer(clf, base_seed=8, deterministic=det)
         # (this test is about the BACKWARD kernels: the single-wave forward in every case, so that "same formulation" means bitwise equal
         # logits -- small batches would otherwise take the head-parallel forward wherever the records allow it, which rounds differently;
         # test_head_parallel_small_batch_forward_matches_the_single_wave_forward compares the two forwards)
@@ -432,9 +429,8 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
                 _lib.set_option(o, 0)
         res.append((logits.clone(), tr.gflat.clone()))
     # the forward pass computes the same thing whatever the backward will be: bitwise within a formulation, to rounding across them
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[1][0], res[2][0]) and torch.equal(res[3][0], res[4][0])
-    assert torch.equal(res[3][0], res[5][0]) and torch.equal(res[3][0], res[6][0])
-    assert float((res[3][0] - res[0][0]).abs().max()) <= 2e-5 * max(1.0, float(res[0][0].abs().max()))
+    assert torch.equal(res[1][0], res[2][0])
+    assert float((res[1][0] - res[0][0]).abs().max()) <= 2e-5 * max(1.0, float(res[0][0].abs().max()))
     g0 = res[0][1]
     assert float(g0.abs().max()) > 0
     clf, _ = hip_model(num, 64, mode, 41)
@@ -445,7 +441,7 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
             continue
         a = g0[o:o + p.numel()]
         scale = max(float(a.abs().max()), 1e-6)
-        for which in (1, 2, 3, 4, 5, 6):
+        for which in (1, 2):
             b = res[which][1][o:o + p.numel()]
             assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (n, which, float((a - b).abs().max()), scale)
     # the K bias (cq . k_j is constant over the keys of a query) has NO gradient: the merged backward returns exact zeros where the
@@ -453,7 +449,7 @@ def test_saved_tiles_backward_matches_recompute(mode, ks):
     for n, p in clf.named_parameters():
         if n == GAUGE:
             o = (p.data_ptr() - rt.flat.data_ptr()) // 4
-            assert float(res[3][1][o:o + p.numel()].abs().max()) <= 1e-12
+            assert float(res[1][1][o:o + p.numel()].abs().max()) <= 1e-12
 
 
 @pytest.mark.parametrize("mode", ["table", "adj"])
@@ -656,7 +652,7 @@ def test_trainer_step_with_empty_rows_half_tile_backward():
     y = (torch.rand(len(x), device="cuda") < 0.3).float()
     w = torch.rand(len(x), device="cuda") + 0.5
     res = []
-    for options in ((), ("disable_merged", "disable_qkv_save"), ("disable_fused",)):
+    for options in ((), ("disable_merged",), ("disable_fused",)):
         clf, _ = hip_model(num, 64, "table", 9)
         clf.train(True)
         tr = Trainer(clf, base_seed=3)

@@ -30,6 +30,6 @@ for name, layout, seed, mode in (("c23_table_d64", "c23", 44, "table"), ("c1_tab
     for ps in (0, 1, 2):
         e, pn = oracle_self_noise(name, layout, 64, mode, seed, 1.0, 0.001, "phase2", 10, perm_seed=ps)
         print(f"{name:16s} oracle perm{ps}  ", " ".join(f"{v:.1e}" for v in e), " max param noise %.1e" % max(pn.values()))
-    for tag, opts in (("merged", {}), ("4-product", {"disable_merged": 1}), ("old fwd", {"disable_fwd32": 1}), ("layerwise", {"disable_fused": 1})):
+    for tag, opts in (("merged", {}), ("4-product", {"disable_merged": 1}), ("layerwise", {"disable_fused": 1})):
         e = run(name, layout, seed, mode, opts)
         print(f"{name:16s} {tag:13s}", " ".join(f"{v:.1e}" for v in e))
