@@ -197,6 +197,7 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
     clf.train()                                                           # dropout ON, as in the reference's training step
     trainer = Trainer(clf, lr=1e-3, base_seed=99, table_exchange=table_exchange, deterministic=deterministic)
     trainer.force_collectives = dist.launched and world == 1       # 1-rank torchrun: still go through RCCL
+    trainer.time_collectives = world > 1 or dist.launched           # HIP events around every collective: the first multi-GPU run diagnoses itself
 
     x = torch.zeros((B, L), dtype=torch.long, device=device)
     y = torch.cat([torch.ones(P, device=device), torch.zeros(B - P, device=device)])      # main.py:444-445
@@ -326,7 +327,8 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
                         with open(mf) as fh2:
                             mm = json.load(fh2)
                         if mm.get("csrc_sha16") == csrc_sha16():
-                            roof["mfma_util_pmc"] = mm.get("classes", {}).get(prof_cls, {}).get("mfma_util")
+                            mu = mm.get("kernels", {}).get(prof_cls, {}).get("MfmaUtil_percent")
+                            roof["mfma_util_pmc"] = None if mu is None else round(mu / 100.0, 4)
                     break
             except (OSError, ValueError, KeyError):
                 pass
@@ -343,6 +345,18 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
         dist.barrier()
         model_only_ms = (time.perf_counter() - t1) / k2 * 1e3
     trainer.check_status()
+    coll = {}
+    if trainer.time_collectives:
+        # per-collective time on this rank (mean over the calls of the timed windows) and what every rank saw of the process group
+        mine = {k: float(np.mean(v)) * 1e3 for k, v in trainer.collective_ms().items()}
+        names = sorted(mine)
+        t = torch.tensor([mine[k] for k in names] + [float(torch.distributed.get_world_size()), float(torch.cuda.current_device())],
+                         dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allr, t)
+        coll = {"collective_us_per_call_by_rank": {k: [round(float(a[i]), 1) for a in allr] for i, k in enumerate(names)},
+                "world_size_seen_by_rank": [int(a[len(names)]) for a in allr], "device_by_rank": [int(a[len(names) + 1]) for a in allr],
+                "backend": torch.distributed.get_backend()}
     exhausted = sampler.check_status()
     losses = trainer.losses.cpu().tolist()
     # every MFMA- / HBM-bound kernel class against its roofline, from the same two-step measurement that picked the dominant one
@@ -365,7 +379,8 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
     out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, windows=win, roof=roof, roof_all=roof_all, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
                pool=pool, wts=None if pool is None else wts, num=num, known_edges=workload_edges, sparse_exchange=bool(trainer._sparse),
-               exhausted_negatives=exhausted, comm_bytes=dict(trainer.comm_bytes), overlap=bool(trainer._side is not None and trainer._overlap()))
+               exhausted_negatives=exhausted, comm_bytes=dict(trainer.comm_bytes), overlap=bool(trainer._side is not None and trainer._overlap()),
+               collectives=coll)
     del trainer, clf, sampler, hset, pool_all
     gc.collect()
     torch.cuda.empty_cache()
@@ -563,7 +578,7 @@ def main():
                    "embedding_backward": "sorted, one writer per row (bitwise reproducible)" if args.deterministic else "float atomics",
                    # bytes each collective of one step moves per rank (payload; a ring all-reduce sends and receives 2 (N-1)/N of it,
                    # the all-gather receives what is listed), and whether the encoder part overlaps the front-end backward
-                   "collective_payload_bytes_per_step": m["comm_bytes"], "exchange_overlapped": m["overlap"]},
+                   "collective_payload_bytes_per_step": m["comm_bytes"], "exchange_overlapped": m["overlap"], "collectives": m["collectives"]},
         "positives_per_s": round(P * world * args.steps / elapsed, 1),
         "last_bce": round(m["losses"][0], 5),
         "model_step_only": None if m["model_only_ms"] is None else {"ms_per_step": round(m["model_only_ms"], 4),

@@ -109,6 +109,7 @@ struct Options {
   int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward;
   int disable_merged;     // the reference formulation of the heads (four products per head, recompute backward): the A/B variant
   int disable_fwd32h;     // small batches: one wavefront per half tile (fused_fwd32_kernel) instead of eight, one per head
+  int disable_plan_small; // small batches: the ragged plan as five launches instead of one
   int disable_wide_gemm, disable_bmm_heads;
   int debug_nan, fused_dbg, fwd_lds_pad;
   int tune;       // development: a free integer read by whatever kernel is being tuned (0 = defaults)

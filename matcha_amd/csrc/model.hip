@@ -98,7 +98,7 @@ struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
     {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
     {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
-    {"disable_merged", &Options::disable_merged}, {"disable_fwd32h", &Options::disable_fwd32h}, {"disable_bmm_heads", &Options::disable_bmm_heads},
+    {"disable_merged", &Options::disable_merged}, {"disable_fwd32h", &Options::disable_fwd32h}, {"disable_plan_small", &Options::disable_plan_small}, {"disable_bmm_heads", &Options::disable_bmm_heads},
     {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg},
     {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune}};
 Options& options() {

@@ -171,21 +171,14 @@ constexpr int kFullTok = 63;
 constexpr int kHalfTok = 31;
 constexpr int kSuperTok = 63 * 32;
 
-// blockIdx.y = 0: tiles of <= 63 tokens; 1: half tiles of <= 31 tokens (same superblocks, own lists)
-__global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb0, int cap_per_sb1,
-                                                       const int32_t* __restrict__ sb_first, int32_t* __restrict__ sb_tiles0,
-                                                       int32_t* __restrict__ sb_cnt0, int32_t* __restrict__ sb_tiles1, int32_t* __restrict__ sb_cnt1, int y0) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const bool half = (int)blockIdx.y + y0 != 0;
+// one wavefront packs superblock s of one list (half = the <= 31-token list); returns the number of tiles written to out[0 .. cap_per_sb)
+__device__ __forceinline__ int tile_pack_wave(const int32_t* __restrict__ row_off, int64_t B, int nsb, int s, bool half, int cap_per_sb,
+                                              const int32_t* __restrict__ sb_first, int4* __restrict__ out, int lane) {
   const int kTileTok = half ? kHalfTok : kFullTok;
-  const int cap_per_sb = half ? cap_per_sb1 : cap_per_sb0;
-  int32_t* sb_tiles = half ? sb_tiles1 : sb_tiles0;
-  int32_t* sb_cnt = half ? sb_cnt1 : sb_cnt0;
-  const int b_lo = sb_first[s];                        // marked by row_fill_kernel (B: nothing starts here)
+  const int b_lo = sb_first[s];                        // marked by the fill pass (B: nothing starts here)
   int b_hi = (int)B;
   for (int q = s + 1; q < nsb; ++q)                    // next superblock that has a first hyperedge (normally s + 1)
     if (sb_first[q] < (int)B) { b_hi = sb_first[q]; break; }
-  int4* out = reinterpret_cast<int4*>(sb_tiles) + (int64_t)s * cap_per_sb;
   int nt = 0;
   if (b_lo < b_hi) {
     int tile_b0 = b_lo;
@@ -210,7 +203,20 @@ __global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict
     if (lane == 0 && nt < cap_per_sb) out[nt] = make_int4(tile_tok0, end - tile_tok0, tile_b0, b_hi - tile_b0);
     ++nt;
   }
-  if (lane == 0) sb_cnt[s] = nt < cap_per_sb ? nt : cap_per_sb;
+  return nt < cap_per_sb ? nt : cap_per_sb;
+}
+
+// blockIdx.y = 0: tiles of <= 63 tokens; 1: half tiles of <= 31 tokens (same superblocks, own lists)
+__global__ __launch_bounds__(64) void tile_pack_kernel(const int32_t* __restrict__ row_off, int64_t B, int nsb, int cap_per_sb0, int cap_per_sb1,
+                                                       const int32_t* __restrict__ sb_first, int32_t* __restrict__ sb_tiles0,
+                                                       int32_t* __restrict__ sb_cnt0, int32_t* __restrict__ sb_tiles1, int32_t* __restrict__ sb_cnt1, int y0) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const bool half = (int)blockIdx.y + y0 != 0;
+  const int cap_per_sb = half ? cap_per_sb1 : cap_per_sb0;
+  int32_t* sb_tiles = half ? sb_tiles1 : sb_tiles0;
+  int32_t* sb_cnt = half ? sb_cnt1 : sb_cnt0;
+  const int nt = tile_pack_wave(row_off, B, nsb, s, half, cap_per_sb, sb_first, reinterpret_cast<int4*>(sb_tiles) + (int64_t)s * cap_per_sb, lane);
+  if (lane == 0) sb_cnt[s] = nt;
 }
 
 // exclusive scan of the superblock tile counts (one block, 1024 counts per pass), compaction, zero fill; count[2] = tiles
@@ -279,6 +285,116 @@ __global__ __launch_bounds__(64) void tok_tile_kernel(const int32_t* __restrict_
   if ((int)threadIdx.x < m.y) tok_tile[m.x + threadIdx.x] = (int32_t)((blockIdx.x << 6) | threadIdx.x);
 }
 
+// ---- the whole plan in ONE launch for small batches (B <= 1024 rows, <= 8 planning superblocks: the reference's own 384-row step) ------------
+// The five kernels above are five dependent launches of a few microseconds each -- at 384 rows a tenth of the step (main.py:527-528).  Here
+// one workgroup of 1024 threads does the same work in the same order and writes the SAME plan bit for bit (tests/test_hip_kernels.py compares
+// both paths with oracle/c/ragged_plan.c): thread b owns hyperedge b (count, block scan, token lists), wavefronts pack the superblocks of the
+// two lists side by side, the lists are compacted by offset, the token -> tile map follows.
+constexpr int kSmallRows = 1024;
+constexpr int kSmallSb = 8;
+struct PlanSmallArgs {
+  const int64_t* x; int64_t B; int L; int64_t n_nodes; int32_t* status;
+  int32_t *row_off, *tok_slot; int64_t* tok_id; int32_t *tok_pos, *tok_key, *count, *sb_first;
+  int nsb, level;
+  int32_t* sb_tiles[2]; int cap_per_sb[2]; int ntiles_cap[2]; int32_t* meta[2];
+  int32_t* tok_tile;
+};
+__global__ __launch_bounds__(1024) void plan_small_kernel(PlanSmallArgs a) {
+  __shared__ int wtot[16];
+  __shared__ int sbf[kSmallSb + 1];
+  __shared__ int cnt[2][kSmallSb];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = a.L;
+  const int64_t B = a.B;
+  const bool on = tid < B;
+  int64_t v[MATCHA_MAX_L];
+  int k = 0;
+#pragma unroll
+  for (int l = 0; l < MATCHA_MAX_L; ++l) {
+    v[l] = (on && l < L) ? a.x[(int64_t)tid * L + l] : 0;
+    k += v[l] != 0 ? 1 : 0;
+  }
+  if (tid <= a.nsb && tid <= kSmallSb) sbf[tid] = (int)B;              // superblocks in which no hyperedge starts: empty range
+  int incl = k;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < 16; ++w2) { const int t = wtot[w2]; if (w2 < wave) wbase += t; total += t; }
+  int pos = wbase + incl - k;
+  const int kprev = __shfl_up(k, 1, 64);
+  int kp = lane > 0 ? kprev : 0;
+  // (the row in front of a wave's first row: its k through LDS)
+  __shared__ int klast[16];
+  if (lane == 63) klast[wave] = k;
+  __syncthreads();
+  if (lane == 0 && wave > 0) kp = klast[wave - 1];
+  if (on) {
+    a.row_off[tid] = pos;
+    if (tid == 0 || pos / kSuperTok != (pos - kp) / kSuperTok) sbf[pos / kSuperTok] = tid;
+    int nth = 0, p = pos;
+#pragma unroll
+    for (int l = 0; l < MATCHA_MAX_L; ++l) {
+      int64_t id = v[l];
+      if (id != 0) {
+        if (id < 0 || id > a.n_nodes) {                  // the reference raises IndexError here (nn.Embedding, Modules.py:34)
+          if (a.status) atomicOr(a.status, MATCHA_STATUS_BAD_ID);
+          id = 0;
+        }
+        a.tok_slot[p] = (int32_t)(tid * L + l); a.tok_id[p] = id; a.tok_key[p] = (int32_t)id; a.tok_pos[p] = nth | (k << 8); ++p; ++nth;
+      }
+    }
+  }
+  if (tid == 0) {
+    a.row_off[B] = total;
+    a.tok_slot[total] = (int32_t)(B * L);
+    a.tok_id[total] = 0;
+    a.tok_pos[total] = 0;
+    a.count[0] = total + 1;
+    a.count[1] = total;
+    if (a.level <= 0) { a.count[2] = 0; a.count[3] = 0; }
+  }
+  for (int64_t i = total + tid; i < B * L + 1; i += 1024) a.tok_key[i] = 0;
+  __syncthreads();                                       // row_off (global) and sbf (LDS) are complete
+  if (tid <= a.nsb) a.sb_first[tid] = sbf[tid < kSmallSb ? tid : kSmallSb];
+  if (a.level <= 0) return;
+  const int first = a.level >= 2 ? 0 : 1;                // list 0: 64-row tiles, list 1: half tiles
+  for (int task = wave; task < a.nsb * (2 - first); task += 16) {
+    const int which = first + task / a.nsb, sb = task - (task / a.nsb) * a.nsb;
+    const int nt = tile_pack_wave(a.row_off, B, a.nsb, sb, which != 0, a.cap_per_sb[which], sbf,
+                                  reinterpret_cast<int4*>(a.sb_tiles[which]) + (int64_t)sb * a.cap_per_sb[which], lane);
+    if (lane == 0) cnt[which][sb] = nt;
+  }
+  __syncthreads();                                       // the per-superblock lists (global scratch) and their counts
+  for (int which = first; which < 2; ++which) {
+    int off[kSmallSb + 1];
+    int run = 0;
+    for (int sb = 0; sb < a.nsb; ++sb) { off[sb] = run; run += cnt[which][sb]; }
+    const int tot = run < a.ntiles_cap[which] ? run : a.ntiles_cap[which];
+    if (tid == 0) a.count[2 + which] = tot;
+    const int4* src = reinterpret_cast<const int4*>(a.sb_tiles[which]);
+    int4* dst = reinterpret_cast<int4*>(a.meta[which]);
+    for (int sb = wave; sb < a.nsb; sb += 16)
+      for (int j = lane; j < cnt[which][sb]; j += 64)
+        if (off[sb] + j < a.ntiles_cap[which]) dst[off[sb] + j] = src[(int64_t)sb * a.cap_per_sb[which] + j];
+    for (int i = tot + tid; i < a.ntiles_cap[which] + 2; i += 1024) dst[i] = make_int4(0, 0, 0, 0);
+  }
+  if (first != 0 && tid == 0) a.count[2] = 0;            // half tiles only: no 64-row tile list this time
+  if (a.level >= 2) {
+    __syncthreads();                                     // tile_meta complete
+    const int4* tm = reinterpret_cast<const int4*>(a.meta[0]);
+    for (int t = wave; t < a.ntiles_cap[0]; t += 16) {
+      const int4 m = tm[t];
+      if (lane < m.y) a.tok_tile[m.x + lane] = (int32_t)((t << 6) | lane);
+    }
+  }
+}
+
 static inline int super_blocks(int64_t T) { return (int)cdiv(T + 1, kSuperTok); }
 static inline int super_cap(int L) { return (int)cdiv(kSuperTok + L, 64 - L) + 2; }
 static inline int tiles_cap(int64_t T, int L) { return (int)cdiv(T + 1, 64 - L) + super_blocks(T); }   // every tile but a superblock's last holds > 63 - L tokens
@@ -339,6 +455,18 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
 // level 2: everything; 1: no 64-row tile list and no token -> tile map (the fused kernels that run work on half tiles only); 0: rows and
 // tokens only (no fused kernel will read a tile list)
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st, int level) {
+  if (B <= kSmallRows && r.nsb <= kSmallSb && !options().disable_plan_small) {
+    PlanSmallArgs a;
+    a.x = x; a.B = B; a.L = L; a.n_nodes = n_nodes; a.status = status;
+    a.row_off = r.row_off; a.tok_slot = r.tok_slot; a.tok_id = r.tok_id; a.tok_pos = r.tok_pos; a.tok_key = r.tok_key; a.count = r.count; a.sb_first = r.sb_first;
+    a.nsb = r.nsb; a.level = level;
+    a.sb_tiles[0] = r.sb_tiles; a.cap_per_sb[0] = r.sb_cap; a.ntiles_cap[0] = r.ntiles; a.meta[0] = r.tile_meta;
+    a.sb_tiles[1] = r.sb_htiles; a.cap_per_sb[1] = r.sb_hcap; a.ntiles_cap[1] = r.nhalves; a.meta[1] = r.half_meta;
+    a.tok_tile = r.tok_tile;
+    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, st, a);
+    MATCHA_CHECK_LAUNCH("plan_small_kernel");
+    return MATCHA_OK;
+  }
   hipLaunchKernelGGL(row_count_kernel, dim3(r.nblk), dim3(256), 0, st, x, B, L, r.blk_sum);
   MATCHA_CHECK_LAUNCH("row_count_kernel");
   hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, r.blk_sum, r.nblk, r.count, r.sb_first, r.nsb, (int32_t)B);

@@ -131,8 +131,11 @@ class Trainer:
         self.rt.check_status("Trainer.step")
 
     # ---- one step -------------------------------------------------------------------------------------
-    def forward_backward(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0):
-        """forward + backward into the flat gradient buffer (accumulating).  x int64 [B,L]; y, w float [B] or [B,1]."""
+    def forward_backward(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0, max_tokens: Optional[int] = None):
+        """forward + backward into the flat gradient buffer (accumulating).  x int64 [B,L]; y, w float [B] or [B,1].
+        ``max_tokens`` (row-sparse exchange): the largest number of real tokens (x != 0) any rank holds this step, when the caller knows
+        it on the host -- every rank must pass the same value -- so that the lists travel compacted WITHOUT the device-side count
+        exchange and its host wait (all_reduce).  The driver knows it: every rank holds the whole global batch on the host."""
         rt = self.rt
         if not rt.still_packed():
             raise _lib.MatchaHipError("model parameters moved after the Trainer was built; create a new Trainer")
@@ -143,6 +146,7 @@ class Trainer:
         opts = self._opts(alpha, beta, random_chrom)
         st = rt.stream()
         self.comm_bytes = {}
+        self._host_max_tokens = None if max_tokens is None else int(max_tokens)
         self._begin_exchange(x)
         overlap = self._overlap()
         if overlap:
@@ -192,7 +196,7 @@ class Trainer:
         if not (self.world > 1 or self.force_collectives):
             return
         self._exchange_setup()
-        if self._sparse and self.compact_exchange:
+        if self._sparse and self.compact_exchange and self._host_max_tokens is None:
             main = torch.cuda.current_stream(self.rt.device)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
@@ -215,6 +219,27 @@ class Trainer:
             self._enc_work = torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
         self.comm_bytes["encoder_allreduce"] = 4 * (rt.n_flat - self._n_enc_off)
 
+    def _timed(self, name: str, fn):
+        """bench.py --gpus N: HIP events around one collective on the stream it runs on (self.time_collectives); read back with
+        collective_ms() after a synchronisation."""
+        if not getattr(self, "time_collectives", False):
+            return fn()
+        st = torch.cuda.current_stream(self.rt.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = fn()
+        e1.record(st)
+        self.__dict__.setdefault("_coll_events", []).append((name, e0, e1))
+        return out
+
+    def collective_ms(self):
+        """{collective: [ms per call]} of the timed collectives since the last call (synchronises)."""
+        torch.cuda.synchronize(self.rt.device)
+        out = {}
+        for name, e0, e1 in self.__dict__.pop("_coll_events", []):
+            out.setdefault(name, []).append(e0.elapsed_time(e1))
+        return out
+
     def all_reduce(self):
         """Gradient exchange of one step (matcha_amd/parallel.py).  Dense: the flat bucket [gradients | touched flags] in ONE RCCL
         all-reduce -- or, with the table front end, in two parts: the encoder tail already in flight on the side stream
@@ -230,13 +255,13 @@ class Trainer:
             # table mode: both touched flags are set by every rank's backward -- nothing to exchange behind the gradients
             front = self.gflat[lo:self._n_enc_off]
             if front.numel():
-                torch.distributed.all_reduce(front, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self._timed("front_allreduce", lambda: torch.distributed.all_reduce(front, op=torch.distributed.ReduceOp.SUM, group=self.pg))
             self.comm_bytes["front_allreduce"] = 4 * front.numel()
             self._enc_work.wait()                                          # main stream waits for the side stream's collective
             torch.cuda.current_stream(dev).wait_stream(self._side)
             self._enc_work = None
         else:
-            allreduce_bucket(self.gbuf[lo:], rt.n_flat - lo, self.touched, self.pg, force=self.force_collectives)
+            self._timed("bucket_allreduce", lambda: allreduce_bucket(self.gbuf[lo:], rt.n_flat - lo, self.touched, self.pg, force=self.force_collectives))
             self.comm_bytes["bucket_allreduce"] = 4 * (rt.n_flat - lo + self._n_touched)
         if not self._sparse:
             return
@@ -247,8 +272,12 @@ class Trainer:
                                                    C.byref(p_n), C.byref(cap)), "matcha_table_grad_rows")
         cap, d, base = int(cap.value), rt.d, ws.data_ptr()
         n_send = cap
-        if self.compact_exchange:
-            self._cnt_event.synchronize()                                  # counts were gathered while forward + backward ran
+        if self.compact_exchange and self._host_max_tokens is not None:
+            n_send = min(cap, (self._host_max_tokens + 1 + 63) // 64 * 64)        # the caller knew the count: no device read-back, no host wait
+        elif self.compact_exchange:
+            # the ranks' counts were all-gathered on the side stream at the start of the step; the host waits for that 4-byte copy -- i.e.
+            # it cannot run more than one step ahead of the GPU in this mode (pass max_tokens to avoid it)
+            self._cnt_event.synchronize()
             n_send = min(cap, (int(self._cnt_host.max()) + 1 + 63) // 64 * 64)   # real tokens of the fullest rank + the padding token
         ids = ws[p_ids.value - base:p_ids.value - base + 4 * n_send].view(torch.int32)
         rows = ws[p_rows.value - base:p_rows.value - base + 4 * n_send * d].view(torch.float32).view(n_send, d)
@@ -259,7 +288,7 @@ class Trainer:
                               torch.empty(self.lib.matcha_scatter_rows_workspace_bytes(world * cap, d, rt.n_nodes), dtype=torch.uint8, device=dev))
         ids_buf, rows_buf, xws = self._xws[key]
         n = self.world * n_send
-        ids_all, rows_all = exchange_table_rows(ids, rows, self.pg, out=(ids_buf[:n], rows_buf[:n * d].view(n, d)))
+        ids_all, rows_all = self._timed("table_rows_allgather", lambda: exchange_table_rows(ids, rows, self.pg, out=(ids_buf[:n], rows_buf[:n * d].view(n, d))))
         self.comm_bytes["table_rows_allgather"] = 4 * (self.world - 1) * n_send * (d + 1)
         self.comm_bytes["table_rows_fill"] = n_send / cap
         _lib.check(self.lib.matcha_scatter_rows(_lib.ptr(ids_all), _lib.ptr(rows_all), n, d, rt.n_nodes, _lib.ptr(self.gflat), _lib.ptr(xws),
@@ -272,14 +301,14 @@ class Trainer:
                                               _lib.ptr(self.seg_step), _lib.ptr(self.seg_coef), self.lr, self.betas[0], self.betas[1],
                                               self.eps, self.wd, 1.0 / self.world, rt.stream()), "matcha_adamw_step")
 
-    def step(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0):
+    def step(self, x, y, w, alpha=1.0, beta=0.001, random_chrom=0, max_tokens: Optional[int] = None):
         """One optimisation step.  Returns device tensors (bce [scalar view], recon [1], logits [B]); nothing syncs.
         ``random_chrom``: the chromosome of the reconstruction branch (Modules.py:192) as an int, or as a one-element int32 device
         tensor the kernels read when they run (what a captured step needs, ``capture``)."""
         x = x.contiguous()
         y = y.reshape(-1).contiguous()
         w = w.reshape(-1).contiguous()
-        logits = self.forward_backward(x, y, w, alpha, beta, random_chrom)
+        logits = self.forward_backward(x, y, w, alpha, beta, random_chrom, max_tokens=max_tokens)
         self.all_reduce()
         self.optimizer_step()
         return self.losses[0], self.losses[1:2], logits

@@ -234,11 +234,18 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
     model.train()
     e = torch.from_numpy(edges).to(dev)
     w = torch.from_numpy(weights.astype(np.float32)).to(dev)
-    perm = torch.from_numpy(np.random.permutation(len(e))).to(dev)              # sync_shuffle, utils.py:142-149 (rank-shared stream)
+    perm_host = np.random.permutation(len(e))                                    # sync_shuffle, utils.py:142-149 (rank-shared stream)
+    perm = torch.from_numpy(perm_host).to(dev)
     e, w = e[perm], w[perm]
     gb = batch_size * sess.world                                                # global batch: every rank steps on batch_size positives
     n_batch = len(e) // gb
     mine = torch.from_numpy(shard_rows(gb, sess.rank, sess.world)).to(dev)      # this rank's rows of a global batch (strided)
+    # data parallel: every rank holds the epoch's whole (shuffled) positive list on the host, a negative has the size of its positive, so
+    # the largest token count of any rank in step i is host arithmetic -- the row-sparse exchange then needs no device-side count
+    tok_max = None
+    if sess.world > 1:
+        k_host = (edges != 0).sum(1)[perm_host][:n_batch * gb].reshape(n_batch, batch_size, sess.world)        # [step, row, rank]: strided shards
+        tok_max = ((1 + NEG_NUM) * k_host.sum(1).max(1)).tolist()
     tm = sess.__dict__.setdefault("timing", {})          # wall clock of the epoch's phases (tools/epoch_bench.py reads it)
     t_loop = time.perf_counter()
     if n_batch > 0 and sess.graph_ok(beta):
@@ -252,7 +259,8 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
     for i in range(n_batch):
         pos, pw = e[i * gb:(i + 1) * gb][mine], w[i * gb:(i + 1) * gb][mine]
         x, y, ww, s = sess.make_batch(pos, pw)
-        bce, recon, logits = sess.trainer.step(x, y, ww, alpha=alpha, beta=beta, random_chrom=sess.random_chrom())
+        bce, recon, logits = sess.trainer.step(x, y, ww, alpha=alpha, beta=beta, random_chrom=sess.random_chrom(),
+                                               max_tokens=None if tok_max is None else tok_max[i])
         bce_sum += bce
         rec_sum += recon[0]
         sess.__dict__.setdefault("_rec_steps", []).append(recon.clone())

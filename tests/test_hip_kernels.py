@@ -304,14 +304,20 @@ def _oracle_lib():
     return C.CDLL(path)
 
 
-@pytest.mark.parametrize("B,L,ks,bad", [(1, 1, [1], False), (7, 3, [0, 1, 3], False), (4096, 5, [2, 3, 4, 5], False), (65536, 5, [2, 3, 4, 5], False),
+@pytest.mark.parametrize("five_launches", [False, True])
+@pytest.mark.parametrize("B,L,ks,bad", [(1, 1, [1], False), (7, 3, [0, 1, 3], False), (384, 5, [2, 3, 4, 5], False), (1024, 8, [0, 2, 8], True),
+                                        (1000, 8, [8], False), (900, 2, [0], False), (4096, 5, [2, 3, 4, 5], False), (65536, 5, [2, 3, 4, 5], False),
                                         (20000, 8, [0, 2, 8], True), (3000, 8, [8], False), (5000, 2, [0], False)])
-def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad):
-    """The execution plan is integer / index work: the five plan kernels must equal the plain-C restatement
+def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad, five_launches):
+    """The execution plan is integer / index work: the plan kernels -- five launches, or ONE for batches of up to 1024 rows
+    (plan_small_kernel; ``five_launches`` forces the general path there too) -- must equal the plain-C restatement
     (oracle/c/ragged_plan.c) bit for bit -- CSR offsets, compact token lists, per-token keys, tile list -- including rows that
     are all padding, pads in the middle of a row, and node ids outside [0, N] (flagged, read as 0)."""
     import ctypes as C
     lib = _lib.load()
+    if five_launches and B > 1024:
+        pytest.skip("the general path is the only one at this size")
+    _lib.set_option("disable_plan_small", 1 if five_launches else 0)
     ora = _oracle_lib()
     rng = np.random.default_rng(B + L)
     N = 1000
@@ -331,8 +337,11 @@ def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad):
     status = torch.zeros(4, dtype=torch.int32, device="cuda")
     view = _lib.RaggedView()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.matcha_ragged_plan(_lib.ptr(xt), B, L, N, _lib.ptr(status), _lib.ptr(ws), ws.numel(), C.byref(view), st), "matcha_ragged_plan")
-    torch.cuda.synchronize()
+    try:
+        _lib.check(lib.matcha_ragged_plan(_lib.ptr(xt), B, L, N, _lib.ptr(status), _lib.ptr(ws), ws.numel(), C.byref(view), st), "matcha_ragged_plan")
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("disable_plan_small", 0)
     base = ws.data_ptr()
 
     def grab(p, n, dt):

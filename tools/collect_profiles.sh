@@ -22,3 +22,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_c5_
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_front_stats -- python $R/tools/debug/front_gather.py > $R/gpurun_out/${TAG}_front.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_front_fetch -- python $R/tools/debug/front_gather.py > /dev/null 2>&1
 echo "collected gather/d128/c5/front $TAG"
+# the adj front end (the reference's own mode): kernel stats at 65 536 and 384 rows + the three PMC passes
+bash $R/tools/collect_adj_profiles.sh $TAG pmc

@@ -112,7 +112,8 @@ if glob.glob(f"gpurun_out/{tag}_mfma1/*/*_counter_collection.csv"):
                     res[c][name] = res[c].get(name, 0.0) + vals[i][1]
     for c, v in res.items():
         v["MfmaUtil_percent"] = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 1)
-    json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --prof none "
+    json.dump({"csrc_sha16": h.hexdigest()[:16],
+               "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --prof none "
                           "--no-cpu-baseline  (second pass: --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES); tools/collect_profiles.sh",
                "note": "sums over the launches of one step; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so MfmaUtil = 100 * MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs); "
                        "SQ_VALU_MFMA_COEXEC_CYCLES counts cycles in which vector and matrix instructions execute together",
@@ -195,8 +196,10 @@ if frows and ff:
             for key in ("front_fwd_kernel", "embed_fwd_kernel"):
                 if key in r["Kernel_Name"]:
                     acc[key].append(float(r["Counter_Value"]) * 1024 * 2)
+    # round 4: embed_fwd rebuilds the attribute row from the node id (attr_mode 1: nothing read); front_fwd reads it as one 128-byte unit
+    # (rows padded to 32 floats), of which 4 * 24 bytes are algorithmic
     cases = {"front_fwd_kernel": ("front_fwd (d = 64) on a 16 M x 64 table (4 GiB)", 327681, 8 + 256 + 4 * 24),
-             "embed_fwd_kernel": ("embed_fwd (d = 256) on the C5 table 1 M x 256 (1 GiB)", 131073, 8 + 1024 + 4 * 21)}
+             "embed_fwd_kernel": ("embed_fwd (d = 256) on the C5 table 1 M x 256 (1 GiB)", 131073, 8 + 1024)}
     res = []
     for key, vals in acc.items():
         name, tokens, rb = cases[key]
@@ -211,3 +214,42 @@ if frows and ff:
               open(f"profiles/{rnd}_gather_in_step_pmc.json", "w"), indent=1)
     for r in res:
         print(r["kernel"], "fetch/alg", r["fetch_over_algorithmic_read"], "frac", r["frac_of_8tbs_read_roof"])
+
+
+# ---- the adj front end (the reference's own mode, Modules.py:176-201): tools/collect_adj_profiles.sh -------------------------------
+arows = stats_md("adj_stats", f"profiles/{rnd}_adj_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, adj front end, 65 536 rows per step ({rnd})",
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --prof none --no-cpu-baseline --no-extras --front-end adj", n=24)
+stats_md("adj384_stats", f"profiles/{rnd}_adj384_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, adj front end at the reference's batch of 384 rows ({rnd})",
+         "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --rows 384 --prof none --no-cpu-baseline --no-extras --front-end adj", n=30)
+af = glob.glob(f"gpurun_out/{tag}_adj_fetch/*/*_counter_collection.csv")
+if arows and af:
+    def load3(d, name):
+        f = glob.glob(f"gpurun_out/{tag}_{d}/*/*_counter_collection.csv")
+        out = collections.defaultdict(list)
+        if not f:
+            return out
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == name:
+                for key in ("adj_fused_fwd_kernel", "adj_recon_kernel", "adj_fused_bwd_kernel", "front_bwd_kernel", "adj_scan_kernel", "adj_scatter_kernel", "adj_hist_kernel"):
+                    if key in r["Kernel_Name"]:
+                        out[key].append(float(r["Counter_Value"]))
+        return out
+    fe3, wr3 = load3("adj_fetch", "FETCH_SIZE"), load3("adj_write", "WRITE_SIZE")
+    mb3, ga3 = load3("adj_mfma1", "SQ_VALU_MFMA_BUSY_CYCLES"), load3("adj_mfma1", "GRBM_GUI_ACTIVE")
+    res = {}
+    for key in fe3:
+        us = [float(r["AverageNs"]) / 1e3 for r in arows if key in r["Name"]]
+        last = lambda v: v[-1] if v else None            # the last launch of the pass: a steady-state step
+        e = {"rocprof_avg_us": round(us[0], 1) if us else None,
+             "hbm_fetch_bytes_per_launch": None if not fe3[key] else last(fe3[key]) * 1024 * 2,      # x2: gfx950 FETCH_SIZE tallies 128-B requests at 64 B
+             "hbm_write_bytes_per_launch": None if not wr3[key] else last(wr3[key]) * 1024}
+        if mb3[key] and ga3[key]:
+            e["MfmaUtil_percent"] = round(100.0 * last(mb3[key]) / (last(ga3[key]) / 8 * 1024), 1)
+        res[key] = e
+    json.dump({"csrc_sha16": h.hexdigest()[:16],
+               "note": "adj front end at 65 536 rows per step (hg38 1 Mb, k in {2..5}, d = 64): separate rocprofv3 passes --pmc FETCH_SIZE / --pmc WRITE_SIZE / "
+                       "--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of bench.py --steps 2 --warmup 1 --front-end adj (tools/collect_adj_profiles.sh); values of "
+                       "the last launch of each kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; MfmaUtil = 100 * MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs)",
+               "kernels": res}, open(f"profiles/{rnd}_adj_pmc.json", "w"), indent=1)
+    for k_, v in res.items():
+        print(k_, v)
