@@ -88,7 +88,7 @@ __global__ __launch_bounds__(1024) void adj_scan_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ r_dev, float* __restrict__ zero_buf, int zero_n) {
   extern __shared__ int hs[];
   // the fused reconstruction kernel's gradient scratch, zeroed here instead of by a memset in front of it (one launch less; and a memset
-  // NODE of a captured step was seen to run unordered with its consumer -- tools/debug/graph_vs_eager2.py)
+  // NODE of a captured step was seen to run unordered with its consumer -- tools/debug/graph_vs_eager.py)
   for (int i = threadIdx.x; i < zero_n; i += 1024) zero_buf[i] = 0.f;
   if (r_dev) { const int rv = *r_dev; r_chrom = (rv >= 0 && rv < C) ? rv : -1; }     // opts->random_chrom_dev
   __shared__ int tot[kMaxChrom + 2];

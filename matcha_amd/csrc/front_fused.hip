@@ -49,9 +49,6 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
   float* Ds = lds + 3 * kTile;                    // dX0
   float* As = lds + 4 * kTile;                    // attribute rows [64][kLdA]
   int* ids_s = reinterpret_cast<int*>(As + 64 * kLdA);   // [64] node id of each row (0: padding / past the end)
-  __shared__ int abounds[64];                     // attr_mode 1: chromosome bounds (attribute rows are rebuilt from the node id)
-  if (g.attr.mode == 1 && threadIdx.x < g.attr.n_attr) abounds[threadIdx.x] = g.attr.bounds[threadIdx.x];
-  if (g.attr.mode == 1) __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
@@ -90,14 +87,7 @@ __global__ __launch_bounds__(256, 2) void front_bwd_kernel(FrontBwdArgs g) {
     _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__) {                                                \
       const int64_t t__ = tb__ + a_row0 + 32 * j__;                                                      \
       const int64_t id__ = g.ids[t__ < T ? t__ : (int64_t)T - 1];                                        \
-      if (g.attr.mode == 1) {                                                                            \
-        int cl__; float cd__;                                                                            \
-        attr_decode(g.attr, abounds, (int)id__, cl__, cd__);                                             \
-        pav[j__] = make_float4(attr_elem(a_qc, cl__, cd__, g.n_attr), attr_elem(a_qc + 1, cl__, cd__, g.n_attr),  \
-                               attr_elem(a_qc + 2, cl__, cd__, g.n_attr), attr_elem(a_qc + 3, cl__, cd__, g.n_attr)); \
-      } else {                                                                                           \
-        pav[j__] = *reinterpret_cast<const float4*>(g.attr.table + id__ * g.attr.ld + a_qc);             \
-      }                                                                                                  \
+      pav[j__] = *reinterpret_cast<const float4*>(g.attr.table + id__ * g.attr.ld + a_qc);               \
     }                                                                                                    \
   } while (0)
   if ((int)blockIdx.x < ntiles) FBW_GLOAD(blockIdx.x);
@@ -229,9 +219,6 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   float* Es = lds;                                // node rows, then x0 in place
   float* As = lds + kTile;                        // attribute rows [64][kLdA]
   float* Xs = As + 64 * kLdA;                     // X tile on its way out
-  __shared__ int abounds[64];                     // attr_mode 1: chromosome bounds (attribute rows are rebuilt from the node id: ONE random
-  if (g.attr.mode == 1 && threadIdx.x < g.attr.n_attr) abounds[threadIdx.x] = g.attr.bounds[threadIdx.x];   // row per token)
-  if (g.attr.mode == 1) __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
@@ -281,15 +268,7 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
       pe[i__] = *reinterpret_cast<const float4*>(src__ + sc4);                                           \
     }                                                                                                    \
     _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__) {                                                \
-      float4 v__;                                                                                        \
-      if (g.attr.mode == 1) {                                                                            \
-        int cl__; float cd__;                                                                            \
-        attr_decode(g.attr, abounds, (int)id_a[j__], cl__, cd__);                                        \
-        v__ = make_float4(attr_elem(aqc, cl__, cd__, g.n_attr), attr_elem(aqc + 1, cl__, cd__, g.n_attr), \
-                          attr_elem(aqc + 2, cl__, cd__, g.n_attr), attr_elem(aqc + 3, cl__, cd__, g.n_attr)); \
-      } else {                                                                                           \
-        v__ = *reinterpret_cast<const float4*>(g.attr.table + id_a[j__] * g.attr.ld + aqc);              \
-      }                                                                                                  \
+      const float4 v__ = *reinterpret_cast<const float4*>(g.attr.table + id_a[j__] * g.attr.ld + aqc);   \
       pa[j__] = make_float4(v__.x * amask, v__.y * amask, v__.z * amask, v__.w * amask);                 \
     }                                                                                                    \
   } while (0)
@@ -442,7 +421,10 @@ int front_grid() {
 
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const matcha_frozen& f, int n_attr,
                      const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st) {
-  MATCHA_TRY(check_attr(f, n_attr));
+  // the fused front end GATHERS attribute rows (rows padded to one 128-byte unit when the caller padded them, attr_ld): its row pieces are
+  // loaded by eight threads per row inside a register prefetch pipeline; rebuilding them from the node id there (attr_mode 1) put a branch
+  // around the loads and cost 20 % of front_bwd_kernel -- embed_fwd_kernel and the fused adj forward, one thread / one lane pair per row, do rebuild
+  MATCHA_CHECK_ARG(f.attr_table, "front end: attr_table is required (also under attr_mode 1)");
   FrontFwdArgs g;
   g.ids = ids; g.table = table; g.dense = dense; g.attr = attr_src_table_first(f, n_attr); g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
@@ -464,7 +446,7 @@ size_t front_bwd_ws_floats() { return (size_t)1024 * kFrontSlab; }
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const matcha_frozen& f, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,
                      matcha_tensors& grads, hipStream_t st, int32_t* touched) {
-  MATCHA_TRY(check_attr(f, n_attr));
+  MATCHA_CHECK_ARG(f.attr_table, "front end: attr_table is required (also under attr_mode 1)");
   FrontBwdArgs g;
   g.X = X; g.dxh = dxh; g.nslab = nslab; g.tcap = tcap; g.dxpad = dxpad; g.dXs = dXs; g.x0 = x0; g.ids = ids; g.attr = attr_src_table_first(f, n_attr); g.n_attr = n_attr;
   g.Wn = p.next_w; g.count = rg.count; g.dX0 = dX0; g.dtable = dtable; g.slab = ws;

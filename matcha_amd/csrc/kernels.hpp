@@ -118,7 +118,7 @@ Options& options();
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
 // Zero `bytes` bytes (a multiple of 4, 4-byte aligned) with a KERNEL.  The library does not use hipMemsetAsync on paths that callers capture
 // into hipGraphs: a small memset NODE of a captured training step was observed to run unordered with the kernel node that consumes the
-// buffer (wrong reconstruction-head gradients in replayed steps only; tools/debug/graph_vs_eager2.py), kernel nodes keep stream order.
+// buffer (wrong reconstruction-head gradients in replayed steps only; tools/debug/graph_vs_eager.py), kernel nodes keep stream order.
 int zero_async(void* p, size_t bytes, hipStream_t st);
 int launch_ln3_fwd(const float* X, int64_t T, int d, const float* gq, const float* bq, const float* gk, const float* bk,
                    const float* gv, const float* bv, float* qin, float* kin, float* vin, float* stats, hipStream_t st,

@@ -153,8 +153,7 @@ class Session:
     def random_chrom(self) -> int:
         # Modules.py:192 draws np.random.choice(np.arange(C), 1); randint consumes numpy's global stream too, at a sixth of the cost
         # (the draw sits on the per-step host path)
-        self._last_chrom = int(np.random.randint(self.n_chrom)) if self.n_chrom else 0
-        return self._last_chrom
+        return int(np.random.randint(self.n_chrom)) if self.n_chrom else 0
 
     # ---- one epoch as replays of ONE captured step (single GPU) -------------------------------------------------------------------
     # The reference's batch is 96 positives + 288 negatives (main.py:527-528): ~0.25 ms of kernels per step, against which a step
@@ -184,7 +183,7 @@ class Session:
                       y=torch.cat([torch.ones(P, device=dev), torch.zeros(B - P, device=dev)]),           # main.py:444-445
                       ww=torch.ones(B, dtype=torch.float32, device=dev),                                  # main.py:446-447
                       preds=torch.empty((n_batch, B), dtype=torch.float32, device=dev), sizes=torch.empty((n_batch, B), dtype=torch.long, device=dev),
-                      sums=torch.zeros(2, dtype=torch.float32, device=dev), rec=torch.zeros(n_batch, dtype=torch.float32, device=dev))
+                      sums=torch.zeros(2, dtype=torch.float32, device=dev))
             self._graph_state = st
         st["pos"].copy_(e[:n_batch * P]); st["w"].copy_(w[:n_batch * P]); st["chroms"].copy_(torch.from_numpy(chroms))
         st["it"].zero_(); st["sums"].zero_()
@@ -198,7 +197,6 @@ class Session:
             bce, recon, logits = self.trainer.step(st["x"], st["y"], st["ww"], alpha=alpha, beta=beta, random_chrom=st["cell"])
             st["sums"][0] += bce
             st["sums"][1] += recon[0]
-            st["rec"].index_copy_(0, st["it"], recon)
             st["preds"].index_copy_(0, st["it"], torch.sigmoid(logits).view(1, B))                      # main.py:58
             st["sizes"].index_copy_(0, st["it"], (st["x"] != 0).sum(dim=1).view(1, B))
             st["it"] += 1
@@ -263,8 +261,6 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
                                                max_tokens=None if tok_max is None else tok_max[i])
         bce_sum += bce
         rec_sum += recon[0]
-        sess.__dict__.setdefault("_rec_steps", []).append(recon.clone())
-        sess.__dict__.setdefault("_chrom_steps", []).append(sess.__dict__.get("_last_chrom", -1))
         preds.append(torch.sigmoid(logits).clone())                             # main.py:58
         labels.append(y)
         sizes.append(s)
