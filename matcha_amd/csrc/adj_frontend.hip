@@ -173,9 +173,23 @@ __global__ __launch_bounds__(256) void adj_scatter_kernel(const int64_t* __restr
     if (ch[i] >= 0) tc[ch[i] * 256 + tid] += 1;
   }
   __syncthreads();
-  if (tid <= C) {
-    int run = 0;
-    for (int k = 0; k < 256; ++k) { const int v = tc[tid * 256 + k]; tc[tid * 256 + k] = run; run += v; }
+  // exclusive prefix of every bucket's 256 per-thread counts: one wavefront per bucket in turn, four consecutive counts per lane, one
+  // 64-lane shuffle scan (a single thread walking the 256 counts of its bucket was a chain of 512 dependent LDS accesses: 13 us)
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = wave; k <= C; k += 4) {
+      int* row = tc + k * 256 + 4 * lane;
+      const int v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+      const int sum = (v0 + v1) + (v2 + v3);
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+      }
+      const int base = incl - sum;
+      row[0] = base; row[1] = base + v0; row[2] = base + v0 + v1; row[3] = base + v0 + v1 + v2;
+    }
   }
   __syncthreads();
   const int r0 = (r_chrom >= 0 && r_chrom < C) ? seg[r_chrom] : 0, r1 = (r_chrom >= 0 && r_chrom < C) ? seg[r_chrom + 1] : 0;

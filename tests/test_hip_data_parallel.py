@@ -210,8 +210,11 @@ def _nccl_worker(rank, world, port, out_dir):
     N = int(np.sum(num))
     report = {}
     for d, exchange, overlap, compact in ((64, "dense", True, True), (64, "dense", False, True), (64, "sparse", True, True),
-                                          (128, "sparse", True, True), (128, "sparse", False, False), (128, "dense", True, True)):
+                                          (128, "sparse", True, True), (128, "sparse", False, False), (128, "dense", True, True),
+                                          (128, "sparse", True, "host")):     # "host": the caller passes the token count (no device read-back)
         flats = []
+        host_count = compact == "host"
+        compact = bool(compact)
         for forced in (False, True):
             clf, _ = hip_model(num, d, "table", 50)
             clf.train()                                              # dropout on: the same (seed, slot) masks in both runs
@@ -221,7 +224,8 @@ def _nccl_worker(rank, world, port, out_dir):
             rng = np.random.default_rng(8)
             for step in range(4):
                 x, y, w = synth.make_batch(rng, N, [2, 3, 4, 5], 64)
-                tr.step(torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(), torch.from_numpy(w.reshape(-1)).cuda(), alpha=1.0, beta=0.0)
+                tr.step(torch.from_numpy(x).cuda(), torch.from_numpy(y.reshape(-1)).cuda(), torch.from_numpy(w.reshape(-1)).cuda(), alpha=1.0, beta=0.0,
+                        max_tokens=int((x != 0).sum()) if host_count else None)
             torch.cuda.synchronize()
             tr.check_status()
             flats.append(clf._runtime().flat.detach().cpu())
@@ -231,7 +235,7 @@ def _nccl_worker(rank, world, port, out_dir):
                 if exchange == "sparse":
                     assert cb["table_rows_allgather"] == 0 and (cb["table_rows_fill"] < 0.9) == compact      # (world - 1) = 0 peers; mixed k: ~70 % fill
                 assert ("encoder_allreduce" in cb) == overlap and ("bucket_allreduce" in cb) == (not overlap)
-                report[f"{d}-{exchange}-{overlap}-{compact}"] = cb
+                report[f"{d}-{exchange}-{overlap}-{compact}-{host_count}"] = cb
         assert torch.equal(flats[0], flats[1]), (d, exchange, overlap, compact)
     import json
     json.dump(report, open(os.path.join(out_dir, "nccl.json"), "w"))
