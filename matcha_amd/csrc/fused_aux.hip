@@ -101,10 +101,8 @@ int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
 
 size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
 size_t fused_tail_partial_floats() { return (size_t)kTailSplits * kTailSlab; }
-size_t fused_qkv_floats(int64_t B, int L) {
-  const size_t tiles = (size_t)(ragged_tiles_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRec;        // Q, K, V images per 64-row tile (or the merged r rows: kImgRecM)
-  const size_t halves = (size_t)(ragged_halves_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRecH;     // merged r rows per half tile
-  return tiles > halves ? tiles : halves;
+size_t fused_qkv_floats(int64_t B, int L) {          // the training forward's record: r rows + probabilities per (half tile, head)
+  return (size_t)(ragged_halves_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRecH;
 }
 
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves, float* partial) {

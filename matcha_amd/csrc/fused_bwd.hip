@@ -1,22 +1,22 @@
-// Fused backward of the multi-head attention block for embed_dim 64 (training path of the metric's configuration).
+// Fused backward of the multi-head attention block for embed_dim 64 (training path of the metric's configuration), merged heads
+// (per head r = B_h x_hat + b_h, s_ij = r_i . x_hat_j, z_i = sum_j p_ij x_hat_j, dyn += M_h z_i).
 //
-// Given X (the encoder input, [Tn, 64]) and dDyn = dL/d(fc1 output before bias) ([Tn, 64], produced by the pff / tail
-// backward kernels), one kernel recomputes Q, K, V and the attention probabilities of ONE head, and produces for that head
-//   dWfc1[:, head block], dW'q, dW'k, dW'v (LayerNorm-folded projections, fused_fwd.hip), their bias gradients,
-//   the padding token's dK / dV, and the head's contribution to d x_hat,
-// without ever materialising Q/K/V/O/P or their gradients in HBM (Modules.py:519-572 backward).
+// Given X (the encoder input, [Tn, 64]), dDyn = dL/d(fc1 output before bias) ([Tn, 64], produced by the tail's backward inside the
+// forward kernel or by the pff / tail backward kernels) and the record the training forward left per (half tile, head) -- its wavefront's
+// r rows as register images + the attention probabilities --, fused_bwdh_kernel produces for ONE head
+//   dB_h, dM_h, db_h, the column sums of dDyn, the padding token's d x_hat, and the head's contribution to d x_hat
+// without materialising r / z / P or their gradients in HBM (Modules.py:519-572 backward).
 //
-// Work decomposition ("head-major"): workgroup (head, chunk) walks the 64-token tiles of its chunk of hyperedges.  The
-// head's four 64x64 weight blocks stay resident (three in LDS, the fc1 block in registers) and its four 64x64 weight
-// gradients accumulate in MFMA accumulators for the whole walk; they are written once per workgroup into a slab and
-// reduced in a fixed order by fb_unfold_kernel, which also un-folds the LayerNorm affines:
+// Work decomposition ("head-major"): workgroup (head, chunk) walks the half tiles of its chunk of hyperedges.  B_h and M_h stay in
+// registers as MFMA fragments, dB_h and dM_h accumulate in MFMA accumulators for the whole walk and are written once per workgroup into
+// a slab.  fbm_reduce_kernel sums the slabs in a fixed order, fbm_chain_kernel applies the chain rule back to the folded projections
+// (dW'q = W'k dB, dW'k = W'q dB^T + cq (x) db, dWfc1_h = dM W'v^T + ..., dW'v = Wfc1_h^T dM), fb_unfold_kernel un-folds the LayerNorm affines:
 //   W' = W * g, c = W . b   =>   dW = dW' * g + dc (x) b,   dg = sum_n dW' * W,   db = W^T dc.
-// Per token the kernel reads X and dDyn once per head (L2 hits: the 8 heads of a chunk run on the same XCD) and writes
-// one 256 B partial of d x_hat per head; lnhat_bwd_kernel sums the 8 partials and applies the LayerNorm backward.
+// The eight heads of a token add their d x_hat into one [T, 64] buffer (float atomics, one instruction = four token rows x 64 B) or, for
+// deterministic / row-sparse callers, write eight slabs that lnhat_bwd_kernel / front_bwd_kernel sum in a fixed order.
 //
-// LDS: 9 tiles of 64 x 68 floats (W'q W'k W'v | x_hat dDyn | Q K V | F) = 153 KiB -> one workgroup per CU, 256 CUs =
-// 8 heads x 32 chunks.  F holds dO, then O.  Q/K/V are overwritten in place by dQ/dK/dV.  The head's fc1 block lives in
-// registers as MFMA B fragments.
+// The reference's own four-product formulation (Q, K, V, fc1 per head) is NOT in this file any more: option disable_merged runs it on
+// the layer-by-layer kernels (attention.hip, gemm_lds.hip), which is what the merged kernels are tested against.
 #include <stdlib.h>
 
 #include "kernels.hpp"
@@ -29,115 +29,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kLd = 68;              // LDS row stride (floats)
-constexpr int kTile = 64 * kLd;
 constexpr float kEpsLn = 1e-5f;
 constexpr int kWgSlab = 4 * 4096 + 6 * 64;   // dW'q dW'k dW'v dWfc1 | dcq dck dcv dKpad dVpad dfc1_b
 constexpr int kVecOff = 4 * 4096;
 constexpr int kMaxChunks = 64;
 
-struct FusedBwdArgs {
-  const float* X;                 // [Tn, 64]
-  const float* dDyn;              // [Tn, 64]
-  const int32_t* row_off;         // [B+1]
-  const int32_t* count;           // {Tr+1, Tr}
-  const int32_t* tile_meta;       // [ntiles+2][4]
-  const int32_t* tok_pos;         // [Tn]
-  int L;
-  int ntiles;                     // upper bound
-  int nchunks;
-  const float* wq; const float* wk; const float* wv;     // folded [512, 64]
-  const float* cq; const float* ck; const float* cv;     // [512]
-  const float* fc1_w;                                    // [64, 512]
-  float* dxh;                     // [8][tcap][64]
-  int64_t tcap;
-  float* wslab;                   // [8][nchunks][kWgSlab]
-  const float* qkv;               // [ntiles][8][kImgRec] Q, K, V register images + attention probabilities left by the training forward (null: recompute)
-  int dbg;                        // timing ablations only (MATCHA_FUSED_DBG): 1 attention, 2 recompute GEMMs, 4 weight-grad GEMMs, 8 dx_hat GEMMs
-};
-
-#define FB_GLOAD(R, SRC, LD)                                                                             \
-  do {                                                                                                   \
-    const float* src__ = (SRC);                                                                          \
-    R##0 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow) * (LD) + sc4);                       \
-    R##1 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 16) * (LD) + sc4);                  \
-    R##2 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 32) * (LD) + sc4);                  \
-    R##3 = *reinterpret_cast<const float4*>(src__ + (int64_t)(srow + 48) * (LD) + sc4);                  \
-  } while (0)
-#define FB_LSTORE(DST, R)                                                                                \
-  do {                                                                                                   \
-    *reinterpret_cast<float4*>(&(DST)[(srow) * kLd + sc4]) = R##0;                                       \
-    *reinterpret_cast<float4*>(&(DST)[(srow + 16) * kLd + sc4]) = R##1;                                  \
-    *reinterpret_cast<float4*>(&(DST)[(srow + 32) * kLd + sc4]) = R##2;                                  \
-    *reinterpret_cast<float4*>(&(DST)[(srow + 48) * kLd + sc4]) = R##3;                                  \
-  } while (0)
-
-#define LD8(dst, p)                                                                                      \
-  do {                                                                                                   \
-    const float4 a__ = *reinterpret_cast<const float4*>(p), b__ = *reinterpret_cast<const float4*>((p) + 4); \
-    dst[0] = a__.x; dst[1] = a__.y; dst[2] = a__.z; dst[3] = a__.w;                                      \
-    dst[4] = b__.x; dst[5] = b__.y; dst[6] = b__.z; dst[7] = b__.w;                                      \
-  } while (0)
-#define ST8(p, src)                                                                                      \
-  do {                                                                                                   \
-    *reinterpret_cast<float4*>(p) = make_float4(src[0], src[1], src[2], src[3]);                         \
-    *reinterpret_cast<float4*>((p) + 4) = make_float4(src[4], src[5], src[6], src[7]);                   \
-  } while (0)
 #define ZR8(p)                                                                                           \
   do {                                                                                                   \
     *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
     *reinterpret_cast<float4*>((p) + 4) = make_float4(0.f, 0.f, 0.f, 0.f);                               \
   } while (0)
-
-// out[t][n] += A[t][k] . B[n][k]   (A rows and B rows in LDS)
-__device__ __forceinline__ f32x16 gemm_nt(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int r, int h) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLd + 8 * c + 4 * h]);
-    const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLd + 8 * c + 4 * h]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-  }
-  return acc;
-}
-// out[t][k] += A[t][n] . W[n][k]   (A rows in LDS, W stored [n][k] in LDS: its fragment is a column walk)
-__device__ __forceinline__ f32x16 gemm_nn(f32x16 acc, const float* __restrict__ As, const float* __restrict__ Ws, int wr, int wc, int r, int h) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLd + 8 * c + 4 * h]);
-    const float* wp = &Ws[(8 * c + 4 * h) * kLd + 32 * wc + r];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wp[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wp[kLd], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wp[2 * kLd], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wp[3 * kLd], acc, 0, 0, 0);
-  }
-  return acc;
-}
-// Projection as a TRANSPOSED product (weight rows = MFMA row operand, token rows = column operand): lane (r, h) ends with
-// token row 32 wr + r and, in registers 4g..4g+3, the features 32 wc + 8 g + 4 h + {0..3}: the bias is the accumulator's
-// initial value and the tile is written with four ds_write_b128 (VALU work is not free next to f32 MFMAs on this part).
-__device__ __forceinline__ void proj_store_T(float* __restrict__ Ts, const float* __restrict__ As, const float* __restrict__ Bs,
-                                             const float* __restrict__ bias, int wr, int wc, int r, int h) {
-  f32x16 acc;
-#pragma unroll
-  for (int gq = 0; gq < 4; ++gq) {
-    const float4 bv = *reinterpret_cast<const float4*>(&bias[32 * wc + 8 * gq + 4 * h]);
-    acc[4 * gq] = bv.x; acc[4 * gq + 1] = bv.y; acc[4 * gq + 2] = bv.z; acc[4 * gq + 3] = bv.w;
-  }
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const float4 a = *reinterpret_cast<const float4*>(&As[(32 * wr + r) * kLd + 8 * c + 4 * h]);
-    const float4 b = *reinterpret_cast<const float4*>(&Bs[(32 * wc + r) * kLd + 8 * c + 4 * h]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int gq = 0; gq < 4; ++gq)
-    *reinterpret_cast<float4*>(&Ts[(32 * wr + r) * kLd + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
-}
 
 __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rstd) {
   const float s = group_sum<16>((v.x + v.y) + (v.z + v.w));
@@ -189,133 +90,10 @@ __device__ __forceinline__ void axpy8(V8& y, float w, const V8& x) {
 }
 __device__ __forceinline__ V8 zero8() { V8 z; z.a = f2{0.f, 0.f}; z.b = z.a; z.c = z.a; z.d = z.a; return z; }
 
-template <int ML>
-__device__ __forceinline__ void attn_row_fb(const float* __restrict__ Qs, const float* __restrict__ Ks, const float* __restrict__ Vs,
-                                            const float* __restrict__ Fs, const float* __restrict__ kpad, const float* __restrict__ vpad,
-                                            float* __restrict__ Ps, float* __restrict__ dSs, int li, int li0, int k, int n_pad, int sub,
-                                            float inv_temp, V8& o, V8& gq, V8& accK, V8& accV, bool have_p) {
-  // Branch-free over the ML key slots: a wave almost always holds a hyperedge of the full width, so predicating the
-  // slots j >= k (clamped row, probability forced to 0) costs nothing and removes one branch per slot.
-  const float padf = (float)n_pad;
-  const bool hp = n_pad > 0;
-  const int ii = li - li0;
-  // three passes over the hyperedge's rows (K, then V, then K again) keep at most ML x 8 operand registers live
-  float p[ML], ds[ML], pp, dsp;
-  int ro[ML];                                            // element offset of key / value row j (clamped), shared by the three passes
-#pragma unroll
-  for (int j = 0; j < ML; ++j) ro[j] = (li0 + (j < k ? j : 0)) * kLd + 8 * sub;
-  const V8 q = ld8(&Qs[li * kLd + 8 * sub]);
-  if (have_p) {                                          // the forward pass left row i of P in Ps (slot 7: the padding probability)
-    const float4 pa = *reinterpret_cast<const float4*>(&Ps[li * 8]), pb = *reinterpret_cast<const float4*>(&Ps[li * 8 + 4]);
-    const float w[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-#pragma unroll
-    for (int j = 0; j < ML; ++j) p[j] = (j < k) ? w[j] : 0.f;
-    pp = hp ? w[7] : 0.f;
-  } else {
-    float mx = -3.4e38f;
-    {
-      V8 kk[ML];
-#pragma unroll
-      for (int j = 0; j < ML; ++j) kk[j] = ld8(&Ks[ro[j]]);
-      const V8 kp = ld8(kpad + 8 * sub);
-#pragma unroll
-      for (int j = 0; j < ML; ++j) {
-        float a = group_sum8_dpp(dot8(q, kk[j])) * inv_temp;
-        a = (j == ii) ? -1e32f : a;                          // masked diagonal (Modules.py:443-445)
-        p[j] = a;
-        mx = (j < k) ? fmaxf(mx, a) : mx;
-      }
-      pp = group_sum8_dpp(dot8(q, kp)) * inv_temp;
-      mx = hp ? fmaxf(mx, pp) : mx;
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-      p[j] = (j < k) ? __expf(p[j] - mx) : 0.f;
-      den += p[j];
-    }
-    pp = hp ? __expf(pp - mx) : 0.f;
-    den += padf * pp;
-    const float inv = __builtin_amdgcn_rcpf(den);
-#pragma unroll
-    for (int j = 0; j < ML; ++j) p[j] *= inv;
-    pp *= inv;
-  }
-  const float ppf = padf * pp;
-  {
-    const V8 go = ld8(&Fs[li * kLd + 8 * sub]);
-    V8 v[ML];
-#pragma unroll
-    for (int j = 0; j < ML; ++j) v[j] = ld8(&Vs[ro[j]]);
-    const V8 vp = ld8(vpad + 8 * sub);
-    // O_i
-    o = scale8(ppf, vp);
-#pragma unroll
-    for (int j = 0; j < ML; ++j) axpy8(o, p[j], v[j]);
-    // dP_i. -> dS_i.
-    float sig = 0.f;
-#pragma unroll
-    for (int j = 0; j < ML; ++j) {
-      const float a = group_sum8_dpp(dot8(go, v[j]));
-      ds[j] = a;
-      sig += p[j] * a;
-    }
-    dsp = group_sum8_dpp(dot8(go, vp));
-    sig += ppf * dsp;
-#pragma unroll
-    for (int j = 0; j < ML; ++j) ds[j] = p[j] * (ds[j] - sig) * inv_temp;
-    dsp = pp * (dsp - sig) * inv_temp;
-    axpy8(accV, ppf, go);
-  }
-  // dQ_i
-  const float dspf = padf * dsp;
-  {
-    V8 kk[ML];
-#pragma unroll
-    for (int j = 0; j < ML; ++j) kk[j] = ld8(&Ks[ro[j]]);
-    const V8 kp = ld8(kpad + 8 * sub);
-    gq = scale8(dspf, kp);
-#pragma unroll
-    for (int j = 0; j < ML; ++j) axpy8(gq, ds[j], kk[j]);
-  }
-  axpy8(accK, dspf, q);
-  // row i of P and dS for the column phase (every lane of the group holds the same values: lanes 0 / 1 write them)
-  if (have_p ? sub == 1 : sub < 2) {
-    float* dst = (sub == 0 ? Ps : dSs) + li * 8;
-    const float w0 = sub == 0 ? p[0] : ds[0], w1 = sub == 0 ? p[1 % ML] : ds[1 % ML];
-    const float w2 = sub == 0 ? p[2 % ML] : ds[2 % ML], w3 = sub == 0 ? p[3 % ML] : ds[3 % ML];
-    *reinterpret_cast<float4*>(dst) = make_float4(w0, w1, ML > 2 ? w2 : 0.f, ML > 3 ? w3 : 0.f);
-    if (ML > 4) {
-      const float w4 = sub == 0 ? p[4 % ML] : ds[4 % ML], w5 = sub == 0 ? p[5 % ML] : ds[5 % ML];
-      const float w6 = sub == 0 ? p[6 % ML] : ds[6 % ML], w7 = sub == 0 ? p[7 % ML] : ds[7 % ML];
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(w4, ML > 5 ? w5 : 0.f, ML > 6 ? w6 : 0.f, ML > 7 ? w7 : 0.f);
-    }
-  }
-}
-
-template <int ML>
-__device__ __forceinline__ void attn_col_fb(const float* __restrict__ Qs, const float* __restrict__ Fs, const float* __restrict__ Ps,
-                                            const float* __restrict__ dSs, int li, int li0, int k, int sub, V8& gk, V8& gv) {
-  const int jj = li - li0;
-  gk = zero8();
-  gv = zero8();
-#pragma unroll
-  for (int i = 0; i < ML; ++i) {
-    const int ri = li0 + (i < k ? i : 0);
-    const V8 q = ld8(&Qs[ri * kLd + 8 * sub]), go = ld8(&Fs[ri * kLd + 8 * sub]);
-    const float pij = (i < k) ? Ps[ri * 8 + jj] : 0.f, dsij = (i < k) ? dSs[ri * 8 + jj] : 0.f;
-    axpy8(gv, pij, go);
-    axpy8(gk, dsij, q);
-  }
-}
-
-// Streaming variants for the eight-wave kernel (256 registers per lane): one key / value row live at a time plus the next one in
-// flight, fenced so that the scheduler does not hoist all ML rows of a pass (its default: 40 - 80 registers of operands).  With two
-// wavefronts per SIMD the other wave covers the LDS latency this gives up.  The forward pass's probabilities are required (have_p).
-// FB_PIN(addr, x): an empty asm that takes the LDS offset of the NEXT row and the eight registers of the running sum as in/out operands:
-// the load of row j + 1 cannot be issued before the arithmetic on row j - 1 has produced x, so exactly one row is in use and one
-// in flight.  (sched_barrier alone does not do it: instruction selection has already placed the unchained LDS loads of all rows
-// ahead of the arithmetic when the machine scheduler sees the fence.)
+// The attention rows are STREAMED: one key / value row in use and one in flight.  FB_PIN(addr, x): an empty asm that takes the LDS offset
+// of the NEXT row and the eight registers of the running sum as in / out operands: the load of row j + 1 cannot be issued before the
+// arithmetic on row j - 1 has produced x.  (sched_barrier alone does not do it: instruction selection has already placed the unchained
+// LDS loads of all rows ahead of the arithmetic -- 40 to 80 operand registers -- when the machine scheduler sees the fence.)
 #define FB_PIN(addr, x) asm volatile("" : "+v"(addr), "+v"((x).a), "+v"((x).b), "+v"((x).c), "+v"((x).d))
 // Keys = values (merged heads: both are the x_hat rows, kpad = vpad = the padding token's x_hat): ONE pass over the rows.  With the weights
 // w_j = p_ij (w_pad = n_pad p_i,pad) and d_j = dz_i . x_j:   z_i = sum_j w_j x_j,   sig = sum_j w_j d_j,   A = sum_j (w_j d_j) x_j, and
@@ -415,345 +193,6 @@ __device__ __forceinline__ void attn_col8(const float* __restrict__ Qs, const fl
 #else
 #define FB_T(i) do { } while (0)
 #endif
-
-template <int ML>
-__global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef FB_TIMING
-  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = wall_clock64();
-#endif
-  float* Wq = lds;
-  float* Wk = lds + 1 * kTile;
-  float* Wv = lds + 2 * kTile;
-  float* Xs = lds + 3 * kTile;        // x_hat (rows >= n_real are zero)
-  float* Ds = lds + 4 * kTile;        // dDyn  (rows >= n_real are zero)
-  float* Qs = lds + 5 * kTile;        // Q -> dQ
-  float* Ks = lds + 6 * kTile;        // K -> dK
-  float* Vs = lds + 7 * kTile;        // V -> dV
-  float* Fs = lds + 8 * kTile;        // Wfc1 block -> dO -> O
-  float* sm = lds + 9 * kTile;
-  int* tinfo = reinterpret_cast<int*>(sm);  // [64] per local token row: first row of its hyperedge | k << 8
-  float* cb = sm + 64;                // [3][64] folded projection biases of this head
-  float* kpad = cb + 192;             // K / V rows of the shared padding token for this head
-  float* vpad = kpad + 64;
-  float* xpad = vpad + 64;
-  float* Ps = xpad + 64;              // [64][8] attention probabilities of the tile's rows
-  float* dSs = Ps + 512;              // [64][8] score gradients
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int wr = wave & 1, wc = wave >> 1;
-  const int srow = tid >> 4, sc4 = (tid & 15) * 4;
-  const int sub = lane & 7;
-
-  // (head, chunk): the 8 heads of one chunk share an XCD (workgroups are dealt round-robin over the 8 XCDs), so X and
-  // dDyn are fetched from HBM once and served to the other seven heads from that XCD's L2.
-  int head, chunk;
-  if ((g.nchunks & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    head = j & 7;
-    chunk = (j >> 3) * 8 + xcd;
-  } else {
-    head = blockIdx.x & 7;
-    chunk = blockIdx.x >> 3;
-  }
-  const int tr = g.count[1];
-  int ntr = g.count[2];                                // tiles planned by ragged.hip
-  if (ntr > g.ntiles) ntr = g.ntiles;
-  const int per = (ntr + g.nchunks - 1) / g.nchunks;
-  const int tile_lo = chunk * per;
-  const int tile_hi = (tile_lo + per < ntr) ? tile_lo + per : ntr;
-  const float inv_temp = 0.125f;
-
-  // ---- resident weights ----
-  const int64_t wofs = (int64_t)head * 64 * 64;
-  float fcb[32];                      // B fragments of the head's fc1 block for dO = dDyn . Wfc1[:, head block] (constant per workgroup)
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int x = 0; x < 4; ++x) fcb[4 * c + x] = g.fc1_w[(int64_t)(8 * c + 4 * h + x) * 512 + head * 64 + 32 * wc + r];
-  {
-    float4 t0, t1, t2, t3;
-    FB_GLOAD(t, g.wq + wofs, 64); FB_LSTORE(Wq, t);
-    FB_GLOAD(t, g.wk + wofs, 64); FB_LSTORE(Wk, t);
-    FB_GLOAD(t, g.wv + wofs, 64); FB_LSTORE(Wv, t);
-  }
-  if (tid < 192) cb[tid] = (tid < 64 ? g.cq : (tid < 128 ? g.ck : g.cv))[head * 64 + (tid & 63)];
-  if (tid < 16) {
-    const float4 xv = *reinterpret_cast<const float4*>(g.X + (int64_t)tr * 64 + sc4);
-    float m, rs;
-    ln_row16(xv, m, rs);
-    *reinterpret_cast<float4*>(&xpad[sc4]) = make_float4((xv.x - m) * rs, (xv.y - m) * rs, (xv.z - m) * rs, (xv.w - m) * rs);
-  }
-  __syncthreads();
-  if (tid < 128) {
-    const int n = tid & 63;
-    const float* W = tid < 64 ? Wk : Wv;
-    float s = 0.f;
-    for (int k = 0; k < 64; ++k) s += xpad[k] * W[n * kLd + k];
-    (tid < 64 ? kpad : vpad)[n] = s + cb[64 + (tid >> 6) * 64 + n];
-  }
-
-  f32x16 aWq = {0}, aWk = {0}, aWv = {0}, aWf = {0};
-  V8 accK = zero8(), accV = zero8();                 // dK_pad / dV_pad partials of this lane's feature slice
-  f2 csq2 = {0.f, 0.f}, csk2 = csq2, csv2 = csq2, csd2 = csq2;   // column sums of dQ, dK, dV, dDyn (even / odd token pairs): fall out of the weight-gradient operand loads
-
-  // software pipeline: tile metadata two tiles ahead, X / dDyn rows one tile ahead in named registers (a struct passed
-  // by reference ends up in scratch memory: fused_fwd.hip)
-  const int4* meta = reinterpret_cast<const int4*>(g.tile_meta);
-  const int4 mzero = make_int4(0, 0, 0, 0);
-  int4 mc = tile_lo < tile_hi ? meta[tile_lo] : mzero;
-  int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
-  float4 xn0, xn1, xn2, xn3, dn0, dn1, dn2, dn3;
-  int tpn = 0;
-#define FB_ROW_GLOAD(I, M)                                                                               \
-  do {                                                                                                   \
-    const int row__ = srow + 16 * (I);                                                                   \
-    const int64_t tok__ = (M).x + (row__ < (M).y ? row__ : ((M).y > 0 ? (M).y - 1 : 0));                 \
-    xn##I = *reinterpret_cast<const float4*>(g.X + tok__ * 64 + sc4);                                    \
-    dn##I = *reinterpret_cast<const float4*>(g.dDyn + tok__ * 64 + sc4);                                 \
-  } while (0)
-#define FB_ROWS_GLOAD(M)                                                                                 \
-  do {                                                                                                   \
-    FB_ROW_GLOAD(0, M); FB_ROW_GLOAD(1, M); FB_ROW_GLOAD(2, M); FB_ROW_GLOAD(3, M);                      \
-    if (tid < 64) tpn = g.tok_pos[(M).x + (tid < (M).y ? tid : ((M).y > 0 ? (M).y - 1 : 0))];           \
-  } while (0)
-#define FB_ROW_STAGE(I)                                                                                  \
-  do {                                                                                                   \
-    const int row__ = srow + 16 * (I);                                                                   \
-    const float msk__ = row__ < n_real ? 1.f : 0.f;                                                      \
-    const float4 xv__ = xn##I, dv__ = dn##I;                                                             \
-    const float mean__ = group_sum16_dpp((xv__.x + xv__.y) + (xv__.z + xv__.w)) * (1.f / 64.f);          \
-    const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
-    const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
-    const float rs__ = msk__ * __builtin_amdgcn_rsqf(q__ * (1.f / 64.f) + kEpsLn);                                     \
-    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
-    const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
-    *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
-  } while (0)
-  // (round 4: this kernel is the reference variant -- it always recomputes Q, K, V and the softmax; the saved-tile modes of rounds 2-3 went
-  // with the eight-wave kernel they fed)
-  constexpr bool img = false;
-  FB_ROWS_GLOAD(mc);
-
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
-    const int t0 = mc.x, n_real = mc.y;
-    if (n_real <= 0) {                                // no token starts in this window (all-padding rows only)
-      FB_ROWS_GLOAD(mn);
-      mc = mn; mn = mnn;
-      continue;
-    }
-    __syncthreads();                                  // previous tile's GEMMs are done with every working tile
-    FB_T(7);
-    // ---- stage x_hat, dDyn (zero rows beyond the tile's tokens), the fc1 block and the token -> hyperedge map ----
-    FB_ROW_STAGE(0); FB_ROW_STAGE(1); FB_ROW_STAGE(2); FB_ROW_STAGE(3);
-    if (tid < n_real) tinfo[tid] = (tid - (tpn & 255)) | (tpn & ~255);
-    __syncthreads();
-    FB_T(0);
-    // ---- recompute Q, K, V when the forward pass did not leave them (one accumulator at a time: fusing the three loops
-    //      pushed hipcc into spilling) ----
-    if (!img && !(g.dbg & 2)) {
-      proj_store_T(Qs, Xs, Wq, cb, wr, wc, r, h);
-      proj_store_T(Ks, Xs, Wk, cb + 64, wr, wc, r, h);
-      proj_store_T(Vs, Xs, Wv, cb + 128, wr, wc, r, h);
-    }
-    // ---- dO = dDyn . Wfc1[:, head block]  (weight fragments in registers; transposed product like the projections) ----
-    {
-      f32x16 acc = {0};
-      if (!(g.dbg & 2)) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float4 a = *reinterpret_cast<const float4*>(&Ds[(32 * wr + r) * kLd + 8 * c + 4 * h]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 0], a.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 1], a.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 2], a.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fcb[4 * c + 3], a.w, acc, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        *reinterpret_cast<float4*>(&Fs[(32 * wr + r) * kLd + 32 * wc + 8 * gq + 4 * h]) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
-    }
-    __syncthreads();
-    FB_T(1);
-    // ---- attention forward + backward: 8 lanes per token, two passes of 32 tokens ----
-    {
-      V8 o0, q0, k0, v0, o1, q1, k1, v1;
-      const int la = wave * 8 + (lane >> 3), lb = la + 32;
-      const bool acta = la < n_real && !(g.dbg & 1), actb = lb < n_real && !(g.dbg & 1);
-      int ia = 0, ib = 0;
-      if (acta) { ia = tinfo[la]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV, img); }
-      if (actb) { ib = tinfo[lb]; attn_row_fb<ML>(Qs, Ks, Vs, Fs, kpad, vpad, Ps, dSs, lb, ib & 255, ib >> 8, g.L - (ib >> 8), sub, inv_temp, o1, q1, accK, accV, img); }
-      __syncthreads();
-      FB_T(2);
-      if (acta) attn_col_fb<ML>(Qs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
-      if (actb) attn_col_fb<ML>(Qs, Fs, Ps, dSs, lb, ib & 255, ib >> 8, sub, k1, v1);
-      __syncthreads();
-      FB_T(3);
-      if (acta) {
-        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Qs[la * kLd + 8 * sub], q0); st8(&Ks[la * kLd + 8 * sub], k0); st8(&Vs[la * kLd + 8 * sub], v0);
-      } else {                                        // rows past the tile's tokens: zero, the column sums below run over all 64 rows
-        ZR8(&Qs[la * kLd + 8 * sub]); ZR8(&Ks[la * kLd + 8 * sub]); ZR8(&Vs[la * kLd + 8 * sub]);
-      }
-      if (actb) {
-        st8(&Fs[lb * kLd + 8 * sub], o1); st8(&Qs[lb * kLd + 8 * sub], q1); st8(&Ks[lb * kLd + 8 * sub], k1); st8(&Vs[lb * kLd + 8 * sub], v1);
-      } else {
-        ZR8(&Qs[lb * kLd + 8 * sub]); ZR8(&Ks[lb * kLd + 8 * sub]); ZR8(&Vs[lb * kLd + 8 * sub]);
-      }
-    }
-    __syncthreads();
-    FB_T(4);
-    // next tile's rows: in flight during the GEMMs below
-    FB_ROWS_GLOAD(mn);
-    // (stores first, weight gradients after: the stores are acknowledged long before the next tile waits on vmcnt)
-    // ---- this head's share of d x_hat = dQ W'q + dK W'k + dV W'v ----
-    if (!(g.dbg & 8)) {
-      // d x_hat^T: 24 contraction steps (3 products x 8) as one software pipeline: the operands of step s + 1 are read from LDS before
-      // the four MFMAs of step s, and sched_barrier keeps it that way (left alone the reads sink next to their MFMA and
-      // each one waits out the LDS latency: 40 ns per MFMA instead of 27)
-      f32x16 dx = {0};
-      const float* arow = Qs + (32 * wr + r) * kLd + 4 * h;
-      const float* wcol = Wq + (4 * h) * kLd + 32 * wc + r;
-      float4 a0 = *reinterpret_cast<const float4*>(arow), a1;
-      float w00 = wcol[0], w01 = wcol[kLd], w02 = wcol[2 * kLd], w03 = wcol[3 * kLd], w10, w11, w12, w13;
-#define FB_DX_LOAD(A, W, S)                                                                              \
-  do {                                                                                                   \
-    constexpr int m__ = (S) / 8, c__ = (S) % 8;                                                          \
-    const float* ap__ = arow + m__ * kTile + 8 * c__;                                                    \
-    const float* wp__ = wcol + m__ * kTile + (8 * c__) * kLd;                                            \
-    A = *reinterpret_cast<const float4*>(ap__);                                                          \
-    W##0 = wp__[0]; W##1 = wp__[kLd]; W##2 = wp__[2 * kLd]; W##3 = wp__[3 * kLd];                        \
-  } while (0)
-#define FB_DX_MMA(A, W)                                                                                  \
-  do {                                                                                                   \
-    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##0, A.x, dx, 0, 0, 0);                                   \
-    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##1, A.y, dx, 0, 0, 0);                                   \
-    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##2, A.z, dx, 0, 0, 0);                                   \
-    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(W##3, A.w, dx, 0, 0, 0);                                   \
-  } while (0)
-#define FB_DX_PAIR(S)                                                                                    \
-  do {                                                                                                   \
-    FB_DX_LOAD(a1, w1, (S) + 1);                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FB_DX_MMA(a0, w0);                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if ((S) + 2 < 24) FB_DX_LOAD(a0, w0, ((S) + 2 < 24 ? (S) + 2 : 0));                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FB_DX_MMA(a1, w1);                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  } while (0)
-      FB_DX_PAIR(0); FB_DX_PAIR(2); FB_DX_PAIR(4); FB_DX_PAIR(6); FB_DX_PAIR(8); FB_DX_PAIR(10);
-      FB_DX_PAIR(12); FB_DX_PAIR(14); FB_DX_PAIR(16); FB_DX_PAIR(18); FB_DX_PAIR(20); FB_DX_PAIR(22);
-      // transposed product (weights = MFMA row operand): lane (r, h) holds token row 32 wr + r and, in registers 4g..4g+3,
-      // features 32 wc + 8 g + 4 h + {0..3} -- four 16-byte stores under one predicate instead of sixteen predicated dwords
-      if (32 * wr + r < n_real) {
-        f32x4* out = reinterpret_cast<f32x4*>(g.dxh + ((int64_t)head * g.tcap + t0 + 32 * wr + r) * 64 + 32 * wc + 4 * h);
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) out[2 * gq] = (f32x4){dx[4 * gq], dx[4 * gq + 1], dx[4 * gq + 2], dx[4 * gq + 3]};
-      }
-    }
-    FB_T(5);
-    // ---- weight gradients: out[n][k] += sum_t G[t][n] . R[t][k]  (token index is the MFMA contraction index) ----
-    if (!(g.dbg & 4)) {
-      // 8 trips of 4 contraction steps (8 tokens); the operands of trip i + 1 are fetched before the 16 MFMAs of trip i.
-      // sched_barrier pins that order: left alone, the scheduler sinks every LDS read next to its MFMA to save
-      // registers and the wave then waits out the full LDS latency in front of each one.
-      // operands as (u, u + 1) pairs = the two destinations of one ds_read2_b32; the column sums then are v_pk_add_f32 on
-      // exactly those pairs (scalar adds made hipcc pair q with k instead and shuffle ~45 registers per trip to do so)
-      f2 xa01, xa23, oa01, oa23, qa01, qa23, ka01, ka23, va01, va23, da01, da23;
-      f2 xb01, xb23, ob01, ob23, qb01, qb23, kb01, kb23, vb01, vb23, db01, db23;
-      const float* px = Xs + h * kLd + 32 * wc + r;
-      const float* po = Fs + h * kLd + 32 * wc + r;
-      const float* pq = Qs + h * kLd + 32 * wr + r;
-      const float* pk = Ks + h * kLd + 32 * wr + r;
-      const float* pv = Vs + h * kLd + 32 * wr + r;
-      const float* pd = Ds + h * kLd + 32 * wr + r;
-#define FB_TN_LD2(P, OFF) (f2){(P)[(OFF) * kLd], (P)[((OFF) + 2) * kLd]}
-#define FB_TN_LOAD(S, OFF)                                                                               \
-  x##S##01 = FB_TN_LD2(px, OFF); x##S##23 = FB_TN_LD2(px, (OFF) + 4);                                    \
-  o##S##01 = FB_TN_LD2(po, OFF); o##S##23 = FB_TN_LD2(po, (OFF) + 4);                                    \
-  q##S##01 = FB_TN_LD2(pq, OFF); q##S##23 = FB_TN_LD2(pq, (OFF) + 4);                                    \
-  k##S##01 = FB_TN_LD2(pk, OFF); k##S##23 = FB_TN_LD2(pk, (OFF) + 4);                                    \
-  v##S##01 = FB_TN_LD2(pv, OFF); v##S##23 = FB_TN_LD2(pv, (OFF) + 4);                                    \
-  d##S##01 = FB_TN_LD2(pd, OFF); d##S##23 = FB_TN_LD2(pd, (OFF) + 4);
-#define FB_TN_MMA4(S, PR, E)                                                                             \
-  aWq = __builtin_amdgcn_mfma_f32_32x32x2f32(q##S##PR.E, x##S##PR.E, aWq, 0, 0, 0);                      \
-  aWk = __builtin_amdgcn_mfma_f32_32x32x2f32(k##S##PR.E, x##S##PR.E, aWk, 0, 0, 0);                      \
-  aWv = __builtin_amdgcn_mfma_f32_32x32x2f32(v##S##PR.E, x##S##PR.E, aWv, 0, 0, 0);                      \
-  aWf = __builtin_amdgcn_mfma_f32_32x32x2f32(d##S##PR.E, o##S##PR.E, aWf, 0, 0, 0);
-#define FB_TN_MMA(S)                                                                                     \
-  csq2 += q##S##01; csk2 += k##S##01; csv2 += v##S##01; csd2 += d##S##01;                                \
-  csq2 += q##S##23; csk2 += k##S##23; csv2 += v##S##23; csd2 += d##S##23;                                \
-  FB_TN_MMA4(S, 01, x) FB_TN_MMA4(S, 01, y) FB_TN_MMA4(S, 23, x) FB_TN_MMA4(S, 23, y)
-      FB_TN_LOAD(a, 0);
-#pragma unroll 1
-      for (int mm = 0; mm < 4; ++mm) {
-        FB_TN_LOAD(b, 8);
-        __builtin_amdgcn_sched_barrier(0);
-        FB_TN_MMA(a);
-        __builtin_amdgcn_sched_barrier(0);
-        const int nx = (mm == 3) ? -48 : 16;           // last trip: a harmless re-read of trip 0
-        px += nx * kLd; po += nx * kLd; pq += nx * kLd; pk += nx * kLd; pv += nx * kLd; pd += nx * kLd;
-        FB_TN_LOAD(a, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        FB_TN_MMA(b);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    FB_T(6);
-    mc = mn; mn = mnn;
-  }
-
-  // ---- workgroup slab ----
-  __syncthreads();
-#ifdef FB_TIMING
-  if (blockIdx.x == 0 && tid == 0)
-    printf("fused_bwd wg0 us: stage %.1f pre-gemm %.1f attn-row %.1f attn-col %.1f attn-write %.1f dx %.1f tn %.1f barrier-wait %.1f (tiles %d)\n",
-           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[5] * 0.01, tph[6] * 0.01, tph[7] * 0.01, tile_hi - tile_lo);
-#endif
-  float* slab = g.wslab + ((int64_t)head * g.nchunks + chunk) * kWgSlab;
-  {
-    const int col = 32 * wc + r;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      slab[0 * 4096 + row * 64 + col] = aWq[reg];
-      slab[1 * 4096 + row * 64 + col] = aWk[reg];
-      slab[2 * 4096 + row * 64 + col] = aWv[reg];
-      slab[3 * 4096 + row * 64 + col] = aWf[reg];
-    }
-  }
-  // column sums: this lane covered the tokens of one parity for column 32 wr + r (waves with wc = 1 hold duplicates)
-  float* red = Xs;                      // [5][64]: dcq dck dcv dKpad dVpad
-  float csq = csq2.x + csq2.y, csk = csk2.x + csk2.y, csv = csv2.x + csv2.y, csd = csd2.x + csd2.y;
-  csq += __shfl_xor(csq, 32, 64); csk += __shfl_xor(csk, 32, 64); csv += __shfl_xor(csv, 32, 64); csd += __shfl_xor(csd, 32, 64);
-  float* red2 = Ds;                     // [64] fc1 bias gradient
-  if (wc == 0 && h == 0) {
-    red[0 * 64 + 32 * wr + r] = csq; red[1 * 64 + 32 * wr + r] = csk; red[2 * 64 + 32 * wr + r] = csv;
-    red2[32 * wr + r] = csd;
-  }
-  // dK_pad / dV_pad: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
-  float* redp = Xs + 3 * 64;            // [4][2][64]
-  const float accp[16] = {accK.a.x, accK.a.y, accK.b.x, accK.b.y, accK.c.x, accK.c.y, accK.d.x, accK.d.y,
-                          accV.a.x, accV.a.y, accV.b.x, accV.b.y, accV.c.x, accV.c.y, accV.d.x, accV.d.y};
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float v = accp[i];
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 8) redp[(wave * 2 + (i >> 3)) * 64 + 8 * lane + (i & 7)] = v;
-  }
-  __syncthreads();
-  if (tid < 192) slab[kVecOff + tid] = red[tid];
-  if (tid < 128) {
-    const int vec = tid >> 6, f = tid & 63;
-    slab[kVecOff + 192 + tid] = ((redp[(0 * 2 + vec) * 64 + f] + redp[(1 * 2 + vec) * 64 + f]) + redp[(2 * 2 + vec) * 64 + f]) + redp[(3 * 2 + vec) * 64 + f];
-  }
-  if (tid < 64) slab[kVecOff + 320 + tid] = head == 0 ? red2[tid] : 0.f;
-}
 
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
@@ -1365,66 +804,6 @@ const float* fused_bwd_dxpad(const float* ws) { return ws + (size_t)MATCHA_N_HEA
 size_t fused_bwd_ws_floats(int64_t B, int L) {
   (void)B; (void)L;
   return (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab + (size_t)32 * 3 * 3 * 64 + 64;
-}
-
-int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
-                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st) {
-  // the REFERENCE formulation (option disable_merged): four products per head, Q / K / V and the softmax recomputed from X -- the A/B
-  // against which the merged kernels are tested; four wavefronts per workgroup on 64-row tiles
-  const int64_t tcap = B * L + 1;
-  int nchunks = chunks_for(rg.ntiles);
-  float* wslab = ws;
-  float* part = ws + (size_t)MATCHA_N_HEAD * kMaxChunks * kWgSlab;
-  float* dxpad = part + 32 * 3 * 3 * 64;
-  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
-  {
-    FusedBwdArgs g;
-    g.X = X; g.dDyn = dDyn; g.row_off = rg.row_off; g.count = rg.count; g.tile_meta = rg.tile_meta; g.tok_pos = rg.tok_pos; g.L = L; g.ntiles = rg.ntiles; g.nchunks = nchunks;
-    g.wq = folded; g.wk = folded + wsz; g.wv = folded + 2 * wsz;
-    g.cq = folded + 3 * wsz; g.ck = g.cq + csz; g.cv = g.cq + 2 * csz;
-    g.fc1_w = p.fc1_w; g.dxh = dxh; g.tcap = tcap; g.wslab = wslab; g.qkv = nullptr;
-    g.dbg = options().fused_dbg;
-    const size_t lds = ((size_t)9 * kTile + 64 + 192 + 3 * 64 + 2 * 512) * sizeof(float);
-    auto launch = [&](auto kfn) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
-    };
-    // algorithmic flops: 8 heads x 8 GEMMs (dO, dWfc1, 3 dW', 3 d x_hat terms) of 2*64*64 per token; the Q/K/V recompute is not counted
-    ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
-    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
-      case 2: launch(fused_bwd_kernel<2>); break;
-      case 3: launch(fused_bwd_kernel<3>); break;
-      case 4: launch(fused_bwd_kernel<4>); break;
-      case 5: launch(fused_bwd_kernel<5>); break;
-      case 6: launch(fused_bwd_kernel<6>); break;
-      default: launch(fused_bwd_kernel<8>); break;
-    }
-    MATCHA_CHECK_LAUNCH("fused_bwd_kernel");
-  }
-  const int nslabs = nchunks;
-  {
-    UnfoldArgs a;
-    a.wslab = wslab; a.nchunks = nslabs; a.X = X; a.count = rg.count;
-    a.W[0] = p.w_q; a.W[1] = p.w_k; a.W[2] = p.w_v;
-    a.g[0] = p.ln_q_g; a.g[1] = p.ln_k_g; a.g[2] = p.ln_v_g;
-    a.b[0] = p.ln_q_b; a.b[1] = p.ln_k_b; a.b[2] = p.ln_v_b;
-    a.gW[0] = grads.w_q; a.gW[1] = grads.w_k; a.gW[2] = grads.w_v; a.gfc1 = grads.fc1_w;
-    a.part = part;
-    hipLaunchKernelGGL(fb_unfold_kernel, dim3(4, 4, MATCHA_N_HEAD), dim3(256), 0, st, a);
-    MATCHA_CHECK_LAUNCH("fb_unfold_kernel");
-    Unfold2Args b;
-    b.part = part; b.wslab = wslab; b.nchunks = nslabs;
-    b.dg[0] = grads.ln_q_g; b.dg[1] = grads.ln_k_g; b.dg[2] = grads.ln_v_g;
-    b.db[0] = grads.ln_q_b; b.db[1] = grads.ln_k_b; b.db[2] = grads.ln_v_b;
-    b.dfc1_b = grads.fc1_b; b.dxpad = dxpad; b.dxpad_add = 0;
-    hipLaunchKernelGGL(fb_unfold2_kernel, dim3(1), dim3(512), 0, st, b);
-    MATCHA_CHECK_LAUNCH("fb_unfold2_kernel");
-  }
-  if (dZ0) {                                           // null: the caller's front-end backward kernel consumes dxh / dxpad itself
-    hipLaunchKernelGGL(lnhat_bwd_kernel, dim3((unsigned)cdiv(tcap, 16)), dim3(256), 0, st, X, dxh, tcap, dxpad, dXs, dZ0, rg.count, MATCHA_N_HEAD);
-    MATCHA_CHECK_LAUNCH("lnhat_bwd_kernel");
-  }
-  return MATCHA_OK;
 }
 
 // merged heads: fused_bwdh_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)

@@ -1,27 +1,29 @@
-// Wave-independent fused forward for embed_dim 64 (round 3; replaces the four-wave tile kernel of fused_fwd.hip on every path,
-// A/B: matcha_set_option("disable_fwd32", 1)).  Same mathematics (Modules.py:519-572, :353-376, :290-311; main.py:56), other
-// decomposition:
+// Wave-independent fused forward for embed_dim 64, merged heads.  The mathematics of Modules.py:519-572,
+// :353-376, :290-311 and main.py:56 with the per-head products merged (r = B_h x_hat + b_h, s_ij = r_i . x_hat_j, z_i = sum_j p_ij x_hat_j,
+// dyn += M_h z_i), decomposed as
 //
 //   ONE WAVEFRONT = ONE WORKGROUP = one HALF TILE: <= 31 real tokens of whole hyperedges + the shared padding token as local row n
-//   (ragged.hip: half_meta).  Nothing is shared between wavefronts, so there is no workgroup barrier anywhere: the four-wave kernel
-//   spent a third of its time in 59 barrier phases per tile with two waves per SIMD to cover them.
+//   (ragged.hip: half_meta).  Nothing is shared between wavefronts, so there is no workgroup barrier anywhere (the four-wave tile kernel
+//   of rounds 1-2 spent a third of its time in 59 barrier phases per tile).
 //
 //   Layout "FL": lane (r, h) owns token row r and the 32 features  f(e) = 32 wc + 8 g + 4 h + j,  e = 16 wc + 4 g + j  -- exactly what
 //   the 32x32x2 MFMA leaves in a lane when a projection is computed as the TRANSPOSED product  D[feature][token] = W . x^T, and exactly
-//   what the next product needs as its token-side operand.  Q, O, dyn, Y, H1, H2 and their gradients therefore never leave the
-//   registers; only K / V rows (read by the other tokens of a hyperedge) and the weight-gradient operands pass through the
-//   wave's two private LDS tiles (2 x 8.5 KB: eight wavefronts per CU, two per SIMD, limited by the 256 registers).
+//   what the next product needs as its token-side operand.  r, z, dyn, Y, H1, H2 and their gradients therefore never leave the
+//   registers; only the x_hat rows (keys = values of every head, read by the other tokens of a hyperedge) and the weight-gradient
+//   operands pass through the wave's two private LDS tiles (2 x 8.5 KB: eight wavefronts per CU, two per SIMD, limited by the 256
+//   registers).
 //
 //   Weights are STREAMED FROM L2 in fragment-major order (fold_frag_kernel rewrites them once per step: one coalesced 1 KB load per
-//   wave and four MFMAs) through a rolling window of eight float4 per lane; tools/ubench/mfma_l2stream.hip measured 85 - 88 % of the
+//   wave and four MFMAs) through a rolling window of nine float4 per lane; tools/ubench/mfma_l2stream.hip measured 85 - 88 % of the
 //   matrix pipe's rate for that pattern with two decoupled waves per SIMD, without any LDS staging.
 //
 //   Attention: two lanes per query token (32 features each), every token of the half tile at once; the dot products' cross-lane part
-//   is ONE v_permlane32_swap instead of three DPP steps, softmax runs twice instead of eight times per token: ~270 VALU
-//   instructions per head and 32 tokens (four-wave kernel: ~600).
+//   is ONE v_permlane32_swap instead of three DPP steps; cut into pieces that ride between the MFMAs of the next head's r product.
 //
-//   The Q / K / V rows and attention probabilities the fused backward reloads are written in ITS tile layout (fused_bwd.hip walks
-//   64-row tiles that cut the token stream elsewhere): tok_tile[t] = (tile << 6) | row says where each token's rows go.
+//   A training forward leaves, per (half tile, head), the r rows as the lane's accumulator registers + the probabilities [32][8]
+//   (kImgRecH floats): fused_bwdh_kernel walks the same half tiles and reloads them thread for thread.
+//
+// fused_fwd32h_kernel (below) is the same forward for small batches: eight wavefronts per half tile, one per head.
 #include "kernels.hpp"
 
 #ifndef F32_WIN
@@ -43,7 +45,7 @@ constexpr int kLdH = 68;                  // LDS row stride (floats)
 constexpr int kHT = 32 * kLdH;            // one half tile [32 rows][68]
 constexpr float kEps32 = 1e-5f;
 constexpr int kFragF4 = 18 * 64;           // float4 per 64 x 64 matrix in fragment-major order: [wc][c = 0..7 | bias][lane]
-constexpr int kNMat = 36;                 // 8 heads x {K, Q, V, fc1 block}, conv0, conv1, conv1^T, conv0^T -- in consumption order (fold_frag_kernel)
+constexpr int kNMat = 20;                 // R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0, conv1, conv1^T, conv0^T -- in consumption order (fold_frag_kernel)
 constexpr int kTailVec32 = 2 * 4096;      // same slab format as fused_fwd.hip (tail_slab_reduce_kernel reads both)
 constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
 
@@ -294,39 +296,24 @@ __global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
 
 // ---- fragment-major weights, rewritten once per step (after fold_ln_kernel) ----------------------------------------------
 struct FragArgs {
-  const float* wq; const float* wk; const float* wv;      // folded W' [512][64]
-  const float* cq; const float* ck; const float* cv;      // folded biases [512]
-  const float* fc1_w; const float* fc1_b;                 // [64][512], [64]
   const float* p0w; const float* p0b; const float* p1w; const float* p1b;   // [64][64], [64]
   f32x4* out;                                             // [kNMat + 1][kFragF4] (one matrix of zero padding behind the stream)
-  const float* mB; const float* mM; const float* mbvec; const float* mbdyn;   // merged form (null: the four-product stream)
+  const float* mB; const float* mM; const float* mbvec; const float* mbdyn;   // B_h, M_h [8][64][64], b_h [8][64], the merged fc1 bias [64]
 };
-// Stream order = consumption order of fused_fwd32_kernel: K0 Q0 | V_h K_{h+1} Q_{h+1} F_h (h = 0..6) | V7 F7 | conv0 conv1 conv1^T conv0^T.
+// Stream order = consumption order of fused_fwd32_kernel: R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0 conv1 conv1^T conv0^T.
 // grid (kNMat + 1, 9) x 128: fragment (wc, c, lane) of matrix m
 __global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
   const int m = blockIdx.x, idx = blockIdx.y * 128 + threadIdx.x;       // 0 .. 1151
   const int wc = idx / 576, c = (idx % 576) >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
   const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
-  int type = -1, hd = 0;                                 // 0 K, 1 Q, 2 V, 3 fc1 block, 4 conv0, 5 conv1, 6 conv1^T, 7 conv0^T, 8 B_h, 9 M_h
-  if (a.mB) {
-    // merged stream: R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0 conv1 conv1^T conv0^T
-    if (m == 0) { type = 8; }
-    else if (m < 15) { hd = (m - 1) >> 1; if ((m - 1) & 1) type = 9; else { type = 8; ++hd; } }
-    else if (m == 15) { type = 9; hd = 7; }
-    else if (m < 20) type = m - 12;
-  } else
-  if (m == 0) { type = 0; } else if (m == 1) { type = 1; }
-  else if (m < 30) { const int t = (m - 2) & 3; hd = (m - 2) >> 2; type = t == 0 ? 2 : (t == 1 ? 0 : (t == 2 ? 1 : 3)); if (t == 1 || t == 2) ++hd; }
-  else if (m == 30) { type = 2; hd = 7; } else if (m == 31) { type = 3; hd = 7; }
-  else if (m < 36) type = m - 28;
+  int type = -1, hd = 0;                                 // 4 conv0, 5 conv1, 6 conv1^T, 7 conv0^T, 8 B_h, 9 M_h
+  if (m == 0) { type = 8; }
+  else if (m < 15) { hd = (m - 1) >> 1; if ((m - 1) & 1) type = 9; else { type = 8; ++hd; } }
+  else if (m == 15) { type = 9; hd = 7; }
+  else if (m < 20) type = m - 12;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (c < 8) {
-    if (type >= 0 && type < 3) {
-      const float* W = type == 0 ? a.wk : (type == 1 ? a.wq : a.wv);
-      v = *reinterpret_cast<const f32x4*>(W + ((int64_t)hd * 64 + n) * 64 + k0);
-    } else if (type == 3) {
-      v = *reinterpret_cast<const f32x4*>(a.fc1_w + (int64_t)n * 512 + hd * 64 + k0);
-    } else if (type == 4) {
+    if (type == 4) {
       v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
     } else if (type == 5) {
       v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
@@ -341,10 +328,8 @@ __global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
     }
   } else if (h == 0) {                                   // bias fragment: lane (r, 0) supplies A[i = r][k = 0]; B is the constant 1
     float bv = 0.f;
-    if (type == 0) bv = a.ck[hd * 64 + n]; else if (type == 1) bv = a.cq[hd * 64 + n]; else if (type == 2) bv = a.cv[hd * 64 + n];
-    else if (type == 3) bv = hd == 0 ? a.fc1_b[n] : 0.f;   // the fc1 bias enters dyn once
-    else if (type == 4) bv = a.p0b[n]; else if (type == 5) bv = a.p1b[n];
-    else if (type == 8) bv = a.mbvec[hd * 64 + n]; else if (type == 9) bv = hd == 0 ? a.mbdyn[n] : 0.f;
+    if (type == 4) bv = a.p0b[n]; else if (type == 5) bv = a.p1b[n];
+    else if (type == 8) bv = a.mbvec[hd * 64 + n]; else if (type == 9) bv = hd == 0 ? a.mbdyn[n] : 0.f;   // the merged fc1 bias enters dyn once
     v.x = bv;
   }
   a.out[(int64_t)m * kFragF4 + idx] = v;
@@ -352,7 +337,7 @@ __global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
 
 struct Fwd32Args {
   const float* X;
-  const int32_t* row_off; const int32_t* tok_slot; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos; const int32_t* tok_tile;
+  const int32_t* row_off; const int32_t* tok_slot; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos;
   int L;
   const f32x4* wfrag;
   HeadParams hp;
@@ -362,13 +347,11 @@ struct Fwd32Args {
   const uint64_t* seed;
   float p_fc1, p_pff;
   float* ddyn0; float* dXs; float* tslab; float alpha_over_B;
-  float* qkv;
-  int img_half;       // MG: the saved record is per (HALF tile, head) -- this wavefront's own rows, kImgRecH floats (fused_bwdh_kernel) -- instead of per 64-row tile
+  float* qkv;         // training: the record per (half tile, head) -- this wavefront's own r rows + probabilities, kImgRecH floats (fused_bwdh_kernel)
 };
 
-// MG = merged per-head matrices (two products per head: r = B_h x + b_h, dyn += M_h z); the saved record per (tile, head) is then the
-// r rows [64][64] + the probabilities [64][8] (kImgRecM floats) for fused_bwd_merged.hip instead of Q, K, V + probabilities.
-template <int ML, bool MG>
+// Merged per-head matrices (two products per head: r = B_h x + b_h, dyn += M_h z).
+template <int ML>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_fwd32_kernel(Fwd32Args g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef FF_TIMING
@@ -378,8 +361,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #else
 #define FF_T(i) do { } while (0)
 #endif
-  float* TK = lds;                       // K rows of the current head; tail: product tiles, dH2, Y
-  float* TV = lds + kHT;                 // V rows; tail: the parameter vectors until the weight-gradient GEMMs, then H1, dZ1
+  float* TK = lds;                       // the x_hat rows (keys = values of every head); tail: product tiles, dH2, Y
+  float* TV = lds + kHT;                 // tail: the parameter vectors until the weight-gradient GEMMs, then H1, dZ1
   float* outs = lds + 2 * kHT;           // [32] per-token classifier outputs
   float* douts = outs + 32;              // [32] their gradients
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -399,11 +382,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   // ---- x_hat in layout FL straight from global memory ----
   FL xh = fl_load(g.X + tok * 64 + 4 * h);
-  int pos = 0, k = 0, tt = 0;
+  int pos = 0, k = 0;
   if (real) {
     const int tp = g.tok_pos[tok];
     pos = tp & 255; k = tp >> 8;
-    tt = g.tok_tile[tok];
   }
   const int li0 = r - pos;
   // dropout: keep <=> lowbias32(col ^ lowbias32(slot ^ key)) >= threshold (threshold 0 = keep everything: no branches below)
@@ -434,22 +416,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int e = 0; e < 16; ++e) { xh.lo[e] = (xh.lo[e] - mean) * rx; xh.hi[e] = (xh.hi[e] - mean) * rx; }
   }
-  const int kRec = MG ? (g.img_half ? kImgRecH : kImgRecM) : kImgRec;
-  // where this token's rows go in the backward kernel's tile images: float4 index ((2 wr' + wc) * 4 + g) * 64 + 32 h + r'
+  constexpr int kRec = kImgRecH;
+  // where this token's rows go in the backward kernel's record: float4 index (wc * 4 + g) * 64 + 32 h + r of this wavefront's own
+  // record, probabilities [32][8] behind the rows
   float* img_tok = nullptr;
   float* pimg_tok = nullptr;
   if (g.qkv && real) {
-    if (MG && g.img_half) {
-      // half-tile record: float4 index (wc * 4 + g) * 64 + 32 h + r of this wavefront's own record, probabilities [32][8] behind the rows
-      float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
-      img_tok = base + (32 * h + r) * 4;
-      pimg_tok = base + 2048 + r * 8;
-    } else {
-      const int tile = tt >> 6, rho = tt & 63;
-      float* base = g.qkv + (int64_t)tile * MATCHA_N_HEAD * kRec;
-      img_tok = base + ((rho >> 5) * 8 * 64 + 32 * h + (rho & 31)) * 4;
-      pimg_tok = base + (MG ? 4096 : 3 * 4096) + rho * 8;
-    }
+    float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
+    img_tok = base + (32 * h + r) * 4;
+    pimg_tok = base + 2048 + r * 8;
   }
 #define F32_IMG_STORE(ACC, HD, M)                                                                        \
   do {                                                                                                   \
@@ -528,23 +503,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }                                                                                                  \
     }                                                                                                    \
   } while (0)
-#define F32_PV_PIECE(S)                                                                                  \
-  do {                                                                                                   \
-    constexpr int j__ = (S) >> 1, hf__ = (S) & 1;                                                        \
-    if constexpr (j__ <= ML) {                                                                           \
-      const float* rp__ = TV + ro[j__] + 32 * hf__;                                                      \
-      const float w__ = j__ < ML ? p[j__] : padf * p[ML];                                                \
-      const f2 w2__ = {w__, w__};                                                                        \
-      f32x16& oo__ = hf__ ? o.hi : o.lo;                                                                 \
-      _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
-        const f32x4 a__ = *reinterpret_cast<const f32x4*>(rp__ + 8 * g__);                               \
-        const f2 u0__ = __builtin_elementwise_fma(w2__, (f2){a__.x, a__.y}, (f2){oo__[4 * g__], oo__[4 * g__ + 1]});     \
-        const f2 u1__ = __builtin_elementwise_fma(w2__, (f2){a__.z, a__.w}, (f2){oo__[4 * g__ + 2], oo__[4 * g__ + 3]}); \
-        oo__[4 * g__] = u0__.x; oo__[4 * g__ + 1] = u0__.y; oo__[4 * g__ + 2] = u1__.x; oo__[4 * g__ + 3] = u1__.y;      \
-      }                                                                                                  \
-      asm volatile("" : "+v"(oo__));                                                                     \
-    }                                                                                                    \
-  } while (0)
 #define F32_STAGE18(MAC)                                                                                 \
   do {                                                                                                   \
     MAC(0); MAC(1); MAC(2); MAC(3); MAC(4); MAC(5); MAC(6); MAC(7); MAC(8);                              \
@@ -553,7 +511,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   FF_T(0);
   FL dyn = fl_zero();
-  if constexpr (MG) {
+  {
     // ======================= merged heads: two products per head, keys = values = the x_hat rows (written to TK once) =======================
     // pieces of head hd (two per step of the NEXT head's r product): score half-dots, softmax, probabilities out, z half-rows
     FL q = fl_zero(), o;                              // q: the r rows of the current head; o: z = P x_hat
@@ -608,73 +566,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     FF_T(2);
     W32_CHAIN(dyn, o, true);
     FF_T(5);
-  } else {
-  FL q = fl_zero(), o;
-  {
-    // ---- prologue: K_0 -> TK, Q_0 ----
-    FL acc = fl_zero();
-    W32_CHAIN(acc, xh, true);
-    fl_store(krow, acc);
-    F32_IMG_STORE(acc, 0, 1);
-    W32_CHAIN(q, xh, true);
-    F32_IMG_STORE(q, 0, 0);
-    __syncthreads();                                  // (single wave: a compiler fence) K rows visible
   }
-  FF_T(1);
-#if F32_ABL & 1
-#define F32_A_STEP(S) do { W32_MMA(acc, xh, S); W32_REFILL(S, true); } while (0)
-#define F32_B_STEP(S) do { W32_MMA(acc, xh, S); W32_REFILL(S, true); } while (0)
-#define F32_B_ONLY(S) do { o = q; } while (0)
-#else
-#define F32_A_STEP(S) do { W32_MMA(acc, xh, S); F32_SC_PIECE(S); W32_REFILL(S, true); } while (0)
-#define F32_B_STEP(S) do { W32_MMA(acc, xh, S); F32_PV_PIECE(S); W32_REFILL(S, true); } while (0)
-#define F32_B_ONLY(S) do { F32_PV_PIECE(S); } while (0)
-#endif
-  // stage A: V_hd = W'v . x_hat^T + cv, the scores and the softmax of head hd between its MFMAs
-#define F32_STAGE_A()                                                                                    \
-  do {                                                                                                   \
-    FL acc = fl_zero();                                                                                  \
-    F32_STAGE18(F32_A_STEP);                                                                             \
-    if (!(F32_ABL & 1)) { F32_SC_PIECE(18); F32_SC_PIECE(19); }   /* ML = 8: the softmax does not fit between the 18 steps */ \
-    fl_store(vrow, acc);                                                                                 \
-    F32_IMG_STORE(acc, hd, 2);                                                                           \
-    __syncthreads();                                /* V rows visible */                                 \
-  } while (0)
-  int hd = 0;
-  for (; hd + 1 < MATCHA_N_HEAD; ++hd) {
-    F32_STAGE_A();
-    FF_T(2);
-    // ---- stage B: K_{hd+1}, O_hd = P V between its MFMAs ----
-    o = fl_zero();
-    {
-      FL acc = fl_zero();
-      F32_STAGE18(F32_B_STEP);
-      fl_store(krow, acc);                            // the scores of head hd are done with TK
-      F32_IMG_STORE(acc, hd + 1, 1);
-    }
-    FF_T(3);
-    // ---- stage C: Q_{hd+1} ----
-    q = fl_zero();
-    W32_CHAIN(q, xh, true);
-    F32_IMG_STORE(q, hd + 1, 0);
-    __syncthreads();                                  // K rows visible
-    FF_T(4);
-    // ---- stage D: dyn += Wfc1[:, head block] . O^T (+ the fc1 bias with head 0's block) ----
-    W32_CHAIN(dyn, o, true);
-    FF_T(5);
-  }
-  // the last head: no next K / Q to hide P V behind (written after the loop, not as an else-branch inside it: the compiler hoists the
-  // LDS reads common to both branches above the branch and then spills them)
-  F32_STAGE_A();
-  FF_T(2);
-  o = fl_zero();
-  F32_STAGE18(F32_B_ONLY);
-  FF_T(3);
-  W32_CHAIN(dyn, o, true);
-  FF_T(5);
-
   // =========================== tail: pff_n1, LayerNorms, classifier (all in registers) ===========================
-  }
   if (F32_ABL & 8) { if (dyn.lo[0] == 12345.f) g.logits[0] = dyn.hi[3]; return; }
 #define F32_TAIL_SYNC() __syncthreads()
 #include "fused_fwd32_tail.hpp"
@@ -698,7 +591,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // chain: logits differ from the single-wave kernel by ~1e-7 relative (tests/test_hip_properties.py).
 template <int ML>
 __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
-  constexpr bool MG = true;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #undef FF_T
 #define FF_T(i) do { } while (0)
@@ -759,7 +651,7 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   const int kRec = kImgRecH;
   float* img_tok = nullptr;
   float* pimg_tok = nullptr;
-  if (g.qkv && real) {                   // half-tile records (fused_bwdh_kernel): as in fused_fwd32_kernel with img_half
+  if (g.qkv && real) {                   // half-tile records (fused_bwdh_kernel): as in fused_fwd32_kernel
     float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
     img_tok = base + (32 * h + r) * 4;
     pimg_tok = base + 2048 + r * 8;
@@ -840,15 +732,13 @@ int launch_merge_heads(const matcha_tensors& p, const float* folded, float* merg
 }
 
 int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st, const float* merged) {
+  (void)folded;
+  MATCHA_CHECK_ARG(merged, "fold_frag: the merged matrices are required");
   FragArgs a;
-  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64;
-  a.wq = folded; a.wk = folded + wsz; a.wv = folded + 2 * wsz;
-  const size_t csz = (size_t)MATCHA_N_HEAD * 64;
-  a.cq = folded + 3 * wsz; a.ck = a.cq + csz; a.cv = a.cq + 2 * csz;
-  a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b; a.p0w = p.pff0_w; a.p0b = p.pff0_b; a.p1w = p.pff1_w; a.p1b = p.pff1_b;
+  a.p0w = p.pff0_w; a.p0b = p.pff0_b; a.p1w = p.pff1_w; a.p1b = p.pff1_b;
   a.out = reinterpret_cast<f32x4*>(frag);
-  a.mB = a.mM = a.mbvec = a.mbdyn = nullptr;
-  if (merged) { const MergedView v = merged_view(merged); a.mB = v.B; a.mM = v.M; a.mbvec = v.bvec; a.mbdyn = v.bdyn; }
+  const MergedView v = merged_view(merged);
+  a.mB = v.B; a.mM = v.M; a.mbvec = v.bvec; a.mbdyn = v.bdyn;
   hipLaunchKernelGGL(fold_frag_kernel, dim3(kNMat + 1, 9), dim3(128), 0, st, a);
   MATCHA_CHECK_LAUNCH("fold_frag_kernel");
   return MATCHA_OK;
@@ -856,25 +746,24 @@ int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, 
 
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* qkv, bool merged, bool img_half) {
+                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* rimg) {
   Fwd32Args g;
-  g.img_half = (merged && img_half) ? 1 : 0;
-  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.tok_tile = rg.tok_tile;
+  g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos;
   g.L = L;
   g.wfrag = reinterpret_cast<const f32x4*>(frag);
   (void)folded;
   g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
-  g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B; g.qkv = qkv;
+  g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B; g.qkv = rimg;
   size_t lds = ((size_t)2 * kHT + 64) * sizeof(float);
   lds += (size_t)options().fwd_lds_pad;      // occupancy experiments (tools/debug/timing_fwd32.sh): 20000 -> one wavefront per SIMD
   auto launch = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(rg.nhalves), dim3(64), lds, st, g); };
-  // algorithmic flops per token: 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
+  // algorithmic flops per token (the reference formulation's): 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
   ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);
   const int ml = L <= 2 ? 2 : (L <= 6 ? L : 8);
   // small batches (at most two half tiles per CU even at the bound): the heads side by side in eight wavefronts per half tile
-  if (merged && (img_half || !qkv) && rg.nhalves <= fwd32h_max_halves() && !options().disable_fwd32h) {
+  if (rg.nhalves <= fwd32h_max_halves() && !options().disable_small_batch) {
     const size_t ldsh = ((size_t)10 * kHT + 64) * sizeof(float);
     auto launchh = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
@@ -891,24 +780,13 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
     MATCHA_CHECK_LAUNCH("fused_fwd32h_kernel");
     return MATCHA_OK;
   }
-  if (merged) {
-    switch (ml) {
-      case 2: launch(fused_fwd32_kernel<2, true>); break;
-      case 3: launch(fused_fwd32_kernel<3, true>); break;
-      case 4: launch(fused_fwd32_kernel<4, true>); break;
-      case 5: launch(fused_fwd32_kernel<5, true>); break;
-      case 6: launch(fused_fwd32_kernel<6, true>); break;
-      default: launch(fused_fwd32_kernel<8, true>); break;
-    }
-  } else {
-    switch (ml) {
-      case 2: launch(fused_fwd32_kernel<2, false>); break;
-      case 3: launch(fused_fwd32_kernel<3, false>); break;
-      case 4: launch(fused_fwd32_kernel<4, false>); break;
-      case 5: launch(fused_fwd32_kernel<5, false>); break;
-      case 6: launch(fused_fwd32_kernel<6, false>); break;
-      default: launch(fused_fwd32_kernel<8, false>); break;
-    }
+  switch (ml) {
+    case 2: launch(fused_fwd32_kernel<2>); break;
+    case 3: launch(fused_fwd32_kernel<3>); break;
+    case 4: launch(fused_fwd32_kernel<4>); break;
+    case 5: launch(fused_fwd32_kernel<5>); break;
+    case 6: launch(fused_fwd32_kernel<6>); break;
+    default: launch(fused_fwd32_kernel<8>); break;
   }
   MATCHA_CHECK_LAUNCH("fused_fwd32_kernel");
   return MATCHA_OK;

@@ -106,11 +106,10 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
-  int disable_fused, disable_fused_train, disable_fused_front, disable_loss_in_forward;
-  int disable_merged;     // the reference formulation of the heads (four products per head, recompute backward): the A/B variant
-  int disable_fwd32h;     // small batches: one wavefront per half tile (fused_fwd32_kernel) instead of eight, one per head
-  int disable_plan_small; // small batches: the ragged plan as five launches instead of one
-  int disable_wide_gemm, disable_bmm_heads;
+  int disable_fused, disable_fused_front, disable_loss_in_forward;
+  int disable_merged;        // the reference formulation of the heads (four products per head) on the layer-by-layer kernels: the A/B variant
+  int disable_small_batch;   // the large-batch kernels at every size: one wavefront per half tile in the forward, the ragged plan as five launches
+  int disable_wide_gemm;
   int debug_nan, fused_dbg, fwd_lds_pad;
   int tune;       // development: a free integer read by whatever kernel is being tuned (0 = defaults)
 };
@@ -145,30 +144,25 @@ int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tenso
 // MFMA-fragment order (launch_fold_frag rewrites them once per step, after launch_fold_ln), no workgroup barriers
 size_t fused_frag_floats();
 size_t fused_tail_slab32_floats(int64_t B, int L);
-// merged != null: the two-products-per-head form (r = B_h x + b_h, dyn += M_h z); `merged` = fused_merged_floats() floats of workspace
-// that launch_merge_heads fills (B [8][64][64], M [8][64][64], b [8][64], bdyn [64]) after launch_fold_ln
+// the heads in their two-products form (r = B_h x + b_h, dyn += M_h z); `merged` = fused_merged_floats() floats of workspace that
+// launch_merge_heads fills (B [8][64][64], M [8][64][64], b [8][64], bdyn [64]) after launch_fold_ln
 size_t fused_merged_floats();
 struct MergedView { const float* B; const float* M; const float* bvec; const float* bdyn; };
 MergedView merged_view(const float* merged);
 int launch_merge_heads(const matcha_tensors& p, const float* folded, float* merged, hipStream_t st);
-int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st, const float* merged = nullptr);
+int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st, const float* merged);
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                       hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* qkv = nullptr,
-                       bool merged = false, bool img_half = false);
+                       hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* rimg = nullptr);
 
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)
 size_t fused_bwd_ws_floats(int64_t B, int L);
-int launch_fused_bwd(const matcha_tensors& p, const float* folded, const float* X, const float* dDyn, const float* dXs, const Ragged& rg, int64_t B,
-                     int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
                             bool dx_atomic);
-size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (tile, head):
-constexpr int kImgRec = 3 * 4096 + 512;            // the Q, K, V tiles as register images + the attention probabilities [64 tokens][8]
-constexpr int kImgRecM = 4096 + 512;               // merged heads: the r rows (r = B_h x_hat + b_h) + the attention probabilities
-constexpr int kImgRecH = 2048 + 256;               // merged heads, per HALF tile: 32 r rows + their probabilities [32][8] (fused_bwdh_kernel)
+size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (half tile, head):
+constexpr int kImgRecH = 2048 + 256;               // 32 r rows (r = B_h x_hat + b_h; register images) + their attention probabilities [32][8]
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 

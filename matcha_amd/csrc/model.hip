@@ -83,23 +83,21 @@ struct Workspace {
 // A/B switches for tests and profiling (include/matcha_hip.h, matcha_set_option): ONE process-wide struct whose initial values
 // come from the environment (MATCHA_DISABLE_FUSED, ...) when it is first touched; no entry point calls getenv per call.
 //   disable_fused            layer-by-layer kernels everywhere (the d != 64 path, at embed_dim 64 too)
-//   disable_fused_train      fused kernels only for no-grad forwards; training runs layer by layer
 //   disable_fused_front      front end (gather + attribute_nn + next_w; its backward; the fused adj kernels) as separate kernels
 //   disable_loss_in_forward  the tail's backward as separate kernels even when opts->loss_in_forward is set
-//   disable_merged           the REFERENCE formulation of the heads: four products per head forward (fused_fwd32_kernel<ML, false>), eight
-//                            backward with Q / K / V recomputed (fused_bwd_kernel) instead of the merged two / four -- the one variant
-//                            kept for A/B since round 4 (the four-wave forward, the eight-wave and 64-row-tile backward kernels and
-//                            their switches disable_fwd32 / disable_bwd8 / disable_bwdh / disable_qkv_save / disable_dx_atomic are gone:
-//                            what the last one selected is what opts->deterministic / sparse_table_grad select)
-//   disable_fwd32h           small batches: one wavefront per half tile instead of eight (one per head)
-//   disable_bmm_heads        merged layer-wise path (embed_dim >= 128): the per-head weight products as 48 separate GEMM launches
-//   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM kernels (gemm_lds.hip, gemm_f32.hip) instead of gemm_wide.hip
+//   disable_merged           the REFERENCE formulation of the heads (Q, K, V, fc1: four products per head forward, eight backward) instead
+//                            of the merged two / four.  It lives on the layer-by-layer kernels only (attention.hip + the GEMMs), so at
+//                            embed_dim 64 the switch implies disable_fused; the fused four-product kernels of rounds 1-3 (four-wave
+//                            forward, eight-wave / 64-row-tile / recompute backward, their five switches) are gone since round 4
+//   disable_small_batch      the kernels picked for small batches by size -- one workgroup of eight wavefronts (one per head) per half tile
+//                            in the forward, the ragged plan as one launch -- replaced by the large-batch kernels
+//   disable_wide_gemm        embed_dim >= 128: the 64-wide GEMM / attention kernels (gemm_lds.hip, gemm_f32.hip, attention.hip; four-product
+//                            heads) instead of gemm_wide.hip / attention_wide.hip
 struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
-    {"disable_fused", &Options::disable_fused}, {"disable_fused_train", &Options::disable_fused_train},
-    {"disable_fused_front", &Options::disable_fused_front}, {"disable_loss_in_forward", &Options::disable_loss_in_forward},
-    {"disable_merged", &Options::disable_merged}, {"disable_fwd32h", &Options::disable_fwd32h}, {"disable_plan_small", &Options::disable_plan_small}, {"disable_bmm_heads", &Options::disable_bmm_heads},
-    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg},
+    {"disable_fused", &Options::disable_fused}, {"disable_fused_front", &Options::disable_fused_front},
+    {"disable_loss_in_forward", &Options::disable_loss_in_forward}, {"disable_merged", &Options::disable_merged},
+    {"disable_small_batch", &Options::disable_small_batch}, {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg},
     {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune}};
 Options& options() {
   static Options o = [] {
@@ -123,10 +121,9 @@ Options& options() {
 // backward computes dB_all, dM_all and applies the chain rule per head (merged_chain).  Shapes the wide attention kernels take.
 static bool merged_layerwise_shape(const matcha_shape& s) { return s.d >= 128 && s.d % 64 == 0; }
 static bool merged_layerwise(const matcha_shape& s) { return merged_layerwise_shape(s) && attn_wide_eligible(s.d) && !options().disable_merged; }
-static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && !options().disable_fused; }
-static bool fused_train_enabled(const matcha_shape& s) { return fused_enabled(s) && !options().disable_fused_train; }
+static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && !options().disable_fused && !options().disable_merged; }
 static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
-  return o.loss_in_forward && !o.forward_only && y && w && fused_train_enabled(s) && !options().disable_loss_in_forward;
+  return o.loss_in_forward && !o.forward_only && y && w && fused_enabled(s) && !options().disable_loss_in_forward;
 }
 // Which formulation the forward that last ran on a workspace used.  matcha_backward keys off THIS record, not off the option: flipping
 // disable_merged between a forward and its backward (two separate calls on the autograd path) would otherwise make the merged backward
@@ -155,48 +152,22 @@ static bool fwd_ran_merged(const void* ws) { return ws_state(ws) > 0 && (ws_stat
 // B_all[h d + a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b];   M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]   (16 small GEMMs)
 static int merged_weights(const matcha_shape& s, const matcha_tensors& p, Workspace& w, hipStream_t st) {
   const int64_t d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
-  if (bmm_heads_supported(s.d) && !options().disable_bmm_heads) {
-    // both products, all heads, one launch (bmm_heads.hip)
-    const BmmProduct pr[2] = {
-        {p.w_k, 1, d, d * d, p.w_q, d, 1, d * d, w.lwB, d, d * d, 0},            // B_h[a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b]
-        {p.fc1_w, hd, 1, d, p.w_v, d, 1, d * d, w.lwM, hd, d, 0}};               // M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]
-    return launch_bmm_heads(pr, 2, s.d, st);
-  }
-  for (int h = 0; h < MATCHA_N_HEAD; ++h) {
-    MATCHA_TRY(launch_gemm_tn(p.w_k + h * d * d, p.w_q + h * d * d, w.lwB + h * d * d, nullptr, d, d, d, d, d, nullptr, false, w.gemm_ws, w.gemm_ws_bytes, st));
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A[0] = p.fc1_w + h * d; g.B[0] = p.w_v + h * d * d; g.C[0] = w.lwM + h * d; g.batch = 1;
-    g.M = d; g.N = d; g.K = d; g.lda = hd; g.ldb = d; g.ldc = hd; g.aux_scale = 1.f;
-    MATCHA_TRY(launch_gemm_rm(true, g, st));
-  }
-  return MATCHA_OK;
+  // both products, all heads, one launch (bmm_heads.hip; every embed_dim the merged layer-wise path takes is a multiple of 64)
+  const BmmProduct pr[2] = {
+      {p.w_k, 1, d, d * d, p.w_q, d, 1, d * d, w.lwB, d, d * d, 0},            // B_h[a][b] = sum_m W_k[h d + m][a] W_q[h d + m][b]
+      {p.fc1_w, hd, 1, d, p.w_v, d, 1, d * d, w.lwM, hd, d, 0}};               // M_all[n][h d + b] = sum_m Wfc1[n][h d + m] W_v[h d + m][b]
+  return launch_bmm_heads(pr, 2, s.d, st);
 }
 // chain rule from dB_all, dM_all to the projections (accumulating):  dW_q[h] += W_k[h] dB_h;  dW_k[h] += W_q[h] dB_h^T;
 //   dWfc1[:, h] += dM_h W_v[h]^T;  dW_v[h] += Wfc1[:, h]^T dM_h
 static int merged_chain(const matcha_shape& s, const matcha_tensors& p, matcha_tensors& g_, Workspace& w, hipStream_t st) {
   const int64_t d = s.d, hd = (int64_t)MATCHA_N_HEAD * d;
-  if (bmm_heads_supported(s.d) && !options().disable_bmm_heads) {
-    const BmmProduct pr[4] = {
-        {p.w_k, d, 1, d * d, w.lwdB, d, 1, d * d, g_.w_q, d, d * d, 1},          // dW_q[h][m][b] += sum_a W_k[h][m][a] dB_h[a][b]
-        {p.w_q, d, 1, d * d, w.lwdB, 1, d, d * d, g_.w_k, d, d * d, 1},          // dW_k[h][m][a] += sum_b W_q[h][m][b] dB_h[a][b]
-        {w.lwdM, hd, 1, d, p.w_v, 1, d, d * d, g_.fc1_w, hd, d, 1},              // dWfc1[n][h d + m] += sum_b dM[n][h d + b] W_v[h d + m][b]
-        {p.fc1_w, 1, hd, d, w.lwdM, hd, 1, d, g_.w_v, d, d * d, 1}};             // dW_v[h][m][b] += sum_n Wfc1[n][h d + m] dM[n][h d + b]
-    return launch_bmm_heads(pr, 4, s.d, st);
-  }
-  for (int h = 0; h < MATCHA_N_HEAD; ++h) {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.batch = 1; g.M = d; g.N = d; g.K = d; g.aux_scale = 1.f; g.flags = MATCHA_EPI_ACCUM;
-    g.A[0] = p.w_k + h * d * d; g.B[0] = w.lwdB + h * d * d; g.C[0] = g_.w_q + h * d * d; g.lda = d; g.ldb = d; g.ldc = d;
-    MATCHA_TRY(launch_gemm_rm(true, g, st));                                   // NN: [m][a] x [a][b]
-    g.A[0] = p.w_q + h * d * d; g.B[0] = w.lwdB + h * d * d; g.C[0] = g_.w_k + h * d * d;
-    MATCHA_TRY(launch_gemm_rm(false, g, st));                                  // NT: [m][b] x ([a][b])^T
-    g.A[0] = w.lwdM + h * d; g.B[0] = p.w_v + h * d * d; g.C[0] = g_.fc1_w + h * d; g.lda = hd; g.ldb = d; g.ldc = hd;
-    MATCHA_TRY(launch_gemm_rm(false, g, st));                                  // NT: [n][b] x ([m][b])^T
-    MATCHA_TRY(launch_gemm_tn(p.fc1_w + h * d, w.lwdM + h * d, g_.w_v + h * d * d, nullptr, d, d, d, hd, hd, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st));
-  }
-  return MATCHA_OK;
+  const BmmProduct pr[4] = {
+      {p.w_k, d, 1, d * d, w.lwdB, d, 1, d * d, g_.w_q, d, d * d, 1},          // dW_q[h][m][b] += sum_a W_k[h][m][a] dB_h[a][b]
+      {p.w_q, d, 1, d * d, w.lwdB, 1, d, d * d, g_.w_k, d, d * d, 1},          // dW_k[h][m][a] += sum_b W_q[h][m][b] dB_h[a][b]
+      {w.lwdM, hd, 1, d, p.w_v, 1, d, d * d, g_.fc1_w, hd, d, 1},              // dWfc1[n][h d + m] += sum_b dM[n][h d + b] W_v[h d + m][b]
+      {p.fc1_w, 1, hd, d, w.lwdM, hd, 1, d, g_.w_v, d, d * d, 1}};             // dW_v[h][m][b] += sum_n Wfc1[n][h d + m] dM[n][h d + b]
+  return launch_bmm_heads(pr, 4, s.d, st);
 }
 
 // `compact`: layout of a forward that will not be differentiated and runs the fused kernels (d = 64): only the ragged plan,
@@ -265,7 +236,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tpart = take(s.d == 64 ? fused_tail_partial_floats() : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
-  w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever MATCHA_DISABLE_QKV_SAVE says: the layout must not depend on a switch read per call
+  w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever the option table says: the layout must not depend on a switch read per call
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
   w.tg_ws_bytes = (s.mode == 0 && !compact) ? table_grad_ws_bytes(Tn, s.n_nodes) : 0;
   w.tg_ws = take(w.tg_ws_bytes / sizeof(float));
@@ -418,15 +389,13 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const int64_t* ids = w.rg.tok_id;
 
   // which fused kernels will run on this workspace (decided here: the plan, the front end and the saved records depend on it)
-  const bool fused_path = !force_layerwise && fused_enabled(s) && (opts->forward_only || fused_train_enabled(s));
+  const bool fused_path = !force_layerwise && fused_enabled(s);
   const bool lif = fused_path && loss_in_forward(s, *opts, y, w_bce);      // the tail's backward runs in the forward kernel: nothing saved
-  // merged heads: two products per head (fused_fwd32.hip); a training forward then leaves r rows + probabilities per (half tile, head) for
-  // fused_bwdh_kernel.  disable_merged: the reference's four products, nothing saved, the backward recomputes (fused_bwd_kernel).
-  const bool merged = !options().disable_merged;
-  const bool keep_qkv = !opts->forward_only && merged;
-  // CSR plan: real tokens + one shared padding token; tile lists only for the kernels that will read them (the half-tile forward /
-  // backward pair needs neither the 64-row tiles nor the token -> tile map; the recompute backward walks 64-row tiles)
-  const int plan_level = !fused_enabled(s) ? 0 : ((fused_path && (opts->forward_only || merged)) ? 1 : 2);
+  // a training forward leaves r rows + probabilities per (half tile, head) for fused_bwdh_kernel (merged heads: fused_fwd32.hip)
+  const bool keep_rimg = !opts->forward_only;
+  // CSR plan: real tokens + one shared padding token; the fused kernels walk the HALF tiles (level 1: no 64-row tile list, no token -> tile
+  // map -- matcha_ragged_plan still builds those for callers that ask)
+  const int plan_level = fused_enabled(s) ? 1 : 0;
   MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st, plan_level));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
@@ -466,12 +435,12 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
-    note_forward(ws, merged, true);
-    if (merged) MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
-    MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, merged ? w.merged : nullptr));
+    note_forward(ws, true, true);
+    MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
+    MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, w.merged));
     MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_qkv ? w.qkv : nullptr, merged, merged));
+                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -560,7 +529,7 @@ extern "C" int matcha_get_embedding(const matcha_shape* shp, const matcha_tensor
 extern "C" int matcha_random_chrom_dev_supported(const matcha_shape* shp, const matcha_frozen* frozen) {
   if (!shp || !frozen) return 0;
   if (shp->mode == 0) return 1;
-  return adj_fused_eligible(*shp, *frozen) && fused_train_enabled(*shp) && front_bwd_supported(shp->d, shp->n_attr) ? 1 : 0;
+  return adj_fused_eligible(*shp, *frozen) && fused_enabled(*shp) && front_bwd_supported(shp->d, shp->n_attr) ? 1 : 0;
 }
 
 extern "C" int matcha_set_option(const char* name, int32_t value) {
@@ -615,9 +584,11 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   const int32_t* cnt = w.rg.count;             // the plan (row_off, tok_id, tok_slot, count) is still in the workspace
   const int64_t* ids = w.rg.tok_id;
 
-  const bool lif = loss_in_forward(s, *opts, y, w_bce);
+  const int fwd_state = ws_state(ws);
+  MATCHA_CHECK_ARG(fwd_state >= 0, "matcha_backward: no matcha_forward on record for this workspace (one backward per forward, same ws pointer)");
+  const bool fused_fwd = (fwd_state & 2) != 0;          // which kernels the forward ran is what decides, not the option table now
+  const bool lif = fused_fwd && loss_in_forward(s, *opts, y, w_bce);
   MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
-  MATCHA_CHECK_ARG(ws_state(ws) >= 0, "matcha_backward: no matcha_forward on record for this workspace (one backward per forward, same ws pointer)");
   if (lif) {
     // ddyn0 and dXs were produced by matcha_forward; only the per-tile parameter-gradient partials remain to be summed
     MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart));       // one slab per half tile (fused_fwd32.hip)
@@ -643,19 +614,15 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     MATCHA_TRY(launch_gemm_rm(true, g, st));
   }
   }
-  if (fused_train_enabled(s)) {
+  if (fused_fwd) {
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
     const bool front = front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
-    // merged kernel: the eight heads add their d x_hat into ONE buffer with float atomics (they meet in L2; the per-head slabs are 8 x 256 B
-    // per token written and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs
-    // and their fixed summation order
-    const bool merged_bwd = fwd_ran_merged(ws);
-    const bool dx_atomic = merged_bwd && !opts->deterministic && !opts->sparse_table_grad;
-    if (merged_bwd)
-      MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic));
-    else
-      MATCHA_TRY(launch_fused_bwd(p, w.folded, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st));
+    // the eight heads add their d x_hat into ONE buffer with float atomics (they meet in L2; per-head slabs are 8 x 256 B per token written
+    // and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs and their
+    // fixed summation order
+    const bool dx_atomic = !opts->deterministic && !opts->sparse_table_grad;
+    MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic));
     MATCHA_TRY(encoder_done(*opts, st));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel

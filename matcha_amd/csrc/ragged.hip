@@ -455,7 +455,7 @@ void ragged_carve(int64_t B, int L, char* base, Ragged& r) {
 // level 2: everything; 1: no 64-row tile list and no token -> tile map (the fused kernels that run work on half tiles only); 0: rows and
 // tokens only (no fused kernel will read a tile list)
 int launch_ragged_plan(const int64_t* x, int64_t B, int L, int64_t n_nodes, int32_t* status, const Ragged& r, hipStream_t st, int level) {
-  if (B <= kSmallRows && r.nsb <= kSmallSb && !options().disable_plan_small) {
+  if (B <= kSmallRows && r.nsb <= kSmallSb && !options().disable_small_batch) {
     PlanSmallArgs a;
     a.x = x; a.B = B; a.L = L; a.n_nodes = n_nodes; a.status = status;
     a.row_off = r.row_off; a.tok_slot = r.tok_slot; a.tok_id = r.tok_id; a.tok_pos = r.tok_pos; a.tok_key = r.tok_key; a.count = r.count; a.sb_first = r.sb_first;

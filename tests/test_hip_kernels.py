@@ -317,7 +317,7 @@ def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad, five_launches):
     lib = _lib.load()
     if five_launches and B > 1024:
         pytest.skip("the general path is the only one at this size")
-    _lib.set_option("disable_plan_small", 1 if five_launches else 0)
+    _lib.set_option("disable_small_batch", 1 if five_launches else 0)
     ora = _oracle_lib()
     rng = np.random.default_rng(B + L)
     N = 1000
@@ -341,7 +341,7 @@ def test_ragged_plan_bit_exact_vs_c_oracle(B, L, ks, bad, five_launches):
         _lib.check(lib.matcha_ragged_plan(_lib.ptr(xt), B, L, N, _lib.ptr(status), _lib.ptr(ws), ws.numel(), C.byref(view), st), "matcha_ragged_plan")
         torch.cuda.synchronize()
     finally:
-        _lib.set_option("disable_plan_small", 0)
+        _lib.set_option("disable_small_batch", 0)
     base = ws.data_ptr()
 
     def grab(p, n, dt):
