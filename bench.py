@@ -628,6 +628,15 @@ def main():
                     extras[key]["hbm_bound_share"] = round(hb / (e["elapsed"] / 8 * 1e3), 4)
                     extras[key]["roofline_by_kernel_class"] = {k: v for k, v in e["roof_all"].items() if k in ("adamw", "embed_fwd", "embed_scatter",
                                                                                                             "adj_encode", "adj_recon", "adj_bwd")}
+            # the reference's DRIVER flow on the clock (main.py:119-197, :261-342; tools/epoch_bench.py): matcha_amd.train running a phase-2
+            # epoch at the reference's batch (96 + 288 rows per step) -- DataGenerator, batch assembly, sampler, step, metrics, save_embeddings;
+            # a quarter epoch here (250 steps per size), the full 4 x 1000 steps with the CPU estimate in profiles/rNN_epoch_bench.jsonl
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import epoch_bench
+                extras["train_driver_epoch"] = {fe: epoch_bench.one_case(fe, 250, True) for fe in ("table", "adj")}
+            except Exception as exc:      # the driver flow is an extra: never lose the headline line over it
+                extras["train_driver_epoch"] = {"error": repr(exc)[:200]}
             result["extra_points"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline and m["pool"] is not None:
         result["cpu_baseline"] = cpu_baseline(args, m["num"], ks, L, m["pool"], m["wts"], 3)

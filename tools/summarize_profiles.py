@@ -221,6 +221,8 @@ arows = stats_md("adj_stats", f"profiles/{rnd}_adj_kernel_stats.md", f"rocprofv3
                  "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --prof none --no-cpu-baseline --no-extras --front-end adj", n=24)
 stats_md("adj384_stats", f"profiles/{rnd}_adj384_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, adj front end at the reference's batch of 384 rows ({rnd})",
          "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --rows 384 --prof none --no-cpu-baseline --no-extras --front-end adj", n=30)
+stats_md("table384_stats", f"profiles/{rnd}_table384_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, table front end at the reference's batch of 384 rows ({rnd})",
+         "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --rows 384 --prof none --no-cpu-baseline --no-extras", n=30)
 af = glob.glob(f"gpurun_out/{tag}_adj_fetch/*/*_counter_collection.csv")
 if arows and af:
     def load3(d, name):
