@@ -61,16 +61,19 @@ def one_case(front_end, steps_per_k, graph, ks=(2, 3, 4, 5), d=64, layout="hg38_
     # device time of one step: replays (or eager steps) back to back between two events, no host work in between that the GPU waits for
     st = sess.__dict__.get("_graph_state")
     if graph and st is not None and st["graph"] is not None:
-        st["it"].zero_()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k = min(500, st["chroms"].numel())
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(k):
-            st["graph"].replay()
-        ev1.record()
-        torch.cuda.synchronize()
-        out["device_us_per_step"] = round(ev0.elapsed_time(ev1) / k * 1e3, 1)
+        best = float("inf")
+        for _ in range(3):                     # the fastest of three passes (a pass right after the host-side metrics can catch the GPU clocked down)
+            st["it"].zero_()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(k):
+                st["graph"].replay()
+            ev1.record()
+            torch.cuda.synchronize()
+            best = min(best, ev0.elapsed_time(ev1) / k * 1e3)
+        out["device_us_per_step"] = round(best, 1)
         out["host_overhead_over_device"] = round(out["wall_us_per_step"] / out["device_us_per_step"] - 1.0, 3)
     out.update(front_end=front_end, epoch_loop="hipGraph replay of one captured step" if graph else "call by call",
                rows_per_step=T.BATCH_SIZE * (1 + T.NEG_NUM), hyperedges_per_s=round(T.BATCH_SIZE * (1 + T.NEG_NUM) / (out["wall_us_per_step"] * 1e-6), 1))
