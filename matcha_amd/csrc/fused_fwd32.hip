@@ -692,8 +692,10 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   }
   wp = g.wfrag + (int64_t)16 * kFragF4 + lane;      // conv0, conv1, conv1^T, conv0^T follow the heads in the merged stream
   W32_PRIME();
-  // one wavefront: its LDS accesses execute in order, a compiler fence is all an ordering point needs
-#define F32_TAIL_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+  // one wavefront is left: the other seven have terminated and no longer count at the barrier, so __syncthreads() costs one wait -- and,
+  // unlike a wavefront-scope fence (which emits no instruction), it stays an ordering point for the machine scheduler: the tail writes
+  // LDS rows as float4 and reads other lanes' rows as floats, accesses that type-based alias analysis is free to reorder
+#define F32_TAIL_SYNC() __syncthreads()
 #include "fused_fwd32_tail.hpp"
 #undef F32_TAIL_SYNC
 }

@@ -248,7 +248,8 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
     t_loop = time.perf_counter()
     if n_batch > 0 and sess.graph_ok(beta):
         bce_sum, rec_sum, p2, y1, s2 = sess.graph_epoch(e, w, n_batch, batch_size, alpha, beta)
-        pred, label, size = p2.reshape(-1).cpu(), y1.repeat(n_batch).cpu(), s2.reshape(-1).cpu()         # the epoch's one synchronisation
+        pred, label, size = p2.reshape(-1), y1.repeat(n_batch), s2.reshape(-1)
+        torch.cuda.synchronize(dev)                                              # the epoch's one synchronisation
         tm["loop_s"] = time.perf_counter() - t_loop
         return _epoch_metrics(sess, bce_sum, rec_sum, pred, label, size, n_batch)
     bce_sum = torch.zeros((), device=dev)
@@ -268,7 +269,8 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
         both = torch.stack([bce_sum, rec_sum])
         torch.distributed.all_reduce(both)
         bce_sum, rec_sum = both[0] / sess.world, both[1] / sess.world
-    pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()     # the epoch's one synchronisation
+    pred, label, size = torch.cat(preds), torch.cat(labels), torch.cat(sizes)
+    torch.cuda.synchronize(dev)                                                  # the epoch's one synchronisation
     tm["loop_s"] = time.perf_counter() - t_loop
     return _epoch_metrics(sess, bce_sum, rec_sum, pred, label, size, n_batch)
 
@@ -317,7 +319,7 @@ def eval_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, batch_size
             labels.append(y)
             sizes.append(s)
     bce_sum, rec_sum = float(bce_sum), float(rec_sum)
-    pred, label, size = torch.cat(preds).cpu(), torch.cat(labels).cpu(), torch.cat(sizes).cpu()
+    pred, label, size = torch.cat(preds), torch.cat(labels), torch.cat(sizes)
     auc, aupr = U.roc_auc_cuda(label, pred, size, sess.max_size)
     acc = U.accuracy(pred, label, size, sess.max_size)
     return bce_sum / max(n_batch, 1), rec_sum / max(n_batch, 1), acc, auc, aupr
