@@ -320,6 +320,19 @@ int matcha_neg_sample(const void* set, const int64_t* set_edges, int64_t n_set_e
                       const int32_t* node2chrom, int32_t n_nodes, const int32_t* chrom_range, int32_t n_chrom,
                       const uint64_t* seed, int64_t* neg, int32_t* status, matcha_stream_t stream);
 
+/* The bookkeeping of one step of the reference's epoch loop (main.py:155-188) on the device, so that an epoch can replay one captured
+ * step (matcha_amd/train.py).  `it` is a device int64 step counter.
+ * matcha_step_select (main.py:160-161, Modules.py:192): x[0:P] = pos[it*P .. it*P+P) (rows of the epoch's shuffled positives,
+ * int64 [n_rows, L]), ww[0:P] = w[it*P ..], and, when `cell` is given, cell[0] = chroms[it] (the step's reconstruction chromosome);
+ * seed0 / seed1 (optional device uint64): counter-RNG seeds to advance by one (the sampler's and the dropout masks').
+ * matcha_step_record (main.py:58, :185-188, :449-451): preds[it][b] = sigmoid(logits[b]), sizes[it][b] = non-zero entries of x[b]
+ * (x int64 [B, L]), sums[0] += losses[0] (bce), sums[1] += losses[1] (recon), then it += 1.  preds / sizes are [n_steps, B]. */
+int matcha_step_select(const int64_t* pos, const float* w, int64_t n_rows, int32_t L, const int64_t* it, int32_t P, int64_t* x,
+                       float* ww, const int32_t* chroms, int64_t n_chroms, int32_t* cell, uint64_t* seed0, uint64_t* seed1,
+                       matcha_stream_t stream);
+int matcha_step_record(const float* logits, const float* losses, const int64_t* x, int64_t B, int32_t L, int64_t* it, int64_t n_steps,
+                       float* sums, float* preds, int64_t* sizes, matcha_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Op-level entry points (the kernels behind matcha_forward/backward, exposed so that each one is
  * parity-tested on its own against the oracle).

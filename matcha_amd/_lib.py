@@ -93,6 +93,8 @@ SIGNATURES = {
     "matcha_hashset_bytes": (_SZ, [_I64]),
     "matcha_hashset_build": (C.c_int, [_fp, _SZ, _fp, _I64, _I32, _fp]),
     "matcha_hashset_contains": (C.c_int, [_fp, _fp, _I32, _fp, _I64, _I32, _fp, _fp]),
+    "matcha_step_select": (C.c_int, [_fp, _fp, _I64, _I32, _fp, _I32, _fp, _fp, _fp, _I64, _fp, _fp, _fp, _fp]),
+    "matcha_step_record": (C.c_int, [_fp, _fp, _fp, _I64, _I32, _fp, _I64, _fp, _fp, _fp, _fp]),
     "matcha_neg_sample": (C.c_int, [_fp, _fp, _I64, _I32, _fp, _I64, _I32, _I32, _I32, _fp, _I32, _fp, _I32, _fp, _fp, _fp, _fp]),
     "matcha_gemm_tn_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "matcha_gemm": (C.c_int, [_I32, _fp, _fp, _fp, _I64, _I64, _I64, C.POINTER(GemmEpilogue), _fp, _fp, _fp, _SZ, _fp]),

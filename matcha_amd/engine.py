@@ -58,6 +58,7 @@ class Trainer:
         self.seg_coef = torch.zeros(3 * n_seg, dtype=torch.float32, device=dev)
         self.touched = torch.zeros(rt.n_touched, dtype=torch.int32, device=dev)
         self.losses = torch.zeros(3, dtype=torch.float32, device=dev)     # bce, recon, rows of the recon mean
+        self.seed_advanced_by_caller = False      # train.py's captured step advances self.seed inside matcha_step_select (one launch less)
         self._ws = {}
         self._logits = {}
         self._xws = {}
@@ -151,7 +152,8 @@ class Trainer:
         overlap = self._overlap()
         if overlap:
             opts.encoder_done_event = self._enc_event.cuda_event
-        self.seed.add_(1)                                   # new dropout masks every step (graph-replay safe)
+        if not self.seed_advanced_by_caller:
+            self.seed.add_(1)                               # new dropout masks every step (graph-replay safe)
         _lib.check(self.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
                                            _lib.ptr(y), _lib.ptr(w), _lib.ptr(logits), _lib.ptr(self.losses), _lib.ptr(ws), ws.numel(),
                                            st), "matcha_forward")

@@ -58,13 +58,14 @@ class NegativeSampler:
         # trials were exhausted (returned equal to their positive); read it with check_status() at a point that syncs anyway
         self.status = torch.zeros(4, dtype=torch.int32, device=dev)
 
-    def sample_into(self, pos: torch.Tensor, neg_out: torch.Tensor):
+    def sample_into(self, pos: torch.Tensor, neg_out: torch.Tensor, advance_seed: bool = True):
         """pos int64 [P,L] -> neg_out int64 [P*neg_num, L]; negatives of positive j at rows neg_num*j ... (main.py:383-428).
-        Advances the seed on the device (graph-replay safe)."""
+        Advances the seed on the device (graph-replay safe) unless the caller already did (``advance_seed=False``)."""
         lib = _lib.load()
         P, L = pos.shape
         st = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
-        self.seed.add_(1)
+        if advance_seed:
+            self.seed.add_(1)
         _lib.check(lib.matcha_neg_sample(_lib.ptr(self.hset.table), _lib.ptr(self.hset.edges), self.hset.n, self.hset.L, _lib.ptr(pos), P, L,
                                          self.neg_num, self.min_dis, _lib.ptr(self.node2chrom), self.n_nodes, _lib.ptr(self.chrom_range),
                                          self.n_chrom, _lib.ptr(self.seed), _lib.ptr(neg_out), _lib.ptr(self.status), st), "matcha_neg_sample")

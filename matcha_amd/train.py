@@ -29,7 +29,9 @@ from typing import List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import utils as U
+import ctypes as C
+
+from . import _lib, utils as U
 from .Modules import Classifier, DataGenerator, MultipleEmbedding, Wrap_Embedding
 from .engine import Trainer
 from .parallel import shard_rows
@@ -178,7 +180,7 @@ class Session:
             st = dict(key=key, graph=None,
                       pos=torch.empty((n_batch * P, L), dtype=torch.long, device=dev), w=torch.empty(n_batch * P, dtype=torch.float32, device=dev),
                       chroms=torch.empty(n_batch, dtype=torch.int32, device=dev), cell=torch.zeros(1, dtype=torch.int32, device=dev),
-                      it=torch.zeros(1, dtype=torch.long, device=dev), ar=torch.arange(P, device=dev),
+                      it=torch.zeros(1, dtype=torch.long, device=dev),
                       x=torch.zeros((B, L), dtype=torch.long, device=dev),
                       y=torch.cat([torch.ones(P, device=dev), torch.zeros(B - P, device=dev)]),           # main.py:444-445
                       ww=torch.ones(B, dtype=torch.float32, device=dev),                                  # main.py:446-447
@@ -188,18 +190,26 @@ class Session:
         st["pos"].copy_(e[:n_batch * P]); st["w"].copy_(w[:n_batch * P]); st["chroms"].copy_(torch.from_numpy(chroms))
         st["it"].zero_(); st["sums"].zero_()
 
+        lib = _lib.load()
+        n_rows = n_batch * P
+
         def one_step():
-            idx = st["it"] * P + st["ar"]
-            torch.index_select(st["pos"], 0, idx, out=st["x"][:P])
-            torch.index_select(st["w"], 0, idx, out=st["ww"][:P])
-            self.sampler.sample_into(st["x"][:P], st["x"][P:])
-            torch.index_select(st["chroms"], 0, st["it"], out=st["cell"])
-            bce, recon, logits = self.trainer.step(st["x"], st["y"], st["ww"], alpha=alpha, beta=beta, random_chrom=st["cell"])
-            st["sums"][0] += bce
-            st["sums"][1] += recon[0]
-            st["preds"].index_copy_(0, st["it"], torch.sigmoid(logits).view(1, B))                      # main.py:58
-            st["sizes"].index_copy_(0, st["it"], (st["x"] != 0).sum(dim=1).view(1, B))
-            st["it"] += 1
+            # everything that changes from step to step lives on the device: the step counter `it` picks the step's positives, weights
+            # and reconstruction chromosome (matcha_step_select) and the row of the epoch's prediction / size buffers (matcha_step_record)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.matcha_step_select(_lib.ptr(st["pos"]), _lib.ptr(st["w"]), n_rows, L, _lib.ptr(st["it"]), P, _lib.ptr(st["x"]),
+                                              _lib.ptr(st["ww"]), _lib.ptr(st["chroms"]), n_batch, _lib.ptr(st["cell"]),
+                                              _lib.ptr(self.sampler.seed), _lib.ptr(self.trainer.seed), stream),
+                       "matcha_step_select")
+            self.sampler.sample_into(st["x"][:P], st["x"][P:], advance_seed=False)
+            self.trainer.seed_advanced_by_caller = True
+            try:
+                bce, recon, logits = self.trainer.step(st["x"], st["y"], st["ww"], alpha=alpha, beta=beta, random_chrom=st["cell"])
+            finally:
+                self.trainer.seed_advanced_by_caller = False
+            _lib.check(lib.matcha_step_record(_lib.ptr(logits), _lib.ptr(self.trainer.losses), _lib.ptr(st["x"]), B, L, _lib.ptr(st["it"]),
+                                              n_batch, _lib.ptr(st["sums"]), _lib.ptr(st["preds"]), _lib.ptr(st["sizes"]), stream),
+                       "matcha_step_record")
 
         done = 0
         if os.environ.get("MATCHA_TRAIN_GRAPH") == "steps":      # development: the same device-side step function, enqueued call by call
