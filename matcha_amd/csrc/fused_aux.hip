@@ -3,6 +3,7 @@
 //   fold_ln_kernel           the three LayerNorm affines in front of Q / K / V folded into the projection weights once per step
 //                            (W' = W * g, c = W . b; Modules.py:519-529)
 //   tail_slab_reduce/finish  fixed-order sum of the per-half-tile slabs of parameter-gradient partials the training forward writes
+//   (tail_slab_small_kernel: the same in one launch for small batches)
 //                            (pff_n1, the three LayerNorms of the tail, the classifier) into the gradient tensors
 #include <stdlib.h>
 
@@ -38,7 +39,20 @@ struct TailReduceArgs {
   const float* tslab; const int32_t* count; int L; int ntiles_cap; int count_idx;
   float* partial;     // [kTailSplits][kTailSlab]
   float* dst[12];     // pff1_w, pff0_w, gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b, bc
+  float4* zero_buf; int64_t zero_n4;     // tail_slab_small_kernel: a buffer to zero in the same launch (the backward kernel's d x_hat)
 };
+// element i of a summed slab into the gradient tensors: the two weight-gradient matrices arrive in the MFMA accumulator layout
+// [wave][lane][register] (fused_fwd32_tail.hpp), the vectors as they are
+__device__ __forceinline__ void tail_slab_add(const TailReduceArgs& a, int i, float s) {
+  if (i < 8192) {
+    const int e = i & 4095, wv = e >> 10, ln = (e >> 4) & 63, reg = e & 15;
+    const int row = 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), col = 32 * (wv >> 1) + (ln & 31);
+    a.dst[i >> 12][row * 64 + col] += s;
+  } else {
+    const int v = (i - kTailVec) >> 6, j = (i - kTailVec) & 63;
+    a.dst[2 + v][j] += s;
+  }
+}
 __global__ __launch_bounds__(512) void tail_slab_reduce_kernel(TailReduceArgs a) {
   __shared__ float4 part[8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,15 +88,40 @@ __global__ __launch_bounds__(256) void tail_slab_finish_kernel(TailReduceArgs a)
   float s = 0.f;
 #pragma unroll
   for (int sp = 0; sp < kTailSplits; ++sp) s += a.partial[sp * kTailSlab + i];
-  if (i < 8192) {
-    // the two weight-gradient matrices arrive in the MFMA accumulator layout [wave][lane][register] (fused_fwd_kernel)
-    const int e = i & 4095, wv = e >> 10, ln = (e >> 4) & 63, reg = e & 15;
-    const int row = 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), col = 32 * (wv >> 1) + (ln & 31);
-    a.dst[i >> 12][row * 64 + col] += s;
-  } else {
-    const int v = (i - kTailVec) >> 6, j = (i - kTailVec) & 63;
-    a.dst[2 + v][j] += s;
+  tail_slab_add(a, i, s);
+}
+// Small batches (a few dozen half tiles: the reference's own 384-row step): ONE pass.  Block = column block of 64 float4; its eight
+// wavefronts take the slabs t = wave, wave + 8, ... (four rows in flight), the eight partial sums meet in LDS in wavefront order and the
+// block adds its 256 elements into the gradient tensors itself: one launch instead of two, and the d x_hat buffer of the backward kernel
+// is zeroed on the side (a third launch saved).  Another summation order than the two-pass kernels (like every small-batch kernel:
+// compared at 2e-6 in tests/test_hip_properties.py), fixed from run to run.
+__global__ __launch_bounds__(512) void tail_slab_small_kernel(TailReduceArgs a) {
+  __shared__ float4 part[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 64 + lane;
+  if (a.zero_buf)
+    for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < a.zero_n4; i += (int64_t)gridDim.x * 512) a.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int nt = a.count[a.count_idx];
+  if (nt > a.ntiles_cap) nt = a.ntiles_cap;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (c4 < kTailF4) {
+    const float4* base = reinterpret_cast<const float4*>(a.tslab) + c4;
+    int t = wave;
+    for (; t + 24 < nt; t += 32) {
+      const float4 v0 = base[(int64_t)t * kTailF4], v1 = base[(int64_t)(t + 8) * kTailF4], v2 = base[(int64_t)(t + 16) * kTailF4], v3 = base[(int64_t)(t + 24) * kTailF4];
+      TSR_ADD(s0, v0); TSR_ADD(s1, v1); TSR_ADD(s2, v2); TSR_ADD(s3, v3);
+    }
+    for (; t < nt; t += 8) { const float4 v = base[(int64_t)t * kTailF4]; TSR_ADD(s0, v); }
   }
+  part[wave][lane] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x >= 256 || i > kTailVec + 9 * 64) return;
+  const float* pf = reinterpret_cast<const float*>(&part[0][0]);
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) s += pf[w * 256 + threadIdx.x];
+  tail_slab_add(a, i, s);
 }
 
 size_t fused_fold_floats() { return (size_t)3 * (MATCHA_N_HEAD * 64 * 64 + MATCHA_N_HEAD * 64); }
@@ -105,12 +144,20 @@ size_t fused_qkv_floats(int64_t B, int L) {          // the training forward's r
   return (size_t)(ragged_halves_cap(B, L) + 2) * MATCHA_N_HEAD * kImgRecH;
 }
 
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves, float* partial) {
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves, float* partial, bool small,
+                       float* zero_buf, size_t zero_bytes) {
+  MATCHA_CHECK_ARG(zero_bytes % 16 == 0 && (uintptr_t)zero_buf % 16 == 0 && (small || !zero_buf), "tail_reduce: zero_buf");
   TailReduceArgs a;
   a.tslab = tslab; a.count = rg.count; a.L = L; a.ntiles_cap = halves ? rg.nhalves : rg.ntiles; a.count_idx = halves ? 3 : 2;
   a.partial = partial;
+  a.zero_buf = reinterpret_cast<float4*>(zero_buf); a.zero_n4 = (int64_t)(zero_bytes / 16);
   float* dst[12] = {g_.pff1_w, g_.pff0_w, g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.pff1_b, g_.pff0_b, g_.cls_b};
   for (int i = 0; i < 12; ++i) a.dst[i] = dst[i];
+  if (small) {
+    hipLaunchKernelGGL(tail_slab_small_kernel, dim3(kTailColBlocks), dim3(512), 0, st, a);
+    MATCHA_CHECK_LAUNCH("tail_slab_small_kernel");
+    return MATCHA_OK;
+  }
   hipLaunchKernelGGL(tail_slab_reduce_kernel, dim3(kTailColBlocks, kTailSplits), dim3(512), 0, st, a);
   MATCHA_CHECK_LAUNCH("tail_slab_reduce_kernel");
   hipLaunchKernelGGL(tail_slab_finish_kernel, dim3((unsigned)cdiv(kTailSlab, 256)), dim3(256), 0, st, a);

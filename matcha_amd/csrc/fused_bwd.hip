@@ -809,9 +809,9 @@ size_t fused_bwd_ws_floats(int64_t B, int L) {
 // merged heads: fused_bwdh_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic) {
+                            bool dx_atomic, bool dx_zeroed) {
   const int64_t tcap = B * L + 1;
-  if (dx_atomic) MATCHA_TRY(zero_async(dxh, (size_t)tcap * 64 * sizeof(float), st));
+  if (dx_atomic && !dx_zeroed) MATCHA_TRY(zero_async(dxh, (size_t)tcap * 64 * sizeof(float), st));
   int nchunks = 2 * chunks_for(rg.nhalves);                  // two four-wave workgroups per CU
   if (nchunks > kMaxChunks) nchunks = kMaxChunks;
   if (nchunks > rg.nhalves) nchunks = rg.nhalves > 0 ? rg.nhalves : 1;

@@ -713,6 +713,8 @@ static int fwd32h_max_halves() {
   return n;
 }
 
+bool fused_small_batch(const Ragged& rg) { return rg.nhalves <= fwd32h_max_halves() && !options().disable_small_batch; }
+
 size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragF4 * 4; }
 size_t fused_tail_slab32_floats(int64_t B, int L) { return (size_t)(ragged_halves_cap(B, L) + 2) * kTailSlab32; }
 
@@ -765,7 +767,7 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
   ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);
   const int ml = L <= 2 ? 2 : (L <= 6 ? L : 8);
   // small batches (at most two half tiles per CU even at the bound): the heads side by side in eight wavefronts per half tile
-  if (rg.nhalves <= fwd32h_max_halves() && !options().disable_small_batch) {
+  if (fused_small_batch(rg)) {
     const size_t ldsh = ((size_t)10 * kHT + 64) * sizeof(float);
     auto launchh = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);

@@ -138,7 +138,10 @@ size_t fused_fold_floats();
 int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st);
 size_t fused_tail_slab_floats(int64_t B, int L);
 size_t fused_tail_partial_floats();
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial);
+// small: one launch (small batches; another summation order); it can also zero zero_bytes of zero_buf (the backward kernel's d x_hat buffer)
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial,
+                       bool small = false, float* zero_buf = nullptr, size_t zero_bytes = 0);
+bool fused_small_batch(const Ragged& rg);          // the size rule of the small-batch kernels (fused_fwd32h_kernel, tail_slab_small_kernel)
 
 // fused_fwd32.hip (embed_dim 64): the same forward with ONE wavefront per half tile (<= 31 tokens), weights streamed from L2 in
 // MFMA-fragment order (launch_fold_frag rewrites them once per step, after launch_fold_ln), no workgroup barriers
@@ -160,7 +163,7 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
 size_t fused_bwd_ws_floats(int64_t B, int L);
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic);
+                            bool dx_atomic, bool dx_zeroed = false);   // dx_zeroed: the caller already zeroed dxh[(B L + 1) x 64] on this stream
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (half tile, head):
 constexpr int kImgRecH = 2048 + 256;               // 32 r rows (r = B_h x_hat + b_h; register images) + their attention probabilities [32][8]
 

@@ -589,9 +589,13 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   const bool fused_fwd = (fwd_state & 2) != 0;          // which kernels the forward ran is what decides, not the option table now
   const bool lif = fused_fwd && loss_in_forward(s, *opts, y, w_bce);
   MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
+  bool dx_zeroed = false;
   if (lif) {
-    // ddyn0 and dXs were produced by matcha_forward; only the per-tile parameter-gradient partials remain to be summed
-    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart));       // one slab per half tile (fused_fwd32.hip)
+    // ddyn0 and dXs were produced by matcha_forward; only the per-half-tile parameter-gradient partials remain to be summed
+    // (fused_fwd32.hip).  Small batches: one launch, which also zeroes the buffer the backward kernel's heads add their d x_hat into
+    const bool small = fused_small_batch(w.rg);
+    dx_zeroed = small && !opts->deterministic && !opts->sparse_table_grad;
+    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, small, dx_zeroed ? w.dO : nullptr, dx_zeroed ? (size_t)Tn * 64 * sizeof(float) : 0));
   } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
@@ -622,7 +626,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs and their
     // fixed summation order
     const bool dx_atomic = !opts->deterministic && !opts->sparse_table_grad;
-    MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic));
+    MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic, dx_zeroed));
     MATCHA_TRY(encoder_done(*opts, st));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel
