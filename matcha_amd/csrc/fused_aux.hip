@@ -1,10 +1,8 @@
 // Per-step helpers of the fused embed_dim-64 kernels (round 4: what is left of fused_fwd.hip after the four-wave tile forward went --
-// fused_fwd32.hip is the forward on every path):
-//   fold_ln_kernel           the three LayerNorm affines in front of Q / K / V folded into the projection weights once per step
-//                            (W' = W * g, c = W . b; Modules.py:519-529)
+// fused_fwd32.hip is the forward on every path and prepares its own weights):
 //   tail_slab_reduce/finish  fixed-order sum of the per-half-tile slabs of parameter-gradient partials the training forward writes
-//   (tail_slab_small_kernel: the same in one launch for small batches)
 //                            (pff_n1, the three LayerNorms of the tail, the classifier) into the gradient tensors
+//   tail_slab_small_kernel   the same in one launch for small batches
 #include <stdlib.h>
 
 #include "kernels.hpp"
@@ -13,19 +11,6 @@ namespace matcha {
 
 constexpr int kTailVec = 2 * 4096;                 // offset of the vectors inside a slab
 constexpr int kTailSlab = 2 * 4096 + 10 * 64;      // dW1, dW0, {gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b} x 64, then bc (+ padding)
-
-// W'[n][k] = W[n][k] * g[k];  c[n] = sum_k W[n][k] * b[k]      (grid: (H*d rows, 3 matrices), 64 threads)
-struct FoldArgs {
-  const float* W[3]; const float* g[3]; const float* b[3];
-  float* Wp[3]; float* c[3];
-};
-__global__ __launch_bounds__(64) void fold_ln_kernel(FoldArgs a) {
-  const int z = blockIdx.y, n = blockIdx.x, k = threadIdx.x;
-  const float w = a.W[z][n * 64 + k];
-  a.Wp[z][n * 64 + k] = w * a.g[z][k];
-  const float s = group_sum<64>(w * a.b[z][k]);
-  if (k == 0) a.c[z][n] = s;
-}
 
 // Sum the per-tile slabs of the training forward in a fixed order and accumulate into the gradient tensors: a pure stream (133 MB per
 // 65 536-row step with the four-wave forward, twice that with one slab per half tile), so what matters is bytes in flight.  Pass 1:
@@ -125,18 +110,6 @@ __global__ __launch_bounds__(512) void tail_slab_small_kernel(TailReduceArgs a) 
 }
 
 size_t fused_fold_floats() { return (size_t)3 * (MATCHA_N_HEAD * 64 * 64 + MATCHA_N_HEAD * 64); }
-
-int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st) {
-  FoldArgs a;
-  const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
-  a.W[0] = p.w_q; a.W[1] = p.w_k; a.W[2] = p.w_v;
-  a.g[0] = p.ln_q_g; a.g[1] = p.ln_k_g; a.g[2] = p.ln_v_g;
-  a.b[0] = p.ln_q_b; a.b[1] = p.ln_k_b; a.b[2] = p.ln_v_b;
-  for (int z = 0; z < 3; ++z) { a.Wp[z] = ws + z * wsz; a.c[z] = ws + 3 * wsz + z * csz; }
-  hipLaunchKernelGGL(fold_ln_kernel, dim3(MATCHA_N_HEAD * 64, 3), dim3(64), 0, st, a);
-  MATCHA_CHECK_LAUNCH("fold_ln_kernel");
-  return MATCHA_OK;
-}
 
 size_t fused_tail_slab_floats(int64_t B, int L) { return (size_t)(ragged_tiles_cap(B, L) + 2) * kTailSlab; }
 size_t fused_tail_partial_floats() { return (size_t)kTailSplits * kTailSlab; }

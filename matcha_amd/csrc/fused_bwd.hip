@@ -217,7 +217,7 @@ constexpr int kTileH = 32 * kLd;
 struct FusedBwdHArgs {
   const float* X; const float* dDyn; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos;
   int L; int nhalves; int nchunks;
-  const float* mB; const float* mM;               // merged matrices [8][64][64] (launch_merge_heads)
+  const float* mB; const float* mM;               // merged matrices [8][64][64] (launch_prep_heads)
   float* dxh; int64_t tcap;
   int dx_atomic;                                   // 1: every head adds into ONE [tcap][64] buffer with float atomics (zeroed by the launcher); 0: one slab per head
   float* wslab;                                    // [8][nchunks][kWgSlabM]

@@ -13,7 +13,7 @@
 //   operands pass through the wave's two private LDS tiles (2 x 8.5 KB: eight wavefronts per CU, two per SIMD, limited by the 256
 //   registers).
 //
-//   Weights are STREAMED FROM L2 in fragment-major order (fold_frag_kernel rewrites them once per step: one coalesced 1 KB load per
+//   Weights are STREAMED FROM L2 in fragment-major order (prep_heads_kernel rewrites them once per step: one coalesced 1 KB load per
 //   wave and four MFMAs) through a rolling window of nine float4 per lane; tools/ubench/mfma_l2stream.hip measured 85 - 88 % of the
 //   matrix pipe's rate for that pattern with two decoupled waves per SIMD, without any LDS staging.
 //
@@ -45,7 +45,7 @@ constexpr int kLdH = 68;                  // LDS row stride (floats)
 constexpr int kHT = 32 * kLdH;            // one half tile [32 rows][68]
 constexpr float kEps32 = 1e-5f;
 constexpr int kFragF4 = 18 * 64;           // float4 per 64 x 64 matrix in fragment-major order: [wc][c = 0..7 | bias][lane]
-constexpr int kNMat = 20;                 // R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0, conv1, conv1^T, conv0^T -- in consumption order (fold_frag_kernel)
+constexpr int kNMat = 20;                 // R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0, conv1, conv1^T, conv0^T -- in consumption order (prep_heads_kernel)
 constexpr int kTailVec32 = 2 * 4096;      // same slab format as fused_fwd.hip (tail_slab_reduce_kernel reads both)
 constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
 
@@ -211,75 +211,159 @@ __device__ __forceinline__ FL fl_zero() {
 //   output   sum_j p_ij v_j = W'v (sum_j p_ij x_j) + cv  (the probabilities, padding slots included, sum to 1)
 //            dyn += Wfc1_h O_i                                   ->  z_i = sum_j p_ij x_j,  dyn += M_h z_i,   M_h = Wfc1_h W'v_h
 // (x = the LayerNorm-normalised row, the same for every head: it is the key AND the value of every head, written to LDS once per tile.)
-// The constants Wfc1_h cv_h join the fc1 bias.  merge_heads_kernel builds B_h, b_h, M_h and that bias once per step.
-struct MergeArgs {
-  const float* wq; const float* wk; const float* wv; const float* cq; const float* cv;   // folded [512][64], [512]
+// The constants Wfc1_h cv_h join the fc1 bias.  prep_heads_kernel builds B_h, b_h, M_h and that bias once per step.
+// ---- the per-step weight forms in ONE launch (rounds 1-3: fold_ln_kernel -> merge_heads_kernel -> fold_frag_kernel, 23 us of dependent
+// latency in front of every forward; now 12) ------------------------------------------------------------------------------------------
+//   fold:      W' = W * g, c = W . b for the three LayerNorm affines in front of Q / K / V (Modules.py:519-529); the fold happens on the way
+//              into LDS and is written out for the backward's chain rule (fbm_chain_kernel reads W'q, W'k, W'v, cq, cv)
+//   merge:     B_h = W'k^T W'q, b_h = W'k^T cq, M_h = Wfc1_h W'v, merged fc1 bias = fc1_b + Wfc1 cv   (16 products of 64^3 on MFMA tiles)
+//   fragments: every matrix the forward streams, in MFMA-fragment order, in consumption order (R_0 | R_{h+1} M_h | M_7 | conv0 conv1
+//              conv1^T conv0^T | one matrix of zeros): per 64 x 64 matrix 18 fragments of one float4 per lane, [wc][c = 0..7 | bias][lane],
+//              lane (r, h) holds W[32 wc + r][8 c + 4 h .. + 3]; the bias fragment enters the accumulator as one more MFMA against 1
+// grid (4 row slices of 16, 2 matrices, 8 heads + 1): block (slice, y, hd) computes 16 rows of B_hd (y = 0) or M_hd (y = 1) and writes them
+// row-major (for the backward) and as fragments; slice 0 also computes the bias vector(s) it needs; z = 8: the conv fragments.
+struct PrepArgs {
+  const float* Wq; const float* Wk; const float* Wv;      // [512][64] as the reference holds them
+  const float* gq; const float* gk; const float* gv; const float* bq; const float* bv;   // LayerNorm affines in front of them [64]
   const float* fc1_w; const float* fc1_b;
-  float* B; float* M; float* bvec; float* bdyn;          // [8][64][64], [8][64][64], [8][64], [64]
+  const float* p0w; const float* p0b; const float* p1w; const float* p1b;
+  float* fwq; float* fwk; float* fwv; float* fcq; float* fcv;          // folded forms (read by fbm_chain_kernel)
+  float* B; float* M; float* bvec; float* bdyn;                        // merged forms (read by fused_bwdh_kernel / fbm_chain_kernel)
+  f32x4* frag;                                                         // [kNMat + 1][kFragF4]
 };
-// grid (4 row slices, 2 matrices, 8 heads): 16 rows of B_h (y = 0; slice 0 also b_h) or of M_h (y = 1; slice 0 of head 0 also bdyn)
-__global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
+__device__ __forceinline__ void frag_put(f32x4* frag, int m, int n, int k, float v) {
+  // element (row n, column k) of matrix m in fragment order: float4 (wc, c, lane = r + 32 h), component j
+  const int wc = n >> 5, r = n & 31, c = k >> 3, h = (k & 7) >> 2, j = k & 3;
+  reinterpret_cast<float*>(frag + (int64_t)m * kFragF4 + (wc * 9 + c) * 64 + r + 32 * h)[j] = v;
+}
+__global__ __launch_bounds__(256) void prep_heads_kernel(PrepArgs a) {
   __shared__ float As[16 * 65];
   __shared__ __attribute__((aligned(16))) float Bs[64 * 68];
+  __shared__ __attribute__((aligned(16))) float cs[512];               // cq of this head (y = 0) / cv of this head or of all heads (y = 1, head 0)
+  __shared__ float bs[64];                                             // b_h or the merged fc1 bias
   const int slice = blockIdx.x, hd = blockIdx.z, tid = threadIdx.x;
-  const float* Wk = a.wk + (int64_t)hd * 4096;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (hd == MATCHA_N_HEAD) {
+    // conv0, conv1, conv1^T, conv0^T (matrices 16..19) and one matrix of zeros behind the stream
+    const int id = blockIdx.x + 4 * blockIdx.y;
+    if (id > 4) return;
+    for (int idx = tid; idx < kFragF4; idx += 256) {
+      const int wc = idx / 576, c = (idx % 576) >> 6, ln = idx & 63, r = ln & 31, h = ln >> 5;
+      const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (id < 4) {
+        if (c < 8) {
+          if (id == 0) v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
+          else if (id == 1) v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
+          else if (id == 2) v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
+          else v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
+        } else if (h == 0) {
+          v.x = id == 0 ? a.p0b[n] : (id == 1 ? a.p1b[n] : 0.f);
+        }
+      }
+      a.frag[(int64_t)(16 + id) * kFragF4 + idx] = v;
+    }
+    return;
+  }
   const bool isB = blockIdx.y == 0;
-  // B_h[r][c] = sum_m W'k[m][r] W'q[m][c];   M_h[n][c] = sum_m Wf[n][hd * 64 + m] W'v[m][c]
-  const float* A = isB ? Wk : a.fc1_w + hd * 64;
-  const int a_rs = isB ? 1 : 512, a_cs = isB ? 64 : 1;
-  const float* Bm = (isB ? a.wq : a.wv) + (int64_t)hd * 4096;
-  float* out = (isB ? a.B : a.M) + (int64_t)hd * 4096;
+  const int64_t ho = (int64_t)hd * 4096;
+  const float* Braw = (isB ? a.Wq : a.Wv) + ho;
+  const float* gB = isB ? a.gq : a.gv;
+  float* Bfold = (isB ? a.fwq : a.fwv) + ho;
+  float* out = (isB ? a.B : a.M) + ho;
+  const int mat = isB ? (hd == 0 ? 0 : 2 * hd - 1) : (hd < 7 ? 2 * hd + 2 : 15);     // position in the fragment stream
   {
-    // the 16 x 64 left operand, its four loads per thread in flight together.  B_h: A(i, x) = W'k[x][16 slice + i] -- walk W'k's rows
-    // (16 consecutive floats per x) instead of its columns
+    // the 16 x 64 left operand.  B_h: A(i, x) = W'k[x][16 slice + i] = Wk[x][16 slice + i] * gk[16 slice + i] (folded here, written out for
+    // the backward); M_h: A(i, x) = Wfc1[16 slice + i][hd 64 + x]
     float av[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = tid + 256 * t;
-      av[t] = isB ? A[(int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)] : A[(int64_t)(16 * slice + (i >> 6)) * a_rs + (int64_t)(i & 63) * a_cs];
+      if (isB) av[t] = a.Wk[ho + (int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)] * a.gk[16 * slice + (i & 15)];
+      else av[t] = a.fc1_w[(int64_t)(16 * slice + (i >> 6)) * 512 + hd * 64 + (i & 63)];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = tid + 256 * t;
       As[isB ? (i & 15) * 65 + (i >> 4) : (i >> 6) * 65 + (i & 63)] = av[t];
+      if (isB) a.fwk[ho + (int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)] = av[t];
     }
   }
   {
-    // the 64 x 64 right operand: four float4 per thread, all in flight before the first LDS store (one scalar load per trip serialised
-    // sixteen global round trips)
-    float4 bv[4];
+    // the 64 x 64 right operand W'q_h / W'v_h = W * g (column scale), four float4 per thread in flight
+    f32x4 bvv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bv[u] = reinterpret_cast<const float4*>(Bm)[tid + 256 * u];
+    for (int u = 0; u < 4; ++u) bvv[u] = reinterpret_cast<const f32x4*>(Braw)[tid + 256 * u];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int f = (tid + 256 * u) * 4;
-      *reinterpret_cast<float4*>(&Bs[(f >> 6) * 68 + (f & 63)]) = bv[u];
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(gB + (f & 63));
+      f32x4 w = bvv[u];
+      w.x *= gg.x; w.y *= gg.y; w.z *= gg.z; w.w *= gg.w;
+      *reinterpret_cast<f32x4*>(&Bs[(f >> 6) * 68 + (f & 63)]) = w;
+      if (slice == 0) reinterpret_cast<f32x4*>(Bfold)[tid + 256 * u] = w;
     }
   }
   __syncthreads();
   {
-    // 16 x 64 outputs = one 16 x 16 MFMA tile per wavefront, 16 steps of v_mfma_f32_16x16x4_f32 over the contraction index (the scalar
-    // loop this replaces read two LDS words per multiply-add: 18 us for sixteen 64^3 products)
-    const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int c16 = lane & 15, kq = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[c16 * 65 + 4 * kk + kq], Bs[(4 * kk + kq) * 68 + 16 * wave + c16], acc, 0, 0, 0);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) out[(16 * slice + 4 * kq + reg) * 64 + 16 * wave + c16] = acc[reg];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int n = 16 * slice + 4 * kq + reg, k = 16 * wave + c16;
+      out[n * 64 + k] = acc[reg];
+      frag_put(a.frag, mat, n, k, acc[reg]);
+    }
   }
-  if (slice == 0) {
-    // the two bias vectors: four lanes per output, float4 reads, a fixed xor tree (one thread per output walked 512 terms alone: it was
-    // the longest path of the kernel)
+  if (slice != 0) return;
+  // ---- slice 0 of every (matrix, head): the folded bias vector(s) it needs, the merged bias, the bias fragment -------------------------
+  {
+    // c[m] = sum_k W[m][k] b[k] (one xor tree over the 64 lanes per row).  y = 0: cq of this head;
+    // y = 1: cv of this head -- of ALL heads for head 0, whose block builds the merged fc1 bias from them
+    const float* Wraw = isB ? a.Wq : a.Wv;
+    const float* bb = isB ? a.bq : a.bv;
+    const int row0 = (!isB && hd == 0) ? 0 : hd * 64, nrow = (!isB && hd == 0) ? 512 : 64;
+    const float bk = bb[lane];
+    // 64 rows per wavefront and trip, lane = column: the 64 x 64 products are summed over the lanes by a TRANSPOSING butterfly -- at
+    // offset o a lane keeps the rows whose index has bit o like its own lane id and hands the others to its partner -- 63 shuffles for 64
+    // rows instead of 384, the same additions in the same order as group_sum<64> row by row (both partners of a butterfly step
+    // compute the same sum), and lane l ends with row l
+#pragma unroll 1
+    for (int m0 = 64 * wave; m0 < nrow; m0 += 256) {
+      float v[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) v[j] = Wraw[(int64_t)(row0 + m0 + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) v[j] *= bk;
+#pragma unroll
+      for (int half = 32; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+          const float keep = up ? v[j + half] : v[j];
+          const float send = up ? v[j] : v[j + half];
+          v[j] = keep + __shfl_xor(send, half, 64);
+        }
+      }
+      cs[m0 + lane] = v[0];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) (isB ? a.fcq : a.fcv)[hd * 64 + tid] = cs[tid];        // (head 0 of y = 1 holds all 512 but writes its own 64: the others write theirs)
+  {
     const int o = tid >> 2, part = tid & 3;
     if (isB) {
-      float s = 0.f;
-      for (int m = 16 * part; m < 16 * part + 16; ++m) s += Wk[m * 64 + o] * a.cq[hd * 64 + m];
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-      if (part == 0) a.bvec[hd * 64 + o] = s;
+      // b_h[o] = sum_m W'k[m][o] cq[m]
+      float s_ = 0.f;
+      for (int m = 16 * part; m < 16 * part + 16; ++m) s_ += (a.Wk[ho + m * 64 + o] * a.gk[o]) * cs[m];
+      s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64);
+      if (part == 0) { a.bvec[hd * 64 + o] = s_; bs[o] = s_; }
     } else if (hd == 0) {
       const float4* wrow = reinterpret_cast<const float4*>(a.fc1_w + o * 512 + 128 * part);
-      const float4* cvp = reinterpret_cast<const float4*>(a.cv + 128 * part);
+      const float4* cvp = reinterpret_cast<const float4*>(cs + 128 * part);
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll 4
       for (int m = 0; m < 32; m += 2) {
@@ -287,52 +371,21 @@ __global__ __launch_bounds__(256) void merge_heads_kernel(MergeArgs a) {
         s0 += (w0.x * c0.x + w0.y * c0.y) + (w0.z * c0.z + w0.w * c0.w);
         s1 += (w1.x * c1.x + w1.y * c1.y) + (w1.z * c1.z + w1.w * c1.w);
       }
-      float s = s0 + s1;
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-      if (part == 0) a.bdyn[o] = a.fc1_b[o] + s;
+      float s_ = s0 + s1;
+      s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64);
+      if (part == 0) { const float v = a.fc1_b[o] + s_; a.bdyn[o] = v; bs[o] = v; }
+    } else if (part == 0) {
+      bs[o] = 0.f;                                                     // the merged fc1 bias enters dyn once, with head 0
     }
   }
-}
-
-// ---- fragment-major weights, rewritten once per step (after fold_ln_kernel) ----------------------------------------------
-struct FragArgs {
-  const float* p0w; const float* p0b; const float* p1w; const float* p1b;   // [64][64], [64]
-  f32x4* out;                                             // [kNMat + 1][kFragF4] (one matrix of zero padding behind the stream)
-  const float* mB; const float* mM; const float* mbvec; const float* mbdyn;   // B_h, M_h [8][64][64], b_h [8][64], the merged fc1 bias [64]
-};
-// Stream order = consumption order of fused_fwd32_kernel: R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0 conv1 conv1^T conv0^T.
-// grid (kNMat + 1, 9) x 128: fragment (wc, c, lane) of matrix m
-__global__ __launch_bounds__(128) void fold_frag_kernel(FragArgs a) {
-  const int m = blockIdx.x, idx = blockIdx.y * 128 + threadIdx.x;       // 0 .. 1151
-  const int wc = idx / 576, c = (idx % 576) >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
-  const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
-  int type = -1, hd = 0;                                 // 4 conv0, 5 conv1, 6 conv1^T, 7 conv0^T, 8 B_h, 9 M_h
-  if (m == 0) { type = 8; }
-  else if (m < 15) { hd = (m - 1) >> 1; if ((m - 1) & 1) type = 9; else { type = 8; ++hd; } }
-  else if (m == 15) { type = 9; hd = 7; }
-  else if (m < 20) type = m - 12;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (c < 8) {
-    if (type == 4) {
-      v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
-    } else if (type == 5) {
-      v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
-    } else if (type == 6) {                              // conv1^T: A[i][contraction n'] = W1[n'][i]
-      v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
-    } else if (type == 7) {
-      v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
-    } else if (type == 8) {
-      v = *reinterpret_cast<const f32x4*>(a.mB + ((int64_t)hd * 64 + n) * 64 + k0);
-    } else if (type == 9) {
-      v = *reinterpret_cast<const f32x4*>(a.mM + ((int64_t)hd * 64 + n) * 64 + k0);
-    }
-  } else if (h == 0) {                                   // bias fragment: lane (r, 0) supplies A[i = r][k = 0]; B is the constant 1
-    float bv = 0.f;
-    if (type == 4) bv = a.p0b[n]; else if (type == 5) bv = a.p1b[n];
-    else if (type == 8) bv = a.mbvec[hd * 64 + n]; else if (type == 9) bv = hd == 0 ? a.mbdyn[n] : 0.f;   // the merged fc1 bias enters dyn once
-    v.x = bv;
+  __syncthreads();
+  if (tid < 128) {
+    // the bias fragment (c = 8) of this matrix: lane (r, 0) supplies A[i = r][k = 0]; B is the constant 1
+    const int wc = tid >> 6, ln = tid & 63, r = ln & 31, h = ln >> 5;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (h == 0) v.x = bs[32 * wc + r];
+    a.frag[(int64_t)mat * kFragF4 + (wc * 9 + 8) * 64 + ln] = v;
   }
-  a.out[(int64_t)m * kFragF4 + idx] = v;
 }
 
 struct Fwd32Args {
@@ -610,7 +663,7 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   const bool real = r < n;
   const int64_t tok = real ? (int64_t)(t0 + r) : (int64_t)tok_pad;
 
-  // weight stream of THIS head: R_hd sits at matrix 0 (hd = 0) or 2 hd - 1, M_hd at 2 hd + 2 (hd < 7) or 15 (fold_frag_kernel's merged order)
+  // weight stream of THIS head: R_hd sits at matrix 0 (hd = 0) or 2 hd - 1, M_hd at 2 hd + 2 (hd < 7) or 15 (prep_heads_kernel's stream order)
   const f32x4* wp = g.wfrag + (int64_t)(hd == 0 ? 0 : 2 * hd - 1) * kFragF4 + lane;
   f32x4 W_[F32_WIN];
   W32_PRIME();
@@ -722,29 +775,19 @@ size_t fused_merged_floats() { return (size_t)2 * MATCHA_N_HEAD * 4096 + MATCHA_
 MergedView merged_view(const float* m) {
   return MergedView{m, m + (size_t)MATCHA_N_HEAD * 4096, m + (size_t)2 * MATCHA_N_HEAD * 4096, m + (size_t)2 * MATCHA_N_HEAD * 4096 + MATCHA_N_HEAD * 64};
 }
-int launch_merge_heads(const matcha_tensors& p, const float* folded, float* merged, hipStream_t st) {
-  MergeArgs a;
+// the per-step weight forms (prep_heads_kernel): `folded` = fused_fold_floats() floats, `merged` = fused_merged_floats()
+int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, float* frag, hipStream_t st) {
+  PrepArgs a;
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
-  a.wq = folded; a.wk = folded + wsz; a.wv = folded + 2 * wsz;
-  a.cq = folded + 3 * wsz; a.cv = a.cq + 2 * csz;
-  a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b;
+  a.Wq = p.w_q; a.Wk = p.w_k; a.Wv = p.w_v;
+  a.gq = p.ln_q_g; a.gk = p.ln_k_g; a.gv = p.ln_v_g; a.bq = p.ln_q_b; a.bv = p.ln_v_b;
+  a.fc1_w = p.fc1_w; a.fc1_b = p.fc1_b; a.p0w = p.pff0_w; a.p0b = p.pff0_b; a.p1w = p.pff1_w; a.p1b = p.pff1_b;
+  a.fwq = folded; a.fwk = folded + wsz; a.fwv = folded + 2 * wsz; a.fcq = folded + 3 * wsz; a.fcv = a.fcq + 2 * csz;
   const MergedView v = merged_view(merged);
   a.B = const_cast<float*>(v.B); a.M = const_cast<float*>(v.M); a.bvec = const_cast<float*>(v.bvec); a.bdyn = const_cast<float*>(v.bdyn);
-  hipLaunchKernelGGL(merge_heads_kernel, dim3(4, 2, MATCHA_N_HEAD), dim3(256), 0, st, a);
-  MATCHA_CHECK_LAUNCH("merge_heads_kernel");
-  return MATCHA_OK;
-}
-
-int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st, const float* merged) {
-  (void)folded;
-  MATCHA_CHECK_ARG(merged, "fold_frag: the merged matrices are required");
-  FragArgs a;
-  a.p0w = p.pff0_w; a.p0b = p.pff0_b; a.p1w = p.pff1_w; a.p1b = p.pff1_b;
-  a.out = reinterpret_cast<f32x4*>(frag);
-  const MergedView v = merged_view(merged);
-  a.mB = v.B; a.mM = v.M; a.mbvec = v.bvec; a.mbdyn = v.bdyn;
-  hipLaunchKernelGGL(fold_frag_kernel, dim3(kNMat + 1, 9), dim3(128), 0, st, a);
-  MATCHA_CHECK_LAUNCH("fold_frag_kernel");
+  a.frag = reinterpret_cast<f32x4*>(frag);
+  hipLaunchKernelGGL(prep_heads_kernel, dim3(4, 2, MATCHA_N_HEAD + 1), dim3(256), 0, st, a);
+  MATCHA_CHECK_LAUNCH("prep_heads_kernel");
   return MATCHA_OK;
 }
 

@@ -135,7 +135,6 @@ int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStre
 
 // fused_aux.hip (embed_dim 64): per-step weight folding, reduction of the training forward's parameter-gradient slabs
 size_t fused_fold_floats();
-int launch_fold_ln(const matcha_tensors& p, float* ws, hipStream_t st);
 size_t fused_tail_slab_floats(int64_t B, int L);
 size_t fused_tail_partial_floats();
 // small: one launch (small batches; another summation order); it can also zero zero_bytes of zero_buf (the backward kernel's d x_hat buffer)
@@ -144,16 +143,15 @@ int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tenso
 bool fused_small_batch(const Ragged& rg);          // the size rule of the small-batch kernels (fused_fwd32h_kernel, tail_slab_small_kernel)
 
 // fused_fwd32.hip (embed_dim 64): the same forward with ONE wavefront per half tile (<= 31 tokens), weights streamed from L2 in
-// MFMA-fragment order (launch_fold_frag rewrites them once per step, after launch_fold_ln), no workgroup barriers
+// MFMA-fragment order (launch_prep_heads rewrites them once per step), no workgroup barriers
 size_t fused_frag_floats();
 size_t fused_tail_slab32_floats(int64_t B, int L);
 // the heads in their two-products form (r = B_h x + b_h, dyn += M_h z); `merged` = fused_merged_floats() floats of workspace that
-// launch_merge_heads fills (B [8][64][64], M [8][64][64], b [8][64], bdyn [64]) after launch_fold_ln
+// launch_prep_heads fills (B [8][64][64], M [8][64][64], b [8][64], bdyn [64])
 size_t fused_merged_floats();
 struct MergedView { const float* B; const float* M; const float* bvec; const float* bdyn; };
 MergedView merged_view(const float* merged);
-int launch_merge_heads(const matcha_tensors& p, const float* folded, float* merged, hipStream_t st);
-int launch_fold_frag(const matcha_tensors& p, const float* folded, float* frag, hipStream_t st, const float* merged);
+int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, float* frag, hipStream_t st);     // the three per-step weight forms, one launch
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
                        hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* rimg = nullptr);

@@ -431,13 +431,11 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
     // token); every training forward also leaves its Q/K/V tiles and attention probabilities for the fused backward (w.qkv)
     const bool save = !opts->forward_only && !lif;
-    MATCHA_TRY(launch_fold_ln(p, w.folded, st));
+    MATCHA_TRY(launch_prep_heads(p, w.folded, w.merged, w.frag, st));      // folded / merged / fragment-order weights of this step
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
     note_forward(ws, true, true);
-    MATCHA_TRY(launch_merge_heads(p, w.folded, w.merged, st));
-    MATCHA_TRY(launch_fold_frag(p, w.folded, w.frag, st, w.merged));
     MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr));
