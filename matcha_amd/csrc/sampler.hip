@@ -141,15 +141,30 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restri
     if (orig[i] != 0) k = i + 1;
   }
   int64_t* out = neg + n * L;
+  // The chromosome range of EVERY position is looked up before the membership test of the positive, not after it and only for the
+  // positions drawn: node -> chromosome -> range is a chain of two dependent loads that then runs next to the hash probe's two
+  // instead of behind them (this kernel is a chain of global-memory round trips; at the reference's 288 negatives per step it is
+  // nothing else).  Clamped indices, no branch around the loads.
+  const uint64_t seed_v = *seed;
+  int cidx[MATCHA_MAX_L];
+#pragma unroll
+  for (int i = 0; i < MATCHA_MAX_L; ++i) {
+    const bool in = i < k && orig[i] >= 1 && orig[i] <= n_nodes;
+    const int c = node2chrom[in ? orig[i] : 0];
+    cidx[i] = (in && c >= 0 && c < n_chrom) ? c : -1;
+  }
+  int2 crange[MATCHA_MAX_L];
+#pragma unroll
+  for (int i = 0; i < MATCHA_MAX_L; ++i) crange[i] = reinterpret_cast<const int2*>(chrom_range)[cidx[i] >= 0 ? cidx[i] : 0];
   // `while neighbor_check(temp, dict)` with temp == the positive on entry (main.py:390-392): if the positive is
   // not a member (in particular: empty set, the reference's phase 1, main.py:589) the loop never runs.
   bool resample = (n_set > 0) && (k > 0) && set_contains_reg(set, set_edges, L_set, orig, L);
   bool done = false;
   if (resample) {
-    const uint32_t key = rng_key(*seed, kStreamNeg);
+    const uint32_t key = rng_key(seed_v, kStreamNeg);
     uint32_t mask = 0;
     for (uint32_t a = 0; mask == 0; ++a) mask = rng_u32(key, (uint32_t)n, 0xFFFF0000u + a) & ((1u << k) - 1u);
-    // the chromosome ranges of the positions that may be redrawn do not change between trials: looked up once
+    // the chromosome ranges of the positions that may be redrawn do not change between trials
     int64_t cstart[MATCHA_MAX_L], clen[MATCHA_MAX_L];
 #pragma unroll
     for (int i = 0; i < MATCHA_MAX_L; ++i) {
@@ -157,10 +172,9 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int32_t* __restri
       if (i < k && ((mask >> i) & 1u)) {
         // a node outside [1, n_nodes] or without a chromosome (node2chrom = -1, the default fill of train.run) cannot be
         // redrawn: it is kept and the call is flagged (the reference raises KeyError / IndexError at main.py:401-403)
-        const int c = (orig[i] >= 1 && orig[i] <= n_nodes) ? node2chrom[orig[i]] : -1;
-        if (c >= 0 && c < n_chrom) {
-          cstart[i] = chrom_range[2 * c];
-          clen[i] = (int64_t)chrom_range[2 * c + 1] - cstart[i];
+        if (cidx[i] >= 0) {
+          cstart[i] = crange[i].x;
+          clen[i] = (int64_t)crange[i].y - cstart[i];
         } else if (status) {
           atomicOr(status, MATCHA_STATUS_BAD_CHROM);
         }
