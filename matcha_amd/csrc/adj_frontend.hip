@@ -203,6 +203,80 @@ __global__ __launch_bounds__(256) void adj_scatter_kernel(const int64_t* __restr
   }
 }
 
+// The same sort for SMALL batches (T <= 4096 token slots: the reference's own 384-row step) in ONE launch: one workgroup of 512 threads,
+// eight consecutive slots per thread; per-thread bucket counts in LDS, their exclusive prefix per bucket by one wavefront (eight counts
+// per lane + a 64-lane shuffle scan), the segment starts by thread 0, then every thread places its slots.  Same outputs as
+// hist + scan + scatter (order, other_map, seg, counts, touched; the reconstruction scratch zeroed), which it replaces at that size.
+constexpr int kSortSmallTok = 4096;
+__global__ __launch_bounds__(512) void adj_sort_small_kernel(const int64_t* __restrict__ x, int64_t T, const int32_t* __restrict__ bounds, int C, int r_chrom,
+                                                             int32_t* __restrict__ seg, int32_t* __restrict__ counts, int32_t* __restrict__ touched,
+                                                             int32_t* __restrict__ order, int32_t* __restrict__ other_map,
+                                                             const int32_t* __restrict__ t_dev, const int32_t* __restrict__ r_dev,
+                                                             float* __restrict__ zero_buf, int zero_n) {
+  extern __shared__ int tc[];                       // [C + 1][512]
+  __shared__ int tot[kMaxChrom + 2];
+  __shared__ int segs[kMaxChrom + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < zero_n; i += 512) zero_buf[i] = 0.f;
+  if (r_dev) { const int rv = *r_dev; r_chrom = (rv >= 0 && rv < C) ? rv : -1; }
+  if (t_dev) T = *t_dev;
+  for (int k = 0; k <= C; ++k) tc[k * 512 + tid] = 0;
+  const int64_t t0 = (int64_t)tid * 8;
+  int ch[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ch[i] = (t0 + i < T) ? chrom_of(x[t0 + i], bounds, C) : -1;
+    if (ch[i] >= 0) tc[ch[i] * 512 + tid] += 1;
+  }
+  __syncthreads();
+  for (int k = wave; k <= C; k += 8) {
+    int* row = tc + k * 512 + 8 * lane;
+    int v[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = row[i]; sum += v[i]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { row[i] = run; run += v[i]; }
+    if (lane == 63) tot[k] = incl;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k <= C; ++k) { segs[k] = run; seg[k] = run; run += tot[k]; }
+    seg[C + 1] = run;
+    segs[C + 1] = run;
+    const int nonpad = segs[C];
+    const int in_r = (r_chrom >= 0 && r_chrom < C) ? tot[r_chrom] : 0;
+    counts[0] = (r_chrom >= 0) ? nonpad - in_r : 0;
+    counts[1] = nonpad;
+    if (touched) {
+      touched[0] = 1;
+      touched[1] = 0;
+      for (int k = 0; k < C; ++k) {
+        touched[2 + k] = tot[k] > 0 ? 1 : 0;
+        touched[2 + C + k] = (k == r_chrom && nonpad - in_r > 0) ? 1 : 0;
+      }
+    }
+  }
+  __syncthreads();
+  const int r0 = (r_chrom >= 0 && r_chrom < C) ? segs[r_chrom] : 0, r1 = (r_chrom >= 0 && r_chrom < C) ? segs[r_chrom + 1] : 0;
+  const int nonpad = segs[C];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (ch[i] < 0) continue;
+    const int pos = segs[ch[i]] + tc[ch[i] * 512 + tid];
+    tc[ch[i] * 512 + tid] += 1;
+    order[pos] = (int32_t)(t0 + i);
+    if (r_chrom >= 0 && pos < nonpad && !(pos >= r0 && pos < r1)) other_map[pos < r0 ? pos : pos - (r1 - r0)] = (int32_t)(t0 + i);
+  }
+}
+
 // ---- gather-GEMM: Hs[p] = tanh( (feats_c[x - lo_c] * dropmask) . W0_c^T ) for sorted rows p ---------------------
 struct AdjEncArgs {
   const int64_t* x;
@@ -554,6 +628,14 @@ static int check_adj(const matcha_shape& s, const matcha_tensors& p, const match
 static int sort_tokens(const matcha_shape& s, const matcha_frozen& f, const int64_t* x, int64_t T, int r_chrom, AdjWs& w, int32_t* touched,
                        const int32_t* t_dev, hipStream_t st, const int32_t* r_dev = nullptr, bool zero_rgrad = false) {
   const int C = s.n_chrom;
+  if (T <= kSortSmallTok && !options().disable_small_batch) {
+    const size_t lds = (size_t)(C + 1) * 512 * sizeof(int);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adj_sort_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(adj_sort_small_kernel, dim3(1), dim3(512), lds, st, x, T, f.bounds, C, r_chrom, w.seg, w.counts, touched, w.order, w.other_map, t_dev,
+                       r_dev, zero_rgrad ? w.rgrad : nullptr, zero_rgrad ? (int)(w.nr_pad * (s.d + 1)) : 0);
+    MATCHA_CHECK_LAUNCH("adj_sort_small_kernel");
+    return MATCHA_OK;
+  }
   hipLaunchKernelGGL(adj_hist_kernel, dim3(w.nblk), dim3(256), 0, st, x, T, f.bounds, C, w.hist, t_dev);
   MATCHA_CHECK_LAUNCH("adj_hist_kernel");
   const int scan_ints = w.nblk * (C + 1) <= 12288 ? w.nblk * (C + 1) : 0;        // <= 48 KB of LDS for the staged histogram
