@@ -149,3 +149,48 @@ def test_graph_replayed_epoch_equals_the_step_by_step_epoch(tmp_path, front_end,
             diff = (p0[n] - p1[n]).abs().reshape(-1)
             assert float(diff.max()) <= 1e-2, n
             assert float(torch.quantile(diff, 0.9)) <= 2e-4, n
+
+
+@pytest.mark.gpu
+def test_step_select_and_record_equal_the_torch_bookkeeping():
+    """matcha_step_select / matcha_step_record (csrc/epoch_step.hip; main.py:58, :160-161, :185-188, :449-451) against the torch ops they
+    replace in the captured step: the step's rows, weights, chromosome cell and seeds; sigmoid, sizes, loss sums, counter -- bit for bit,
+    over several steps including a counter past the epoch's end (clamped: never out of bounds)."""
+    import ctypes as C
+    from matcha_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    P, L, n_steps, B = 96, 5, 7, 384
+    pos = torch.randint(0, 3000, (n_steps * P, L), generator=g).to(dev)
+    pos[:, 3:] *= (torch.rand(n_steps * P, 2, generator=g) < 0.5).to(dev)                    # ragged: zero padding on the right
+    w = torch.rand(n_steps * P, generator=g).to(dev)
+    chroms = torch.randint(0, 23, (n_steps,), generator=g, dtype=torch.int32).to(dev)
+    it = torch.zeros(1, dtype=torch.long, device=dev)
+    x = torch.zeros((B, L), dtype=torch.long, device=dev)
+    ww = torch.ones(B, device=dev)
+    cell = torch.zeros(1, dtype=torch.int32, device=dev)
+    s0 = torch.tensor([11], dtype=torch.int64, device=dev)
+    s1 = torch.tensor([2 ** 40 + 5], dtype=torch.int64, device=dev)
+    sums = torch.zeros(2, device=dev)
+    preds = torch.zeros((n_steps, B), device=dev)
+    sizes = torch.zeros((n_steps, B), dtype=torch.long, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ref_sums = torch.zeros(2, device=dev)
+    for step in range(n_steps + 2):                                                          # two replays past the end
+        _lib.check(lib.matcha_step_select(_lib.ptr(pos), _lib.ptr(w), n_steps * P, L, _lib.ptr(it), P, _lib.ptr(x), _lib.ptr(ww), _lib.ptr(chroms),
+                                          n_steps, _lib.ptr(cell), _lib.ptr(s0), _lib.ptr(s1), st), "matcha_step_select")
+        if step < n_steps:
+            assert torch.equal(x[:P], pos[step * P:(step + 1) * P]) and torch.equal(ww[:P], w[step * P:(step + 1) * P])
+            assert int(cell) == int(chroms[step])
+        assert int(s0) == 11 + step + 1 and int(s1) == 2 ** 40 + 5 + step + 1
+        x[P:] = torch.randint(0, 3000, (B - P, L), generator=g).to(dev)                      # "negatives"
+        logits = torch.randn(B, generator=g).to(dev) * 4
+        losses = torch.rand(3, generator=g).to(dev)
+        _lib.check(lib.matcha_step_record(_lib.ptr(logits), _lib.ptr(losses), _lib.ptr(x), B, L, _lib.ptr(it), n_steps, _lib.ptr(sums),
+                                          _lib.ptr(preds), _lib.ptr(sizes), st), "matcha_step_record")
+        row = min(step, n_steps - 1)
+        assert torch.equal(preds[row], torch.sigmoid(logits)) and torch.equal(sizes[row], (x != 0).sum(1))
+        ref_sums[0] += losses[0]
+        ref_sums[1] += losses[1]
+        assert torch.equal(sums, ref_sums) and int(it) == step + 1
