@@ -185,8 +185,8 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
         perm = rng.permutation(len(pool))
         pool, wts = pool[perm], wts[perm]
         pool_all = torch.from_numpy(pool).to(device)
-        shard = torch.from_numpy(pool[rank::world]).to(device)
-        shard_w = torch.from_numpy(wts[rank::world]).to(device)
+        shard = torch.from_numpy(np.ascontiguousarray(pool[rank::world])).to(device).long().contiguous()
+        shard_w = torch.from_numpy(np.ascontiguousarray(wts[rank::world])).to(device).float().contiguous()
         M_shard = shard.shape[0]
         workload_edges = len(pool)
 
@@ -207,17 +207,30 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
     n_chrom = len(num)
     chrom_rng = np.random.default_rng(7)
 
+    step_no = torch.zeros(1, dtype=torch.long, device=device)
+    lib_ = _lib.load()
+
     def one_step():
-        idx = (cursor + ar) % M_shard                       # next P positives of this rank's (pre-shuffled) shard
-        cursor.add_(P)
-        if layout == "c5":
-            x[:P] = synth.csr_to_padded(csr_off, csr_ids, L, idx)
-        else:
-            torch.index_select(shard, 0, idx, out=x[:P])
-        torch.index_select(shard_w, 0, idx, out=w[:P])
-        sampler.sample_into(x[:P], x[P:])
         rc = int(chrom_rng.integers(n_chrom)) if front_end == "adj" else 0
-        return trainer.step(x, y, w, alpha=1.0, beta=0.001, random_chrom=rc)     # phase-2 weighting (main.py:672-673)
+        if layout == "c5":
+            idx = (cursor + ar) % M_shard                   # next P positives of this rank's (pre-shuffled) shard: CSR rows expanded to [P, L]
+            cursor.add_(P)
+            x[:P] = synth.csr_to_padded(csr_off, csr_ids, L, idx)
+            torch.index_select(shard_w, 0, idx, out=w[:P])
+            sampler.sample_into(x[:P], x[P:])
+            return trainer.step(x, y, w, alpha=1.0, beta=0.001, random_chrom=rc)     # phase-2 weighting (main.py:672-673)
+        # the next P positives (wrapping around the shard), their weights and both RNG seeds + 1 in one launch: what matcha_amd.train's
+        # captured step does (matcha_step_select, main.py:160-161)
+        st_ = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(lib_.matcha_step_select(_lib.ptr(shard), _lib.ptr(shard_w), M_shard, L, _lib.ptr(step_no), P, _lib.ptr(x), _lib.ptr(w), None, 0,
+                                           None, _lib.ptr(sampler.seed), _lib.ptr(trainer.seed), st_), "matcha_step_select")
+        step_no.add_(1)
+        sampler.sample_into(x[:P], x[P:], advance_seed=False)
+        trainer.seed_advanced_by_caller = True
+        try:
+            return trainer.step(x, y, w, alpha=1.0, beta=0.001, random_chrom=rc)     # phase-2 weighting (main.py:672-673)
+        finally:
+            trainer.seed_advanced_by_caller = False
 
     runner = one_step
     if graph and world == 1 and front_end == "table":

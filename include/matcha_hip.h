@@ -323,7 +323,7 @@ int matcha_neg_sample(const void* set, const int64_t* set_edges, int64_t n_set_e
 /* The bookkeeping of one step of the reference's epoch loop (main.py:155-188) on the device, so that an epoch can replay one captured
  * step (matcha_amd/train.py).  `it` is a device int64 step counter.
  * matcha_step_select (main.py:160-161, Modules.py:192): x[0:P] = pos[it*P .. it*P+P) (rows of the epoch's shuffled positives,
- * int64 [n_rows, L]), ww[0:P] = w[it*P ..], and, when `cell` is given, cell[0] = chroms[it] (the step's reconstruction chromosome);
+ * int64 [n_rows, L]; indices wrap around modulo n_rows), ww[0:P] = w[it*P ..], and, when `cell` is given, cell[0] = chroms[it] (the step's reconstruction chromosome);
  * seed0 / seed1 (optional device uint64): counter-RNG seeds to advance by one (the sampler's and the dropout masks').
  * matcha_step_record (main.py:58, :185-188, :449-451): preds[it][b] = sigmoid(logits[b]), sizes[it][b] = non-zero entries of x[b]
  * (x int64 [B, L]), sums[0] += losses[0] (bce), sums[1] += losses[1] (recon), then it += 1.  preds / sizes are [n_steps, B]. */

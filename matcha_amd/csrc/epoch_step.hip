@@ -24,8 +24,7 @@ __global__ __launch_bounds__(256) void step_select_kernel(const int64_t* __restr
   }
   if (i >= P * L) return;
   const int row = i / L, l = i - row * L;
-  int64_t src = step * P + row;
-  if (src >= n_rows) src = n_rows - 1;                      // (a replay past the epoch's end reads the last row: never out of bounds)
+  const int64_t src = (step * P + row) % n_rows;            // (past the end of the list the selection wraps around: never out of bounds)
   x[(int64_t)row * L + l] = pos[src * L + l];
   if (l == 0) ww[row] = w[src];
 }
