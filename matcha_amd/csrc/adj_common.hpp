@@ -55,6 +55,6 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
                       const int32_t* slot_map);
 int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* ids, int64_t T,
                        const AdjWs& w, int r_chrom, const float* dX0, const float* drecon, matcha_tensors& g, hipStream_t st,
-                       const int32_t* slot_map);
+                       const int32_t* slot_map, int32_t* touched);
 
 }  // namespace matcha

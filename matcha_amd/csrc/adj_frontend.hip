@@ -739,11 +739,13 @@ int adj_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_fr
   MATCHA_CHECK_ARG(!o.random_chrom_dev || fused, "adj_backward: opts->random_chrom_dev needs the fused adj front end");
   const int r = o.random_chrom_dev ? 0 : ((o.random_chrom >= 0 && o.random_chrom < C) ? o.random_chrom : -1);
   const bool train = o.training != 0 && o.p_drop_adj > 0.f;
-  if (touched) {     // order/seg/other_map of the forward are still in the workspace; only the flags are (re)written
+  // order/seg/other_map of the forward are still in the workspace; only the `touched` flags are (re)written -- by a block of the fused
+  // backward kernel, or by a kernel of their own on the layer-wise path
+  if (fused) return adj_fused_backward(s, p, f, o, x, T, w, r, dnode, drecon, g_, st, slot_map, touched);
+  if (touched) {
     hipLaunchKernelGGL(adj_flags_kernel, dim3(1), dim3(64), 0, st, w.seg, w.counts, C, r, touched, o.random_chrom_dev);
     MATCHA_CHECK_LAUNCH("adj_flags_kernel");
   }
-  if (fused) return adj_fused_backward(s, p, f, o, x, T, w, r, dnode, drecon, g_, st, slot_map);
   // ---- recon branch: d loss / d rec = g * 200/(m n_r) * (rec - target) ----
   if (r >= 0 && (drecon || o.beta != 0.f)) {
     MATCHA_CHECK_ARG(g_.recon_w && g_.recon_b && f.bounds_host, "adj_backward: recon gradient buffers missing");

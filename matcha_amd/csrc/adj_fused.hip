@@ -518,17 +518,6 @@ __global__ __launch_bounds__(256) void adj_recon_sum_kernel(const float* __restr
   }
 }
 
-// grads.recon_w / recon_b of chromosome r += g * (unscaled gradient of the forward pass)
-__global__ __launch_bounds__(256) void adj_recon_apply_kernel(const float* __restrict__ gW, const float* __restrict__ gb, int n_r, float* __restrict__ dW,
-                                                              float* __restrict__ db, const float* __restrict__ drecon, float beta,
-                                                              const int32_t* __restrict__ r_dev, const int32_t* __restrict__ bounds) {
-  if (r_dev) { const int r = *r_dev, lo = bounds[r]; n_r = bounds[r + 1] - lo; dW += (int64_t)64 * lo; db += lo; }   // dW / db: the packed tensors' bases
-  const float gsc = drecon ? drecon[0] : beta;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_r * 64) dW[i] += gsc * gW[i];
-  if (i < n_r) db[i] += gsc * gb[i];
-}
-
 // ---- encoder backward ---------------------------------------------------------------------------------------------------------------------
 struct AdjBwdArgs {
   const int64_t* ids;
@@ -547,6 +536,12 @@ struct AdjBwdArgs {
   float p_drop;
   const int32_t* slot_map;
   const int32_t* r_dev;
+  // blocks [n_main, n_main + 1 + n_apply) of the same launch: block n_main writes the step's `touched` flags (which per-chromosome tensors
+  // received a gradient: Modules.py:182-183, :195), the others add the reconstruction head's gradient (left unscaled in rgrad by
+  // adj_recon_kernel) into recon_w / recon_b -- two launches less per step than as kernels of their own
+  int n_main;
+  int32_t* touched; const int32_t* counts;
+  const float* rgW; const float* rgb; int n_r; float* dWr; float* dbr;       // dWr / dbr: chromosome r's slices, or the packed bases with r_dev
 };
 
 // work item = (chromosome, window of steps_per_item 64-row steps); the grid is sized for the bound and blocks behind the last item leave
@@ -581,6 +576,31 @@ __global__ __launch_bounds__(256, 2) void adj_fused_bwd_kernel(AdjBwdArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wr = wave & 1, wc = wave >> 1;
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+  if ((int)blockIdx.x >= g.n_main) {
+    const int e = (int)blockIdx.x - g.n_main;
+    int rc = g.r;
+    if (g.r_dev) { const int rv = *g.r_dev; rc = (rv >= 0 && rv < g.C) ? rv : -1; }
+    if (e == 0) {
+      if (g.touched && tid < 64) {
+        if (tid == 0) { g.touched[0] = 1; g.touched[1] = 0; }
+        if (tid < g.C) {
+          g.touched[2 + tid] = g.seg[tid + 1] > g.seg[tid] ? 1 : 0;
+          g.touched[2 + g.C + tid] = (tid == rc && g.counts[0] > 0) ? 1 : 0;
+        }
+      }
+      return;
+    }
+    if (!g.rgW || rc < 0) return;
+    int n_r = g.n_r;
+    float* dW = g.dWr;
+    float* db = g.dbr;
+    if (g.r_dev) { const int lo_r = g.bounds[rc]; n_r = g.bounds[rc + 1] - lo_r; dW += (int64_t)64 * lo_r; db += lo_r; }
+    const float gs = g.drecon ? g.drecon[0] : g.beta;
+    const int i = (e - 1) * 256 + tid;
+    if (i < n_r * 64) dW[i] += gs * g.rgW[i];
+    if (i < n_r) db[i] += gs * g.rgb[i];
+    return;
+  }
   int c, p_lo, p_hi;
   if (!find_window(g.seg, g.C, blockIdx.x, g.steps_per_item, c, p_lo, p_hi)) return;
   const int lo = g.bounds[c], n_c = g.bounds[c + 1] - lo;
@@ -841,20 +861,21 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
 
 int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* ids, int64_t T,
                        const AdjWs& w, int r_chrom, const float* dX0, const float* drecon, matcha_tensors& g_, hipStream_t st,
-                       const int32_t* slot_map) {
+                       const int32_t* slot_map, int32_t* touched) {
   const int C = s.n_chrom;
   const bool train = o.training != 0 && o.p_drop_adj > 0.f;
   const bool recon = r_chrom >= 0 && (drecon || o.beta != 0.f);
+  AdjBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  int n_apply = 0;
   if (recon) {
     MATCHA_CHECK_ARG(g_.recon_w && g_.recon_b && f.bounds_host, "adj_backward: recon gradient buffers missing");
     const int32_t* r_dev = o.random_chrom_dev;
     const int lo_r = r_dev ? 0 : f.bounds_host[r_chrom], n_r = r_dev ? s.max_bins : f.bounds_host[r_chrom + 1] - lo_r;
-    hipLaunchKernelGGL(adj_recon_apply_kernel, dim3((unsigned)cdiv((int64_t)n_r * 64, 256)), dim3(256), 0, st, w.rgrad, w.rgrad + w.nr_pad * 64, n_r,
-                       g_.recon_w + (int64_t)64 * lo_r, g_.recon_b + lo_r, drecon, o.beta, r_dev, f.bounds);
-    MATCHA_CHECK_LAUNCH("adj_recon_apply_kernel");
+    a.rgW = w.rgrad; a.rgb = w.rgrad + w.nr_pad * 64; a.n_r = n_r; a.dWr = g_.recon_w + (int64_t)64 * lo_r; a.dbr = g_.recon_b + lo_r;
+    n_apply = (int)cdiv((int64_t)n_r * 64, 256);
   }
-  AdjBwdArgs a;
-  memset(&a, 0, sizeof(a));
+  a.touched = touched; a.counts = w.counts;
   a.ids = ids; a.order = w.order; a.seg = w.seg; a.bounds = f.bounds; a.feat_off = f.feat_off; a.feats = f.feats; a.feat_pad = f.feat_row_pad;
   a.w1 = p.adj_w1; a.dX0 = dX0; a.dnr = recon ? w.dTH : nullptr; a.drecon = drecon; a.beta = o.beta; a.Hs = w.Hs; a.gW0 = g_.adj_w0; a.gW1 = g_.adj_w1;
   a.C = C; a.r = r_chrom; a.seed = o.seed; a.p_drop = train ? o.p_drop_adj : 0.f; a.slot_map = slot_map; a.r_dev = o.random_chrom_dev;
@@ -864,7 +885,8 @@ int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const mat
   spi = spi < 1 ? 1 : (spi > 16 ? 16 : spi);
   if (options().tune > 0) spi = options().tune;
   a.steps_per_item = spi;
-  const unsigned grid = (unsigned)(cdiv(steps, spi) + C);
+  a.n_main = (int)(cdiv(steps, spi) + C);
+  const unsigned grid = (unsigned)(a.n_main + 1 + n_apply);
   const size_t lds = (size_t)4 * kTile * sizeof(float);
   auto k = adj_fused_bwd_kernel;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
