@@ -145,6 +145,33 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
   }
 }
 
+// Reload of a row this lane parked earlier (fused_fwd32_tail.hpp): the offset passes through an empty asm, so the compiler cannot prove
+// that the load reads what the park stored and forward the registers (which is the point of parking); the base keeps its address space.
+// Per-lane values that are cheap functions of the lane id and of wave-uniform (scalar) values are REBUILT where they are used instead of
+// living in a register across the kernel -- the token index, its row offset, the record offsets: at 256 registers the allocator spilled
+// exactly those long-lived values.  The empty asm makes the lane id opaque at that point, so nothing is hoisted or kept.
+__device__ __forceinline__ int f32_tok(int lane, int t0, int n, int tok_pad) {
+  asm volatile("" : "+v"(lane));
+  const int rr = lane & 31;
+  return rr < n ? t0 + rr : tok_pad;                 // rows past the tokens compute on the shared padding token's copy (finite, unused)
+}
+// float offset of this lane's half row of its token in a [T, 64] tensor
+__device__ __forceinline__ int64_t f32_row(int lane, int t0, int n, int tok_pad) {
+  asm volatile("" : "+v"(lane));
+  const int rr = lane & 31;
+  return (int64_t)(rr < n ? t0 + rr : tok_pad) * 64 + 4 * (lane >> 5);
+}
+#define F32_TOK() f32_tok(lane, t0, n, tok_pad)
+#define F32_ROW() f32_row(lane, t0, n, tok_pad)
+__device__ __forceinline__ FL fl_unpark(const float* __restrict__ base, int64_t off) { return fl_load(base + off); }
+__device__ __forceinline__ FL fl_unpark_lds(const float* __restrict__ base, int off) {
+  asm volatile("" : "+v"(off));
+  return fl_load(base + off);
+}
+// A wave-local ordering point for the tail: everything this wavefront has issued to the LDS is done (a wavefront's LDS operations execute
+// in order anyway) and the compiler may not move memory accesses across it.  NOT a workgroup barrier: the tail is one wavefront's text.
+#define F32_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 #define MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
 // ---- the weight stream ---------------------------------------------------------------------------------------------------
@@ -153,7 +180,8 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
 // the constant 1 -- the bias costs 2 of 66 MFMAs, no register, no LDS traffic, no wait.  A product in layout FL is 18 STEPS; the
 // window W_[0..8] holds the nine fragments of the current block and every consumed slot is refilled with the fragment nine ahead
 // (one block = 33 MFMAs = 0.9 us of lead), pinned there by a scheduling barrier: left alone the scheduler sinks each refill next to
-// its use and the window's depth becomes 1.
+// its use and the window's depth becomes 1.  `wp` is WAVE-UNIFORM (a scalar register pair; the lane adds its 16 bytes as a 32-bit offset):
+// as a per-lane pointer it was one of three 64-bit values the allocator spilled.
 #define W32_MMA(ACC, B, S)                                                                               \
   do {                                                                                                   \
     constexpr int c__ = (S) % 9;                                                                         \
@@ -174,7 +202,7 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
   } while (0)
 #define W32_REFILL(S, PF)                                                                                \
   do {                                                                                                   \
-    if (PF) W_[(S) % F32_WIN] = wp[F32_WIN * 64];                                                        \
+    if (PF) W_[(S) % F32_WIN] = (wp + F32_WIN * 64)[lane];                                                 \
     wp += 64;                                                                                            \
     asm volatile("" ::: "memory");         /* instruction selection clusters every LDS read of the block at its top otherwise */ \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -191,7 +219,7 @@ __device__ __forceinline__ void fl_store_global(float* __restrict__ rowp_h, cons
   } while (0)
 #define W32_PRIME()                                                                                      \
   do {                                                                                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < F32_WIN; ++i__) W_[i__] = wp[i__ * 64];                    \
+    _Pragma("unroll") for (int i__ = 0; i__ < F32_WIN; ++i__) W_[i__] = (wp + i__ * 64)[lane];                    \
   } while (0)
 
 __device__ __forceinline__ FL fl_zero() {
@@ -426,42 +454,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int tok_pad = g.count[1];
   const float inv_temp = 0.125f;
   const bool real = r < n;
-  const int64_t tok = real ? (int64_t)(t0 + r) : (int64_t)tok_pad;    // rows past the padding token compute on its copy (finite, unused)
 
   // ---- weight stream: prime the window with the first block of head 0's K ----
-  const f32x4* wp = g.wfrag + lane;
+  const f32x4* wp = g.wfrag;
   f32x4 W_[F32_WIN];
   W32_PRIME();
 
   // ---- x_hat in layout FL straight from global memory ----
-  FL xh = fl_load(g.X + tok * 64 + 4 * h);
+  FL xh = fl_load(g.X + F32_ROW());
   int pos = 0, k = 0;
   if (real) {
-    const int tp = g.tok_pos[tok];
+    const int tp = g.tok_pos[F32_TOK()];
     pos = tp & 255; k = tp >> 8;
   }
   const int li0 = r - pos;
-  // dropout: keep <=> lowbias32(col ^ lowbias32(slot ^ key)) >= threshold (threshold 0 = keep everything: no branches below)
-  uint32_t thr1 = 0, thr2 = 0, hrow1 = 0, hrow2 = 0;
-  float ks1 = 1.f, ks2 = 1.f;
-  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
-  if (drop1 || drop2) {
-    const uint32_t slot = (uint32_t)g.tok_slot[tok];
-    const uint64_t seed = *g.seed;
-    hrow1 = lowbias32(slot ^ rng_key(seed, kStreamDropFc1));
-    hrow2 = lowbias32(slot ^ rng_key(seed, kStreamDropPff));
-    if (drop1) { thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
-    if (drop2) { thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
-  }
-  // hyperedges of this half tile: lane e < n_h holds hyperedge b0 + e (the first 64; more only with many all-padding rows)
-  int he_lo = 0, he_k = 0;
-  float he_y = 0.f, he_w = 0.f;
-  if (lane < n_h) {
-    he_lo = g.row_off[b0 + lane];
-    he_k = g.row_off[b0 + lane + 1] - he_lo;
-    he_lo -= t0;
-    if (g.row_loss) { he_y = g.y[b0 + lane]; he_w = g.w[b0 + lane]; }
-  }
   float rx;
   {
     float mean;
@@ -472,17 +478,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   constexpr int kRec = kImgRecH;
   // where this token's rows go in the backward kernel's record: float4 index (wc * 4 + g) * 64 + 32 h + r of this wavefront's own
   // record, probabilities [32][8] behind the rows
-  float* img_tok = nullptr;
-  float* pimg_tok = nullptr;
-  if (g.qkv && real) {
-    float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
-    img_tok = base + (32 * h + r) * 4;
-    pimg_tok = base + 2048 + r * 8;
-  }
+  // (wave-uniform base + 32-bit lane offsets; two per-lane pointers held across the head loop were spill candidates)
+  float* const img_base = g.qkv ? g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH : nullptr;
+  const bool img_on = g.qkv != nullptr && real;
 #define F32_IMG_STORE(ACC, HD, M)                                                                        \
   do {                                                                                                   \
-    if (img_tok && !(F32_ABL & 2)) {                                                                     \
-      f32x4* d__ = reinterpret_cast<f32x4*>(img_tok + (int64_t)(HD) * kRec + (M) * 4096);             \
+    if (img_on && !(F32_ABL & 2)) {                                                                      \
+      int l__ = lane;                                                                                    \
+      asm volatile("" : "+v"(l__));                                                                      \
+      f32x4* d__ = reinterpret_cast<f32x4*>(img_base + (HD) * kRec + (M) * 4096 + l__ * 4);             \
       _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
         if (F32_ABL & 16) {                                                                              \
           d__[g__ * 64] = (f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]};   \
@@ -546,11 +550,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }                                                                                                    \
     if constexpr ((S) == 2 * (ML + 1) + 1) {                                                             \
       /* training: row i of P for the backward pass -- slots 0..k-1 the real keys, slot 7 the per-slot padding probability */ \
-      if (pimg_tok && h == 0) {                                                                          \
+      if (img_on && h == 0) {                                                                            \
         float wv__[8];                                                                                   \
         _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) wv__[i__] = i__ < ML ? p[i__ < ML ? i__ : 0] : 0.f; \
         if (hpad) wv__[7] = p[ML];                                                                       \
-        f32x4* dst__ = reinterpret_cast<f32x4*>(pimg_tok + (int64_t)hd * kRec);                       \
+        int l__ = lane;                                                                                  \
+        asm volatile("" : "+v"(l__));                                                                    \
+        f32x4* dst__ = reinterpret_cast<f32x4*>(img_base + hd * kRec + 2048 + (l__ & 31) * 8);          \
         __builtin_nontemporal_store((f32x4){wv__[0], wv__[1], wv__[2], wv__[3]}, dst__);                 \
         __builtin_nontemporal_store((f32x4){wv__[4], wv__[5], wv__[6], wv__[7]}, dst__ + 1);             \
       }                                                                                                  \
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     fl_store(krow, xh);
     W32_CHAIN(q, xh, true);                           // r_0 = B_0 x_hat + b_0
     F32_IMG_STORE(q, 0, 0);
-    __syncthreads();                                  // x_hat rows visible
+    F32_WAVE_SYNC();                                  // x_hat rows visible (one wavefront = the whole workgroup)
     FF_T(1);
     float* const TVsave = TV;
     (void)TVsave;
@@ -622,9 +628,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   // =========================== tail: pff_n1, LayerNorms, classifier (all in registers) ===========================
   if (F32_ABL & 8) { if (dyn.lo[0] == 12345.f) g.logits[0] = dyn.hi[3]; return; }
-#define F32_TAIL_SYNC() __syncthreads()
+  // Y and H1 are parked in the workspace's Y / H1 rows (every lane stores: the rows past the tokens are copies of the padding token's row,
+  // identical in every lane and in every half tile) -- in a saving forward they are what the layer-wise backward reads anyway
+#define F32_TAIL_SYNC() F32_WAVE_SYNC()
+#define F32_PARK_Y(V) do { if (g.Y) fl_store_global(g.Y + F32_ROW(), V); } while (0)
+#define F32_PARK_H1(V) do { if (g.H1) fl_store_global(g.H1 + F32_ROW(), V); } while (0)
+#define F32_UNPARK_Y() fl_unpark(g.Y, F32_ROW())
+#define F32_UNPARK_H1() fl_unpark(g.H1, F32_ROW())
 #include "fused_fwd32_tail.hpp"
 #undef F32_TAIL_SYNC
+#undef F32_PARK_Y
+#undef F32_PARK_H1
+#undef F32_UNPARK_Y
+#undef F32_UNPARK_H1
 #ifdef FF_TIMING
   if (blockIdx.x == 2000 && lane == 0)
     printf("fused_fwd32 wave 2000 us: setup %.1f prologue K0 Q0 %.1f | 8 heads: V+scores %.1f K'+PV %.1f Q' %.1f fc1 %.1f | pff fwd %.1f ln+logit %.1f | ln-bwd+colsums %.1f dW1 %.1f dZ1 %.1f dW0 %.1f ddyn %.1f\n",
@@ -653,7 +669,7 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   float* douts = outs + 32;
   float* Pd = lds + 2 * kHT + 64;        // [8][32][kLdH] the heads' dyn contributions
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int hd = threadIdx.x >> 6;       // this wavefront's head
+  const int hd = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wavefront's head (wave-uniform: a scalar register)
 
   const int4 meta = reinterpret_cast<const int4*>(g.half_meta)[blockIdx.x];
   const int t0 = meta.x, n = meta.y, b0 = meta.z, n_h = meta.w;
@@ -661,39 +677,19 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   const int tok_pad = g.count[1];
   const float inv_temp = 0.125f;
   const bool real = r < n;
-  const int64_t tok = real ? (int64_t)(t0 + r) : (int64_t)tok_pad;
 
   // weight stream of THIS head: R_hd sits at matrix 0 (hd = 0) or 2 hd - 1, M_hd at 2 hd + 2 (hd < 7) or 15 (prep_heads_kernel's stream order)
-  const f32x4* wp = g.wfrag + (int64_t)(hd == 0 ? 0 : 2 * hd - 1) * kFragF4 + lane;
+  const f32x4* wp = g.wfrag + (hd == 0 ? 0 : 2 * hd - 1) * kFragF4;
   f32x4 W_[F32_WIN];
   W32_PRIME();
 
-  FL xh = fl_load(g.X + tok * 64 + 4 * h);
+  FL xh = fl_load(g.X + F32_ROW());
   int pos = 0, k = 0;
   if (real) {
-    const int tp = g.tok_pos[tok];
+    const int tp = g.tok_pos[F32_TOK()];
     pos = tp & 255; k = tp >> 8;
   }
   const int li0 = r - pos;
-  uint32_t thr1 = 0, thr2 = 0, hrow1 = 0, hrow2 = 0;
-  float ks1 = 1.f, ks2 = 1.f;
-  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
-  if (drop1 || drop2) {
-    const uint32_t slot = (uint32_t)g.tok_slot[tok];
-    const uint64_t seed = *g.seed;
-    hrow1 = lowbias32(slot ^ rng_key(seed, kStreamDropFc1));
-    hrow2 = lowbias32(slot ^ rng_key(seed, kStreamDropPff));
-    if (drop1) { thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
-    if (drop2) { thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
-  }
-  int he_lo = 0, he_k = 0;
-  float he_y = 0.f, he_w = 0.f;
-  if (lane < n_h) {
-    he_lo = g.row_off[b0 + lane];
-    he_k = g.row_off[b0 + lane + 1] - he_lo;
-    he_lo -= t0;
-    if (g.row_loss) { he_y = g.y[b0 + lane]; he_w = g.w[b0 + lane]; }
-  }
   float rx;
   {
     float mean;
@@ -702,13 +698,8 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
     for (int e = 0; e < 16; ++e) { xh.lo[e] = (xh.lo[e] - mean) * rx; xh.hi[e] = (xh.hi[e] - mean) * rx; }
   }
   const int kRec = kImgRecH;
-  float* img_tok = nullptr;
-  float* pimg_tok = nullptr;
-  if (g.qkv && real) {                   // half-tile records (fused_bwdh_kernel): as in fused_fwd32_kernel
-    float* base = g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH;
-    img_tok = base + (32 * h + r) * 4;
-    pimg_tok = base + 2048 + r * 8;
-  }
+  float* const img_base = g.qkv ? g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH : nullptr;     // half-tile records: as in fused_fwd32_kernel
+  const bool img_on = g.qkv != nullptr && real;
   const int n_pad = g.L - k;
   const float padf = (float)n_pad;
   const bool hpad = n_pad > 0;
@@ -724,7 +715,7 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   FL q = fl_zero(), o = fl_zero();
   W32_CHAIN(q, xh, false);                            // r_hd = B_hd x_hat + b_hd
   F32_IMG_STORE(q, hd, 0);
-  wp = g.wfrag + (int64_t)(hd < 7 ? 2 * hd + 2 : 15) * kFragF4 + lane;
+  wp = g.wfrag + (hd < 7 ? 2 * hd + 2 : 15) * kFragF4;
   W32_PRIME();                                        // M_hd: in flight during the attention
   __syncthreads();                                    // x_hat rows visible
   F32_STAGE18(F32_MG_ONLY);                           // scores, softmax, probabilities out, z = P x_hat
@@ -734,8 +725,8 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
     W32_CHAIN(dynp, o, false);                        // M_hd z (+ the merged bias with head 0)
     fl_store(Pd + hd * kHT + r * kLdH + 4 * h, dynp);
   }
-  __syncthreads();
-  if (hd != 0) return;                                // wavefront 0 alone from here: no workgroup barrier below
+  __syncthreads();                                    // the LAST workgroup barrier of this kernel
+  if (hd != 0) return;                                // wavefront 0 alone from here: the tail's ordering points are wave-local (F32_WAVE_SYNC)
   FL dyn = fl_load(Pd + r * kLdH + 4 * h);
 #pragma unroll 1
   for (int j = 1; j < MATCHA_N_HEAD; ++j) {
@@ -743,14 +734,40 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dyn.lo[e] += t.lo[e]; dyn.hi[e] += t.hi[e]; }
   }
-  wp = g.wfrag + (int64_t)16 * kFragF4 + lane;      // conv0, conv1, conv1^T, conv0^T follow the heads in the merged stream
+  wp = g.wfrag + 16 * kFragF4;      // conv0, conv1, conv1^T, conv0^T follow the heads in the merged stream
   W32_PRIME();
-  // one wavefront is left: the other seven have terminated and no longer count at the barrier, so __syncthreads() costs one wait -- and,
-  // unlike a wavefront-scope fence (which emits no instruction), it stays an ordering point for the machine scheduler: the tail writes
-  // LDS rows as float4 and reads other lanes' rows as floats, accesses that type-based alias analysis is free to reorder
-#define F32_TAIL_SYNC() __syncthreads()
+  // one wavefront is left, so the tail needs no workgroup barrier (round 4 called __syncthreads() here after seven of the eight wavefronts
+  // had returned: it worked -- terminated wavefronts no longer count -- but it is outside HIP's barrier contract).  Y and H1 are parked in
+  // the first two of the heads' partial-product tiles, which are dead once `dyn` has been summed; a saving forward also writes them out.
+#define F32_TAIL_SYNC() F32_WAVE_SYNC()
+#define F32_PARK_Y(V) do { fl_store(Pd + r * kLdH + 4 * h, V); if (g.Y && !g.ddyn0 && r <= n) fl_store_global(g.Y + F32_ROW(), V); } while (0)
+#define F32_PARK_H1(V) do { fl_store(Pd + kHT + r * kLdH + 4 * h, V); if (g.H1 && !g.ddyn0 && r <= n) fl_store_global(g.H1 + F32_ROW(), V); } while (0)
+#define F32_UNPARK_Y() fl_unpark_lds(Pd, r * kLdH + 4 * h)
+#define F32_UNPARK_H1() fl_unpark_lds(Pd + kHT, r * kLdH + 4 * h)
 #include "fused_fwd32_tail.hpp"
 #undef F32_TAIL_SYNC
+#undef F32_PARK_Y
+#undef F32_PARK_H1
+#undef F32_UNPARK_Y
+#undef F32_UNPARK_H1
+#ifdef F32H_REPRO
+  // tools/debug/fwd32h_repro.sh: round 4's failing variant -- an UNREACHABLE block with a fence, an atomic, a wave shuffle
+  // and a loop appended to the kernel.  It never runs (L <= MATCHA_MAX_L); what it changes is the register allocation of everything above.
+  if (g.L == 0x40000000) {
+    __threadfence();
+    unsigned int* ctr = reinterpret_cast<unsigned int*>(g.tslab);
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(ctr, 1u);
+    t = __shfl(t, 0, 64);
+    if (t == gridDim.x - 1) {
+      float s = 0.f;
+      for (int i = lane; i < g.L * 977; i += 64) s += g.row_loss[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) g.logits[0] = s;
+    }
+  }
+#endif
 }
 
 static int fwd32h_max_halves() {

@@ -1,9 +1,29 @@
 // The tail of the fused embed_dim-64 forward -- pff_n1 (Modules.py:353-376), the LayerNorms and the classifier (:290-311), the weighted BCE
 // (main.py:56) and, in a training step, the backward of all of that -- as ONE WAVEFRONT computes it for its half tile, everything in
 // registers (layout FL).  Included verbatim into the body of fused_fwd32_kernel (one wavefront per workgroup) and of
-// fused_fwd32h_kernel (eight wavefronts per half tile, one per head; wavefront 0 runs the tail alone): the including kernel defines
-// F32_TAIL_SYNC -- the workgroup barrier in the first, a wave-local ordering point in the second -- and the locals the tail works on
-// (g, lane, r, h, n, n_h, b0, t0, real, tok, xh, rx, dyn, TK, TV, outs, douts, krow, he_*, hrow1/2, thr1/2, ks1/2, drop1/2, wp, W_).
+// fused_fwd32h_kernel (eight wavefronts per half tile, one per head; wavefront 0 runs the tail alone).  ONE wavefront executes this text in
+// both kernels, so no workgroup barrier appears in it: F32_TAIL_SYNC is a wave-local ordering point (s_waitcnt lgkmcnt(0) + a compiler
+// memory barrier; a wavefront's LDS operations execute in order).  The including kernel defines it, the locals the tail works on
+// (g, lane, r, h, n, n_h, b0, t0, real, tok, xh, rx, dyn, TK, TV, outs, douts, krow, he_*, hrow1/2, thr1/2, ks1/2, drop1/2, wp, W_) and
+// where Y and H1 are PARKED between the forward and the backward half of the tail -- F32_PARK_Y / F32_PARK_H1 (store this lane's row) and
+// F32_UNPARK_Y / F32_UNPARK_H1 (an FL loaded back through a laundered pointer, so that the values do not stay in registers): the
+// single-wave kernel parks them in the workspace rows the layer-wise backward reads (Y, H1: L2-resident, 2 x 256 B per token), the
+// eight-wave kernel in two of the heads' dead LDS tiles.  Round 5: with Y and H1 in registers across the LayerNorm backward both kernels
+// spilled ~75 VGPRs (260 B of scratch per lane); parked, and with H2 / U replaced by their normalised forms as soon as those exist, the
+// tail's live set is x_hat, hh, uh, df + two temporaries.
+  // ---- what only the tail needs is set up here, not in front of the head loop (registers held across it were spilled) ----
+  // dropout: keep <=> lowbias32(col ^ lowbias32(slot ^ key)) >= threshold (threshold 0 = keep everything: no branches below)
+  uint32_t thr1 = 0, thr2 = 0, hrow1 = 0, hrow2 = 0;
+  float ks1 = 1.f, ks2 = 1.f;
+  const bool drop1 = g.p_fc1 > 0.f, drop2 = g.p_pff > 0.f;
+  if (drop1 || drop2) {
+    const uint32_t slot = (uint32_t)g.tok_slot[F32_TOK()];
+    const uint64_t seed = *g.seed;
+    hrow1 = lowbias32(slot ^ rng_key(seed, kStreamDropFc1));
+    hrow2 = lowbias32(slot ^ rng_key(seed, kStreamDropPff));
+    if (drop1) { thr1 = dropout_threshold(g.p_fc1); ks1 = 1.f / (1.f - g.p_fc1); }
+    if (drop2) { thr2 = dropout_threshold(g.p_pff); ks2 = 1.f / (1.f - g.p_pff); }
+  }
   // the tail's seven parameter vectors -> TV [7][64]: gp bp g1 b1 g2 b2 wc  (the biases of fc1 / conv0 / conv1 come with the weight stream)
   F32_TAIL_SYNC();                                    // the last head's P V reads of TV are done
   for (int i4 = lane; i4 < 112; i4 += 64) {
@@ -27,7 +47,7 @@
       v = (kp && real) ? v * ks1 : 0.f;               // the padding token's row is masked (Modules.py:614)
       if (e < 16) y.lo[e] = v; else y.hi[e - 16] = v;
     }
-    if (g.Y && r <= n) fl_store_global(g.Y + tok * 64 + 4 * h, y);
+    F32_PARK_Y(y);
   }
   FL h1 = fl_zero();
   W32_CHAIN(h1, y, true);                             // conv0 (+ bias)
@@ -41,31 +61,41 @@
       v = kp ? v * ks2 : 0.f;
       if (e < 16) h1.lo[e] = v; else h1.hi[e - 16] = v;
     }
-    if (g.H1 && r <= n) fl_store_global(g.H1 + tok * 64 + 4 * h, h1);
+    F32_PARK_H1(h1);
   }
   FL h2 = y;                                          // residual as the accumulator's initial value
   W32_CHAIN(h2, h1, false);                           // conv1 (+ bias); the window is primed again before the backward GEMMs
-  if (g.H2 && r <= n) fl_store_global(g.H2 + tok * 64 + 4 * h, h2);
+  if (g.H2 && r <= n) fl_store_global(g.H2 + F32_ROW(), h2);
   FF_T(7);
   F32_TAIL_SYNC();                                    // the parameter vectors in T2 are visible
   // ---- out_t = sum_f (LN1(LN_pff(H2)) - LN2(X))_f^2 wc_f + bc ----
-  float mh, rh, mu, ru;
-  fl_stats(h2, mh, rh);
-  FL u;                                               // LN_pff output (before layer_norm1)
+  // only the NORMALISED rows stay live: hh = LN_pff's x_hat (H2 itself is dead from here), uh = layer_norm1's (U = hh gp + bp likewise)
+  float rh, ru;
+  FL hh, uh;
   {
+    float mh;
+    fl_stats(h2, mh, rh);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { hh.lo[e] = (h2.lo[e] - mh) * rh; hh.hi[e] = (h2.hi[e] - mh) * rh; }
+  }
+  {
+    FL u;                                             // LN_pff output (before layer_norm1)
     const FL Gp = fl_vec(tpar + 0 * 64), Bp = fl_vec(tpar + 1 * 64);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { u.lo[e] = (h2.lo[e] - mh) * rh * Gp.lo[e] + Bp.lo[e]; u.hi[e] = (h2.hi[e] - mh) * rh * Gp.hi[e] + Bp.hi[e]; }
+    for (int e = 0; e < 16; ++e) { u.lo[e] = hh.lo[e] * Gp.lo[e] + Bp.lo[e]; u.hi[e] = hh.hi[e] * Gp.hi[e] + Bp.hi[e]; }
+    float mu;
+    fl_stats(u, mu, ru);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { uh.lo[e] = (u.lo[e] - mu) * ru; uh.hi[e] = (u.hi[e] - mu) * ru; }
   }
-  fl_stats(u, mu, ru);
   FL df;                                              // dynamic - static
   {
     const FL G1 = fl_vec(tpar + 2 * 64), B1 = fl_vec(tpar + 3 * 64);
     const FL G2 = fl_vec(tpar + 4 * 64), B2 = fl_vec(tpar + 5 * 64);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      df.lo[e] = ((u.lo[e] - mu) * ru * G1.lo[e] + B1.lo[e]) - (xh.lo[e] * G2.lo[e] + B2.lo[e]);
-      df.hi[e] = ((u.hi[e] - mu) * ru * G1.hi[e] + B1.hi[e]) - (xh.hi[e] * G2.hi[e] + B2.hi[e]);
+      df.lo[e] = (uh.lo[e] * G1.lo[e] + B1.lo[e]) - (xh.lo[e] * G2.lo[e] + B2.lo[e]);
+      df.hi[e] = (uh.hi[e] * G1.hi[e] + B1.hi[e]) - (xh.hi[e] * G2.hi[e] + B2.hi[e]);
     }
   }
   {
@@ -77,15 +107,13 @@
     if (h == 0) outs[r] = real ? o : 0.f;
   }
   F32_TAIL_SYNC();
-  // ---- per-hyperedge masked mean -> logit (+ BCE term, + its gradient) ----
+  // ---- per-hyperedge masked mean -> logit (+ BCE term, + its gradient): lane e takes hyperedge b0 + e (+ 64, ... only with many all-padding rows) ----
   for (int e = lane; e < n_h; e += 64) {
     const int64_t b = b0 + e;
-    int lo = he_lo, kk = he_k;
-    float yb = he_y, wb = he_w;
-    if (e >= 64) {                                    // beyond the prefetched 64 (many all-padding rows in one half tile)
-      lo = g.row_off[b] - t0; kk = g.row_off[b + 1] - g.row_off[b];
-      if (g.row_loss) { yb = g.y[b]; wb = g.w[b]; }
-    }
+    const int lo_g = g.row_off[b];
+    const int lo = lo_g - t0, kk = g.row_off[b + 1] - lo_g;
+    float yb = 0.f, wb = 0.f;
+    if (g.row_loss) { yb = g.y[b]; wb = g.w[b]; }
     float tot = 0.f;
     for (int i = 0; i < kk; ++i) tot += outs[lo + i];
     const float z = tot / ((float)kk + 1e-15f);
@@ -145,12 +173,9 @@
       const float a = xhalf_sum(fl_sum(t)) * (1.f / 64.f), b = xhalf_sum(fl_dot(t, xh)) * (1.f / 64.f);
 #pragma unroll
       for (int e = 0; e < 16; ++e) { t.lo[e] = rx * (t.lo[e] - a - xh.lo[e] * b); t.hi[e] = rx * (t.hi[e] - a - xh.hi[e] * b); }
-      if (r <= n) fl_store_global(g.dXs + tok * 64 + 4 * h, t);      // the padding token's row is zero (dout = 0)
+      if (r <= n) fl_store_global(g.dXs + F32_ROW(), t);      // the padding token's row is zero (dout = 0)
     }
     // layer_norm1 (dynamic branch)
-    FL uh;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { uh.lo[e] = (u.lo[e] - mu) * ru; uh.hi[e] = (u.hi[e] - mu) * ru; }
     {
       FL t;
 #pragma unroll
@@ -169,9 +194,6 @@
       for (int e = 0; e < 16; ++e) { du.lo[e] = ru * (du.lo[e] - a - uh.lo[e] * b); du.hi[e] = ru * (du.hi[e] - a - uh.hi[e] * b); }
     }
     // pff_n1.layer_norm
-    FL hh;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { hh.lo[e] = (h2.lo[e] - mh) * rh; hh.hi[e] = (h2.hi[e] - mh) * rh; }
     {
       FL t;
 #pragma unroll
@@ -202,7 +224,10 @@
   // ---- conv1: dW1[n][k] = sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2 ----
   F32_TAIL_SYNC();
   fl_store(myrow, dh2);                               // T1 = dH2 [token][feature] (rows past the tokens are zero: dout = 0)
-  fl_store(T2 + r * kLdH + 4 * h, h1);                // T2 = H1 (the parameter vectors are dead)
+  {
+    const FL h1b = F32_UNPARK_H1();
+    fl_store(T2 + r * kLdH + 4 * h, h1b);             // T2 = H1 (the parameter vectors are dead)
+  }
   F32_TAIL_SYNC();
 #define F32_TN(A_T, B_T, SLAB, CS_SLOT)                                                                  \
   do {                                                                                                   \
@@ -234,9 +259,10 @@
   W32_CHAIN(dz, dh2, true);
   {
     const float unscale = drop2 ? 1.f - g.p_pff : 1.f;
+    const FL h1b = fl_load(T2 + r * kLdH + 4 * h);    // this lane's own H1 row, still in T2 (overwritten with dZ1 below)
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
-      const float hval = (e < 16 ? h1.lo[e] : h1.hi[e - 16]) * unscale;       // tanh value (0 where dropped)
+      const float hval = (e < 16 ? h1b.lo[e] : h1b.hi[e - 16]) * unscale;     // tanh value (0 where dropped)
       float v = e < 16 ? dz.lo[e] : dz.hi[e - 16];
       if (drop2) v = ((keep2 >> e) & 1u) ? v * ks2 : 0.f;
       v *= 1.f - hval * hval;
@@ -246,7 +272,10 @@
   // ---- conv0: dW0[n][k] = sum_t dZ1[t][n] Y[t][k];  d b0 = column sums of dZ1 ----
   F32_TAIL_SYNC();                                    // the column walks over dH2 and H1 are done
   fl_store(T2 + r * kLdH + 4 * h, dz);
-  fl_store(myrow, y);
+  {
+    const FL yb = F32_UNPARK_Y();
+    fl_store(myrow, yb);
+  }
   F32_TAIL_SYNC();
   FF_T(11);
   F32_TN(T2, T1, tsl + 4096, 8);
@@ -261,5 +290,5 @@
     v = real ? v : 0.f;
     if (e < 16) dd.lo[e] = v; else dd.hi[e - 16] = v;
   }
-  if (r <= n) fl_store_global(g.ddyn0 + tok * 64 + 4 * h, dd);     // the padding token's row: zeros (every half tile writes the same)
+  if (r <= n) fl_store_global(g.ddyn0 + F32_ROW(), dd);     // the padding token's row: zeros (every half tile writes the same)
   FF_T(13);

@@ -436,7 +436,9 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
     note_forward(ws, true, true);
-    MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, save ? w.Y : nullptr, save ? w.H1 : nullptr, save ? w.H2 : nullptr,
+    // (with the tail's backward in the forward kernel, Y and H1 are still handed over: the single-wave kernel PARKS the two rows there
+    // between the tail's forward and backward halves instead of holding 64 registers per lane -- fused_fwd32_tail.hpp)
+    MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, (save || lif) ? w.Y : nullptr, (save || lif) ? w.H1 : nullptr, save ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
@@ -522,6 +524,32 @@ extern "C" int matcha_get_embedding(const matcha_shape* shp, const matcha_tensor
     set_error("matcha_get_embedding: attention copy failed"); return MATCHA_EHIP;
   }
   return launch_expand_embedding(x, B, L, shp->d, w.rg.row_off, w.H2, w.X, params->pff_ln_g, params->pff_ln_b, dynamic, static_, (hipStream_t)stream);
+}
+
+// Development aid, not part of include/matcha_hip.h: the workspace layout as text, one "name offset bytes" line per buffer, so that
+// tools/debug/ws_diff.py can say WHICH buffer a differing workspace byte belongs to (round 5: which output the failing forward variant lost).
+extern "C" int matcha_debug_layout(const matcha_shape* shp, int64_t B, int32_t L, char* out, size_t cap) {
+  MATCHA_TRY(check_shape(shp, B, L));
+  MATCHA_CHECK_ARG(out && cap > 0, "matcha_debug_layout: null buffer");
+  Workspace w;
+  char* const base = reinterpret_cast<char*>((uintptr_t)1 << 20);
+  const size_t total = carve(*shp, B, L, base, w);
+  struct { const char* name; const void* p; } f[] = {
+      {"plan", w.rg.row_off}, {"x0", w.x0}, {"X", w.X}, {"qin", w.qin}, {"kin", w.kin}, {"vin", w.vin}, {"stats", w.stats}, {"Q", w.Q}, {"K", w.K}, {"V", w.V},
+      {"P", w.P}, {"O_dxh", w.O}, {"Y", w.Y}, {"H1", w.H1}, {"H2", w.H2}, {"row_loss", w.row_loss}, {"logits", w.logits}, {"node", w.node}, {"dH2", w.dH2},
+      {"dXs", w.dXs}, {"dZ1", w.dZ1}, {"ddyn0", w.ddyn0}, {"dZ0", w.dZ0}, {"dX0", w.dX0}, {"slab", w.slab}, {"gemm_ws", w.gemm_ws}, {"adj_ws", w.adj_ws},
+      {"folded", w.folded}, {"frag", w.frag}, {"merged", w.merged}, {"lwB", w.lwB}, {"lwM", w.lwM}, {"lwdB", w.lwdB}, {"lwdM", w.lwdM}, {"fb_ws", w.fb_ws},
+      {"tpart", w.tpart}, {"tslab", w.tslab}, {"qkv_records", w.qkv}, {"front_ws", w.front_ws}, {"tg_ws", w.tg_ws}};
+  size_t n = 0;
+  for (const auto& e : f) {
+    if (!e.p) continue;
+    const int k = snprintf(out + n, cap - n, "%s %zu\n", e.name, (size_t)((const char*)e.p - base));
+    if (k < 0 || (size_t)k >= cap - n) { set_error("matcha_debug_layout: buffer too small"); return MATCHA_ENOMEM; }
+    n += (size_t)k;
+  }
+  const int k = snprintf(out + n, cap - n, "end %zu\n", total);
+  if (k < 0 || (size_t)k >= cap - n) { set_error("matcha_debug_layout: buffer too small"); return MATCHA_ENOMEM; }
+  return MATCHA_OK;
 }
 
 extern "C" int matcha_random_chrom_dev_supported(const matcha_shape* shp, const matcha_frozen* frozen) {
