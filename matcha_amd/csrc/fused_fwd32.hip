@@ -26,9 +26,6 @@
 // fused_fwd32h_kernel (below) is the same forward for small batches: eight wavefronts per half tile, one per head.
 #include "kernels.hpp"
 
-#ifndef F32_WIN
-#define F32_WIN 9                     // weight-window depth in fragments (divides 18)
-#endif
 #ifndef F32_ABL
 #define F32_ABL 0                     // timing ablations (tools/debug/abl_fwd32.sh): 1 no attention, 2 no image stores, 4 no tail backward, 8 no tail
 #endif
@@ -44,7 +41,6 @@ namespace {
 constexpr int kLdH = 68;                  // LDS row stride (floats)
 constexpr int kHT = 32 * kLdH;            // one half tile [32 rows][68]
 constexpr float kEps32 = 1e-5f;
-constexpr int kFragF4 = 18 * 64;           // float4 per 64 x 64 matrix in fragment-major order: [wc][c = 0..7 | bias][lane]
 constexpr int kNMat = 20;                 // R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0, conv1, conv1^T, conv0^T -- in consumption order (prep_heads_kernel)
 constexpr int kTailVec32 = 2 * 4096;      // same slab format as fused_fwd.hip (tail_slab_reduce_kernel reads both)
 constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
@@ -174,52 +170,101 @@ __device__ __forceinline__ FL fl_unpark_lds(const float* __restrict__ base, int 
 
 #define MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
-// ---- the weight stream ---------------------------------------------------------------------------------------------------
-// One 64 x 64 matrix = 18 fragments of one float4 per lane: for wc = 0, 1 the eight k-groups c (W[32 wc + r][8 c + 4 h .. + 3]) and a
-// BIAS fragment (.x = bias[32 wc + r] in the lower half-wave, zero elsewhere) that enters the accumulator as one more MFMA against
-// the constant 1 -- the bias costs 2 of 66 MFMAs, no register, no LDS traffic, no wait.  A product in layout FL is 18 STEPS; the
-// window W_[0..8] holds the nine fragments of the current block and every consumed slot is refilled with the fragment nine ahead
-// (one block = 33 MFMAs = 0.9 us of lead), pinned there by a scheduling barrier: left alone the scheduler sinks each refill next to
-// its use and the window's depth becomes 1.  `wp` is WAVE-UNIFORM (a scalar register pair; the lane adds its 16 bytes as a 32-bit offset):
-// as a per-lane pointer it was one of three 64-bit values the allocator spilled.
-#define W32_MMA(ACC, B, S)                                                                               \
+// ---- the weight stream (round 5: fp32-accurate products on the bf16 matrix pipe) -------------------------------------------------------
+// The f32 MFMA runs at the f32 VECTOR rate (64 FLOP / clk / SIMD, tools/ubench/mfma_rate.hip) and shares the vector ALUs with every other
+// instruction of the wave (mfma_valu.hip: no co-issue), the bf16 MFMA at 16 x that rate on its own pipe.  Every operand is therefore split
+// into THREE bf16 planes, v = h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) (round to nearest: |v - (h + m + l)| <=
+// 2^-27 |v|), and a product is the six plane products whose magnitude exceeds 2^-26 of the result --
+//     A B  ~=  Al Bh + Ah Bl + Am Bm + Am Bh + Ah Bm + Ah Bh          (dropped: Am Bl, Al Bm ~ 2^-27, Al Bl ~ 2^-36)
+// -- each ONE v_mfma_f32_32x32x16_bf16 (K = 16, f32 accumulate; bf16 x bf16 products are exact in f32): 6 x 32 cycles instead of the
+// 8 x 64 cycles of eight v_mfma_f32_32x32x2_f32 for the same 16 contraction indices, and the vector ALUs stay free for the attention
+// arithmetic.  The result differs from an f32 fma chain by ~1e-7 relative, the size of that chain's own rounding (tests compare with the
+// oracle at the same tolerances as before; tests/test_cpu_bf16x3.py restates the arithmetic in numpy).
+//
+// The WEIGHT side is split once per step by prep_heads_kernel; one 64 x 64 matrix = 24 fragments of one u32x4 (eight bf16) per lane, in
+// consumption order [chunk c = 0..3][output block wc = 0, 1][plane h, m, l]: lane (r, hf), element j holds
+//     W[32 wc + r][16 c + 8 (j >> 2) + 4 hf + (j & 3)]
+// -- the contraction slot k = 8 hf + j of the MFMA paired with the feature that layout FL keeps in register 8 c + j of lane half hf, so
+// the TOKEN side (a register-resident FL row) needs no shuffle: its chunk c is split in registers (36 vector instructions per eight
+// values) right before the two steps that use it; x_hat, the operand of all eight r products, is split once per half tile.  Biases are
+// f32 vectors added to the accumulator (kBias*: b_0..b_7, the merged fc1 bias, conv0, conv1), not part of the stream.
+// The window W_[0..5] holds the six fragments of the current chunk; every consumed step refills its three slots with the fragments six
+// ahead (`wp`, wave-uniform, points at the PREFETCH position), pinned there by a scheduling barrier.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)), __builtin_bit_cast(bf16x8, (B)), (C), 0, 0, 0)
+#undef F32_WIN
+#define F32_WIN 6
+constexpr int kFragPerMat = 24;
+constexpr int kFragU4 = kFragPerMat * 64;       // u32x4 per matrix
+constexpr int kBiasR = 0, kBiasDyn = 8, kBiasConv0 = 9, kBiasConv1 = 10, kNBias = 11;    // rows of the f32 bias table behind the stream
+
+struct B3 { u32x4 h, m, l; };                   // eight f32 values as three bf16 planes
+struct P3 { uint32_t h, m, l; };                // two f32 values as three packed bf16 pairs
+__device__ __forceinline__ P3 split2(float a, float b) {
+  const f2 v = {a, b};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);                 // v_cvt_pk_bf16_f32: round to nearest even
+  const f2 r1 = v - __builtin_convertvector(hb, f2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f2 r2 = r1 - __builtin_convertvector(mb, f2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  return P3{__builtin_bit_cast(uint32_t, hb), __builtin_bit_cast(uint32_t, mb), __builtin_bit_cast(uint32_t, lb)};
+}
+// register 8 C + J of an FL row (C = 0..3 compile-time): features 16 C + 8 (J >> 2) + 4 hf + (J & 3)
+#define FL_CHUNK(V, C, J) ((C) < 2 ? (V).lo[8 * ((C) & 1) + (J)] : (V).hi[8 * ((C) & 1) + (J)])
+#define FL_SPLIT(OUT, V, C)                                                                              \
   do {                                                                                                   \
-    constexpr int c__ = (S) % 9;                                                                         \
-    if constexpr (c__ == 8) {                                                                            \
-      if constexpr ((S) < 9) ACC.lo = MFMA32(W_[(S) % F32_WIN].x, 1.f, ACC.lo); else ACC.hi = MFMA32(W_[(S) % F32_WIN].x, 1.f, ACC.hi); \
-    } else {                                                                                             \
-      constexpr int e__ = 4 * (c__ & 3);                                                                 \
-      const float b0__ = c__ < 4 ? B.lo[e__] : B.hi[e__], b1__ = c__ < 4 ? B.lo[e__ + 1] : B.hi[e__ + 1]; \
-      const float b2__ = c__ < 4 ? B.lo[e__ + 2] : B.hi[e__ + 2], b3__ = c__ < 4 ? B.lo[e__ + 3] : B.hi[e__ + 3]; \
-      if constexpr ((S) < 9) {                                                                           \
-        ACC.lo = MFMA32(W_[(S) % F32_WIN].x, b0__, ACC.lo); ACC.lo = MFMA32(W_[(S) % F32_WIN].y, b1__, ACC.lo);              \
-        ACC.lo = MFMA32(W_[(S) % F32_WIN].z, b2__, ACC.lo); ACC.lo = MFMA32(W_[(S) % F32_WIN].w, b3__, ACC.lo);              \
-      } else {                                                                                           \
-        ACC.hi = MFMA32(W_[(S) % F32_WIN].x, b0__, ACC.hi); ACC.hi = MFMA32(W_[(S) % F32_WIN].y, b1__, ACC.hi);              \
-        ACC.hi = MFMA32(W_[(S) % F32_WIN].z, b2__, ACC.hi); ACC.hi = MFMA32(W_[(S) % F32_WIN].w, b3__, ACC.hi);              \
-      }                                                                                                  \
+    _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__) {                                                \
+      const P3 p__ = split2(FL_CHUNK(V, C, 2 * q__), FL_CHUNK(V, C, 2 * q__ + 1));                       \
+      (OUT).h[q__] = p__.h; (OUT).m[q__] = p__.m; (OUT).l[q__] = p__.l;                                  \
     }                                                                                                    \
   } while (0)
-#define W32_REFILL(S, PF)                                                                                \
+// step S = 2 c + wc of a product: the six plane products of (chunk c, output block wc), smallest terms first
+#define WB_MMA(ACC, XB, S)                                                                               \
   do {                                                                                                   \
-    if (PF) W_[(S) % F32_WIN] = (wp + F32_WIN * 64)[lane];                                                 \
-    wp += 64;                                                                                            \
-    asm volatile("" ::: "memory");         /* instruction selection clusters every LDS read of the block at its top otherwise */ \
+    const u32x4 ah__ = W_[(3 * (S)) % F32_WIN], am__ = W_[(3 * (S) + 1) % F32_WIN], al__ = W_[(3 * (S) + 2) % F32_WIN]; \
+    if constexpr (((S) & 1) == 0) {                                                                      \
+      ACC.lo = MFMA_BF(al__, (XB).h, ACC.lo); ACC.lo = MFMA_BF(ah__, (XB).l, ACC.lo); ACC.lo = MFMA_BF(am__, (XB).m, ACC.lo); \
+      ACC.lo = MFMA_BF(am__, (XB).h, ACC.lo); ACC.lo = MFMA_BF(ah__, (XB).m, ACC.lo); ACC.lo = MFMA_BF(ah__, (XB).h, ACC.lo); \
+    } else {                                                                                             \
+      ACC.hi = MFMA_BF(al__, (XB).h, ACC.hi); ACC.hi = MFMA_BF(ah__, (XB).l, ACC.hi); ACC.hi = MFMA_BF(am__, (XB).m, ACC.hi); \
+      ACC.hi = MFMA_BF(am__, (XB).h, ACC.hi); ACC.hi = MFMA_BF(ah__, (XB).m, ACC.hi); ACC.hi = MFMA_BF(ah__, (XB).h, ACC.hi); \
+    }                                                                                                    \
+  } while (0)
+#define WB_REFILL(S, PF)                                                                                 \
+  do {                                                                                                   \
+    if (PF) {                                                                                            \
+      W_[(3 * (S)) % F32_WIN] = wp[lane]; W_[(3 * (S) + 1) % F32_WIN] = (wp + 64)[lane]; W_[(3 * (S) + 2) % F32_WIN] = (wp + 128)[lane]; \
+    }                                                                                                    \
+    wp += 192;                                                                                           \
+    asm volatile("" ::: "memory");         /* instruction selection clusters every load of the product at its top otherwise */ \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
   } while (0)
-#define W32_STEP(ACC, B, S) do { W32_MMA(ACC, B, S); W32_REFILL(S, true); } while (0)
-// a whole product without anything interleaved; PF_LAST = false stops refilling in the second block (the window is primed again later)
-#define W32_CHAIN(ACC, B, PF_LAST)                                                                       \
+// a whole product ACC += W . B^T with nothing interleaved, B an FL row in f32 (split chunk by chunk on the way); PF_LAST = false stops
+// refilling in the last chunk (the caller re-primes the window at another matrix: W32_PRIME_AT)
+#define WB_CHUNK(ACC, B, C, PF)                                                                          \
   do {                                                                                                   \
-    W32_STEP(ACC, B, 0); W32_STEP(ACC, B, 1); W32_STEP(ACC, B, 2); W32_STEP(ACC, B, 3); W32_STEP(ACC, B, 4);                 \
-    W32_STEP(ACC, B, 5); W32_STEP(ACC, B, 6); W32_STEP(ACC, B, 7); W32_STEP(ACC, B, 8);                                      \
-    W32_MMA(ACC, B, 9); W32_REFILL(9, PF_LAST); W32_MMA(ACC, B, 10); W32_REFILL(10, PF_LAST); W32_MMA(ACC, B, 11); W32_REFILL(11, PF_LAST); \
-    W32_MMA(ACC, B, 12); W32_REFILL(12, PF_LAST); W32_MMA(ACC, B, 13); W32_REFILL(13, PF_LAST); W32_MMA(ACC, B, 14); W32_REFILL(14, PF_LAST); \
-    W32_MMA(ACC, B, 15); W32_REFILL(15, PF_LAST); W32_MMA(ACC, B, 16); W32_REFILL(16, PF_LAST); W32_MMA(ACC, B, 17); W32_REFILL(17, PF_LAST); \
+    B3 xb__;                                                                                             \
+    FL_SPLIT(xb__, B, C);                                                                                \
+    WB_MMA(ACC, xb__, 2 * (C)); WB_REFILL(2 * (C), PF); WB_MMA(ACC, xb__, 2 * (C) + 1); WB_REFILL(2 * (C) + 1, PF); \
   } while (0)
-#define W32_PRIME()                                                                                      \
+#define W32_CHAIN(ACC, B, PF_LAST)                                                                       \
+  do { WB_CHUNK(ACC, B, 0, true); WB_CHUNK(ACC, B, 1, true); WB_CHUNK(ACC, B, 2, true); WB_CHUNK(ACC, B, 3, PF_LAST); } while (0)
+// the same with B already split (x_hat)
+#define W32_CHAIN_XS(ACC, XS, PF_LAST)                                                                   \
   do {                                                                                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < F32_WIN; ++i__) W_[i__] = (wp + i__ * 64)[lane];                    \
+    WB_MMA(ACC, XS[0], 0); WB_REFILL(0, true); WB_MMA(ACC, XS[0], 1); WB_REFILL(1, true);                \
+    WB_MMA(ACC, XS[1], 2); WB_REFILL(2, true); WB_MMA(ACC, XS[1], 3); WB_REFILL(3, true);                \
+    WB_MMA(ACC, XS[2], 4); WB_REFILL(4, true); WB_MMA(ACC, XS[2], 5); WB_REFILL(5, true);                \
+    WB_MMA(ACC, XS[3], 6); WB_REFILL(6, PF_LAST); WB_MMA(ACC, XS[3], 7); WB_REFILL(7, PF_LAST);          \
+  } while (0)
+// window <- the first six fragments of matrix MAT of the stream; wp = the prefetch position behind them
+#define W32_PRIME_AT(MAT)                                                                                \
+  do {                                                                                                   \
+    wp = g.wfrag + (MAT) * kFragU4;                                                                      \
+    _Pragma("unroll") for (int i__ = 0; i__ < F32_WIN; ++i__) W_[i__] = (wp + i__ * 64)[lane];           \
+    wp += F32_WIN * 64;                                                                                  \
   } while (0)
 
 __device__ __forceinline__ FL fl_zero() {
@@ -257,12 +302,18 @@ struct PrepArgs {
   const float* p0w; const float* p0b; const float* p1w; const float* p1b;
   float* fwq; float* fwk; float* fwv; float* fcq; float* fcv;          // folded forms (read by fbm_chain_kernel)
   float* B; float* M; float* bvec; float* bdyn;                        // merged forms (read by fused_bwdh_kernel / fbm_chain_kernel)
-  f32x4* frag;                                                         // [kNMat + 1][kFragF4]
+  u32x4* frag;                                                         // [kNMat + 1][kFragU4] bf16 planes, then the f32 bias table [kNBias][64]
 };
-__device__ __forceinline__ void frag_put(f32x4* frag, int m, int n, int k, float v) {
-  // element (row n, column k) of matrix m in fragment order: float4 (wc, c, lane = r + 32 h), component j
-  const int wc = n >> 5, r = n & 31, c = k >> 3, h = (k & 7) >> 2, j = k & 3;
-  reinterpret_cast<float*>(frag + (int64_t)m * kFragF4 + (wc * 9 + c) * 64 + r + 32 * h)[j] = v;
+// eight f32 values of one lane's contraction slots -> the three bf16 planes of fragment (c, wc) of matrix m, lane ln
+__device__ __forceinline__ void frag_put8(u32x4* frag, int m, int c, int wc, int ln, const float* v8) {
+  B3 b;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const P3 t = split2(v8[2 * q], v8[2 * q + 1]);
+    b.h[q] = t.h; b.m[q] = t.m; b.l[q] = t.l;
+  }
+  u32x4* d = frag + (int64_t)m * kFragU4 + ((2 * c + wc) * 3) * 64 + ln;
+  d[0] = b.h; d[64] = b.m; d[128] = b.l;
 }
 __global__ __launch_bounds__(256) void prep_heads_kernel(PrepArgs a) {
   __shared__ float As[16 * 65];
@@ -272,25 +323,22 @@ __global__ __launch_bounds__(256) void prep_heads_kernel(PrepArgs a) {
   const int slice = blockIdx.x, hd = blockIdx.z, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   if (hd == MATCHA_N_HEAD) {
-    // conv0, conv1, conv1^T, conv0^T (matrices 16..19) and one matrix of zeros behind the stream
+    // conv0, conv1, conv1^T, conv0^T (matrices 16..19), one matrix of zeros behind the stream, and the two conv biases of the bias table
     const int id = blockIdx.x + 4 * blockIdx.y;
     if (id > 4) return;
-    for (int idx = tid; idx < kFragF4; idx += 256) {
-      const int wc = idx / 576, c = (idx % 576) >> 6, ln = idx & 63, r = ln & 31, h = ln >> 5;
-      const int n = 32 * wc + r, k0 = 8 * c + 4 * h;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (id < 4) {
-        if (c < 8) {
-          if (id == 0) v = *reinterpret_cast<const f32x4*>(a.p0w + n * 64 + k0);
-          else if (id == 1) v = *reinterpret_cast<const f32x4*>(a.p1w + n * 64 + k0);
-          else if (id == 2) v = (f32x4){a.p1w[(k0 + 0) * 64 + n], a.p1w[(k0 + 1) * 64 + n], a.p1w[(k0 + 2) * 64 + n], a.p1w[(k0 + 3) * 64 + n]};
-          else v = (f32x4){a.p0w[(k0 + 0) * 64 + n], a.p0w[(k0 + 1) * 64 + n], a.p0w[(k0 + 2) * 64 + n], a.p0w[(k0 + 3) * 64 + n]};
-        } else if (h == 0) {
-          v.x = id == 0 ? a.p0b[n] : (id == 1 ? a.p1b[n] : 0.f);
-        }
+    for (int idx = tid; idx < 8 * 64; idx += 256) {       // (chunk c, block wc) x lane: one lane's eight slots, all three planes
+      const int cw = idx >> 6, c = cw >> 1, wc = cw & 1, ln = idx & 63, r = ln & 31, hf = ln >> 5;
+      const int n = 32 * wc + r;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * c + 8 * (j >> 2) + 4 * hf + (j & 3);
+        v[j] = id == 0 ? a.p0w[n * 64 + k] : id == 1 ? a.p1w[n * 64 + k] : id == 2 ? a.p1w[k * 64 + n] : id == 3 ? a.p0w[k * 64 + n] : 0.f;
       }
-      a.frag[(int64_t)(16 + id) * kFragF4 + idx] = v;
+      frag_put8(a.frag, 16 + id, c, wc, ln, v);
     }
+    float* bias = reinterpret_cast<float*>(a.frag + (int64_t)(kNMat + 1) * kFragU4);
+    if (id < 2 && tid < 64) bias[(kBiasConv0 + id) * 64 + tid] = id == 0 ? a.p0b[tid] : a.p1b[tid];
     return;
   }
   const bool isB = blockIdx.y == 0;
@@ -339,11 +387,22 @@ __global__ __launch_bounds__(256) void prep_heads_kernel(PrepArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[c16 * 65 + 4 * kk + kq], Bs[(4 * kk + kq) * 68 + 16 * wave + c16], acc, 0, 0, 0);
+    __syncthreads();                                  // every wavefront is done reading As: it now takes the 16 x 64 result tile
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int n = 16 * slice + 4 * kq + reg, k = 16 * wave + c16;
       out[n * 64 + k] = acc[reg];
-      frag_put(a.frag, mat, n, k, acc[reg]);
+      As[(4 * kq + reg) * 65 + k] = acc[reg];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      // fragments: thread -> (row i of the tile, chunk c, lane half hf): eight contraction slots, three planes, 16-byte stores
+      const int i = tid & 15, c = (tid >> 4) & 3, hf = tid >> 6;
+      const int n = 16 * slice + i, wc = n >> 5, r = n & 31;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = As[i * 65 + 16 * c + 8 * (j >> 2) + 4 * hf + (j & 3)];
+      frag_put8(a.frag, mat, c, wc, r + 32 * hf, v);
     }
   }
   if (slice != 0) return;
@@ -407,20 +466,16 @@ __global__ __launch_bounds__(256) void prep_heads_kernel(PrepArgs a) {
     }
   }
   __syncthreads();
-  if (tid < 128) {
-    // the bias fragment (c = 8) of this matrix: lane (r, 0) supplies A[i = r][k = 0]; B is the constant 1
-    const int wc = tid >> 6, ln = tid & 63, r = ln & 31, h = ln >> 5;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (h == 0) v.x = bs[32 * wc + r];
-    a.frag[(int64_t)mat * kFragF4 + (wc * 9 + 8) * 64 + ln] = v;
-  }
+  // the f32 bias table behind the stream: b_h (row hd) and, from head 0's M block, the merged fc1 bias (row kBiasDyn)
+  if (tid < 64 && (isB || hd == 0))
+    reinterpret_cast<float*>(a.frag + (int64_t)(kNMat + 1) * kFragU4)[(isB ? kBiasR + hd : kBiasDyn) * 64 + tid] = bs[tid];
 }
 
 struct Fwd32Args {
   const float* X;
   const int32_t* row_off; const int32_t* tok_slot; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos;
   int L;
-  const f32x4* wfrag;
+  const u32x4* wfrag;              // the bf16 x 3 fragment stream + the f32 bias table behind it (prep_heads_kernel)
   HeadParams hp;
   const float* y; const float* w;
   float* Y; float* H1; float* H2;
@@ -455,10 +510,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const float inv_temp = 0.125f;
   const bool real = r < n;
 
-  // ---- weight stream: prime the window with the first block of head 0's K ----
-  const f32x4* wp = g.wfrag;
-  f32x4 W_[F32_WIN];
-  W32_PRIME();
+  // ---- weight stream: prime the window with the first chunk of R_0; the f32 bias table -> TV (free until the tail) ----
+  const u32x4* wp;
+  u32x4 W_[F32_WIN];
+  W32_PRIME_AT(0);
+  {
+    const f32x4* bsrc = reinterpret_cast<const f32x4*>(g.wfrag + (kNMat + 1) * kFragU4);
+    for (int i4 = lane; i4 < kNBias * 16; i4 += 64) reinterpret_cast<f32x4*>(TV)[i4] = bsrc[i4];
+  }
+#define F32_BIAS(ROW) fl_vec(TV + (ROW) * 64 + 4 * h)
 
   // ---- x_hat in layout FL straight from global memory ----
   FL xh = fl_load(g.X + F32_ROW());
@@ -562,25 +622,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }                                                                                                  \
     }                                                                                                    \
   } while (0)
-#define F32_STAGE18(MAC)                                                                                 \
-  do {                                                                                                   \
-    MAC(0); MAC(1); MAC(2); MAC(3); MAC(4); MAC(5); MAC(6); MAC(7); MAC(8);                              \
-    MAC(9); MAC(10); MAC(11); MAC(12); MAC(13); MAC(14); MAC(15); MAC(16); MAC(17);                      \
-  } while (0)
+#define F32_STAGE8(MAC) do { MAC(0); MAC(1); MAC(2); MAC(3); MAC(4); MAC(5); MAC(6); MAC(7); } while (0)
 
   FF_T(0);
-  FL dyn = fl_zero();
+  fl_store(krow, xh);
+  // x_hat as three bf16 planes: the token-side operand of all eight r products (x_hat in f32 is dead until the tail, which reads its row back)
+  B3 xs[4];
+  FL_SPLIT(xs[0], xh, 0); FL_SPLIT(xs[1], xh, 1); FL_SPLIT(xs[2], xh, 2); FL_SPLIT(xs[3], xh, 3);
+  F32_WAVE_SYNC();                                    // x_hat rows and the bias table visible (one wavefront = the whole workgroup)
+  FL dyn = F32_BIAS(kBiasDyn);                        // the merged fc1 bias enters once
   {
     // ======================= merged heads: two products per head, keys = values = the x_hat rows (written to TK once) =======================
-    // pieces of head hd (two per step of the NEXT head's r product): score half-dots, softmax, probabilities out, z half-rows
-    FL q = fl_zero(), o;                              // q: the r rows of the current head; o: z = P x_hat
-    fl_store(krow, xh);
-    W32_CHAIN(q, xh, true);                           // r_0 = B_0 x_hat + b_0
+    // pieces of head hd (five per step of the NEXT head's r product): score half-dots, softmax, probabilities out, z half-rows
+    FL q = F32_BIAS(kBiasR), o;                       // q: the r rows of the current head; o: z = P x_hat
+    W32_CHAIN_XS(q, xs, true);                        // r_0 = B_0 x_hat + b_0
     F32_IMG_STORE(q, 0, 0);
-    F32_WAVE_SYNC();                                  // x_hat rows visible (one wavefront = the whole workgroup)
     FF_T(1);
-    float* const TVsave = TV;
-    (void)TVsave;
 #define F32_Z_PIECE(S)                                                                                   \
   do {                                                                                                   \
     constexpr int j__ = (S) >> 1, hf__ = (S) & 1;                                                        \
@@ -603,25 +660,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   do {                                                                                                   \
     if constexpr ((Q) < 2 * (ML + 1) + 2) F32_SC_PIECE(Q); else F32_Z_PIECE((Q) - (2 * (ML + 1) + 2));   \
   } while (0)
-#define F32_MG_STEP(S) do { W32_MMA(acc, xh, S); F32_MG_PIECE(2 * (S)); F32_MG_PIECE(2 * (S) + 1); W32_REFILL(S, true); } while (0)
-#define F32_MG_ONLY(S) do { F32_MG_PIECE(2 * (S)); F32_MG_PIECE(2 * (S) + 1); } while (0)
+    // ML = 8: 4 ML + 6 = 38 pieces over the eight steps of a product, five per step
+#define F32_MG_ONLY(S) do { F32_MG_PIECE(5 * (S)); F32_MG_PIECE(5 * (S) + 1); F32_MG_PIECE(5 * (S) + 2); F32_MG_PIECE(5 * (S) + 3); F32_MG_PIECE(5 * (S) + 4); } while (0)
+#define F32_MG_STEP(S) do { WB_MMA(acc, xs[(S) >> 1], S); F32_MG_ONLY(S); WB_REFILL(S, true); } while (0)
     int hd = 0;
     for (; hd + 1 < MATCHA_N_HEAD; ++hd) {
       o = fl_zero();
       {
-        FL acc = fl_zero();                           // r_{hd+1}
-        F32_STAGE18(F32_MG_STEP);
-        F32_MG_PIECE(36); F32_MG_PIECE(37);           // ML = 8: 38 pieces
+        FL acc = F32_BIAS(kBiasR + hd + 1);           // r_{hd+1} = B_{hd+1} x_hat + b_{hd+1}
+        F32_STAGE8(F32_MG_STEP);
         q = acc;
         F32_IMG_STORE(q, hd + 1, 0);
       }
       FF_T(2);
-      W32_CHAIN(dyn, o, true);                        // dyn += M_hd z  (+ the merged bias with head 0)
+      W32_CHAIN(dyn, o, true);                        // dyn += M_hd z
       FF_T(5);
     }
     o = fl_zero();
-    F32_STAGE18(F32_MG_ONLY);
-    F32_MG_PIECE(36); F32_MG_PIECE(37);
+    F32_STAGE8(F32_MG_ONLY);
     FF_T(2);
     W32_CHAIN(dyn, o, true);
     FF_T(5);
@@ -630,17 +686,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (F32_ABL & 8) { if (dyn.lo[0] == 12345.f) g.logits[0] = dyn.hi[3]; return; }
   // Y and H1 are parked in the workspace's Y / H1 rows (every lane stores: the rows past the tokens are copies of the padding token's row,
   // identical in every lane and in every half tile) -- in a saving forward they are what the layer-wise backward reads anyway
+  // x_hat in f32 is read back from this lane's own row of TK where the tail first needs it (the head loop works on its bf16 planes)
+#define F32_XH_RELOAD() do { xh = fl_load(krow); } while (0)
 #define F32_TAIL_SYNC() F32_WAVE_SYNC()
 #define F32_PARK_Y(V) do { if (g.Y) fl_store_global(g.Y + F32_ROW(), V); } while (0)
 #define F32_PARK_H1(V) do { if (g.H1) fl_store_global(g.H1 + F32_ROW(), V); } while (0)
 #define F32_UNPARK_Y() fl_unpark(g.Y, F32_ROW())
 #define F32_UNPARK_H1() fl_unpark(g.H1, F32_ROW())
+#define F32_PARK_HH(V) do { if (g.H2) fl_store_global(g.H2 + F32_ROW(), V); } while (0)
+#define F32_UNPARK_HH() fl_unpark(g.H2, F32_ROW())
 #include "fused_fwd32_tail.hpp"
 #undef F32_TAIL_SYNC
 #undef F32_PARK_Y
 #undef F32_PARK_H1
 #undef F32_UNPARK_Y
 #undef F32_UNPARK_H1
+#undef F32_PARK_HH
+#undef F32_UNPARK_HH
 #ifdef FF_TIMING
   if (blockIdx.x == 2000 && lane == 0)
     printf("fused_fwd32 wave 2000 us: setup %.1f prologue K0 Q0 %.1f | 8 heads: V+scores %.1f K'+PV %.1f Q' %.1f fc1 %.1f | pff fwd %.1f ln+logit %.1f | ln-bwd+colsums %.1f dW1 %.1f dZ1 %.1f dW0 %.1f ddyn %.1f\n",
@@ -679,9 +741,11 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   const bool real = r < n;
 
   // weight stream of THIS head: R_hd sits at matrix 0 (hd = 0) or 2 hd - 1, M_hd at 2 hd + 2 (hd < 7) or 15 (prep_heads_kernel's stream order)
-  const f32x4* wp = g.wfrag + (hd == 0 ? 0 : 2 * hd - 1) * kFragF4;
-  f32x4 W_[F32_WIN];
-  W32_PRIME();
+  const u32x4* wp;
+  u32x4 W_[F32_WIN];
+  W32_PRIME_AT(hd == 0 ? 0 : 2 * hd - 1);
+#undef F32_BIAS
+#define F32_BIAS(ROW) fl_vec(reinterpret_cast<const float*>(g.wfrag + (kNMat + 1) * kFragU4) + (ROW) * 64 + 4 * h)      /* from L2: two per wavefront */
 
   FL xh = fl_load(g.X + F32_ROW());
   int pos = 0, k = 0;
@@ -712,17 +776,16 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
   float sc_part = 0.f;
 
   if (hd == 0) fl_store(krow, xh);
-  FL q = fl_zero(), o = fl_zero();
+  FL q = F32_BIAS(kBiasR + hd), o = fl_zero();
   W32_CHAIN(q, xh, false);                            // r_hd = B_hd x_hat + b_hd
   F32_IMG_STORE(q, hd, 0);
-  wp = g.wfrag + (hd < 7 ? 2 * hd + 2 : 15) * kFragF4;
-  W32_PRIME();                                        // M_hd: in flight during the attention
+  W32_PRIME_AT(hd < 7 ? 2 * hd + 2 : 15);             // M_hd: in flight during the attention
   __syncthreads();                                    // x_hat rows visible
-  F32_STAGE18(F32_MG_ONLY);                           // scores, softmax, probabilities out, z = P x_hat
-  F32_MG_PIECE(36); F32_MG_PIECE(37);
+  F32_STAGE8(F32_MG_ONLY);                            // scores, softmax, probabilities out, z = P x_hat
   {
     FL dynp = fl_zero();
-    W32_CHAIN(dynp, o, false);                        // M_hd z (+ the merged bias with head 0)
+    if (hd == 0) dynp = F32_BIAS(kBiasDyn);           // the merged fc1 bias enters once, with head 0
+    W32_CHAIN(dynp, o, false);                        // M_hd z
     fl_store(Pd + hd * kHT + r * kLdH + 4 * h, dynp);
   }
   __syncthreads();                                    // the LAST workgroup barrier of this kernel
@@ -734,8 +797,7 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dyn.lo[e] += t.lo[e]; dyn.hi[e] += t.hi[e]; }
   }
-  wp = g.wfrag + 16 * kFragF4;      // conv0, conv1, conv1^T, conv0^T follow the heads in the merged stream
-  W32_PRIME();
+  W32_PRIME_AT(16);                                   // conv0, conv1, conv1^T, conv0^T follow the heads in the stream
   // one wavefront is left, so the tail needs no workgroup barrier (round 4 called __syncthreads() here after seven of the eight wavefronts
   // had returned: it worked -- terminated wavefronts no longer count -- but it is outside HIP's barrier contract).  Y and H1 are parked in
   // the first two of the heads' partial-product tiles, which are dead once `dyn` has been summed; a saving forward also writes them out.
@@ -744,12 +806,16 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
 #define F32_PARK_H1(V) do { fl_store(Pd + kHT + r * kLdH + 4 * h, V); if (g.H1 && !g.ddyn0 && r <= n) fl_store_global(g.H1 + F32_ROW(), V); } while (0)
 #define F32_UNPARK_Y() fl_unpark_lds(Pd, r * kLdH + 4 * h)
 #define F32_UNPARK_H1() fl_unpark_lds(Pd + kHT, r * kLdH + 4 * h)
+#define F32_PARK_HH(V) fl_store(Pd + 2 * kHT + r * kLdH + 4 * h, V)
+#define F32_UNPARK_HH() fl_unpark_lds(Pd + 2 * kHT, r * kLdH + 4 * h)
 #include "fused_fwd32_tail.hpp"
 #undef F32_TAIL_SYNC
 #undef F32_PARK_Y
 #undef F32_PARK_H1
 #undef F32_UNPARK_Y
 #undef F32_UNPARK_H1
+#undef F32_PARK_HH
+#undef F32_UNPARK_HH
 #ifdef F32H_REPRO
   // tools/debug/fwd32h_repro.sh: round 4's failing variant -- an UNREACHABLE block with a fence, an atomic, a wave shuffle
   // and a loop appended to the kernel.  It never runs (L <= MATCHA_MAX_L); what it changes is the register allocation of everything above.
@@ -785,7 +851,7 @@ static int fwd32h_max_halves() {
 
 bool fused_small_batch(const Ragged& rg) { return rg.nhalves <= fwd32h_max_halves() && !options().disable_small_batch; }
 
-size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragF4 * 4; }
+size_t fused_frag_floats() { return (size_t)(kNMat + 1) * kFragU4 * 4 + (size_t)kNBias * 64; }
 size_t fused_tail_slab32_floats(int64_t B, int L) { return (size_t)(ragged_halves_cap(B, L) + 2) * kTailSlab32; }
 
 size_t fused_merged_floats() { return (size_t)2 * MATCHA_N_HEAD * 4096 + MATCHA_N_HEAD * 64 + 64; }
@@ -802,7 +868,7 @@ int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, flo
   a.fwq = folded; a.fwk = folded + wsz; a.fwv = folded + 2 * wsz; a.fcq = folded + 3 * wsz; a.fcv = a.fcq + 2 * csz;
   const MergedView v = merged_view(merged);
   a.B = const_cast<float*>(v.B); a.M = const_cast<float*>(v.M); a.bvec = const_cast<float*>(v.bvec); a.bdyn = const_cast<float*>(v.bdyn);
-  a.frag = reinterpret_cast<f32x4*>(frag);
+  a.frag = reinterpret_cast<u32x4*>(frag);
   hipLaunchKernelGGL(prep_heads_kernel, dim3(4, 2, MATCHA_N_HEAD + 1), dim3(256), 0, st, a);
   MATCHA_CHECK_LAUNCH("prep_heads_kernel");
   return MATCHA_OK;
@@ -814,7 +880,7 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
   Fwd32Args g;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos;
   g.L = L;
-  g.wfrag = reinterpret_cast<const f32x4*>(frag);
+  g.wfrag = reinterpret_cast<const u32x4*>(frag);
   (void)folded;
   g.hp = HeadParams{p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
   g.y = y; g.w = w; g.Y = Y; g.H1 = H1; g.H2 = H2; g.logits = logits; g.row_loss = (y && w) ? row_loss : nullptr;

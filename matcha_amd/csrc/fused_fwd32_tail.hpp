@@ -4,9 +4,9 @@
 // fused_fwd32h_kernel (eight wavefronts per half tile, one per head; wavefront 0 runs the tail alone).  ONE wavefront executes this text in
 // both kernels, so no workgroup barrier appears in it: F32_TAIL_SYNC is a wave-local ordering point (s_waitcnt lgkmcnt(0) + a compiler
 // memory barrier; a wavefront's LDS operations execute in order).  The including kernel defines it, the locals the tail works on
-// (g, lane, r, h, n, n_h, b0, t0, real, tok, xh, rx, dyn, TK, TV, outs, douts, krow, he_*, hrow1/2, thr1/2, ks1/2, drop1/2, wp, W_) and
-// where Y and H1 are PARKED between the forward and the backward half of the tail -- F32_PARK_Y / F32_PARK_H1 (store this lane's row) and
-// F32_UNPARK_Y / F32_UNPARK_H1 (an FL loaded back through a laundered pointer, so that the values do not stay in registers): the
+// (g, lane, r, h, n, n_h, b0, t0, real, xh, rx, dyn, TK, TV, outs, douts, krow, wp, W_, F32_BIAS, F32_XH_RELOAD) and
+// where Y, H1 and hh are PARKED between the forward and the backward half of the tail -- F32_PARK_Y / _H1 / _HH (store this lane's row) and
+// F32_UNPARK_Y / _H1 / _HH (an FL loaded back through a laundered pointer, so that the values do not stay in registers): the
 // single-wave kernel parks them in the workspace rows the layer-wise backward reads (Y, H1: L2-resident, 2 x 256 B per token), the
 // eight-wave kernel in two of the heads' dead LDS tiles.  Round 5: with Y and H1 in registers across the LayerNorm backward both kernels
 // spilled ~75 VGPRs (260 B of scratch per lane); parked, and with H2 / U replaced by their normalised forms as soon as those exist, the
@@ -49,7 +49,7 @@
     }
     F32_PARK_Y(y);
   }
-  FL h1 = fl_zero();
+  FL h1 = F32_BIAS(kBiasConv0);
   W32_CHAIN(h1, y, true);                             // conv0 (+ bias)
   {
 #pragma unroll
@@ -63,31 +63,39 @@
     }
     F32_PARK_H1(h1);
   }
-  FL h2 = y;                                          // residual as the accumulator's initial value
-  W32_CHAIN(h2, h1, false);                           // conv1 (+ bias); the window is primed again before the backward GEMMs
-  if (g.H2 && r <= n) fl_store_global(g.H2 + F32_ROW(), h2);
+  FL h2 = y;                                          // residual (+ bias) as the accumulator's initial value
+  {
+    const FL b1v = F32_BIAS(kBiasConv1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { h2.lo[e] += b1v.lo[e]; h2.hi[e] += b1v.hi[e]; }
+  }
+  W32_CHAIN(h2, h1, false);                           // conv1; the window is primed again before the backward GEMMs
+  if (g.H2 && !g.ddyn0 && r <= n) fl_store_global(g.H2 + F32_ROW(), h2);      // (with the tail's backward in this kernel the H2 rows park hh instead)
   FF_T(7);
   F32_TAIL_SYNC();                                    // the parameter vectors in T2 are visible
   // ---- out_t = sum_f (LN1(LN_pff(H2)) - LN2(X))_f^2 wc_f + bc ----
   // only the NORMALISED rows stay live: hh = LN_pff's x_hat (H2 itself is dead from here), uh = layer_norm1's (U = hh gp + bp likewise)
   float rh, ru;
-  FL hh, uh;
+  FL uh;
   {
-    float mh;
-    fl_stats(h2, mh, rh);
+    FL hh;
+    {
+      float mh;
+      fl_stats(h2, mh, rh);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { hh.lo[e] = (h2.lo[e] - mh) * rh; hh.hi[e] = (h2.hi[e] - mh) * rh; }
-  }
-  {
+      for (int e = 0; e < 16; ++e) { hh.lo[e] = (h2.lo[e] - mh) * rh; hh.hi[e] = (h2.hi[e] - mh) * rh; }
+    }
     FL u;                                             // LN_pff output (before layer_norm1)
     const FL Gp = fl_vec(tpar + 0 * 64), Bp = fl_vec(tpar + 1 * 64);
 #pragma unroll
     for (int e = 0; e < 16; ++e) { u.lo[e] = hh.lo[e] * Gp.lo[e] + Bp.lo[e]; u.hi[e] = hh.hi[e] * Gp.hi[e] + Bp.hi[e]; }
+    if (g.ddyn0) F32_PARK_HH(hh);                     // needed again only at the end of the LayerNorm backward: parked like Y and H1
     float mu;
     fl_stats(u, mu, ru);
 #pragma unroll
     for (int e = 0; e < 16; ++e) { uh.lo[e] = (u.lo[e] - mu) * ru; uh.hi[e] = (u.hi[e] - mu) * ru; }
   }
+  F32_XH_RELOAD();
   FL df;                                              // dynamic - static
   {
     const FL G1 = fl_vec(tpar + 2 * 64), B1 = fl_vec(tpar + 3 * 64);
@@ -194,6 +202,7 @@
       for (int e = 0; e < 16; ++e) { du.lo[e] = ru * (du.lo[e] - a - uh.lo[e] * b); du.hi[e] = ru * (du.hi[e] - a - uh.hi[e] * b); }
     }
     // pff_n1.layer_norm
+    const FL hh = F32_UNPARK_HH();
     {
       FL t;
 #pragma unroll
@@ -220,7 +229,7 @@
   }
   // the weight stream resumes at conv1^T (the window was not refilled across the end of conv1)
   FF_T(9);
-  W32_PRIME();
+  W32_PRIME_AT(18);
   // ---- conv1: dW1[n][k] = sum_t dH2[t][n] H1[t][k];  d b1 = column sums of dH2 ----
   F32_TAIL_SYNC();
   fl_store(myrow, dh2);                               // T1 = dH2 [token][feature] (rows past the tokens are zero: dout = 0)

@@ -437,8 +437,8 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     float* lg_out = (logits && !save) ? logits : w.logits;
     note_forward(ws, true, true);
     // (with the tail's backward in the forward kernel, Y and H1 are still handed over: the single-wave kernel PARKS the two rows there
-    // between the tail's forward and backward halves instead of holding 64 registers per lane -- fused_fwd32_tail.hpp)
-    MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, (save || lif) ? w.Y : nullptr, (save || lif) ? w.H1 : nullptr, save ? w.H2 : nullptr,
+    // (and the normalised H2 row in H2's place) between the tail's forward and backward halves instead of holding 96 registers per lane -- fused_fwd32_tail.hpp)
+    MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, (save || lif) ? w.Y : nullptr, (save || lif) ? w.H1 : nullptr, (save || lif) ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
