@@ -27,7 +27,8 @@
 #include "kernels.hpp"
 
 #ifndef F32_ABL
-#define F32_ABL 0                     // timing ablations (tools/debug/abl_fwd32.sh): 1 no attention, 2 no image stores, 4 no tail backward, 8 no tail
+#define F32_ABL 0                     // timing ablations (tools/debug/abl_fwd32.sh; results are wrong on purpose): 1 no attention pieces, 2 no record stores,
+                                      // 4 no tail backward, 8 no tail, 32 no weight refills (stale window), 128 no operand splits
 #endif
 
 namespace matcha {
@@ -194,8 +195,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_BF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)), __builtin_bit_cast(bf16x8, (B)), (C), 0, 0, 0)
-#undef F32_WIN
-#define F32_WIN 6
+#ifndef F32_WIN
+#define F32_WIN 6                     // fragments in flight ahead of the product (divides 24)
+#endif
 constexpr int kFragPerMat = 24;
 constexpr int kFragU4 = kFragPerMat * 64;       // u32x4 per matrix
 constexpr int kBiasR = 0, kBiasDyn = 8, kBiasConv0 = 9, kBiasConv1 = 10, kNBias = 11;    // rows of the f32 bias table behind the stream
@@ -216,6 +218,7 @@ __device__ __forceinline__ P3 split2(float a, float b) {
 #define FL_SPLIT(OUT, V, C)                                                                              \
   do {                                                                                                   \
     _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__) {                                                \
+      if (F32_ABL & 128) { (OUT).h[q__] = __builtin_bit_cast(uint32_t, FL_CHUNK(V, C, 2 * q__)); (OUT).m[q__] = (OUT).h[q__]; (OUT).l[q__] = (OUT).h[q__]; continue; } \
       const P3 p__ = split2(FL_CHUNK(V, C, 2 * q__), FL_CHUNK(V, C, 2 * q__ + 1));                       \
       (OUT).h[q__] = p__.h; (OUT).m[q__] = p__.m; (OUT).l[q__] = p__.l;                                  \
     }                                                                                                    \
@@ -234,7 +237,7 @@ __device__ __forceinline__ P3 split2(float a, float b) {
   } while (0)
 #define WB_REFILL(S, PF)                                                                                 \
   do {                                                                                                   \
-    if (PF) {                                                                                            \
+    if ((PF) && !(F32_ABL & 32)) {                                                                       \
       W_[(3 * (S)) % F32_WIN] = wp[lane]; W_[(3 * (S) + 1) % F32_WIN] = (wp + 64)[lane]; W_[(3 * (S) + 2) % F32_WIN] = (wp + 128)[lane]; \
     }                                                                                                    \
     wp += 192;                                                                                           \
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // piece index Q: [0, 2 (ML + 1) + 2): the score pieces of F32_SC_PIECE (dots, softmax, probabilities out), then the z half-rows
 #define F32_MG_PIECE(Q)                                                                                  \
   do {                                                                                                   \
+    if constexpr ((F32_ABL & 1) != 0) { } else                                                           \
     if constexpr ((Q) < 2 * (ML + 1) + 2) F32_SC_PIECE(Q); else F32_Z_PIECE((Q) - (2 * (ML + 1) + 2));   \
   } while (0)
     // ML = 8: 4 ML + 6 = 38 pieces over the eight steps of a product, five per step

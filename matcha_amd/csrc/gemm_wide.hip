@@ -1,6 +1,13 @@
-// Wide-tile fp32 MFMA GEMMs for the layer-by-layer path at embed_dim >= 128 (BASELINE configs[3], [4]): the Q/K/V and fc1
+// Wide-tile GEMMs for the layer-by-layer path at embed_dim >= 128 (BASELINE configs[3], [4]): the Q/K/V and fc1
 // projections (NT: Y = X.W^T, Modules.py:527-529, :572), their input gradients (NN: dX = dY.W) and every weight gradient
-// (TN: dW = dY^T.X).  Same arithmetic as gemm_lds.hip / gemm_f32.hip (v_mfma_f32_32x32x2_f32, exact f32), different tiling:
+// (TN: dW = dY^T.X).
+//
+// Round 5: fp32-ACCURATE products on the bf16 matrix pipe.  The f32 MFMA (v_mfma_f32_32x32x2_f32) runs at the f32 vector rate and on the
+// vector ALUs; here every operand fragment -- eight consecutive contraction indices of one row, read from the f32 staging tile -- is split
+// in registers into three bf16 planes (v = h + m + l to 2^-27, round to nearest) and a 32 x 32 x 16 block is the six plane products above
+// 2^-26 (Al Bh + Ah Bl + Am Bm + Am Bh + Ah Bm + Ah Bh, one v_mfma_f32_32x32x16_bf16 each, f32 accumulate): 6 x 32 cycles on the matrix pipe
+// instead of 8 x 64 on the vector ALUs; the result differs from an f32 fma chain by ~1e-7 relative, that chain's own rounding level
+// (tests/test_cpu_bf16x3.py; fused_fwd32.hip has the longer note).  Staging, tiling, pipeline and epilogues are unchanged:
 //
 //   workgroup = 256 threads = 4 waves in a 2 x 2 grid; output tile 128 x 128; each wave owns 64 x 64 = FOUR 32x32 accumulators,
 //   so one 16-byte LDS read per operand row feeds twice the MFMAs of the 32 x 64 wave tile of gemm_lds.hip (4 reads per 16
@@ -21,12 +28,43 @@
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int kWM = 128, kWN = 128, kWK = 32;
 constexpr int kLdK = kWK + 4;          // k-major tiles: [row][k], 36 floats per row (conflict-free 16-byte reads, gemm_lds.hip)
 constexpr int kLdN = kWN + 4;          // n-major tiles: [k][n], 132 floats per row
+
+// eight f32 values (one lane's contraction slots of a 32x32x16 fragment) as three bf16 planes
+struct Frag3 { u32x4 h, m, l; };
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const f2 v = {a, b};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);                 // v_cvt_pk_bf16_f32: round to nearest even
+  const f2 r1 = v - __builtin_convertvector(hb, f2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f2 r2 = r1 - __builtin_convertvector(mb, f2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  h = __builtin_bit_cast(uint32_t, hb); m = __builtin_bit_cast(uint32_t, mb); l = __builtin_bit_cast(uint32_t, lb);
+}
+__device__ __forceinline__ Frag3 split8(const float* v) {
+  Frag3 f;
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
+  f.h = (u32x4){h[0], h[1], h[2], h[3]}; f.m = (u32x4){m[0], m[1], m[2], m[3]}; f.l = (u32x4){l[0], l[1], l[2], l[3]};
+  return f;
+}
+#define WIDE_BF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)), __builtin_bit_cast(bf16x8, (B)), (C), 0, 0, 0)
+// acc += A . B over 16 contraction indices: the six plane products, smallest first
+__device__ __forceinline__ void mma6(f32x16& acc, const Frag3& a, const Frag3& b) {
+  acc = WIDE_BF(a.l, b.h, acc); acc = WIDE_BF(a.h, b.l, acc); acc = WIDE_BF(a.m, b.m, acc);
+  acc = WIDE_BF(a.m, b.h, acc); acc = WIDE_BF(a.h, b.m, acc); acc = WIDE_BF(a.h, b.h, acc);
+}
 
 template <int FLAGS>
 struct Epi {
@@ -142,29 +180,32 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g, int64_t n
     }
     const float* As = lds + (s & 1) * BUF;
     const float* Bs = As + A_SZ;
-    const float* a0p = &As[(64 * wr + r) * kLdK + 4 * h];
+    // lane (r, h) supplies contraction indices 16 s2 + 8 h + {0..7} of its row to both operands of a 32x32x16 step
+    const float* a0p = &As[(64 * wr + r) * kLdK + 8 * h];
     const float* a1p = a0p + 32 * kLdK;
     if (!(dbg & 2))
 #pragma unroll
-    for (int c = 0; c < kWK / 8; ++c) {
-      const float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * c);
-      const float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * c);
-      float4 b0, b1;
-      if (!B_KN) {
-        b0 = *reinterpret_cast<const float4*>(&Bs[(64 * wc + r) * kLdK + 8 * c + 4 * h]);
-        b1 = *reinterpret_cast<const float4*>(&Bs[(64 * wc + 32 + r) * kLdK + 8 * c + 4 * h]);
-      } else {
-        const float* q = &Bs[(8 * c + 4 * h) * kLdN + 64 * wc + r];
-        b0 = make_float4(q[0], q[kLdN], q[2 * kLdN], q[3 * kLdN]);
-        b1 = make_float4(q[32], q[kLdN + 32], q[2 * kLdN + 32], q[3 * kLdN + 32]);
+    for (int s2 = 0; s2 < kWK / 16; ++s2) {
+      float va0[8], va1[8], vb0[8], vb1[8];
+      {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0p + 16 * s2), x1 = *reinterpret_cast<const f32x4*>(a0p + 16 * s2 + 4);
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(a1p + 16 * s2), y1 = *reinterpret_cast<const f32x4*>(a1p + 16 * s2 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va0[j] = x0[j]; va0[4 + j] = x1[j]; va1[j] = y0[j]; va1[4 + j] = y1[j]; }
       }
-#define WIDE_MMA(E)                                                                           \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b0.E, acc[0][0], 0, 0, 0);           \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b1.E, acc[0][1], 0, 0, 0);           \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b0.E, acc[1][0], 0, 0, 0);           \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b1.E, acc[1][1], 0, 0, 0);
-      WIDE_MMA(x) WIDE_MMA(y) WIDE_MMA(z) WIDE_MMA(w)
-#undef WIDE_MMA
+      if (!B_KN) {
+        const float* b0p = &Bs[(64 * wc + r) * kLdK + 16 * s2 + 8 * h];
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(b0p), x1 = *reinterpret_cast<const f32x4*>(b0p + 4);
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(b0p + 32 * kLdK), y1 = *reinterpret_cast<const f32x4*>(b0p + 32 * kLdK + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vb0[j] = x0[j]; vb0[4 + j] = x1[j]; vb1[j] = y0[j]; vb1[4 + j] = y1[j]; }
+      } else {
+        const float* q = &Bs[(16 * s2 + 8 * h) * kLdN + 64 * wc + r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { vb0[j] = q[j * kLdN]; vb1[j] = q[j * kLdN + 32]; }
+      }
+      const Frag3 fa0 = split8(va0), fa1 = split8(va1), fb0 = split8(vb0), fb1 = split8(vb1);
+      mma6(acc[0][0], fa0, fb0); mma6(acc[0][1], fa0, fb1); mma6(acc[1][0], fa1, fb0); mma6(acc[1][1], fa1, fb1);
     }
     float* const idle = lds + ((s + 1) & 1) * BUF;        // the stage the next step's operands will be written to
     if (kci + 1 == nkc && (dbg & 1)) { kci = 0; ++tile; }
@@ -332,18 +373,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide_kernel(WideTnArgs g) {
     if (more) TNW_GLOAD(rbeg + (s + 1) * kWK);
     const float* As = (s & 1) ? As1 : As0;
     const float* Bs = (s & 1) ? Bs1 : Bs0;
-    const float* apx = &As[h * kLdN + 64 * wr + r];
-    const float* bpx = &Bs[h * kLdN + 64 * wc + r];
+    // lane (r, h) supplies tokens 16 s2 + 8 h + {0..7} of its column to both operands of a 32x32x16 step
+    const float* apx = &As[(8 * h) * kLdN + 64 * wr + r];
+    const float* bpx = &Bs[(8 * h) * kLdN + 64 * wc + r];
 #pragma unroll
-    for (int kk = 0; kk < kWK / 2; ++kk) {          // token pairs (2 kk, 2 kk + 1): lane half h supplies token 2 kk + h
-      const float a0 = apx[2 * kk * kLdN], a1 = apx[2 * kk * kLdN + 32];
-      const float b0 = bpx[2 * kk * kLdN], b1 = bpx[2 * kk * kLdN + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      cs0 += a0;
-      cs1 += a1;
+    for (int s2 = 0; s2 < kWK / 16; ++s2) {
+      float va0[8], va1[8], vb0[8], vb1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        va0[j] = apx[(16 * s2 + j) * kLdN]; va1[j] = apx[(16 * s2 + j) * kLdN + 32];
+        vb0[j] = bpx[(16 * s2 + j) * kLdN]; vb1[j] = bpx[(16 * s2 + j) * kLdN + 32];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { cs0 += va0[j]; cs1 += va1[j]; }
+      const Frag3 fa0 = split8(va0), fa1 = split8(va1), fb0 = split8(vb0), fb1 = split8(vb1);
+      mma6(acc[0][0], fa0, fb0); mma6(acc[0][1], fa0, fb1); mma6(acc[1][0], fa1, fb0); mma6(acc[1][1], fa1, fb1);
     }
     if (more) TNW_LSTORE((s & 1) ? As0 : As1, (s & 1) ? Bs0 : Bs1);
     __syncthreads();

@@ -1,8 +1,38 @@
 #!/bin/bash
-# in-situ ablations of fused_fwd32_kernel: rebuild with -DF32_ABL=<bits> on the box and time the step (results are wrong on purpose)
-for a in "$@"; do
-  cd $GRAFT_REPO_ROOT/matcha_amd/csrc
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DF32_ABL=$a $EXTRA -c fused_fwd32.hip -o ../../build/csrc/fused_fwd32.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libmatcha_hip.so ../../build/csrc/*.o || exit 1
-  cd $GRAFT_REPO_ROOT; echo "F32_ABL=$a $EXTRA"; tools/debug/quick_bench.sh 2>&1 | tail -1
-done
+# In-situ ablations of the fused forward (results are wrong on purpose; only the kernel's time is read).
+#   build (here):     tools/debug/abl_fwd32.sh build "<name>:<extra hipcc flags>" ...     e.g.  base:  noattn:-DF32_ABL=1  win12:-DF32_WIN=12
+#   run (GPU box):    tools/debug/abl_fwd32.sh run      -> one line per variant: fused_fwd ms / step ms at 65 536 rows
+# Variants are whole libraries under matcha_amd/lib/abl/ (git-ignored .so files travel to the GPU box; build/ does not).
+set -u
+cd "$(dirname "$0")/../.."
+CS=matcha_amd/csrc
+OUT=build/abl
+LIBOUT=matcha_amd/lib/abl
+FLAGS="--offload-arch=gfx950 --offload-compress -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-unused-parameter"
+case ${1:-build} in
+build)
+  shift
+  make -C $CS -j8 >/dev/null || exit 1
+  mkdir -p $OUT $LIBOUT; rm -f $LIBOUT/*.so
+  for spec in "$@"; do
+    name=${spec%%:*}; extra=${spec#*:}
+    /opt/rocm/bin/hipcc $FLAGS $extra -c $CS/fused_fwd32.hip -o $OUT/fused_fwd32_$name.o || exit 1
+    objs=""
+    for o in build/csrc/*.o; do
+      case $o in *-hip-*) ;; */fused_fwd32.o) objs="$objs $OUT/fused_fwd32_$name.o";; *) objs="$objs $o";; esac
+    done
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIBOUT/libmatcha_hip_$name.so $objs || exit 1
+    echo "built $name ($extra)"
+  done
+  ;;
+run)
+  mkdir -p gpurun_out; LOG=gpurun_out/abl_fwd32.log; : > $LOG
+  for lib in $LIBOUT/*.so; do
+    name=$(basename $lib .so); name=${name#libmatcha_hip_}
+    MATCHA_HIP_LIB=$(pwd)/$lib python bench.py --no-extras --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['roofline_by_kernel_class']
+print('$name', 'fused_fwd', round(c['fused_fwd']['ms_per_step'],4), 'fused_bwd', round(c['fused_bwd']['ms_per_step'],4), 'step', round(d['ms_per_step'],4))" | tee -a $LOG
+  done
+  ;;
+esac
