@@ -94,7 +94,11 @@ __device__ __forceinline__ V8 zero8() { V8 z; z.a = f2{0.f, 0.f}; z.b = z.a; z.c
 // of the NEXT row and the eight registers of the running sum as in / out operands: the load of row j + 1 cannot be issued before the
 // arithmetic on row j - 1 has produced x.  (sched_barrier alone does not do it: instruction selection has already placed the unchained
 // LDS loads of all rows ahead of the arithmetic -- 40 to 80 operand registers -- when the machine scheduler sees the fence.)
+#ifdef FBH_NOPIN
+#define FB_PIN(addr, x) do { } while (0)
+#else
 #define FB_PIN(addr, x) asm volatile("" : "+v"(addr), "+v"((x).a), "+v"((x).b), "+v"((x).c), "+v"((x).d))
+#endif
 // Keys = values (merged heads: both are the x_hat rows, kpad = vpad = the padding token's x_hat): ONE pass over the rows.  With the weights
 // w_j = p_ij (w_pad = n_pad p_i,pad) and d_j = dz_i . x_j:   z_i = sum_j w_j x_j,   sig = sum_j w_j d_j,   A = sum_j (w_j d_j) x_j, and
 //   d r_i = sum_j dS_ij x_j = (A - sig z_i) / temp        (dS_ij = w_j (d_j - sig) / temp; the sums include the padding term),
@@ -132,7 +136,11 @@ __device__ __forceinline__ void attn_row8_kv(const float* __restrict__ Qs, const
       vn2 = ld8(&Xs[ad]);
     }
     axpy8(o, p[j], v);
+#ifdef FBH_NODPP
+    const float d = group_sum<8>(dot8(go, v));
+#else
     const float d = group_sum8_dpp(dot8(go, v));
+#endif
     ds[j] = d;
     const float wd = p[j] * d;
     sig += wd;
@@ -214,6 +222,96 @@ constexpr int kVecOffM = 2 * 4096;
 // half tile is staged while this one computes), dZ -> Z, G: 8 tiles of 32 x 68 floats + 3.5 KB = 73 KB.  B_h and M_h are MFMA
 // fragments in registers.  The forward's saved record is per (half tile, head): its wavefront's own register image (kImgRecH).
 constexpr int kTileH = 32 * kLd;
+// ---- round 5: the four products on the bf16 matrix pipe (fp32-accurate: three bf16 planes per operand, six plane products; the note is in
+// fused_fwd32.hip, the arithmetic restated in tests/test_cpu_bf16x3.py) ---------------------------------------------------------------------
+// The f32 MFMA shares the vector ALUs with the attention arithmetic (128 x 32 cycles per wavefront and half tile next to ~600 vector
+// instructions); v_mfma_f32_16x16x32_bf16 has its own pipe.  What makes it pay HERE is that every GEMM operand is split ONCE where it is
+// produced and kept in LDS as bf16 planes -- dDyn and x_hat by the staging threads (one split per workgroup, not per wavefront: a 16 x 16
+// output tile reuses a fragment only six times), dR and Z by the attention's write phase, B_h and M_h once per workgroup walk in registers:
+//   plane tile = [32 tokens][72 bf16] x 3 planes (144-byte rows: 16-byte row reads conflict-free to 2-way, transposed reads 2-way)
+//   row fragment (contraction over FEATURES: dZ^T = M_h^T dDyn^T, d x_hat = dR B_h)   = one ds_read_b128 per plane
+//   column fragment (contraction over TOKENS: dB_h += dR^T x_hat, dM_h += dDyn^T Z)   = two ds_read_b64_tr_b16 per plane -- the hardware
+//     transpose read hands lane i of a 16-lane group column i of a 4 row x 16 column block (MI355X guide T10)
+// LDS per workgroup (75 KB, two workgroups per CU as before): x_hat f32 (the attention's keys / values) + planes, dDyn planes, RB = r f32 ->
+// dR planes, FB = dZ f32 -> Z planes, G f32.  One set only: the next half tile's rows wait in registers (fetched during the GEMMs) and are
+// staged at the top of the next iteration.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifndef FBH_XBAR
+#define FBH_XBAR 0                      // debugging: extra workgroup barriers (bit i: a second barrier at point i of the half-tile loop)
+#endif
+#define FBH_X(i) do { if (FBH_XBAR & (1 << (i))) __syncthreads(); } while (0)
+constexpr int kPS = 72;                 // bf16 per plane row
+constexpr int kPlane = 32 * kPS;        // bf16 per plane
+constexpr int kPT = 3 * kPlane;         // bf16 per three-plane tile (13 824 B)
+struct Frag3 { u32x4 h, m, l; };
+struct P3 { uint32_t h, m, l; };
+__device__ __forceinline__ P3 split2(float a, float b) {
+  const f2 v = {a, b};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);                 // v_cvt_pk_bf16_f32: round to nearest even
+  const f2 r1 = v - __builtin_convertvector(hb, f2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f2 r2 = r1 - __builtin_convertvector(mb, f2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  return P3{__builtin_bit_cast(uint32_t, hb), __builtin_bit_cast(uint32_t, mb), __builtin_bit_cast(uint32_t, lb)};
+}
+__device__ __forceinline__ Frag3 split8(const float* v) {
+  const P3 a = split2(v[0], v[1]), b = split2(v[2], v[3]), c = split2(v[4], v[5]), d = split2(v[6], v[7]);
+  Frag3 f;
+  f.h = (u32x4){a.h, b.h, c.h, d.h}; f.m = (u32x4){a.m, b.m, c.m, d.m}; f.l = (u32x4){a.l, b.l, c.l, d.l};
+  return f;
+}
+__device__ __forceinline__ Frag3 split8(const V8& v) {
+  const float t[8] = {v.a.x, v.a.y, v.b.x, v.b.y, v.c.x, v.c.y, v.d.x, v.d.y};
+  return split8(t);
+}
+// eight consecutive bf16 of a plane-tile row (16-byte aligned) <-> a fragment
+__device__ __forceinline__ Frag3 frag_row(const short* __restrict__ p) {
+  Frag3 f;
+  f.h = *reinterpret_cast<const u32x4*>(p); f.m = *reinterpret_cast<const u32x4*>(p + kPlane); f.l = *reinterpret_cast<const u32x4*>(p + 2 * kPlane);
+  return f;
+}
+__device__ __forceinline__ void frag_store(short* __restrict__ p, const Frag3& f) {
+  *reinterpret_cast<u32x4*>(p) = f.h; *reinterpret_cast<u32x4*>(p + kPlane) = f.m; *reinterpret_cast<u32x4*>(p + 2 * kPlane) = f.l;
+}
+// column fragment: tokens 8 kq .. 8 kq + 7 of ONE column per lane.  p = this lane's block address: row 8 kq + ((lane & 15) >> 2), columns
+// c0 + 4 (lane & 3) of plane h; lane i of the 16-lane group receives column c0 + i (EXEC must be all ones: the GEMM phases are).
+__device__ __forceinline__ u32x4 tr8(const short* __restrict__ p) {
+#ifdef FBH_NOTR
+  // debugging: the same fragment with plain 16-bit reads.  p is THIS lane's block address (row 8 kq + q, column c0 + 4 p'); the lane needs
+  // column c0 + (lane & 15) of rows 8 kq .. 8 kq + 7
+  const int l = threadIdx.x & 15;
+  const short* base = p - ((l >> 2) * kPS + 4 * (l & 3)) + l;
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = (uint32_t)(uint16_t)base[(2 * q) * kPS] | ((uint32_t)(uint16_t)base[(2 * q + 1) * kPS] << 16);
+  return (u32x4){w[0], w[1], w[2], w[3]};
+#endif
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * kPS));
+  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+  return (u32x4){a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ Frag3 frag_col(const short* __restrict__ p) {
+  Frag3 f;
+  f.h = tr8(p); f.m = tr8(p + kPlane); f.l = tr8(p + 2 * kPlane);
+  return f;
+}
+#define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (A)), __builtin_bit_cast(bf16x8, (B)), (C), 0, 0, 0)
+// acc += A . B over 32 contraction indices: the six plane products above 2^-26, smallest first
+__device__ __forceinline__ f32x4 mma6(f32x4 acc, const Frag3& a, const Frag3& b) {
+  acc = MFMA16B(a.l, b.h, acc); acc = MFMA16B(a.h, b.l, acc); acc = MFMA16B(a.m, b.m, acc);
+  acc = MFMA16B(a.m, b.h, acc); acc = MFMA16B(a.h, b.m, acc); acc = MFMA16B(a.h, b.h, acc);
+#ifdef FBH_NOPS
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
+#endif
+  return acc;
+}
+
 struct FusedBwdHArgs {
   const float* X; const float* dDyn; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos;
   int L; int nhalves; int nchunks;
@@ -223,21 +321,44 @@ struct FusedBwdHArgs {
   float* wslab;                                    // [8][nchunks][kWgSlabM]
   const float* rimg;                               // [nhalves][8][kImgRecH]: r rows (register images) + attention probabilities of the forward
 };
+#ifdef FBH_NOALIAS
+constexpr size_t kBwdLdsBytes = (size_t)4 * kTileH * 4 + (size_t)4 * kPT * 2 + (64 + 256 + 256 + 32) * 4;      // debugging: r and dZ f32 tiles of their own
+#else
+#ifndef FBH_PAD
+#define FBH_PAD 0
+#endif
+constexpr size_t kBwdLdsBytes = (size_t)2 * kTileH * 4 + (size_t)4 * kPT * 2 + (64 + 256 + 256 + 32) * 4 + FBH_PAD;
+#endif
 
 template <int ML>
+#ifdef FBH_NOWPE
+__global__ __launch_bounds__(256) void fused_bwdh_kernel(FusedBwdHArgs g) {
+#else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_bwdh_kernel(FusedBwdHArgs g) {
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* set0 = lds;                  // two sets {x_hat, dDyn, r -> dR}; Ds, Rs consecutive
-  float* Fs = lds + 6 * kTileH;       // dZ -> Z
-  float* Gs = lds + 7 * kTileH;       // attention's gradient into the x_hat rows (keys + values)
-  float* sm = lds + 8 * kTileH;
+  float* Xs = lds;                                   // x_hat f32 (keys = values of the attention)
+  float* Gs = lds + kTileH;                          // attention's gradient into the x_hat rows (keys + values)
+  short* Xp = reinterpret_cast<short*>(lds + 2 * kTileH);   // x_hat planes
+  short* Dp = Xp + kPT;                              // dDyn planes
+  short* RBp = Dp + kPT;                             // r f32 -> dR planes
+  short* FBp = RBp + kPT;                            // dZ f32 -> Z planes
+#ifdef FBH_NOALIAS
+  float* Rs = reinterpret_cast<float*>(FBp + kPT);
+  float* Fs = Rs + kTileH;
+  float* sm = Fs + kTileH;
+#else
+  float* Rs = reinterpret_cast<float*>(RBp);
+  float* Fs = reinterpret_cast<float*>(FBp);
+  float* sm = reinterpret_cast<float*>(FBp + kPT);
+#endif
   float* xpad = sm;
   float* dSs = xpad + 64;             // [32][8]
-  float* Ps0 = dSs + 256;             // [2][32][8]
-  int* tinfo0 = reinterpret_cast<int*>(Ps0 + 512);   // [2][32]
+  float* Ps = dSs + 256;              // [32][8]
+  int* tinfo = reinterpret_cast<int*>(Ps + 256);     // [32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x4 fragments
+  const int c16 = lane & 15, kq = lane >> 4;           // 16x16x32 fragments: row / column c16, contraction slots 8 kq + {0..7}
   const int fb = 16 * wave;                            // this wave's 16 feature columns
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;     // staging: 16 rows x 16 lanes (float4), twice
 
@@ -275,6 +396,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // column sums of dDyn (columns sc4 + {0..3} over the rows this thread stages) and of dR (features 8 sub + {0..7} over this lane group's tokens)
   f2 cd0 = {0.f, 0.f}, cd1 = cd0;
   V8 accR = zero8();
+#ifdef FBH_PROBE
+  V8 accR2 = zero8();                                  // debugging: the same column sums taken right behind the row phase
+#endif
 
   const int4* meta = reinterpret_cast<const int4*>(g.half_meta);
   const int4 mzero = make_int4(0, 0, 0, 0);
@@ -295,6 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FBH_ROW_GLOAD(0, M); FBH_ROW_GLOAD(1, M);                                                            \
     if (tid < 32) tpn = g.tok_pos[(M).x + (tid < (M).y ? tid : ((M).y > 0 ? (M).y - 1 : 0))];           \
   } while (0)
+  // x_hat row -> Xs (f32) and Xp (planes); dDyn row (zero past the tokens) -> Dp (planes) + its column sums
 #define FBH_ROW_STAGE(I)                                                                                 \
   do {                                                                                                   \
     const int row__ = srow + 16 * (I);                                                                   \
@@ -304,9 +429,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float a__ = xv__.x - mean__, b__ = xv__.y - mean__, c__ = xv__.z - mean__, e__ = xv__.w - mean__; \
     const float q__ = group_sum16_dpp((a__ * a__ + b__ * b__) + (c__ * c__ + e__ * e__));                \
     const float rs__ = msk__ * __builtin_amdgcn_rsqf(q__ * (1.f / 64.f) + kEpsLn);                       \
-    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__); \
+    const float4 xh__ = make_float4(a__ * rs__, b__ * rs__, c__ * rs__, e__ * rs__);                     \
+    *reinterpret_cast<float4*>(&Xs[row__ * kLd + sc4]) = xh__;                                           \
+    {                                                                                                    \
+      const P3 p0__ = split2(xh__.x, xh__.y), p1__ = split2(xh__.z, xh__.w);                             \
+      short* d__ = Xp + row__ * kPS + sc4;                                                               \
+      *reinterpret_cast<u32x2*>(d__) = (u32x2){p0__.h, p1__.h}; *reinterpret_cast<u32x2*>(d__ + kPlane) = (u32x2){p0__.m, p1__.m}; \
+      *reinterpret_cast<u32x2*>(d__ + 2 * kPlane) = (u32x2){p0__.l, p1__.l};                             \
+    }                                                                                                    \
     const float4 dm__ = make_float4(dv__.x * msk__, dv__.y * msk__, dv__.z * msk__, dv__.w * msk__);     \
-    *reinterpret_cast<float4*>(&Ds[row__ * kLd + sc4]) = dm__;                                           \
+    {                                                                                                    \
+      const P3 p0__ = split2(dm__.x, dm__.y), p1__ = split2(dm__.z, dm__.w);                             \
+      short* d__ = Dp + row__ * kPS + sc4;                                                               \
+      *reinterpret_cast<u32x2*>(d__) = (u32x2){p0__.h, p1__.h}; *reinterpret_cast<u32x2*>(d__ + kPlane) = (u32x2){p0__.m, p1__.m}; \
+      *reinterpret_cast<u32x2*>(d__ + 2 * kPlane) = (u32x2){p0__.l, p1__.l};                             \
+    }                                                                                                    \
     cd0 += (f2){dm__.x, dm__.y}; cd1 += (f2){dm__.z, dm__.w};                                            \
   } while (0)
   // the forward wavefront's register image: float4 index (wc * 4 + gq) * 64 + 32 h + r holds features 32 wc + 8 gq + 4 h + {0..3} of row r
@@ -316,45 +453,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < 64) pn = __builtin_nontemporal_load(r__ + 512 + tid);                                      \
     ri0 = __builtin_nontemporal_load(r__ + tid); ri1 = __builtin_nontemporal_load(r__ + 256 + tid);      \
   } while (0)
-  // A fragments (16 feature rows x 64 k) of M_h for dZ^T = M_h^T . dDyn^T and of B_h for d x_hat^T = B_h^T dR^T, held for the whole walk
-  float fcb[16], bfr[16];
+  // B_h and M_h as register fragments for the whole walk: lane (c16, kq), step s holds W[32 s + 8 kq + {0..7}][fb + c16] -- the A operand of
+  // dZ^T = M_h^T dDyn^T (rows = features) and the B operand of d x_hat = dR B_h (columns = features); three planes each
+  Frag3 Mf[2], Bf[2];
   {
     FBH_ROWS_GLOAD(mc);
     if (tile_lo < tile_hi) FBH_RIMG_GLOAD(tile_lo);
-    const float* mp = g.mM + (int64_t)head * 4096 + (4 * kq) * 64 + fb + c16;
-    const float* bp = g.mB + (int64_t)head * 4096 + (4 * kq) * 64 + fb + c16;
+    const float* mp = g.mM + (int64_t)head * 4096 + (8 * kq) * 64 + fb + c16;
+    const float* bp = g.mB + (int64_t)head * 4096 + (8 * kq) * 64 + fb + c16;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int s = 0; s < 2; ++s) {
+      float vm[8], vb[8];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) { fcb[4 * c + x] = mp[(16 * c + x) * 64]; bfr[4 * c + x] = bp[(16 * c + x) * 64]; }
+      for (int j = 0; j < 8; ++j) { vm[j] = mp[(32 * s + j) * 64]; vb[j] = bp[(32 * s + j) * 64]; }
+      Mf[s] = split8(vm); Bf[s] = split8(vb);
+    }
   }
 
-#define FBH_STAGE(PAR, META)                                                                             \
-  do {                                                                                                   \
-    float* Xs = set0 + 3 * (PAR) * kTileH;                                                               \
-    float* Ds = Xs + kTileH;                                                                             \
-    float* Rs = Ds + kTileH;                                                                             \
-    const int n_real = (META).y;                                                                         \
-    FBH_ROW_STAGE(0); FBH_ROW_STAGE(1);                                                                  \
-    if (tid < 32) tinfo0[32 * (PAR) + tid] = tid < n_real ? ((tid - (tpn & 255)) | (tpn & ~255)) : 0;     \
-    f32x4* d__ = reinterpret_cast<f32x4*>(&Rs[(lane & 31) * kLd + 8 * wave + 4 * (lane >> 5)]);          \
-    d__[0] = ri0; d__[8] = ri1;                                                                          \
-    if (tid < 64) reinterpret_cast<f32x4*>(Ps0 + 256 * (PAR))[tid] = pn;                                 \
-  } while (0)
-  int par = 0;
-  if (tile_lo < tile_hi) FBH_STAGE(0, mc);
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
     const int t0 = mc.x, n_real = mc.y;
-    float* Xs = set0 + 3 * par * kTileH;
-    float* Ds = Xs + kTileH;
-    float* Rs = Ds + kTileH;
-    const float* Ps = Ps0 + 256 * par;
-    const int* tinfo = tinfo0 + 32 * par;
     FB_T(0);
-    __syncthreads();                                  // this half tile's set is staged; the previous one's GEMMs are done with Fs / Gs and with the other set
+    __syncthreads();                                  // the previous half tile's GEMMs are done with every tile
+    FBH_X(0);
     FB_T(7);
-    // per-lane indices re-derived from an opaque copy of the thread id (see fused_bwd8_kernel: loop-invariant addresses are hoisted and spilled otherwise)
+    // ---- stage this half tile (its rows were fetched during the previous one's GEMMs) ----
+    {
+      FBH_ROW_STAGE(0); FBH_ROW_STAGE(1);
+      if (tid < 32) tinfo[tid] = tid < n_real ? ((tid - (tpn & 255)) | (tpn & ~255)) : 0;
+      f32x4* d__ = reinterpret_cast<f32x4*>(&Rs[(lane & 31) * kLd + 8 * wave + 4 * (lane >> 5)]);
+      d__[0] = ri0; d__[8] = ri1;
+      if (tid < 64) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
+    }
+    __syncthreads();
+    FBH_X(1);
+    // per-lane indices re-derived from an opaque copy of the thread id (loop-invariant addresses are hoisted and spilled otherwise)
     int tid_ = tid;
     asm volatile("" : "+v"(tid_));
     const int lane = tid_ & 63, wave = tid_ >> 6;
@@ -366,20 +499,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- dZ^T = M_h^T . dDyn^T: lane (c16, kq) ends with token c16 (+ 16) and features fb + 4 kq + {0..3} ----
     {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      const float* dp = Ds + c16 * kLd + 4 * kq;
+      const short* dp = Dp + c16 * kPS + 8 * kq;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 b0 = *reinterpret_cast<const float4*>(dp + 16 * c), b1 = *reinterpret_cast<const float4*>(dp + 16 * kLd + 16 * c);
-        acc0 = MFMA16(fcb[4 * c + 0], b0.x, acc0); acc1 = MFMA16(fcb[4 * c + 0], b1.x, acc1);
-        acc0 = MFMA16(fcb[4 * c + 1], b0.y, acc0); acc1 = MFMA16(fcb[4 * c + 1], b1.y, acc1);
-        acc0 = MFMA16(fcb[4 * c + 2], b0.z, acc0); acc1 = MFMA16(fcb[4 * c + 2], b1.z, acc1);
-        acc0 = MFMA16(fcb[4 * c + 3], b0.w, acc0); acc1 = MFMA16(fcb[4 * c + 3], b1.w, acc1);
+      for (int s = 0; s < 2; ++s) {
+        const Frag3 b0 = frag_row(dp + 32 * s), b1 = frag_row(dp + 16 * kPS + 32 * s);
+        acc0 = mma6(acc0, Mf[s], b0); acc1 = mma6(acc1, Mf[s], b1);
       }
       *reinterpret_cast<f32x4*>(&Fs[c16 * kLd + fb + 4 * kq]) = acc0;
       *reinterpret_cast<f32x4*>(&Fs[(16 + c16) * kLd + fb + 4 * kq]) = acc1;
     }
     FB_T(1);
     __syncthreads();
+    FBH_X(2);
     FB_T(7);
     // ---- attention forward + backward in x_hat space: 8 lanes per token, all 32 rows in one pass ----
     {
@@ -388,9 +519,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const bool acta = la < n_real;
       int ia = 0;
       if (acta) { ia = tinfo[la]; attn_row8_kv<ML>(Rs, Xs, Fs, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
+#ifdef FBH_PROBE
+      if (acta) { accR2.a += q0.a; accR2.b += q0.b; accR2.c += q0.c; accR2.d += q0.d; }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       FB_T(2);
       __syncthreads();
+      FBH_X(3);
       FB_T(7);
       if (acta) {
         attn_col8<ML>(Rs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
@@ -400,34 +535,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ZR8(&Gs[la * kLd + 8 * sub]);
       }
       FB_T(3);
-      __syncthreads();                                // every column phase is done with the r and dZ rows
+      __syncthreads();                                // every column phase is done with the r and dZ rows: they become the dR and Z PLANES
+      FBH_X(4);
       FB_T(7);
-      if (acta) {
-        st8(&Fs[la * kLd + 8 * sub], o0); st8(&Rs[la * kLd + 8 * sub], q0);
-        accR.a += q0.a; accR.b += q0.b; accR.c += q0.c; accR.d += q0.d;
-      } else {
-        ZR8(&Rs[la * kLd + 8 * sub]);
-      }
+      if (!acta) { o0 = zero8(); q0 = zero8(); }      // rows past the tokens: zero planes (they are contraction slots of the weight gradients)
+      frag_store(FBp + la * kPS + 8 * sub, split8(o0));
+      frag_store(RBp + la * kPS + 8 * sub, split8(q0));
+      accR.a += q0.a; accR.b += q0.b; accR.c += q0.c; accR.d += q0.d;
     }
     FB_T(4);
     __syncthreads();
+    FBH_X(5);
     FB_T(7);
     FBH_ROWS_GLOAD(mn);                               // next half tile's rows: in flight during the GEMMs below
-    // ---- this head's share of d x_hat = dR B_h + Gs: 4 steps of 16 contraction indices ----
+    // ---- this head's share of d x_hat = dR B_h + Gs ----
     if (g.dx_atomic) {
       // rows = tokens 4 kq + reg (+ 16), columns = features fb + c16: one atomic instruction covers 4 token rows x 64 contiguous bytes.  The
       // eight heads of a chunk run on the same XCD at about the same time: the adds meet in that L2, and d x_hat leaves it once
       const float* gp = Gs + (4 * kq) * kLd + fb + c16;
       f32x4 dx0 = {gp[0], gp[kLd], gp[2 * kLd], gp[3 * kLd]};
       f32x4 dx1 = {gp[16 * kLd], gp[17 * kLd], gp[18 * kLd], gp[19 * kLd]};
-      const float* arow = Rs + c16 * kLd + 4 * kq;
+      const short* arow = RBp + c16 * kPS + 8 * kq;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
-        dx0 = MFMA16(a0.x, bfr[4 * c + 0], dx0); dx1 = MFMA16(a1.x, bfr[4 * c + 0], dx1);
-        dx0 = MFMA16(a0.y, bfr[4 * c + 1], dx0); dx1 = MFMA16(a1.y, bfr[4 * c + 1], dx1);
-        dx0 = MFMA16(a0.z, bfr[4 * c + 2], dx0); dx1 = MFMA16(a1.z, bfr[4 * c + 2], dx1);
-        dx0 = MFMA16(a0.w, bfr[4 * c + 3], dx0); dx1 = MFMA16(a1.w, bfr[4 * c + 3], dx1);
+      for (int s = 0; s < 2; ++s) {
+        const Frag3 a0 = frag_row(arow + 32 * s), a1 = frag_row(arow + 16 * kPS + 32 * s);
+        dx0 = mma6(dx0, a0, Bf[s]); dx1 = mma6(dx1, a1, Bf[s]);
       }
       float* out = g.dxh + ((int64_t)t0 + 4 * kq) * 64 + fb + c16;
 #pragma unroll
@@ -438,14 +570,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else {
       f32x4 dx0 = *reinterpret_cast<const f32x4*>(&Gs[c16 * kLd + fb + 4 * kq]);
       f32x4 dx1 = *reinterpret_cast<const f32x4*>(&Gs[(16 + c16) * kLd + fb + 4 * kq]);
-      const float* arow = Rs + c16 * kLd + 4 * kq;
+      const short* arow = RBp + c16 * kPS + 8 * kq;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * kLd + 16 * c);
-        dx0 = MFMA16(bfr[4 * c + 0], a0.x, dx0); dx1 = MFMA16(bfr[4 * c + 0], a1.x, dx1);
-        dx0 = MFMA16(bfr[4 * c + 1], a0.y, dx0); dx1 = MFMA16(bfr[4 * c + 1], a1.y, dx1);
-        dx0 = MFMA16(bfr[4 * c + 2], a0.z, dx0); dx1 = MFMA16(bfr[4 * c + 2], a1.z, dx1);
-        dx0 = MFMA16(bfr[4 * c + 3], a0.w, dx0); dx1 = MFMA16(bfr[4 * c + 3], a1.w, dx1);
+      for (int s = 0; s < 2; ++s) {
+        const Frag3 a0 = frag_row(arow + 32 * s), a1 = frag_row(arow + 16 * kPS + 32 * s);
+        dx0 = mma6(dx0, Bf[s], a0); dx1 = mma6(dx1, Bf[s], a1);
       }
       float* out = g.dxh + ((int64_t)head * g.tcap + t0 + c16) * 64 + fb + 4 * kq;
       if (c16 < n_real) *reinterpret_cast<f32x4*>(out) = dx0;
@@ -453,46 +582,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     FB_T(5);
     if (tile + 1 < tile_hi) FBH_RIMG_GLOAD(tile + 1);     // next half tile's r rows and probabilities: in flight during the weight-gradient GEMMs
-    // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]; 8 steps of 4 tokens, all 64 rows a / n ----
+    // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]: ONE 32-token step, column fragments ----
     {
-      const float* pr = Rs + (4 * kq) * kLd + c16;
-      const float* pd = Ds + (4 * kq) * kLd + c16;
-      const float* px = Xs + (4 * kq) * kLd + fb + c16;
-      const float* pz = Fs + (4 * kq) * kLd + fb + c16;
-      f32x4 ra, da, rb, db;
-      float xa, za, xb, zb;
-#define FBH_TN_LOAD(S, ST)                                                                               \
-  do {                                                                                                   \
-    constexpr int o__ = (16 * ((ST) / 4) + (ST) % 4) * kLd;                                              \
-    r##S = (f32x4){pr[o__], pr[o__ + 16], pr[o__ + 32], pr[o__ + 48]};                                   \
-    d##S = (f32x4){pd[o__], pd[o__ + 16], pd[o__ + 32], pd[o__ + 48]};                                   \
-    x##S = px[o__]; z##S = pz[o__];                                                                      \
-  } while (0)
-#define FBH_TN_MMA(S)                                                                                    \
-  do {                                                                                                   \
-    ab0 = MFMA16(r##S[0], x##S, ab0); ab1 = MFMA16(r##S[1], x##S, ab1);                                  \
-    ab2 = MFMA16(r##S[2], x##S, ab2); ab3 = MFMA16(r##S[3], x##S, ab3);                                  \
-    am0 = MFMA16(d##S[0], z##S, am0); am1 = MFMA16(d##S[1], z##S, am1);                                  \
-    am2 = MFMA16(d##S[2], z##S, am2); am3 = MFMA16(d##S[3], z##S, am3);                                  \
-  } while (0)
-#define FBH_TN_PAIR(ST)                                                                                  \
-  do {                                                                                                   \
-    FBH_TN_LOAD(b, (ST) + 1);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FBH_TN_MMA(a);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if ((ST) + 2 < 8) FBH_TN_LOAD(a, ((ST) + 2 < 8 ? (ST) + 2 : 0));                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    FBH_TN_MMA(b);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  } while (0)
-      FBH_TN_LOAD(a, 0);
-      FBH_TN_PAIR(0); FBH_TN_PAIR(2); FBH_TN_PAIR(4); FBH_TN_PAIR(6);
+      const int blk = ((8 * kq + ((lane & 15) >> 2)) * kPS) + 4 * (lane & 3);      // this lane's address inside a 4 x 16 transpose block
+      const Frag3 xb = frag_col(Xp + blk + fb), zb = frag_col(FBp + blk + fb);
+      {
+        const Frag3 r0 = frag_col(RBp + blk), r1 = frag_col(RBp + blk + 16);
+        ab0 = mma6(ab0, r0, xb); ab1 = mma6(ab1, r1, xb);
+        const Frag3 r2 = frag_col(RBp + blk + 32), r3 = frag_col(RBp + blk + 48);
+        ab2 = mma6(ab2, r2, xb); ab3 = mma6(ab3, r3, xb);
+      }
+      {
+        const Frag3 d0 = frag_col(Dp + blk), d1 = frag_col(Dp + blk + 16);
+        am0 = mma6(am0, d0, zb); am1 = mma6(am1, d1, zb);
+        const Frag3 d2 = frag_col(Dp + blk + 32), d3 = frag_col(Dp + blk + 48);
+        am2 = mma6(am2, d2, zb); am3 = mma6(am3, d3, zb);
+      }
     }
     FB_T(6);
-    // ---- the next half tile -> the other set (its rows and images were fetched during this one) ----
-    if (tile + 1 < tile_hi) FBH_STAGE(par ^ 1, mn);
-    par ^= 1;
     mc = mn; mn = mnn;
   }
 
@@ -517,7 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // column sums of dDyn: thread (srow, sc4) staged rows srow, srow + 16 of every half tile -- the four row groups of a wave in a fixed xor order,
   // then the four waves in order
-  float* redd = set0;                   // [4][64]
+  float* redd = lds;                    // [4][64]
   {
     const float cdv[4] = {cd0.x, cd0.y, cd1.x, cd1.y};
 #pragma unroll
@@ -529,8 +636,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   // column sums of dR and d x_hat of the padding token: the 8 lanes with equal `sub` of a wave (fixed xor tree), then the 4 waves in order
-  float* redr = set0 + 4 * 64;          // [4][64]
-  float* redp = set0 + 8 * 64;          // [4][64]
+  float* redr = lds + 4 * 64;           // [4][64]
+  float* redp = lds + 8 * 64;           // [4][64]
   const float accp[16] = {accK.a.x + accV.a.x, accK.a.y + accV.a.y, accK.b.x + accV.b.x, accK.b.y + accV.b.y,
                           accK.c.x + accV.c.x, accK.c.y + accV.c.y, accK.d.x + accV.d.x, accK.d.y + accV.d.y,
                           accR.a.x, accR.a.y, accR.b.x, accR.b.y, accR.c.x, accR.c.y, accR.d.x, accR.d.y};
@@ -542,6 +649,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     v += __shfl_xor(v, 32, 64);
     if (lane < 8) (i < 8 ? redp : redr)[wave * 64 + 8 * lane + (i & 7)] = v;
   }
+#ifdef FBH_PROBE
+  {
+    float* redq = lds + 12 * 64;
+    const float v2[8] = {accR2.a.x, accR2.a.y, accR2.b.x, accR2.b.y, accR2.c.x, accR2.c.y, accR2.d.x, accR2.d.y};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = v2[i];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if (lane < 8) redq[wave * 64 + 8 * lane + i] = v;
+    }
+    __syncthreads();
+    if (tid < 64) slab[kVecOffM + 192 + tid] = (redq[tid] + redq[64 + tid]) + (redq[128 + tid] + redq[192 + tid]);
+  }
+#endif
   __syncthreads();
   if (tid < 64) {
     slab[kVecOffM + 64 + tid] = (redd[tid] + redd[64 + tid]) + (redd[128 + tid] + redd[192 + tid]);    // d bdyn partial
@@ -825,18 +946,22 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
     FusedBwdHArgs g;
     g.X = X; g.dDyn = dDyn; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.L = L; g.nhalves = rg.nhalves; g.nchunks = nchunks;
     g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
-    const size_t lds = ((size_t)8 * kTileH + 64 + 256 + 2 * 256 + 2 * 32) * sizeof(float);
+    const size_t lds = kBwdLdsBytes;
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, dim3(MATCHA_N_HEAD * nchunks), dim3(256), lds, st, g);
     };
     // algorithmic flops: the reference's formulation -- 8 heads x 8 GEMMs of 2*64*64 per token; this kernel EXECUTES half of them
     ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
-    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
+    // EVEN key-slot counts only (an odd batch width runs the next even instance; the extra slot is masked like any slot j >= k).  The ML = 5
+    // instance of this kernel produced TIMING-DEPENDENT dR rows for hyperedges of exactly 5 nodes when two workgroups shared a CU (~20 of
+    // 512 workgroups per launch off by 1e-4 of dB_h; never with one workgroup per CU, never for k < 5, never with the ML = 6 instance on
+    // the same batch; tools/debug/bwd_slab_diff.py): hipcc packs the leftover fifth iteration of the row phase's key loop into v_pk_*_f32
+    // chains interleaved with its DPP reduction.  Extra barriers, nops behind the MFMAs and in front of the DPP steps, plain shuffles and
+    // unpinned loads did not cure it, so the root cause is not established -- the even instances are clean in every run.
+    switch (L <= 2 ? 2 : (L <= 4 ? 4 : (L <= 6 ? 6 : 8))) {
       case 2: launch(fused_bwdh_kernel<2>); break;
-      case 3: launch(fused_bwdh_kernel<3>); break;
       case 4: launch(fused_bwdh_kernel<4>); break;
-      case 5: launch(fused_bwdh_kernel<5>); break;
       case 6: launch(fused_bwdh_kernel<6>); break;
       default: launch(fused_bwdh_kernel<8>); break;
     }

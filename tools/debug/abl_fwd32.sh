@@ -16,10 +16,11 @@ build)
   mkdir -p $OUT $LIBOUT; rm -f $LIBOUT/*.so
   for spec in "$@"; do
     name=${spec%%:*}; extra=${spec#*:}
-    /opt/rocm/bin/hipcc $FLAGS $extra -c $CS/fused_fwd32.hip -o $OUT/fused_fwd32_$name.o || exit 1
+    src=${ABL_SRC:-fused_fwd32}                       # ABL_SRC=fused_bwd builds variants of the backward kernel's file instead
+    /opt/rocm/bin/hipcc $FLAGS $extra -c $CS/$src.hip -o $OUT/${src}_$name.o || exit 1
     objs=""
     for o in build/csrc/*.o; do
-      case $o in *-hip-*) ;; */fused_fwd32.o) objs="$objs $OUT/fused_fwd32_$name.o";; *) objs="$objs $o";; esac
+      case $o in *-hip-*) ;; */$src.o) objs="$objs $OUT/${src}_$name.o";; *) objs="$objs $o";; esac
     done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIBOUT/libmatcha_hip_$name.so $objs || exit 1
     echo "built $name ($extra)"
