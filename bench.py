@@ -41,6 +41,13 @@ from matcha_amd import _lib, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: measured float4 copy (read + write)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA peak (no xf32/TF32 on gfx950)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
+# Round 5: the fused embed_dim-64 kernels and the wide GEMMs of embed_dim >= 128 compute every f32 product as SIX bf16 MFMAs over three bf16
+# planes per operand (v = h + m + l to 2^-27, f32 accumulate: fp32-accurate) -- 6 x 32 cycles on the matrix pipe instead of
+# 8 x 64 on the vector ALUs.  `achieved` / `frac` stay what the contract defines (the reference formulation's ALGORITHMIC f32 flops over the
+# kernel's time, against the f32 MFMA peak the dtype names) and may now exceed 1; `frac_bf16_pipe` is what the silicon's matrix pipe does:
+# executed plane-product flops (6 per executed f32 flop) against the dense bf16 peak.
+BF16X3_FLOPS_PER_F32_FLOP = 6.0
 # MFMA-bound kernel classes.  The fused kernels count ALGORITHMIC GEMM flops only: fused_fwd 4 projections per
 # head + the two pff GEMMs; fused_bwd 8 GEMMs per head (dO, dWfc1, 3 dW', 3 d x_hat terms) -- the Q/K/V recompute of the
 # backward kernel and the O(k) attention arithmetic are not counted.
@@ -97,6 +104,14 @@ def make_model(front_end, dim, num, device):
     torch.manual_seed(0)
     if front_end == "table":
         ne = M.Wrap_Embedding(N + 1, d, padding_idx=0)
+    elif N > 10000:
+        # hg38 100 kb (BASELINE configs[3] in the reference's own mode, main.py:609-613): correlation-like features (one [n_c, n_c] block
+        # per chromosome, 190 MB) and a sparse positive inter matrix (3.7 GB), generated on the device -- the host generator of
+        # synth.make_adjacency would need two dense N x N float32 matrices
+        gen = torch.Generator(device=device).manual_seed(9)
+        feats = [torch.rand((n, n), device=device, generator=gen) * 2 - 1 for n in num]
+        inter = torch.rand((N, N), device=device, generator=gen) * (torch.rand((N, N), device=device, generator=gen) < 0.3)
+        ne = M.MultipleEmbedding(feats, d, False, torch.as_tensor(np.cumsum(num)), synth.chrom_range(num), inter)
     else:
         intra, inter = synth.make_adjacency(np.random.default_rng(2), num)
         cr = synth.chrom_range(num)
@@ -118,6 +133,13 @@ def executed_fraction(lib, kernel_class, dim):
             and lib.matcha_get_option(b"disable_fused") == 0:
         return EXECUTED_FRACTION_MERGED[kernel_class]
     return 1.0
+
+
+def bf16x3_class(lib, kernel_class, dim):
+    """Does this kernel class run its products as 3 x bf16 split-operand MFMAs (round 5)?"""
+    if dim == 64:
+        return kernel_class in ("fused_fwd", "fused_bwd") and lib.matcha_get_option(b"disable_fused") == 0 and lib.matcha_get_option(b"disable_merged") == 0
+    return dim >= 128 and kernel_class in ("gemm_nt", "gemm_nn", "gemm_tn") and lib.matcha_get_option(b"disable_wide_gemm") == 0
 
 
 def csrc_sha16():
@@ -314,7 +336,16 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
                 roof["executed_tflops"] = round(ach * ex, 3)
                 roof["frac_executed"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
                 roof["mfma_util_pmc"] = None
-                if ex < 1.0:
+                if bf16x3_class(lib, prof_cls, dim):
+                    roof["matrix_pipe"] = "bf16, 3 planes per f32 operand, 6 plane products per f32 product, f32 accumulate (fp32-accurate)"
+                    roof["executed_bf16_tflops"] = round(ach * ex * BF16X3_FLOPS_PER_F32_FLOP, 2)
+                    roof["peak_bf16_dense"] = MFMA_BF16_PEAK_TFLOPS
+                    roof["frac_bf16_pipe"] = round(ach * ex * BF16X3_FLOPS_PER_F32_FLOP / MFMA_BF16_PEAK_TFLOPS, 4)
+                    roof["note"] = ("frac = the reference formulation's algorithmic f32 flops / time / the f32 MFMA peak (the contract's figure; it can exceed 1: "
+                                    "the products no longer run on the f32 pipe); merged heads execute executed_fraction of those products, each as 6 bf16 "
+                                    "MFMAs: frac_bf16_pipe = executed plane-product flops / time / the dense bf16 peak is what the matrix pipe does -- the "
+                                    "kernel is bound by its vector work (attention, operand splits), not by the matrix pipe (DESIGN.md §4.0, §5)")
+                elif ex < 1.0:
                     roof["note"] = ("frac = the reference formulation's algorithmic flops / time / peak; merged heads execute "
                                     "executed_fraction of them: frac_executed is what the silicon does (DESIGN.md §4.1)")
             else:
@@ -385,11 +416,16 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             ach = work / (ms_step * 1e-3) / 1e12
             roof_all[name] = dict(bound="mfma", ms_per_step=round(ms_step, 4), achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
             ex = executed_fraction(lib, name, dim)
-            if ex < 1.0:
+            if bf16x3_class(lib, name, dim):
+                roof_all[name]["frac_bf16_pipe"] = round(ach * ex * BF16X3_FLOPS_PER_F32_FLOP / MFMA_BF16_PEAK_TFLOPS, 4)
+            elif ex < 1.0:
                 roof_all[name]["executed_frac_of_peak"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
         else:
             ach = work / (ms_step * 1e-3) / 1e9
             roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+            if name == "adamw":
+                # SURVEY §8 d4 prices the update at 28 B per element (p, g, m, v read; p, m, v written); the kernel also zeroes g (zero_grad): 32 B moved
+                roof_all[name]["frac_incl_grad_zeroing_32B"] = round(ach * 32.0 / 28.0 / HBM_PEAK_GBS, 4)
     out = dict(B=B, P=P, L=L, N=N, elapsed=elapsed, windows=win, roof=roof, roof_all=roof_all, class_ms=class_ms, model_only_ms=model_only_ms, losses=losses,
                pool=pool, wts=None if pool is None else wts, num=num, known_edges=workload_edges, sparse_exchange=bool(trainer._sparse),
                exhausted_negatives=exhausted, comm_bytes=dict(trainer.comm_bytes), overlap=bool(trainer._side is not None and trainer._overlap()),
@@ -582,7 +618,8 @@ def main():
                           "ms_per_step_min": round(min(m["windows"]) / args.steps * 1e3, 4),
                           "ms_per_step_max": round(max(m["windows"]) / args.steps * 1e3, 4)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "dtype_note": "f32 in, f32 accumulate; the matrix products run as 3 x bf16 split-operand MFMAs (fp32-accurate: tests/test_cpu_bf16x3.py)",
+        "data": "synthetic",
         "config": {"workload": f"{args.layout} bins (N={N}), k in {{{args.ks}}} mixed-k zero-padded to L={L}, embed_dim={args.dim}, "
                                f"front end={args.front_end}, neg_num=3, dropout on, AdamW lr=1e-3, {m['known_edges']} known hyperedges",
                    "rows_per_gpu_per_step": B, "positives_per_gpu_per_step": P, "global_rows_per_step": B * world,
@@ -615,7 +652,10 @@ def main():
                             # the reference's own set-up (main.py:609-613 builds MultipleEmbedding = the adj front end; 96 positives x (1 + 3) rows per step;
                             # 80 ms per such step on 8 CPU cores)
                             ("reference_batch_384_rows_adj", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="adj")),
-                            ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table")),
+                            ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table", prof="auto")),
+                            # the same configuration in the mode the reference itself would run there (MultipleEmbedding: per-chromosome gather-GEMMs
+                            # over up to 2 491 feature columns + the reconstruction branch); embed_dim 128 takes the unfused adj kernels (adj_frontend.hip)
+                            ("configs3_hg38_100kb_d128_adj", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="adj", prof="auto")),
                             # BASELINE configs[4] at its FULL size: 1 M nodes, 100 M known hyperedges (generated, hashed and CSR-sharded on the
                             # device), k in {2..8}, d = 256.  kernel classes on: the HBM-bound part of this step is the dense AdamW over
                             # the 1 M x 256 table + the gather + the scatter (hbm_bound_share)
@@ -630,7 +670,13 @@ def main():
                                                            edges=10_000_000, zipf=True))):
                 kw = dict(kw)
                 kw.setdefault("prof", "none")
-                e = run_workload(dist, steps=8, warmup=3, model_only=False, windows=3, **kw)
+                try:
+                    e = run_workload(dist, steps=8, warmup=3, model_only=False, windows=3, **kw)
+                except Exception as exc:      # an extra point never costs the headline line
+                    extras[key] = {"error": repr(exc)[:300]}
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    continue
                 extras[key] = {"hyperedges_per_s": round(e["B"] * 8 / e["elapsed"], 1), "ms_per_step": round(e["elapsed"] / 8 * 1e3, 4),
                                "rows_per_step": e["B"], "known_hyperedges": e["known_edges"], "steps": 8, "windows": 3,
                                "exhausted_negatives": e["exhausted_negatives"]}
@@ -639,8 +685,8 @@ def main():
                     extras[key]["kernel_class_ms_per_step"] = {k: round(v, 4) for k, v in top}
                     hb = sum(e["class_ms"].get(k, 0.0) for k in ("adamw", "embed_fwd", "embed_scatter", "front_fwd", "front_bwd"))
                     extras[key]["hbm_bound_share"] = round(hb / (e["elapsed"] / 8 * 1e3), 4)
-                    extras[key]["roofline_by_kernel_class"] = {k: v for k, v in e["roof_all"].items() if k in ("adamw", "embed_fwd", "embed_scatter",
-                                                                                                            "adj_encode", "adj_recon", "adj_bwd")}
+                    extras[key]["roofline_by_kernel_class"] = {k: v for k, v in e["roof_all"].items() if k in ("adamw", "embed_fwd", "embed_scatter", "adj_encode", "adj_recon",
+                                                                                                            "adj_bwd", "gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd")}
             # the reference's DRIVER flow on the clock (main.py:119-197, :261-342; tools/epoch_bench.py): matcha_amd.train running a phase-2
             # epoch at the reference's batch (96 + 288 rows per step) -- DataGenerator, batch assembly, sampler, step, metrics, save_embeddings;
             # a quarter epoch here (250 steps per size), the full 4 x 1000 steps with the CPU estimate in profiles/rNN_epoch_bench.jsonl

@@ -204,7 +204,8 @@ typedef struct matcha_step_opts {
                                 Modules.py:192, read by the kernels when they run -- a step captured in a hipGraph then replays with a new
                                 draw every time the caller rewrites the cell (random_chrom itself is a launch parameter and would be
                                 frozen into the graph).  Honoured by the fused adj front end (embed_dim 64, feat_row_pad 64:
-                                matcha_random_chrom_dev_supported); other shapes return MATCHA_EINVAL                              */
+                                matcha_random_chrom_dev_supported); other shapes return MATCHA_EINVAL.  Valid range [0, n_chrom): any other
+                                value in the cell means "no reconstruction branch" (loss 0, no gradient), like random_chrom = -1   */
 } matcha_step_opts;
 
 /* 1 if matcha_forward / matcha_backward honour opts->random_chrom_dev for this shape and these frozen inputs (table mode: always --

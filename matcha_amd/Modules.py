@@ -395,6 +395,9 @@ class _Runtime:
         self.n_touched = 2 + 2 * self.n_chrom
         # frozen inputs
         self.attr_table = attr_mod.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
+        # the kernels work on a (padded) COPY of this frozen table and on structure decided from it once: remember which tensor state that was
+        self._attr_src = attr_mod.weight
+        self._attr_src_state = (attr_mod.weight.data_ptr(), attr_mod.weight._version)
         self._keep = [self.attr_table]
         self.frozen = _lib.Frozen()
         self.frozen.attr_table = self.attr_table.data_ptr()
@@ -469,6 +472,11 @@ class _Runtime:
         return t
 
     def still_packed(self) -> bool:
+        """The live parameters still sit where the kernels were told, and the frozen attribute table has not been rewritten in place
+        (load_state_dict after the first forward: the runtime holds a padded copy and a cached structure decision) -- otherwise the
+        owner rebuilds the runtime."""
+        if (self._attr_src.data_ptr(), self._attr_src._version) != self._attr_src_state:
+            return False
         return all(p.data_ptr() == e for p, e in zip(self.live, self.expected_ptrs))
 
     def workspace(self, B: int, L: int, forward_only: bool = False) -> torch.Tensor:

@@ -97,7 +97,7 @@ extern "C" int matcha_adamw_step(float* params, float* grads, float* exp_avg, fl
   if (n == 0) return MATCHA_OK;
   // python-double scalars rounded to f32 once, as torch does for `1 - lr*wd`, `1 - beta1`, `1 - beta2`
   const float decay = (float)(1.0 - lr * weight_decay);
-  ProfScope ps(MATCHA_PROF_ADAMW, 32.0 * (double)n, st);   // p,g,m,v read + written (g := 0)
+  ProfScope ps(MATCHA_PROF_ADAMW, 28.0 * (double)n, st);   // p, g, m, v read + p, m, v written (the kernel also writes g := 0: 32 B moved)
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
                      seg_off, n_seg, seg_coef, decay, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);
   MATCHA_CHECK_LAUNCH("adamw_kernel");

@@ -312,6 +312,7 @@ struct AdjReconArgs {
   int64_t n_nodes;
   int r, lo_r, n_r;
   const int32_t *r_dev, *bounds;      // opts->random_chrom_dev: the chromosome is read here (graph replay), its range from bounds
+  int C;                              // number of chromosomes: a device-side value outside [0, C) means: no reconstruction branch
   float* dnr;                         // GRAD: [sorted rows][64] = (d loss / d node) of the branch, unscaled
   float *gW, *gb;                     // GRAD: unscaled head gradient [n_r][64], [n_r] (zeroed by the caller; float atomics)
   float* slab;                        // per-workgroup partial sums of the squared residuals
@@ -320,7 +321,12 @@ struct AdjReconArgs {
 template <bool GRAD>
 __global__ __launch_bounds__(256, 2) void adj_recon_kernel(AdjReconArgs g) {
   if (g.r_dev) {
-    g.r = *g.r_dev; g.lo_r = g.bounds[g.r]; g.n_r = g.bounds[g.r + 1] - g.lo_r;
+    const int rv = *g.r_dev;
+    if (rv < 0 || rv >= g.C) {                    // like the host-int path's random_chrom = -1 (adj_scan_kernel clamps the same way): no branch, loss 0
+      if (threadIdx.x == 0) g.slab[blockIdx.x] = 0.f;
+      return;
+    }
+    g.r = rv; g.lo_r = g.bounds[g.r]; g.n_r = g.bounds[g.r + 1] - g.lo_r;
     g.Wr += (int64_t)64 * g.lo_r; g.br += g.lo_r;
   }
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -500,10 +506,15 @@ __global__ __launch_bounds__(256, 2) void adj_recon_kernel(AdjReconArgs g) {
 
 // recon_loss = 100 * sum / (m * n_r)  (mean over columns, mean over rows, * 100; Modules.py:199), 0 when m == 0 (:195)
 __global__ __launch_bounds__(256) void adj_recon_sum_kernel(const float* __restrict__ slab, int nslab, const int32_t* __restrict__ counts, int n_r,
-                                                            float* __restrict__ out, const int32_t* __restrict__ r_dev, const int32_t* __restrict__ bounds) {
+                                                            float* __restrict__ out, const int32_t* __restrict__ r_dev, const int32_t* __restrict__ bounds, int C) {
   __shared__ float red[256];
-  if (r_dev) { const int r = *r_dev; n_r = bounds[r + 1] - bounds[r]; }
-  const int m = counts[0];
+  bool valid = true;
+  if (r_dev) {
+    const int r = *r_dev;
+    valid = r >= 0 && r < C;
+    if (valid) n_r = bounds[r + 1] - bounds[r];
+  }
+  const int m = valid ? counts[0] : 0;
   float s = 0.f;
   for (int i = threadIdx.x; i < nslab; i += 256) s += slab[i];
   red[threadIdx.x] = s;
@@ -609,8 +620,10 @@ __global__ __launch_bounds__(256, 2) void adj_fused_bwd_kernel(AdjBwdArgs g) {
   uint32_t key = 0, thr = 0;
   float keep_scale = 1.f;
   if (drop) { key = rng_key(*g.seed, kStreamDropAdj); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
-  const int r_chrom = g.r_dev ? *g.r_dev : g.r;
-  const bool with_r = g.dnr != nullptr && c != r_chrom;
+  int r_chrom = g.r;
+  bool r_valid = true;
+  if (g.r_dev) { r_chrom = *g.r_dev; r_valid = r_chrom >= 0 && r_chrom < g.C; }      // outside [0, C): no reconstruction branch ran (adj_recon_kernel)
+  const bool with_r = g.dnr != nullptr && r_valid && c != r_chrom;
   const float gsc = with_r ? (g.drecon ? g.drecon[0] : g.beta) : 0.f;
   {
     const float* W1 = g.w1 + (int64_t)c * 4096;
@@ -838,7 +851,7 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
   memset(&b, 0, sizeof(b));
   b.ids = ids; b.order = w.order; b.seg = w.seg; b.counts = w.counts; b.TH = w.TH; b.Wr = p.recon_w + (int64_t)64 * lo_r; b.br = p.recon_b + lo_r;
   b.inter = f.inter; b.n_nodes = s.n_nodes; b.r = r_chrom; b.lo_r = lo_r; b.n_r = n_r; b.dnr = w.dTH; b.gW = w.rgrad; b.gb = w.rgrad + w.nr_pad * 64;
-  b.slab = w.lossslab; b.r_dev = r_dev; b.bounds = f.bounds;
+  b.slab = w.lossslab; b.r_dev = r_dev; b.bounds = f.bounds; b.C = s.n_chrom;
   int rgrid = (int)cdiv(T, 64);
   if (rgrid > 512) rgrid = 512;
   const size_t rlds = (size_t)3 * kTile * sizeof(float);
@@ -854,7 +867,7 @@ int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matc
     hipLaunchKernelGGL(k, dim3(rgrid), dim3(256), rlds, st, b);
   }
   MATCHA_CHECK_LAUNCH("adj_recon_kernel");
-  hipLaunchKernelGGL(adj_recon_sum_kernel, dim3(1), dim3(256), 0, st, w.lossslab, rgrid, w.counts, n_r, recon_out, r_dev, f.bounds);
+  hipLaunchKernelGGL(adj_recon_sum_kernel, dim3(1), dim3(256), 0, st, w.lossslab, rgrid, w.counts, n_r, recon_out, r_dev, f.bounds, (int)s.n_chrom);
   MATCHA_CHECK_LAUNCH("adj_recon_sum_kernel");
   return MATCHA_OK;
 }

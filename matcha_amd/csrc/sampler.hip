@@ -268,6 +268,7 @@ extern "C" int matcha_neg_sample(const void* set, const int64_t* set_edges, int6
                                  const int32_t* node2chrom, int32_t n_nodes, const int32_t* chrom_range, int32_t n_chrom,
                                  const uint64_t* seed, int64_t* neg, int32_t* status, matcha_stream_t stream) {
   MATCHA_CHECK_ARG(pos && neg && node2chrom && chrom_range && seed, "matcha_neg_sample: null pointer");
+  MATCHA_CHECK_ARG(((uintptr_t)chrom_range) % 8 == 0, "matcha_neg_sample: chrom_range must be 8-byte aligned (the kernel reads [lo, hi] pairs as one int2)");
   MATCHA_CHECK_ARG(n_nodes >= 1 && n_chrom >= 1, "matcha_neg_sample: n_nodes=%d n_chrom=%d", n_nodes, n_chrom);
   MATCHA_CHECK_ARG(n_set_edges == 0 || (set && set_edges), "matcha_neg_sample: non-empty set without buffers");
   MATCHA_CHECK_ARG(L >= 1 && L <= MATCHA_MAX_L && neg_num >= 1, "matcha_neg_sample: L=%d neg_num=%d", L, neg_num);

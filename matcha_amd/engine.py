@@ -296,6 +296,27 @@ class Trainer:
         _lib.check(self.lib.matcha_scatter_rows(_lib.ptr(ids_all), _lib.ptr(rows_all), n, d, rt.n_nodes, _lib.ptr(self.gflat), _lib.ptr(xws),
                                                 xws.numel(), rt.stream()), "matcha_scatter_rows")
 
+    def eval_forward(self, x, y, w, random_chrom=0):
+        """Forward + weighted BCE + reconstruction loss only (eval_epoch, main.py:200-258): no dropout, nothing kept for a backward, the
+        compact forward workspace.  Returns the logits [B]; ``self.losses`` holds (bce, recon, rows of the recon mean).  Nothing
+        synchronises and nothing allocates after the first call of a shape, so the call can be captured in a hipGraph (train.py)."""
+        rt = self.rt
+        if not rt.still_packed():
+            raise _lib.MatchaHipError("model parameters moved after the Trainer was built; create a new Trainer")
+        B, L = x.shape
+        key = (B, L, "eval")
+        if key not in self._ws:
+            self._ws[key] = rt.workspace(B, L, forward_only=True)
+            self._logits[key] = torch.empty(B, dtype=torch.float32, device=rt.device)
+        ws, logits = self._ws[key], self._logits[key]
+        opts = self._opts(1.0, 1.0, random_chrom)
+        opts.training, opts.forward_only, opts.loss_in_forward = 0, 1, 0
+        opts.sparse_table_grad, opts.deterministic = 0, 0
+        _lib.check(self.lib.matcha_forward(C.byref(rt.shape), C.byref(rt.params), C.byref(rt.frozen), C.byref(opts), _lib.ptr(x), B, L,
+                                           _lib.ptr(y), _lib.ptr(w), _lib.ptr(logits), _lib.ptr(self.losses), _lib.ptr(ws), ws.numel(),
+                                           rt.stream()), "matcha_forward")
+        return logits
+
     def optimizer_step(self):
         rt = self.rt
         _lib.check(self.lib.matcha_adamw_step(_lib.ptr(rt.flat), _lib.ptr(self.gflat), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),

@@ -125,12 +125,16 @@ class Session:
         self.n_chrom = len(chrom_range)
         self.rank, self.world = _dist()
         self.trainer = Trainer(model, lr=1e-3, base_seed=seed, deterministic=deterministic)      # AdamW(lr=1e-3), main.py:630
+        self._generation = 0          # bumped whenever the trainer or the sampler is replaced: a captured step belongs to ONE pair of them
         self.set_known(None)
         self.rng = np.random.default_rng(seed)
 
     def new_optimizer(self):
         """main.py:671 builds a fresh AdamW (moments and step counts reset) for phase 2."""
         self.trainer = Trainer(self.model, lr=1e-3, base_seed=int(self.rng.integers(1 << 30)), deterministic=self.deterministic)
+        self._generation += 1
+        self.__dict__.pop("_graph_state", None)
+        self.__dict__.pop("_eval_state", None)
 
     def set_known(self, edges: Optional[np.ndarray]):
         """The 'dict' negatives are checked against (main.py:589 empty sets in phase 1; build_hash at :664)."""
@@ -141,6 +145,9 @@ class Session:
         # the draw is rank-shared (numpy's global stream is); the rank offset gives every rank its own negative stream
         self.sampler = NegativeSampler(hs, self.node2chrom, self.chrom_range, neg_num=NEG_NUM, min_dis=self.min_dis,
                                        seed=int(np.random.randint(1 << 30)) + 7919 * self.rank)
+        self._generation = getattr(self, "_generation", 0) + 1
+        self.__dict__.pop("_graph_state", None)         # a captured step has the old sampler's tables and seed baked in
+        self.__dict__.pop("_eval_state", None)
 
     def make_batch(self, pos: torch.Tensor, pos_w: torch.Tensor):
         """generate_negative's output (main.py:443-448): x = [pos; neg], y = [1..; 0..], w = [pos_w..; 1..]."""
@@ -174,8 +181,13 @@ class Session:
         dev, L, B = self.dev, int(e.shape[1]), P * (1 + NEG_NUM)
         # the chromosome of every step's reconstruction branch, drawn exactly as the step-by-step loop draws them (Modules.py:192)
         chroms = np.asarray([self.random_chrom() for _ in range(n_batch)], dtype=np.int32)
-        key = (n_batch, P, L, float(alpha), float(beta), id(self.trainer), id(self.sampler))
+        # (a monotonically increasing generation, not id(): CPython reuses the id of a freed Trainer / sampler)
+        key = (n_batch, P, L, float(alpha), float(beta), self._generation)
         st = self.__dict__.get("_graph_state")
+        if st is not None and not self.trainer.rt.still_packed():
+            # parameters moved since the capture (model.to(), a rebuilt runtime): the graph would train the old buffers -- as
+            # Trainer.forward_backward refuses to
+            raise _lib.MatchaHipError("model parameters moved after the step was captured; create a new Session / Trainer")
         if st is None or st["key"] != key:
             st = dict(key=key, graph=None,
                       pos=torch.empty((n_batch * P, L), dtype=torch.long, device=dev), w=torch.empty(n_batch * P, dtype=torch.float32, device=dev),
@@ -233,6 +245,57 @@ class Session:
         for _ in range(n_batch - done):
             st["graph"].replay()
         return st["sums"][0], st["sums"][1], st["preds"], st["y"], st["sizes"]
+
+
+def _graph_eval(sess: Session, e: torch.Tensor, w: torch.Tensor, n_batch: int, P: int):
+    """eval_epoch's loop as replays of ONE captured forward-only step (round 5): device-side batch selection
+    (matcha_step_select), negative sampling, matcha_forward(forward_only) with the loss inside, matcha_step_record.  Same device-side
+    state machine as Session.graph_epoch; returns (bce_sum, recon_sum, preds [n_batch, B], labels [B], sizes [n_batch, B])."""
+    dev, L, B = sess.dev, int(e.shape[1]), P * (1 + NEG_NUM)
+    chroms = np.asarray([sess.random_chrom() for _ in range(n_batch)], dtype=np.int32)          # Modules.py:192, one draw per forward
+    key = (n_batch, P, L, sess._generation)
+    st = sess.__dict__.get("_eval_state")
+    if st is None or st["key"] != key:
+        st = dict(key=key, graph=None,
+                  pos=torch.empty((n_batch * P, L), dtype=torch.long, device=dev), w=torch.empty(n_batch * P, dtype=torch.float32, device=dev),
+                  chroms=torch.empty(n_batch, dtype=torch.int32, device=dev), cell=torch.zeros(1, dtype=torch.int32, device=dev),
+                  it=torch.zeros(1, dtype=torch.long, device=dev), x=torch.zeros((B, L), dtype=torch.long, device=dev),
+                  y=torch.cat([torch.ones(P, device=dev), torch.zeros(B - P, device=dev)]), ww=torch.ones(B, dtype=torch.float32, device=dev),
+                  preds=torch.empty((n_batch, B), dtype=torch.float32, device=dev), sizes=torch.empty((n_batch, B), dtype=torch.long, device=dev),
+                  sums=torch.zeros(2, dtype=torch.float32, device=dev))
+        sess._eval_state = st
+    st["pos"].copy_(e[:n_batch * P]); st["w"].copy_(w[:n_batch * P]); st["chroms"].copy_(torch.from_numpy(chroms))
+    st["it"].zero_(); st["sums"].zero_()
+    lib = _lib.load()
+    n_rows = n_batch * P
+    tr = sess.trainer
+
+    def one_step():
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.matcha_step_select(_lib.ptr(st["pos"]), _lib.ptr(st["w"]), n_rows, L, _lib.ptr(st["it"]), P, _lib.ptr(st["x"]), _lib.ptr(st["ww"]),
+                                          _lib.ptr(st["chroms"]), n_batch, _lib.ptr(st["cell"]), _lib.ptr(sess.sampler.seed), _lib.ptr(tr.seed), stream),
+                   "matcha_step_select")
+        sess.sampler.sample_into(st["x"][:P], st["x"][P:], advance_seed=False)
+        logits = tr.eval_forward(st["x"], st["y"], st["ww"], random_chrom=st["cell"])
+        _lib.check(lib.matcha_step_record(_lib.ptr(logits), _lib.ptr(tr.losses), _lib.ptr(st["x"]), B, L, _lib.ptr(st["it"]), n_batch, _lib.ptr(st["sums"]),
+                                          _lib.ptr(st["preds"]), _lib.ptr(st["sizes"]), stream), "matcha_step_record")
+
+    done = 0
+    if st["graph"] is None:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(min(2, n_batch)):
+                one_step()
+                done += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step()
+        st["graph"] = g
+    for _ in range(n_batch - done):
+        st["graph"].replay()
+    return st["sums"][0], st["sums"][1], st["preds"], st["y"], st["sizes"]
 
 
 def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: float, beta: float, batch_size: int = BATCH_SIZE):
@@ -316,6 +379,18 @@ def eval_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, batch_size
     perm = torch.from_numpy(np.random.permutation(len(e))[:max_rows]).to(dev)   # rank-shared stream: every rank evaluates the same rows
     e, w = e[perm], w[perm]
     n_batch = len(e) // batch_size
+    tm = sess.__dict__.setdefault("timing", {})
+    t_loop = time.perf_counter()
+    if n_batch > 0 and sess.graph_ok(1.0):
+        # the forward-only step captured once and replayed per batch (the training epoch's mechanism); metrics as in _epoch_metrics
+        bce_t, rec_t, p2, y1, s2 = _graph_eval(sess, e, w, n_batch, batch_size)
+        pred, label, size = p2.reshape(-1), y1.repeat(n_batch), s2.reshape(-1)
+        torch.cuda.synchronize(dev)
+        tm["eval_loop_s"] = time.perf_counter() - t_loop
+        sess.trainer.check_status()
+        auc, aupr = U.roc_auc_cuda(label, pred, size, sess.max_size)
+        acc = U.accuracy(pred, label, size, sess.max_size)
+        return float(bce_t) / n_batch, float(rec_t) / n_batch, acc, auc, aupr
     bce_sum, rec_sum = torch.zeros((), device=dev), torch.zeros((), device=dev)
     preds, labels, sizes = [], [], []
     with model.deferred_id_check():                     # nothing synchronises inside the loop; ids are checked once behind it

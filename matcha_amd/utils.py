@@ -64,6 +64,9 @@ def _auc_ap(y: torch.Tensor, p: torch.Tensor):
     AP = sum_i (R_i - R_{i-1}) P_i over the distinct thresholds, R_{-1} = 0.  ValueError with one class only, like sklearn."""
     if y.numel() == 0:
         raise ValueError("no samples")
+    if not bool(torch.isfinite(p).all()):
+        # sklearn's input validation: the reference's `except` then logs (0.0, 0.0) for the epoch -- a diverged run must not look like a score
+        raise ValueError("Input contains NaN or infinity.")
     fps, tps = _binary_counts(y, p)
     n_pos, n_neg = float(tps[-1]), float(fps[-1])
     if n_pos <= 0 or n_neg <= 0:

@@ -49,3 +49,15 @@ def test_one_class_subset_gives_the_reference_failure_value():
     assert U.roc_auc_cuda(y, p, s, 3) == (0.0, 0.0)
     with pytest.raises(ValueError):
         U._auc_ap(torch.tensor([True, True]), torch.tensor([0.1, 0.2]))
+
+
+def test_non_finite_scores_give_the_reference_failure_value():
+    """sklearn refuses NaN / inf scores, so the reference's `except` logs (0.0, 0.0) for such an epoch (utils.py:32-54): a diverged run
+    must not come back looking like a score."""
+    import torch
+    from matcha_amd.utils import roc_auc_cuda
+    y = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0, 0.0])
+    sz = torch.tensor([2, 2, 3, 3, 2, 3])
+    for bad in (float("nan"), float("inf")):
+        p = torch.tensor([0.9, 0.1, 0.8, bad, 0.7, 0.3])
+        assert roc_auc_cuda(y, p, sz, 3) == (0.0, 0.0)

@@ -194,3 +194,35 @@ def test_step_select_and_record_equal_the_torch_bookkeeping():
         ref_sums[0] += losses[0]
         ref_sums[1] += losses[1]
         assert torch.equal(sums, ref_sums) and int(it) == step + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front_end,d,layout", [("table", 64, "c23"), ("adj", 64, "c23"), ("table", 16, "tiny")])
+def test_graph_replayed_eval_epoch_equals_the_call_by_call_eval(front_end, d, layout):
+    """eval_epoch (main.py:200-258) replays ONE captured forward-only step per batch -- device-side batch selection, sampler,
+    matcha_forward(forward_only) with the loss inside, matcha_step_record (train._graph_eval) -- and must report what the eager loop over
+    model(x, return_recon=True) + torch's BCE reports: same rows, same negatives (same sampler seed sequence), same metrics."""
+    from matcha_amd import train as T
+    from tests.test_hip_model import hip_model
+    num = synth.LAYOUTS[layout]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(4)
+    edges = np.concatenate([np.pad(synth.make_edges(rng, N, k, 300), ((0, 0), (0, 3 - k))) for k in (2, 3)])
+    weights = rng.uniform(0.6, 1.0, size=len(edges)).astype(np.float32)
+    res = {}
+    for graph in (False, True):
+        T.GRAPH_EPOCHS = graph
+        try:
+            np.random.seed(6)
+            torch.manual_seed(6)
+            clf, _ = hip_model(num, d, front_end, 82)
+            sess = T.Session(clf, synth.node2chrom(num), synth.chrom_range(num).astype(np.int32), 2, 3, 0, seed=12)
+            sess.set_known(edges)
+            out = [T.eval_epoch(sess, edges, weights, batch_size=24) for _ in range(2)]      # the second call replays the captured graph
+            res[graph] = out
+        finally:
+            T.GRAPH_EPOCHS = True
+    for a, b in zip(res[False], res[True]):
+        assert abs(a[0] - b[0]) < 2e-5 * max(1.0, abs(a[0])), (a, b)                          # mean bce over the batches
+        assert abs(a[1] - b[1]) < 1e-4 * max(1.0, abs(a[1])), (a, b)                          # mean reconstruction loss
+        assert a[2:] == b[2:], (a, b)                                                         # accuracy / AUROC / AUPR strings

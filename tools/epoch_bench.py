@@ -38,6 +38,11 @@ def one_case(front_end, steps_per_k, graph, ks=(2, 3, 4, 5), d=64, layout="hg38_
     sess.set_known(edges)
     rows = [r[r != 0] for r in edges]
     gen = T.DataGenerator(rows, weights, T.BATCH_SIZE, steps_per_k, min_size=min(ks), max_size=max(ks))
+    # the validation set of the reference's 80 / 20 split (main.py:569-592): eval_epoch takes <= 10 000 shuffled rows of it = 104 batches of 96
+    val_n = min(len(edges) // 5, 20000)
+    val_e, val_w = edges[-val_n:], weights[-val_n:]
+    import tempfile
+    ckdir = tempfile.mkdtemp(prefix="matcha_epoch_bench_")
     out = {}
     for ep in range(2):                       # epoch 0 pays the capture / first-touch costs; epoch 1 is the steady state that is reported
         t0 = time.perf_counter()
@@ -52,12 +57,25 @@ def one_case(front_end, steps_per_k, graph, ks=(2, 3, 4, 5), d=64, layout="hg38_
         torch.cuda.synchronize()
         t_train = time.perf_counter() - t0
         n_steps = len(e_part) // T.BATCH_SIZE
+        # ... and the rest of the reference's epoch (main.py:300-322): the validation pass and the two checkpoint files
+        t0 = time.perf_counter()
+        T.eval_epoch(sess, val_e, val_w)
+        torch.cuda.synchronize()
+        t_eval = time.perf_counter() - t0
+        clf.train()
+        t0 = time.perf_counter()
+        torch.save({"model_link": clf.state_dict(), "epoch": ep}, os.path.join(ckdir, T.MODEL_NAME))
+        torch.save(clf, os.path.join(ckdir, "model2load"))
+        t_ck = time.perf_counter() - t0
         tm = sess.timing
         # loop = upload + shuffle of the epoch's positives, the step loop, the copy of predictions / sizes back (the epoch's one sync);
         # metrics = the reference's per-epoch sklearn AUROC / AUPR + accuracy per size on the host (utils.py:32-72)
         out = dict(save_embeddings_s=round(t_emb, 4), data_generator_s=round(t_gen, 4), train_epoch_s=round(t_train, 4),
                    loop_s=round(tm.get("loop_s", 0.0), 4), epoch_metrics_s=round(tm.get("metrics_s", 0.0), 4), steps=n_steps,
-                   wall_us_per_step=round(tm.get("loop_s", t_train) / n_steps * 1e6, 1))
+                   wall_us_per_step=round(tm.get("loop_s", t_train) / n_steps * 1e6, 1),
+                   eval_epoch_s=round(t_eval, 4), eval_loop_s=round(tm.get("eval_loop_s", 0.0), 4), eval_batches=min(len(val_e), 10000) // T.BATCH_SIZE,
+                   checkpoint_s=round(t_ck, 4),
+                   full_epoch_s=round(t_emb + t_gen + t_train + t_eval + t_ck, 4))
     # device time of one step: replays (or eager steps) back to back between two events, no host work in between that the GPU waits for
     st = sess.__dict__.get("_graph_state")
     if graph and st is not None and st["graph"] is not None:
@@ -78,6 +96,8 @@ def one_case(front_end, steps_per_k, graph, ks=(2, 3, 4, 5), d=64, layout="hg38_
     out.update(front_end=front_end, epoch_loop="hipGraph replay of one captured step" if graph else "call by call",
                rows_per_step=T.BATCH_SIZE * (1 + T.NEG_NUM), hyperedges_per_s=round(T.BATCH_SIZE * (1 + T.NEG_NUM) / (out["wall_us_per_step"] * 1e-6), 1))
     T.GRAPH_EPOCHS = True
+    import shutil
+    shutil.rmtree(ckdir, ignore_errors=True)
     return out
 
 
