@@ -953,15 +953,19 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
     };
     // algorithmic flops: the reference's formulation -- 8 heads x 8 GEMMs of 2*64*64 per token; this kernel EXECUTES half of them
     ProfScope ps(MATCHA_PROF_FUSED_BWD, (double)tcap * MATCHA_N_HEAD * 8.0 * 2.0 * 64.0 * 64.0, st);
-    // EVEN key-slot counts only (an odd batch width runs the next even instance; the extra slot is masked like any slot j >= k).  The ML = 5
-    // instance of this kernel produced TIMING-DEPENDENT dR rows for hyperedges of exactly 5 nodes when two workgroups shared a CU (~20 of
-    // 512 workgroups per launch off by 1e-4 of dB_h; never with one workgroup per CU, never for k < 5, never with the ML = 6 instance on
-    // the same batch; tools/debug/bwd_slab_diff.py): hipcc packs the leftover fifth iteration of the row phase's key loop into v_pk_*_f32
-    // chains interleaved with its DPP reduction.  Extra barriers, nops behind the MFMAs and in front of the DPP steps, plain shuffles and
-    // unpinned loads did not cure it, so the root cause is not established -- the even instances are clean in every run.
-    switch (L <= 2 ? 2 : (L <= 4 ? 4 : (L <= 6 ? 6 : 8))) {
+    // ROUND-5 FINDING, kept here because it is a property of how this file must be built: compiled with the SLP vectoriser, the ML = 5 instance
+    // produced TIMING-DEPENDENT dR rows for hyperedges of exactly 5 nodes when two workgroups shared a CU (~20-120 of 512 workgroups per launch
+    // off by 1e-4 of dB_h; never with one workgroup per CU, never for k < 5, never with ML = 6 on the same batch; tools/debug/bwd_slab_diff.py,
+    // probes in DESIGN.md 4.1c).  hipcc packs the leftover fifth iteration of the row phase's key loop into v_pk_*_f32 chains whose halves
+    // interleave the sig accumulation with the DPP reduction of d_4.  Extra barriers, nops behind the MFMAs and in front of the DPP steps,
+    // plain shuffles and unpinned loads did not cure it; -fno-slp-vectorize (no packed f32 in that loop) does -- 0 differing workgroups in
+    // every run -- and is faster.  The Makefile sets the flag for this file; tests/test_hip_properties.py::test_full_size_train_step_is_reproducible
+    // is the run-time guard.
+    switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
       case 2: launch(fused_bwdh_kernel<2>); break;
+      case 3: launch(fused_bwdh_kernel<3>); break;
       case 4: launch(fused_bwdh_kernel<4>); break;
+      case 5: launch(fused_bwdh_kernel<5>); break;
       case 6: launch(fused_bwdh_kernel<6>); break;
       default: launch(fused_bwdh_kernel<8>); break;
     }

@@ -252,7 +252,12 @@ def _graph_eval(sess: Session, e: torch.Tensor, w: torch.Tensor, n_batch: int, P
     (matcha_step_select), negative sampling, matcha_forward(forward_only) with the loss inside, matcha_step_record.  Same device-side
     state machine as Session.graph_epoch; returns (bce_sum, recon_sum, preds [n_batch, B], labels [B], sizes [n_batch, B])."""
     dev, L, B = sess.dev, int(e.shape[1]), P * (1 + NEG_NUM)
-    chroms = np.asarray([sess.random_chrom() for _ in range(n_batch)], dtype=np.int32)          # Modules.py:192, one draw per forward
+    # the reconstruction chromosome of every forward, drawn exactly as Classifier.forward draws it (Modules.py:192: np.random.choice on numpy's
+    # global stream, adj front end only) so that the call-by-call loop and this one leave the stream in the same state
+    if sess.trainer.rt.mode == 1:
+        chroms = np.asarray([int(np.random.choice(np.arange(sess.n_chrom), 1)[0]) for _ in range(n_batch)], dtype=np.int32)
+    else:
+        chroms = np.zeros(n_batch, dtype=np.int32)
     key = (n_batch, P, L, sess._generation)
     st = sess.__dict__.get("_eval_state")
     if st is None or st["key"] != key:
