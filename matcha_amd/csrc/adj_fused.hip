@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void adj_fused_bwd_kernel(AdjBwdArgs g) {
 }  // namespace
 
 bool adj_fused_eligible(const matcha_shape& s, const matcha_frozen& f) {
-  return s.mode == 1 && s.d == 64 && f.feat_row_pad == 64 && s.n_chrom >= 1 && s.n_chrom <= kMaxChrom && !options().disable_fused_front;
+  return s.mode == 1 && s.d == 64 && f.feat_row_pad == 64 && s.n_chrom >= 1 && s.n_chrom <= kMaxChrom && (options().disable_fused & 2) == 0;
 }
 
 int adj_fused_forward(const matcha_shape& s, const matcha_tensors& p, const matcha_frozen& f, const matcha_step_opts& o, const int64_t* ids, int64_t T,
@@ -896,7 +896,6 @@ int adj_fused_backward(const matcha_shape& s, const matcha_tensors& p, const mat
   const int64_t steps = cdiv(T, 64);
   int spi = (int)(steps / 640);
   spi = spi < 1 ? 1 : (spi > 16 ? 16 : spi);
-  if (options().tune > 0) spi = options().tune;
   a.steps_per_item = spi;
   a.n_main = (int)(cdiv(steps, spi) + C);
   const unsigned grid = (unsigned)(a.n_main + 1 + n_apply);

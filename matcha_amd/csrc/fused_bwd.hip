@@ -8,8 +8,8 @@
 // without materialising r / z / P or their gradients in HBM (Modules.py:519-572 backward).
 //
 // Work decomposition ("head-major"): workgroup (head, chunk) walks the half tiles of its chunk of hyperedges.  B_h and M_h stay in
-// registers as MFMA fragments, dB_h and dM_h accumulate in MFMA accumulators for the whole walk and are written once per workgroup into
-// a slab.  fbm_reduce_kernel sums the slabs in a fixed order, fbm_chain_kernel applies the chain rule back to the folded projections
+// registers as MFMA fragments (three bf16 planes each, round 5), dB_h and dM_h accumulate in MFMA accumulators for the whole walk and are
+// written once per workgroup into a slab.  fbm_reduce_kernel sums the slabs in a fixed order, fbm_chain_kernel applies the chain rule back to the folded projections
 // (dW'q = W'k dB, dW'k = W'q dB^T + cq (x) db, dWfc1_h = dM W'v^T + ..., dW'v = Wfc1_h^T dM), fb_unfold_kernel un-folds the LayerNorm affines:
 //   W' = W * g, c = W . b   =>   dW = dW' * g + dc (x) b,   dg = sum_n dW' * W,   db = W^T dc.
 // The eight heads of a token add their d x_hat into one [T, 64] buffer (float atomics, one instruction = four token rows x 64 B) or, for
@@ -202,25 +202,19 @@ __device__ __forceinline__ void attn_col8(const float* __restrict__ Qs, const fl
 #define FB_T(i) do { } while (0)
 #endif
 
-#define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+#define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)      /* the small per-step products (fbm_chain_kernel) */
 
-// ---- merged heads (round 3): the backward of  r = B_h x + b_h,  s_ij = r_i . x_j,  z_i = sum_j p_ij x_j,  dyn += M_h z  ---------------
-// (fused_fwd32.hip, MG = true).  Per (tile, head) FOUR 64 x 64 products instead of eight:  dZ = dDyn M_h;  d x_hat = dR B_h + (the
-// attention's own gradient into its keys / values, which ARE the x_hat rows);  dB_h += dR^T x_hat;  dM_h += dDyn^T Z.  Same walk as
-// fused_bwd8_kernel (workgroup = (head, chunk of tiles), eight wavefronts, 16x16x4 MFMAs, streamed attention rows) on SIX LDS tiles:
-// the attention runs attn_row8 / attn_col8 with Q := r, K := V := x_hat, dO := dZ; what those return as dK + dV is d x_hat's attention
-// part (tile Gs), what they accumulate for the padding key / value is d x_hat of the padding token.  fbm_chain_kernel then applies the
-// chain rule from (dB_h, db_h, dM_h, d bdyn) to the folded projections, and the LayerNorm un-folding runs as before.
+// ---- the backward of  r = B_h x + b_h,  s_ij = r_i . x_j,  z_i = sum_j p_ij x_j,  dyn += M_h z  (merged heads) ----------
+// Per (half tile, head) FOUR 64 x 64 products instead of the reference formulation's eight:  dZ = dDyn M_h;  d x_hat = dR B_h + (the
+// attention's own gradient into its keys / values, which ARE the x_hat rows);  dB_h += dR^T x_hat;  dM_h += dDyn^T Z.  The attention runs
+// attn_row8_kv / attn_col8 with Q := r, K := V := x_hat, dO := dZ; what those return as dK + dV is d x_hat's attention part (tile Gs), what
+// they accumulate for the padding key / value is d x_hat of the padding token.  fbm_chain_kernel then applies the chain rule from
+// (dB_h, db_h, dM_h, d bdyn) to the folded projections, and the LayerNorm un-folding follows.
 constexpr int kWgSlabM = 2 * 4096 + 4 * 64;     // dB_h dM_h | db_h (column sums of dR), d bdyn (column sums of dDyn), dxpad, spare
 constexpr int kVecOffM = 2 * 4096;
-// ---- merged heads on HALF tiles: the same four products per (rows, head) as fused_bwdm_kernel, on the forward's own half tiles ----
-// (whole hyperedges, <= 31 tokens: ragged.hip half_meta), FOUR wavefronts per workgroup and TWO workgroups per CU.  fused_bwdm_kernel's
-// eight wavefronts walk one tile in lock step: GEMM phases (MFMA) and the attention phases (latency-bound VALU + LDS, a sixth of the
-// issue slots used) alternate behind five barriers and the MFMA pipe idles for 40 % of a tile (tools/debug/timing_bwdm.sh).  Here every
-// wavefront does the same work per 32 rows as there (16 feature columns of each product), but the two workgroups of a CU are at
-// different phases, so one's attention runs under the other's GEMMs.  LDS per workgroup: two sets {x_hat, dDyn, r -> dR} (the next
-// half tile is staged while this one computes), dZ -> Z, G: 8 tiles of 32 x 68 floats + 3.5 KB = 73 KB.  B_h and M_h are MFMA
-// fragments in registers.  The forward's saved record is per (half tile, head): its wavefront's own register image (kImgRecH).
+// Walk: workgroup = (head, chunk of the forward's own HALF tiles: whole hyperedges, <= 31 tokens, ragged.hip half_meta), FOUR wavefronts,
+// TWO workgroups per CU -- at different phases, so one's attention (latency-bound vector + LDS work) runs under the other's GEMMs.  Every
+// wavefront owns 16 feature columns of each product.  The forward's saved record is per (half tile, head): its wavefront's register image.
 constexpr int kTileH = 32 * kLd;
 // ---- round 5: the four products on the bf16 matrix pipe (fp32-accurate: three bf16 planes per operand, six plane products; the note is in
 // fused_fwd32.hip, the arithmetic restated in tests/test_cpu_bf16x3.py) ---------------------------------------------------------------------
@@ -959,7 +953,7 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
     // probes in DESIGN.md 4.1c).  hipcc packs the leftover fifth iteration of the row phase's key loop into v_pk_*_f32 chains whose halves
     // interleave the sig accumulation with the DPP reduction of d_4.  Extra barriers, nops behind the MFMAs and in front of the DPP steps,
     // plain shuffles and unpinned loads did not cure it; -fno-slp-vectorize (no packed f32 in that loop) does -- 0 differing workgroups in
-    // every run -- and is faster.  The Makefile sets the flag for this file; tests/test_hip_properties.py::test_full_size_train_step_is_reproducible
+    // every run -- and is faster.  The Makefile sets the flag for the whole library; tests/test_hip_properties.py::test_full_size_train_step_is_reproducible
     // is the run-time guard.
     switch (L <= 2 ? 2 : (L <= 6 ? L : 8)) {
       case 2: launch(fused_bwdh_kernel<2>); break;

@@ -891,7 +891,6 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
   g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   g.ddyn0 = (y && w) ? ddyn0 : nullptr; g.dXs = dXs; g.tslab = tslab; g.alpha_over_B = alpha / (float)B; g.qkv = rimg;
   size_t lds = ((size_t)2 * kHT + 64) * sizeof(float);
-  lds += (size_t)options().fwd_lds_pad;      // occupancy experiments (tools/debug/timing_fwd32.sh): 20000 -> one wavefront per SIMD
   auto launch = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(rg.nhalves), dim3(64), lds, st, g); };
   // algorithmic flops per token (the reference formulation's): 8 heads x 4 GEMMs (Q, K, V, fc1 block) + the two pff GEMMs, 2*64*64 each
   ProfScope ps(MATCHA_PROF_FUSED_FWD, (double)(B * L + 1) * (MATCHA_N_HEAD * 4.0 + 2.0) * 2.0 * 64.0 * 64.0, st);

@@ -106,12 +106,11 @@ int launch_table_grad(const int32_t* ids, const float* rows, int64_t n, int d, i
 
 // process-wide A/B switches (matcha_set_option; initial values from the environment, read once)
 struct Options {
-  int disable_fused, disable_fused_front, disable_loss_in_forward;
+  int disable_fused;         // 1: layer-by-layer kernels everywhere; 2: the front end only (encoder stays fused)
   int disable_merged;        // the reference formulation of the heads (four products per head) on the layer-by-layer kernels: the A/B variant
   int disable_small_batch;   // the large-batch kernels at every size: one wavefront per half tile in the forward, the ragged plan as five launches
-  int disable_wide_gemm;
-  int debug_nan, fused_dbg, fwd_lds_pad;
-  int tune;       // development: a free integer read by whatever kernel is being tuned (0 = defaults)
+  int disable_wide_gemm;     // embed_dim >= 128: the 64-wide GEMM / attention kernels
+  int debug_nan, fused_dbg;  // development
 };
 Options& options();
 int launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);

@@ -82,9 +82,9 @@ struct Workspace {
 
 // A/B switches for tests and profiling (include/matcha_hip.h, matcha_set_option): ONE process-wide struct whose initial values
 // come from the environment (MATCHA_DISABLE_FUSED, ...) when it is first touched; no entry point calls getenv per call.
-//   disable_fused            layer-by-layer kernels everywhere (the d != 64 path, at embed_dim 64 too)
-//   disable_fused_front      front end (gather + attribute_nn + next_w; its backward; the fused adj kernels) as separate kernels
-//   disable_loss_in_forward  the tail's backward as separate kernels even when opts->loss_in_forward is set
+//   disable_fused            1: layer-by-layer kernels everywhere (the d != 64 path, at embed_dim 64 too); 2: only the FRONT END (gather +
+//                            attribute_nn + next_w; its backward; the fused adj kernels) as separate kernels, the encoder stays fused
+//                            (the tail's backward inside the forward kernel is a per-call choice: opts->loss_in_forward)
 //   disable_merged           the REFERENCE formulation of the heads (Q, K, V, fc1: four products per head forward, eight backward) instead
 //                            of the merged two / four.  It lives on the layer-by-layer kernels only (attention.hip + the GEMMs), so at
 //                            embed_dim 64 the switch implies disable_fused; the fused four-product kernels of rounds 1-3 (four-wave
@@ -95,10 +95,8 @@ struct Workspace {
 //                            heads) instead of gemm_wide.hip / attention_wide.hip
 struct OptionName { const char* name; int Options::*field; };
 static const OptionName kOptionNames[] = {
-    {"disable_fused", &Options::disable_fused}, {"disable_fused_front", &Options::disable_fused_front},
-    {"disable_loss_in_forward", &Options::disable_loss_in_forward}, {"disable_merged", &Options::disable_merged},
-    {"disable_small_batch", &Options::disable_small_batch}, {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg},
-    {"fwd_lds_pad", &Options::fwd_lds_pad}, {"tune", &Options::tune}};
+    {"disable_fused", &Options::disable_fused}, {"disable_merged", &Options::disable_merged}, {"disable_small_batch", &Options::disable_small_batch},
+    {"disable_wide_gemm", &Options::disable_wide_gemm}, {"debug_nan", &Options::debug_nan}, {"fused_dbg", &Options::fused_dbg}};
 Options& options() {
   static Options o = [] {
     Options v;
@@ -121,9 +119,10 @@ Options& options() {
 // backward computes dB_all, dM_all and applies the chain rule per head (merged_chain).  Shapes the wide attention kernels take.
 static bool merged_layerwise_shape(const matcha_shape& s) { return s.d >= 128 && s.d % 64 == 0; }
 static bool merged_layerwise(const matcha_shape& s) { return merged_layerwise_shape(s) && attn_wide_eligible(s.d) && !options().disable_merged; }
-static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && !options().disable_fused && !options().disable_merged; }
+static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && options().disable_fused != 1 && !options().disable_merged; }
+static bool fused_front_enabled() { return (options().disable_fused & 2) == 0; }
 static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
-  return o.loss_in_forward && !o.forward_only && y && w && fused_enabled(s) && !options().disable_loss_in_forward;
+  return o.loss_in_forward && !o.forward_only && y && w && fused_enabled(s);
 }
 // Which formulation the forward that last ran on a workspace used.  matcha_backward keys off THIS record, not off the option: flipping
 // disable_merged between a forward and its backward (two separate calls on the autograd path) would otherwise make the merged backward
@@ -399,7 +398,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st, plan_level));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
-  const bool front = !force_layerwise && fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
+  const bool front = !force_layerwise && fused_enabled(s) && front_bwd_supported(s.d, s.n_attr) && fused_front_enabled();
   // table front end: the two reconstruction-loss slots are zero; loss_reduce_kernel writes them when it runs anyway
   const bool recon_zero_in_loss = s.mode == 0 && recon_out && fused_path && y && w_bce && losses;
   // adj front end at embed_dim 64: gather-GEMM, W1, attribute path and next_w in ONE kernel over the chromosome-sorted rows (adj_fused.hip)
@@ -647,7 +646,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   if (fused_fwd) {
     // attention block (fc1, attention, Q/K/V projections, the three LayerNorms) from X and ddyn0 in one head-major kernel;
     // the forward pass left the folded weights in w.folded.  w.dO doubles as the 8 per-head d x_hat slabs.
-    const bool front = front_bwd_supported(s.d, s.n_attr) && !options().disable_fused_front;
+    const bool front = front_bwd_supported(s.d, s.n_attr) && fused_front_enabled();
     // the eight heads add their d x_hat into ONE buffer with float atomics (they meet in L2; per-head slabs are 8 x 256 B per token written
     // and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs and their
     // fixed summation order

@@ -58,6 +58,7 @@ class Trainer:
         self.seg_coef = torch.zeros(3 * n_seg, dtype=torch.float32, device=dev)
         self.touched = torch.zeros(rt.n_touched, dtype=torch.int32, device=dev)
         self.losses = torch.zeros(3, dtype=torch.float32, device=dev)     # bce, recon, rows of the recon mean
+        self.loss_in_forward = True               # the tail's backward inside the forward kernel (opts.loss_in_forward); tests set False for the separate kernels
         self.seed_advanced_by_caller = False      # train.py's captured step advances self.seed inside matcha_step_select (one launch less)
         self._ws = {}
         self._logits = {}
@@ -111,7 +112,7 @@ class Trainer:
         else:
             o.random_chrom = int(random_chrom)
         o.seed = self.seed.data_ptr()
-        o.loss_in_forward = 1            # the loss is alpha*bce + beta*recon here: the tail's backward runs inside the forward kernel
+        o.loss_in_forward = 1 if self.loss_in_forward else 0      # the loss is alpha*bce + beta*recon here: the tail's backward can run inside the forward kernel
         o.status = self.rt.status.data_ptr()
         o.sparse_table_grad = 1 if self._sparse else 0
         o.deterministic = 1 if self.deterministic else 0

@@ -266,13 +266,9 @@ def test_loss_in_forward_matches_separate_tail_backward(mode):
         clf, _ = hip_model(num, 64, mode, 29)
         clf.train(True)
         tr = Trainer(clf, base_seed=77)
-        if separate:
-            _lib.set_option("disable_loss_in_forward", 1)
-        try:
-            tr.forward_backward(x, y, w, alpha=0.7, beta=0.01, random_chrom=3)
-            torch.cuda.synchronize()
-        finally:
-            _lib.set_option("disable_loss_in_forward", 0)
+        tr.loss_in_forward = not separate
+        tr.forward_backward(x, y, w, alpha=0.7, beta=0.01, random_chrom=3)
+        torch.cuda.synchronize()
         res.append((tr.gflat.clone(), tr.losses.clone(), {n: (p.data_ptr() - tr.rt.flat.data_ptr()) // 4 for n, p in clf.named_parameters()
                                                           if p.data_ptr() >= tr.rt.flat.data_ptr() and p.data_ptr() < tr.rt.flat.data_ptr() + tr.rt.n_flat * 4},
                     {n: p.numel() for n, p in clf.named_parameters()}))
@@ -372,12 +368,12 @@ def test_fused_front_end_matches_separate_kernels(mode):
         clf.train(True)
         tr = Trainer(clf, base_seed=5)
         if separate:
-            _lib.set_option("disable_fused_front", 1)
+            _lib.set_option("disable_fused", 2)            # level 2: the front end as separate kernels, the encoder stays fused
         try:
             logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.01, random_chrom=2)
             torch.cuda.synchronize()
         finally:
-            _lib.set_option("disable_fused_front", 0)
+            _lib.set_option("disable_fused", 0)
         res.append((logits.clone(), tr.gflat.clone()))
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
     g0, g1 = res[0][1], res[1][1]
