@@ -7,7 +7,7 @@ TAG=$1; PMC=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 B="--prof none --no-cpu-baseline --no-extras --front-end adj"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_adj_stats -- python $R/bench.py --steps 5 --warmup 2 $B > $R/gpurun_out/${TAG}_adj_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_adj_stats -- python $R/bench.py --steps 20 --warmup 5 $B > $R/gpurun_out/${TAG}_adj_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_adj384_stats -- python $R/bench.py --steps 20 --warmup 5 --rows 384 $B > $R/gpurun_out/${TAG}_adj384_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_table384_stats -- python $R/bench.py --steps 20 --warmup 5 --rows 384 --prof none --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_table384_stats.log 2>&1
 if [ -n "$PMC" ]; then

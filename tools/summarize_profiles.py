@@ -22,8 +22,8 @@ shutil.copy(src, f"profiles/{rnd}_kernel_stats.csv")
 rows = list(csv.DictReader(open(src)))
 with open(f"profiles/{rnd}_kernel_stats.md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats ({rnd})\n\n")
-    f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 "
-            "--prof none --no-cpu-baseline`\n(65536 rows per step; calls = warm-up + timed steps of the end-to-end leg and of the model-step-only leg; hg38-1Mb, table front end, d=64, L=5; raw CSV next to this file)\n\n")
+    f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 "
+            "--prof none --no-cpu-baseline --no-extras`\n(65536 rows per step; calls = 5 warm-up + 7 windows x 20 timed steps; hg38-1Mb, table front end, d=64, L=5; raw CSV next to this file)\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows[:26]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
@@ -123,7 +123,7 @@ if glob.glob(f"gpurun_out/{tag}_mfma1/*/*_counter_collection.csv"):
 
 
 # ---- the embedding gather alone + the other configurations (tools/collect_profiles.sh, second half) -------------------------
-def stats_md(subdir, out_md, title, cmd, n=18):
+def stats_md(subdir, out_md, title, cmd, n=18, must=()):
     g = glob.glob(f"gpurun_out/{tag}_{subdir}/*/*_kernel_stats.csv")
     if not g:
         return None
@@ -131,15 +131,15 @@ def stats_md(subdir, out_md, title, cmd, n=18):
     rws = list(csv.DictReader(open(g[0])))
     with open(out_md, "w") as f:
         f.write(f"# {title}\n\nCommand (on the MI355X box): `{cmd}`\n\n| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
-        for r in rws[:n]:
+        for r in [r for i, r in enumerate(rws) if i < n or any(m in r["Name"] for m in must)]:
             f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
     return rws
 
 
 stats_md("d128_stats", f"profiles/{rnd}_d128_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, BASELINE configs[3] shape on one GPU ({rnd})",
-         "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --prof none --no-cpu-baseline --no-extras --layout hg38_100kb --dim 128")
+         "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --prof none --no-cpu-baseline --no-extras --layout hg38_100kb --dim 128")
 stats_md("c5_stats", f"profiles/{rnd}_c5_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, BASELINE configs[4] (C5: 1 M nodes, d = 256, 10 M known hyperedges) on one GPU ({rnd})",
-         "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --prof none --no-cpu-baseline --no-extras --layout c5 --dim 256 --ks 2,3,4,5,6,7,8 --rows 16384 --edges 10000000")
+         "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --prof none --no-cpu-baseline --no-extras --layout c5 --dim 256 --ks 2,3,4,5,6,7,8 --rows 16384 --edges 10000000")
 grows = stats_md("gather_stats", f"profiles/{rnd}_gather_kernel_stats.md", f"rocprofv3 --kernel-trace --stats of the embedding gather alone ({rnd})",
                  "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/gather_bench.py  (gather_rows_kernel<1>: d = 64, three tables; <4>: d = 256)")
 if grows and glob.glob(f"gpurun_out/{tag}_gather_fetch/*/*_counter_collection.csv"):
@@ -180,14 +180,20 @@ if grows and glob.glob(f"gpurun_out/{tag}_gather_fetch/*/*_counter_collection.cs
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of tools/gather_bench.py); FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM "
                        "(it counts Infinity-Cache hits too: requests that leave the XCD's L2); averages over the 10 timed launches per table",
                "cases": res}, open(f"profiles/{rnd}_gather_pmc.json", "w"), indent=1)
+    with open(f"profiles/{rnd}_gather_kernel_stats.md", "a") as f:
+        f.write("\nPer table (the kernel-trace durations of the 10 timed launches of each case, in launch order; HBM bytes from the two PMC passes):\n\n"
+                "| table | d | rows per launch | avg us | read GB/s (4d+8) | frac of 8 TB/s | FETCH / algorithmic read | WRITE / algorithmic write |\n|---|---:|---:|---:|---:|---:|---:|---:|\n")
+        for r in res:
+            f.write(f"| {r['table']} | {r['d']} | {r['rows_per_launch']} | {r['rocprof_avg_us']} | {r['read_gbs_of_4d_plus_8']} | {r['frac_of_8tbs_read_roof']} | "
+                    f"{r['fetch_over_algorithmic_read']} | {r['write_over_algorithmic_write']} |\n")
     for r in res:
         print(r["table"], "fetch/alg", r["fetch_over_algorithmic_read"], "write/alg", r["write_over_algorithmic_write"])
 
 
-# ---- the gather the model step executes on HBM-resident tables (tools/debug/front_gather.py = bench.py roofline_gather_in_step) ----
+# ---- the gather the model step executes on HBM-resident tables (tools/front_gather_bench.py = bench.py roofline_gather_in_step) ----
 frows = stats_md("front_stats", f"profiles/{rnd}_gather_in_step_kernel_stats.md", f"rocprofv3 --kernel-trace --stats of the in-step gather on HBM-resident tables ({rnd})",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/debug/front_gather.py  (front_fwd_kernel: d = 64, 16 M x 64 table, "
-                 "327 681 tokens per launch; embed_fwd_kernel<4>: d = 256, C5 table 1 M x 256, 131 073 tokens per launch)", n=8)
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/front_gather_bench.py  (front_fwd_kernel: d = 64, 16 M x 64 table, "
+                 "327 681 tokens per launch; embed_fwd_kernel<4>: d = 256, C5 table 1 M x 256, 131 073 tokens per launch)", n=8, must=("front_fwd_kernel", "embed_fwd_kernel"))
 ff = glob.glob(f"gpurun_out/{tag}_front_fetch/*/*_counter_collection.csv")
 if frows and ff:
     acc = collections.defaultdict(list)
@@ -209,7 +215,7 @@ if frows and ff:
         res.append({"kernel": key, "table": name, "tokens_per_launch": tokens, "algorithmic_read_bytes_per_token": rb, "pmc_fetch_bytes_per_launch": avg,
                     "fetch_over_algorithmic_read": round(avg / (tokens * rb), 3), "rocprof_avg_us": round(us[0], 1) if us else None,
                     "frac_of_8tbs_read_roof": round(tokens * rb / us[0] / 1e3 / 8000.0, 4) if us else None})
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE pass of tools/debug/front_gather.py (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); uniform random ids, "
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE pass of tools/front_gather_bench.py (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); uniform random ids, "
                        "inference forwards; the kernels also write 4 d bytes per token (X / x0 rows)", "cases": res},
               open(f"profiles/{rnd}_gather_in_step_pmc.json", "w"), indent=1)
     for r in res:
@@ -218,7 +224,7 @@ if frows and ff:
 
 # ---- the adj front end (the reference's own mode, Modules.py:176-201): tools/collect_adj_profiles.sh -------------------------------
 arows = stats_md("adj_stats", f"profiles/{rnd}_adj_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, adj front end, 65 536 rows per step ({rnd})",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --prof none --no-cpu-baseline --no-extras --front-end adj", n=24)
+                 "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --prof none --no-cpu-baseline --no-extras --front-end adj", n=24)
 stats_md("adj384_stats", f"profiles/{rnd}_adj384_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, adj front end at the reference's batch of 384 rows ({rnd})",
          "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --rows 384 --prof none --no-cpu-baseline --no-extras --front-end adj", n=30)
 stats_md("table384_stats", f"profiles/{rnd}_table384_kernel_stats.md", f"rocprofv3 --kernel-trace --stats, table front end at the reference's batch of 384 rows ({rnd})",
