@@ -166,6 +166,17 @@ constexpr int kImgRecH = 2048 + 256;               // 32 r rows (r = B_h x_hat +
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 
+// enc128.hip (embed_dim 128): the attention block (three LayerNorms, merged heads, attention, fc1 + dropout) as ONE forward and ONE backward
+// kernel in x_hat space with the LayerNorm affines folded into the merged matrices; r / z / dR / dZ never reach HBM
+bool enc128_shape(int d);
+size_t enc128_ws_floats();
+size_t enc128_rec_floats(const Ragged& rg);        // what a training forward leaves for the backward: r rows + probabilities per (half tile, head)
+int launch_enc128_fwd(const matcha_tensors& p, const float* lwB, const float* lwM, const float* X, const Ragged& rg, int64_t B, int L, float* Y, float* rec,
+                      float* ws, const int32_t* tok_slot, const uint64_t* seed, float p_drop, hipStream_t st);
+int launch_enc128_bwd(const matcha_tensors& p, const float* lwB, const float* lwM, const float* X, const float* dDyn, const float* dXs, const Ragged& rg,
+                      int64_t B, int L, float* dxh, const float* rec, float* ws, float* lwdB, float* lwdM, matcha_tensors& grads, float* dZ0,
+                      hipStream_t st);
+
 // front_fused.hip (embed_dim 64, n_attr <= 32): forward = gather + attribute_nn + next_w + tanh in one kernel;
 // backward = LayerNorm backward of the summed d x_hat partials, next_w and attribute_nn
 // backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel

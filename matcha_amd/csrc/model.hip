@@ -69,6 +69,8 @@ struct Workspace {
   void* adj_ws;     size_t adj_ws_bytes;
   float* folded;                          // LayerNorm-folded projection weights of the fused d = 64 kernels
   float* lwB; float* lwM; float* lwdB; float* lwdM;   // embed_dim >= 128, merged heads: B_all [8d, d], M_all [d, 8d] and their gradients
+  float* enc;                             // embed_dim 128: the fused attention block's folded weights, fragments and slabs (enc128.hip)
+  float* enc_rec; size_t enc_rec_floats;  // ... and its forward records, over the Q / K / V / P / O buffers the fused path does not use
   float* merged;                          // merged per-head matrices B_h = W'k^T W'q, M_h = Wfc1_h W'v (two products per head instead of four)
   float* frag;                            // the same weights + fc1 / pff_n1 blocks in MFMA-fragment order (fused_fwd32.hip streams them from L2)
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
@@ -119,6 +121,11 @@ Options& options() {
 // backward computes dB_all, dM_all and applies the chain rule per head (merged_chain).  Shapes the wide attention kernels take.
 static bool merged_layerwise_shape(const matcha_shape& s) { return s.d >= 128 && s.d % 64 == 0; }
 static bool merged_layerwise(const matcha_shape& s) { return merged_layerwise_shape(s) && attn_wide_eligible(s.d) && !options().disable_merged; }
+// embed_dim 128: attention block as one fused forward / backward kernel pair (enc128.hip).  The heads' d x_hat meet through float atomics, so the
+// callers that need a bitwise reproducible embedding gradient stay on the layer-by-layer kernels.
+static bool enc128_enabled(const matcha_shape& s, const matcha_step_opts& o) {
+  return enc128_shape(s.d) && merged_layerwise(s) && options().disable_fused != 1 && !o.deterministic && !o.sparse_table_grad;
+}
 static bool fused_enabled(const matcha_shape& s) { return s.d == 64 && options().disable_fused != 1 && !options().disable_merged; }
 static bool fused_front_enabled() { return (options().disable_fused & 2) == 0; }
 static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, const float* y, const float* w) {
@@ -129,9 +136,9 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
 // consume records nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so it cannot live in device memory
 // without a synchronisation); bounded, evicted oldest-first, guarded by a mutex.  A backward on a workspace WITHOUT a record is refused.
 static std::mutex g_fwd_mu;
-static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward
+static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward, bit 2: fused d = 128 attention block
 static uint64_t g_fwd_clock = 0;
-static void note_forward(const void* ws, bool merged, bool fused) {
+static void note_forward(const void* ws, bool merged, bool fused, bool enc = false) {
   std::lock_guard<std::mutex> lk(g_fwd_mu);
   if (g_fwd_state.size() >= 4096 && g_fwd_state.find(ws) == g_fwd_state.end()) {
     auto old = g_fwd_state.begin();
@@ -139,7 +146,7 @@ static void note_forward(const void* ws, bool merged, bool fused) {
       if (it->second.second < old->second.second) old = it;
     g_fwd_state.erase(old);
   }
-  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0), ++g_fwd_clock);
+  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0) | (enc ? 4 : 0), ++g_fwd_clock);
 }
 static int ws_state(const void* ws) {       // -1: no forward on record for this workspace
   std::lock_guard<std::mutex> lk(g_fwd_mu);
@@ -232,6 +239,9 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
     w.lwB = take_always(nm); w.lwM = take_always(nm);
     w.lwdB = take(nm); w.lwdM = take(nm);
   }
+  w.enc = take_always(enc128_shape((int)d) ? enc128_ws_floats() : 0);
+  w.enc_rec = w.Q;                                        // [Q, K, V, P, O] are consecutive: Tn * 32 d + B * 8 L^2 floats
+  w.enc_rec_floats = (w.Q && w.O) ? (size_t)((w.O + Tn * hd) - w.Q) : 0;
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tpart = take(s.d == 64 ? fused_tail_partial_floats() : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
@@ -394,7 +404,8 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const bool keep_rimg = !opts->forward_only;
   // CSR plan: real tokens + one shared padding token; the fused kernels walk the HALF tiles (level 1: no 64-row tile list, no token -> tile
   // map -- matcha_ragged_plan still builds those for callers that ask)
-  const int plan_level = fused_enabled(s) ? 1 : 0;
+  const bool enc = !force_layerwise && enc128_enabled(s, *opts);      // embed_dim 128: the attention block as one kernel (enc128.hip)
+  const int plan_level = (fused_enabled(s) || enc) ? 1 : 0;
   MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st, plan_level));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)
   float* recon_out = losses ? losses + 1 : nullptr;
@@ -448,10 +459,18 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   }
   nan_check("x0", w.x0, cnt, 0, d, st);
   nan_check("X", w.X, cnt, 0, d, st);
+  const bool mlw = merged_layerwise(s);
+  note_forward(ws, mlw, false, enc);                 // the backward pass on this workspace must use the same formulation
+  if (enc) {
+    // LayerNorms, merged heads, attention, fc1 + dropout + mask: X -> Y in one kernel; a training forward leaves r rows + probabilities
+    MATCHA_TRY(merged_weights(s, p, w, st));
+    const bool keep = !opts->forward_only;
+    if (keep && enc128_rec_floats(w.rg) > w.enc_rec_floats) { set_error("matcha_forward: the fused d = 128 records do not fit the workspace"); return MATCHA_ENOMEM; }
+    MATCHA_TRY(launch_enc128_fwd(p, w.lwB, w.lwM, w.X, w.rg, B, L, w.Y, keep ? w.enc_rec : nullptr, w.enc, w.rg.tok_slot, opts->seed,
+                                 (train && opts->p_drop_fc1 > 0.f) ? opts->p_drop_fc1 : 0.f, st));
+  } else {
   // three LayerNorms on the same row (Modules.py:519-521), then Q/K/V projections (:527-529), one batched launch
   MATCHA_TRY(launch_ln3_fwd(w.X, Tn, d, p.ln_q_g, p.ln_q_b, p.ln_k_g, p.ln_k_b, p.ln_v_g, p.ln_v_b, w.qin, w.kin, w.vin, w.stats, st, cnt));
-  const bool mlw = merged_layerwise(s);
-  note_forward(ws, mlw, false);                      // the backward pass on this workspace must use the same formulation
   if (mlw) {
     MATCHA_TRY(merged_weights(s, p, w, st));
     GemmArgs g = gemm1(w, w.qin, w.lwB, w.Q, Tn, hd, d, false);                 // r = qin B_all^T  (in Q's buffer)
@@ -476,6 +495,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     g.flags = MATCHA_EPI_BIAS | MATCHA_EPI_ROWMASK; g.bias[0] = p.fc1_b; g.row_ids = ids;
     if (train && opts->p_drop_fc1 > 0.f) { g.flags |= MATCHA_EPI_DROPOUT; g.seed = opts->seed; g.stream_id = kStreamDropFc1; g.p_drop = opts->p_drop_fc1; }
     MATCHA_TRY(launch_gemm_rm(false, g, st));
+  }
   }
   // pff_n1: H1 = dropout(tanh(conv0(Y)));  H2 = conv1(H1) + Y      (Modules.py:353-371)
   {
@@ -537,7 +557,7 @@ extern "C" int matcha_debug_layout(const matcha_shape* shp, int64_t B, int32_t L
       {"plan", w.rg.row_off}, {"x0", w.x0}, {"X", w.X}, {"qin", w.qin}, {"kin", w.kin}, {"vin", w.vin}, {"stats", w.stats}, {"Q", w.Q}, {"K", w.K}, {"V", w.V},
       {"P", w.P}, {"O_dxh", w.O}, {"Y", w.Y}, {"H1", w.H1}, {"H2", w.H2}, {"row_loss", w.row_loss}, {"logits", w.logits}, {"node", w.node}, {"dH2", w.dH2},
       {"dXs", w.dXs}, {"dZ1", w.dZ1}, {"ddyn0", w.ddyn0}, {"dZ0", w.dZ0}, {"dX0", w.dX0}, {"slab", w.slab}, {"gemm_ws", w.gemm_ws}, {"adj_ws", w.adj_ws},
-      {"folded", w.folded}, {"frag", w.frag}, {"merged", w.merged}, {"lwB", w.lwB}, {"lwM", w.lwM}, {"lwdB", w.lwdB}, {"lwdM", w.lwdM}, {"fb_ws", w.fb_ws},
+      {"folded", w.folded}, {"frag", w.frag}, {"merged", w.merged}, {"lwB", w.lwB}, {"lwM", w.lwM}, {"lwdB", w.lwdB}, {"lwdM", w.lwdM}, {"enc", w.enc}, {"fb_ws", w.fb_ws},
       {"tpart", w.tpart}, {"tslab", w.tslab}, {"qkv_records", w.qkv}, {"front_ws", w.front_ws}, {"tg_ws", w.tg_ws}};
   size_t n = 0;
   for (const auto& e : f) {
@@ -668,6 +688,13 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       return MATCHA_OK;
     }
   } else {
+  if ((fwd_state & 4) != 0) {
+    // embed_dim 128, fused attention block: dB_all / dM_all (LayerNorm affines taken back out) + d x_hat in one kernel, then the chain rule to
+    // w_qs / w_ks / w_vs / fc1 and the LayerNorm backward (enc128.hip); dxh lives in qin's buffer
+    MATCHA_TRY(launch_enc128_bwd(p, w.lwB, w.lwM, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dqin, w.enc_rec, w.enc, w.lwdB, w.lwdM, g_, w.dZ0, st));
+    MATCHA_TRY(merged_chain(s, p, g_, w, st));
+    MATCHA_TRY(encoder_done(*opts, st));
+  } else {
   if (fwd_ran_merged(ws)) {
     // merged heads: dM_all = ddyn0^T Z ; d fc1_b += colsum ; dZ = ddyn0 M_all   (the scratch gradients start from zero: the TN GEMM
     // accumulates C and the column sums alike, and fc1_b's gradient must accumulate)
@@ -712,6 +739,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   MATCHA_TRY(launch_ln3_bwd(w.X, w.dqin, w.dkin, w.dvin, w.dXs, Tn, d, p.ln_q_g, p.ln_k_g, p.ln_v_g, w.dZ0, w.slab, g_.ln_q_g,
                             g_.ln_q_b, g_.ln_k_g, g_.ln_k_b, g_.ln_v_g, g_.ln_v_b, st, cnt));
   MATCHA_TRY(encoder_done(*opts, st));
+  }
   }
   // next_w: dW += dZ0^T x0 ; db += colsum ; dX0 = dZ0 Wn
   MATCHA_TRY(launch_gemm_tn(w.dZ0, w.x0, g_.next_w, g_.next_b, d, d, Tn, d, d, nullptr, true, w.gemm_ws, w.gemm_ws_bytes, st, cnt));

@@ -630,6 +630,55 @@ def test_merged_layerwise_heads_match_the_four_product_formulation(d):
         assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("ks,L,n", [((2, 3, 4, 5), 5, 300), ((2, 5), 5, 4000), ((2, 3, 6, 8), 8, 500), ((2,), 2, 64)])
+def test_fused_d128_attention_block_matches_the_layerwise_kernels(ks, L, n):
+    """embed_dim 128: the attention block as one forward / one backward kernel in x_hat space with the LayerNorm affines folded into the merged
+    matrices (enc128.hip) against the layer-by-layer kernels (option disable_fused = 1: ln3 + GEMMs + attention_wide), same weights, dropout
+    seed and batch -- logits and every gradient agree to rounding; rows of all-padding and k = 1 rows included."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["c1"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(29)
+    x = _mixed_batch(N, ks, n, rng)
+    if x.shape[1] < L:
+        x = torch.nn.functional.pad(x, (0, L - x.shape[1]))
+    x[5] = 0                                            # a row of padding only
+    x[7, 1:] = 0                                        # a k = 1 row
+    y = (torch.rand(len(x), device="cuda") < 0.3).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    res = []
+    for fused_off in (0, 1):
+        clf, _ = hip_model(num, 128, "table", 31)
+        with torch.no_grad():                           # non-trivial LayerNorm affines: the folding has something to fold
+            for nme, p_ in clf.named_parameters():
+                if "layer_norm" in nme:
+                    p_.add_(0.2 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(len(nme))).to(p_.device))
+        clf.train(True)
+        tr = Trainer(clf, base_seed=9)
+        _lib.set_option("disable_fused", fused_off)
+        try:
+            logits = tr.forward_backward(x, y, w, alpha=1.0, beta=0.0, random_chrom=0)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("disable_fused", 0)
+        res.append((logits.clone(), tr.gflat.clone(), clf))
+    assert torch.isfinite(res[0][0]).all()
+    scale_l = max(1.0, float(res[1][0].abs().max()))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * scale_l
+    clf = res[0][2]
+    rt = clf._runtime()
+    for nme, p_ in clf.named_parameters():
+        o = (p_.data_ptr() - rt.flat.data_ptr()) // 4
+        if nme == GAUGE or o < 0 or o >= rt.n_flat:
+            continue
+        a = res[1][1][o:o + p_.numel()]
+        scale = max(float(a.abs().max()), 1e-6)
+        b = res[0][1][o:o + p_.numel()]
+        # (1e-8 absolute: gradients that are zero by construction -- keys / queries of k = 2 hyperedges without padding -- are exact zeros in
+        # one path and 1e-10 rounding noise in the other; both paths add the table / d x_hat rows with float atomics)
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-8, (nme, float((a - b).abs().max()), scale)
+
+
 def test_trainer_step_with_empty_rows_half_tile_backward():
     """The Trainer's default d = 64 step (merged heads, half-tile backward, heads' d x_hat through float atomics) on a batch with 300
     all-padding rows in the middle and k = 1 rows (a half tile then holds more than 31 hyperedges, some with no token at all), against

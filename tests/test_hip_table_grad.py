@@ -80,7 +80,21 @@ def test_sorted_table_gradient_equals_atomic_scatter_and_is_bitwise_reproducible
         assert float((c - e).abs().max()) <= 2e-5 * float(c.abs().max())
         assert int((c != e).sum()) <= 2 * (64 * 64 + 64) + 64 * 8 + 64         # next_w / attribute_nn and their biases at most
     else:
-        assert torch.equal(grads[0][nt:], grads[2][nt:])                        # everything else is untouched by the switch
+        # d = 128: the deterministic Trainer stays on the layer-by-layer kernels, the default runs the fused attention block (enc128.hip:
+        # d x_hat through float atomics, bf16-plane products) -- equal to rounding; with the fused block switched off, the rest is bitwise
+        # untouched by the deterministic switch
+        c, e = grads[0][nt:], grads[2][nt:]
+        assert float((c - e).abs().max()) <= 1e-4 * float(c.abs().max())
+        _lib.set_option("disable_fused", 1)
+        try:
+            clf, _ = hip_model(num, d, "table", 3)
+            clf.train()
+            tr = Trainer(clf, base_seed=5, deterministic=False)
+            tr.forward_backward(x, y, w, 1.0, 0.001, 0)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("disable_fused", 0)
+        assert torch.equal(grads[0][nt:], tr.gflat[nt:])
 
 
 def test_out_of_range_ids_are_flagged_not_dereferenced():
