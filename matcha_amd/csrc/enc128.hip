@@ -143,6 +143,35 @@ __device__ __forceinline__ f32x4 mma6(f32x4 acc, const Frag3& a, const Frag3& b)
   return acc;
 }
 
+// the same six plane products for TWO accumulators that share one operand, chains interleaved (no MFMA waits on the one before it)
+__device__ __forceinline__ void mma6x2_a(f32x4& c0, f32x4& c1, const Frag3& a, const Frag3& b0, const Frag3& b1) {     // shared A operand
+  c0 = MFMA16B(a.l, b0.h, c0); c1 = MFMA16B(a.l, b1.h, c1); c0 = MFMA16B(a.h, b0.l, c0); c1 = MFMA16B(a.h, b1.l, c1);
+  c0 = MFMA16B(a.m, b0.m, c0); c1 = MFMA16B(a.m, b1.m, c1); c0 = MFMA16B(a.m, b0.h, c0); c1 = MFMA16B(a.m, b1.h, c1);
+  c0 = MFMA16B(a.h, b0.m, c0); c1 = MFMA16B(a.h, b1.m, c1); c0 = MFMA16B(a.h, b0.h, c0); c1 = MFMA16B(a.h, b1.h, c1);
+}
+__device__ __forceinline__ void mma6x2_b(f32x4& c0, f32x4& c1, const Frag3& a0, const Frag3& a1, const Frag3& b) {    // shared B operand
+  c0 = MFMA16B(a0.l, b.h, c0); c1 = MFMA16B(a1.l, b.h, c1); c0 = MFMA16B(a0.h, b.l, c0); c1 = MFMA16B(a1.h, b.l, c1);
+  c0 = MFMA16B(a0.m, b.m, c0); c1 = MFMA16B(a1.m, b.m, c1); c0 = MFMA16B(a0.m, b.h, c0); c1 = MFMA16B(a1.m, b.h, c1);
+  c0 = MFMA16B(a0.h, b.m, c0); c1 = MFMA16B(a1.h, b.m, c1); c0 = MFMA16B(a0.h, b.h, c0); c1 = MFMA16B(a1.h, b.h, c1);
+}
+// Feature-contraction product of a 32-token tile against this wavefront's weight fragments W[0..3] (the A operand when WEIGHT_A, else the B
+// operand): the plane fragments of K step s + 1 are read BEFORE the twelve MFMAs of step s (sched_group_barrier keeps that order: without it
+// the compiler issues each read two instructions ahead of its MFMA and every K step waits out the LDS latency)
+template <bool WEIGHT_A>
+__device__ __forceinline__ void gemm_k128(f32x4& c0, f32x4& c1, const Frag3 (&W)[4], const short* __restrict__ x0) {
+  Frag3 p0 = frag_row(x0), p1 = frag_row(x0 + 16 * kPS);
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const Frag3 q0 = p0, q1 = p1;
+    if (s < 3) { p0 = frag_row(x0 + 32 * (s + 1)); p1 = frag_row(x0 + 16 * kPS + 32 * (s + 1)); }
+    if (WEIGHT_A) mma6x2_a(c0, c1, W[s], q0, q1);
+    else mma6x2_b(c0, c1, q0, q1, W[s]);
+    if (s < 3) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+  }
+}
+
 // x_hat of eight features of a 128-wide row spread over 16 lanes (two-pass statistics like row_stats of token_kernels.hip)
 __device__ __forceinline__ V8 ln_row8(const V8& x, float msk, float* rstd_out = nullptr, float* mean_out = nullptr) {
   const f2 s2 = (x.a + x.b) + (x.c + x.d);
@@ -164,6 +193,9 @@ __device__ __forceinline__ V8 ln_row8(const V8& x, float msk, float* rstd_out = 
 #define ENC_T(i) do { const long long now__ = wall_clock64(); tph[i] += now__ - tlast; tlast = now__; } while (0)
 #else
 #define ENC_T(i) do { } while (0)
+#endif
+#ifndef ENC_ABL
+#define ENC_ABL 0                       // in-situ ablations of the forward (wrong results on purpose; tools/debug/abl_fwd32.sh with ABL_SRC=enc128)
 #endif
 #define ENC_PIN(addr, x) asm volatile("" : "+v"(addr), "+v"((x).a), "+v"((x).b), "+v"((x).c), "+v"((x).d))
 
@@ -232,17 +264,22 @@ struct FwdArgs {
   float* Y; float* rec;                                       // rec == nullptr: a forward that will not be differentiated
   const uint64_t* seed; float p_drop;
 };
-constexpr size_t kFwdLdsBytes = (size_t)2 * 32 * kLdF * 4 + (size_t)2 * kPT * 2 + (kD + 32) * 4;
+constexpr size_t kFwdLdsBytes = (size_t)3 * 32 * kLdF * 4 + (size_t)3 * kPT * 2 + (kD + 64) * 4;
 
+// Two phases per (head, half tile) step, two workgroup barriers:
+//   phase Y  attention of step s (vector + LDS work): r rows (Rs) and x_hat rows (Xs[s & 1]) -> z planes (Zp), records
+//   phase X  the matrix work around it, back to back: GEMM2 of step s (Zp -> Y), GEMM1 of step s + 1 (Xp[(s + 1) & 1] -> Rs), and the staging of
+//            step s + 2 (vector work that runs under the other wavefront's MFMAs); the rows of step s + 3 are fetched for the next phase X
+// Steps are the flattened (head, tile) pairs of the workgroup's share, so a head's last GEMM2 and the next head's first GEMM1 share a phase.
 template <int ML>
 __global__ __launch_bounds__(512) void enc128_fwd_kernel(FwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Xs = lds;                                    // x_hat f32: the attention's keys = values
-  float* Rs = Xs + 32 * kLdF;                         // r rows of this head
-  short* Xp = reinterpret_cast<short*>(Rs + 32 * kLdF);
-  short* Zp = Xp + kPT;                               // z planes
+  float* Xs = lds;                                    // [2] x_hat f32: the attention's keys = values
+  float* Rs = Xs + 2 * 32 * kLdF;                     // r rows of the step
+  short* Xp = reinterpret_cast<short*>(Rs + 32 * kLdF);   // [2] x_hat planes
+  short* Zp = Xp + 2 * kPT;                           // z planes
   float* xpad = reinterpret_cast<float*>(Zp + kPT);
-  int* tinfo = reinterpret_cast<int*>(xpad + kD);
+  int* tinfo = reinterpret_cast<int*>(xpad + kD);     // [2][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, kq = lane >> 4, fb = 16 * wave;
@@ -264,176 +301,190 @@ __global__ __launch_bounds__(512) void enc128_fwd_kernel(FwdArgs g) {
   float keep_scale = 1.f;
   if (g.p_drop > 0.f) { key = rng_key(*g.seed, kStreamDropFc1); thr = dropout_threshold(g.p_drop); keep_scale = 1.f / (1.f - g.p_drop); }
 
-  const int4* meta = reinterpret_cast<const int4*>(g.half_meta);
+  const int4* meta = reinterpret_cast<const int4*>(g.half_meta) + tile_lo;
   const int ntile = tile_hi - tile_lo;
-  // staging registers of the NEXT (head, tile) step: this thread's 8 floats of its row + the row's position word
+  const int nsteps = MATCHA_N_HEAD * ntile;
+  // staging registers: this thread's 8 floats of its row + the row's position word
   V8 xn;
   int tpn;
-  int4 mnext = meta[tile_lo];
 #define ENC_GLOAD(M)                                                                                     \
   do {                                                                                                   \
     const int64_t tok__ = (M).x + (la < (M).y ? la : ((M).y > 0 ? (M).y - 1 : 0));                        \
     xn = ld8(g.X + tok__ * kD + 8 * sub);                                                                \
     tpn = g.tok_pos[tok__];                                                                              \
   } while (0)
-#define ENC_STAGE(NREAL)                                                                                 \
+#define ENC_STAGE(BUF, NREAL)                                                                            \
   do {                                                                                                   \
     const V8 xh__ = ln_row8(xn, la < (NREAL) ? 1.f : 0.f);                                               \
-    st8(&Xs[la * kLdF + 8 * sub], xh__);                                                                 \
-    frag_store(Xp + la * kPS + 8 * sub, split8(xh__));                                                   \
-    if (sub == 0) tinfo[la] = la < (NREAL) ? ((la - (tpn & 255)) | (tpn & ~255)) : 0;                    \
+    st8(&Xs[(BUF) * 32 * kLdF + la * kLdF + 8 * sub], xh__);                                             \
+    frag_store(Xp + (BUF) * kPT + la * kPS + 8 * sub, split8(xh__));                                     \
+    if (sub == 0) tinfo[(BUF) * 32 + la] = la < (NREAL) ? ((la - (tpn & 255)) | (tpn & ~255)) : 0;       \
   } while (0)
-  ENC_GLOAD(mnext);
-  ENC_STAGE(mnext.y);
+  // this wavefront's 16 output features of B'_h (GEMM1) / M'_h (GEMM2) as register fragments
+  Frag3 Bw[4], Mw[4];
+  f32x4 bias4, cvec4 = {0.f, 0.f, 0.f, 0.f};
+#define ENC_LOAD_B(H)                                                                                    \
+  do {                                                                                                   \
+    const u32x4* fp__ = g.frag + (int64_t)(H) * kFragHead + (int64_t)wave * (4 * 3 * 64) + lane;         \
+    _Pragma("unroll") for (int s__ = 0; s__ < 4; ++s__) {                                                \
+      Bw[s__].h = fp__[(s__ * 3 + 0) * 64]; Bw[s__].m = fp__[(s__ * 3 + 1) * 64]; Bw[s__].l = fp__[(s__ * 3 + 2) * 64]; \
+    }                                                                                                    \
+    bias4 = *reinterpret_cast<const f32x4*>(g.bvec + (H) * kD + fb + 4 * kq);                            \
+  } while (0)
+#define ENC_LOAD_M(H)                                                                                    \
+  do {                                                                                                   \
+    const u32x4* fp__ = g.frag + (int64_t)(H) * kFragHead + (int64_t)(8 + wave) * (4 * 3 * 64) + lane;   \
+    _Pragma("unroll") for (int s__ = 0; s__ < 4; ++s__) {                                                \
+      Mw[s__].h = fp__[(s__ * 3 + 0) * 64]; Mw[s__].m = fp__[(s__ * 3 + 1) * 64]; Mw[s__].l = fp__[(s__ * 3 + 2) * 64]; \
+    }                                                                                                    \
+    if ((H) == MATCHA_N_HEAD - 1) cvec4 = *reinterpret_cast<const f32x4*>(g.bvec + 8 * kD + fb + 4 * kq); \
+  } while (0)
+  // r^T = B'_h x_hat^T + b'_h: lane (c16, kq) ends with token c16 (+ 16), features fb + 4 kq + {0..3}
+#define ENC_GEMM1(BUF)                                                                                   \
+  do {                                                                                                   \
+    f32x4 acc0__ = bias4, acc1__ = bias4;                                                                \
+    if (!(ENC_ABL & 2)) gemm_k128<true>(acc0__, acc1__, Bw, Xp + (BUF) * kPT + c16 * kPS + 8 * kq);      \
+    *reinterpret_cast<f32x4*>(&Rs[c16 * kLdF + fb + 4 * kq]) = acc0__;                                   \
+    *reinterpret_cast<f32x4*>(&Rs[(16 + c16) * kLdF + fb + 4 * kq]) = acc1__;                            \
+  } while (0)
+
+  // ---- prologue: stage steps 0 and 1, GEMM1 of step 0, fetch the rows of step 2 ----
+  int4 mA = meta[0];                                  // step s: tile s % ntile, head s / ntile
+  int4 mB = meta[1 < ntile ? 1 : 0];
+  int4 mC = meta[2 % ntile];
+  int4 mD = mC;
+  ENC_GLOAD(mA);
+  ENC_LOAD_B(0);
+  ENC_STAGE(0, mA.y);
+  if (nsteps > 1) ENC_GLOAD(mB);
+  __syncthreads();
+  ENC_GEMM1(0);
+  if (nsteps > 1) ENC_STAGE(1, mB.y);
+  if (nsteps > 2) ENC_GLOAD(mC);
+  __syncthreads();
 #ifdef ENC_TIMING
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = wall_clock64();
 #endif
-
-  for (int h = 0; h < MATCHA_N_HEAD; ++h) {
-    // this wavefront's 16 output features of B'_h and M'_h as register fragments for the whole chunk
-    Frag3 Bw[4], Mw[4];
+  int tiA = 0, hA = 0;                                // tile index (inside the share) and head of step st
+  int ti3 = 3 % ntile;                                // tile index of step st + 3
+  for (int st = 0; st < nsteps; ++st) {
+    const int t0 = mA.x, n_real = mA.y, buf = st & 1;
+    const int tiB = tiA + 1 == ntile ? 0 : tiA + 1;
+    const int hB = tiB == 0 ? hA + 1 : hA;
+    // ---- phase Y: attention in x_hat space, 16 lanes per query token ----
     {
-      const u32x4* fp = g.frag + (int64_t)h * kFragHead + (int64_t)wave * (4 * 3 * 64) + lane;
+      V8 z = zero8();
+      const float* Xb = Xs + buf * 32 * kLdF;
+      if (!(ENC_ABL & 1) && la < n_real) {
+        const int ia = tinfo[buf * 32 + la];
+        const int li0 = ia & 255, k = ia >> 8, pos = la - li0, n_pad = g.L - k;
+        const float padf = (float)n_pad;
+        const V8 r = ld8(&Rs[la * kLdF + 8 * sub]);
+        const V8 xp8 = ld8(&xpad[8 * sub]);
+        V8 xk[ML];
+        float s[ML];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        Bw[s].h = fp[(s * 3 + 0) * 64]; Bw[s].m = fp[(s * 3 + 1) * 64]; Bw[s].l = fp[(s * 3 + 2) * 64];
-        Mw[s].h = fp[(8 * 4 * 3 + s * 3 + 0) * 64]; Mw[s].m = fp[(8 * 4 * 3 + s * 3 + 1) * 64]; Mw[s].l = fp[(8 * 4 * 3 + s * 3 + 2) * 64];
+        for (int j = 0; j < ML; ++j) xk[j] = ld8(&Xb[(li0 + (j < k ? j : 0)) * kLdF + 8 * sub]);
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int j = 0; j < ML; ++j) {
+          float v = group_sum16_dpp(dot8(r, xk[j])) * inv_temp;
+          if (j == pos) v = -1e32f;
+          s[j] = v;
+          if (j < k) mx = fmaxf(mx, v);
+        }
+        float sp = group_sum16_dpp(dot8(r, xp8)) * inv_temp;
+        if (n_pad > 0) mx = fmaxf(mx, sp);
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < ML; ++j) { s[j] = (j < k) ? __expf(s[j] - mx) : 0.f; den += s[j]; }
+        sp = (n_pad > 0) ? __expf(sp - mx) : 0.f;
+        den += padf * sp;
+        const float inv = 1.f / den;
+        sp *= inv;
+        z = scale8(padf * sp, xp8);
+#pragma unroll
+        for (int j = 0; j < ML; ++j) { s[j] *= inv; axpy8(z, s[j], xk[j]); }
+        if (!(ENC_ABL & 32) && g.rec) {
+          float* rb = g.rec + ((int64_t)(tile_lo + tiA) * MATCHA_N_HEAD + hA) * kRec;
+          float* rr = rb + la * kD + 8 * sub;
+          __builtin_nontemporal_store((f32x4){r.a.x, r.a.y, r.b.x, r.b.y}, reinterpret_cast<f32x4*>(rr));
+          __builtin_nontemporal_store((f32x4){r.c.x, r.c.y, r.d.x, r.d.y}, reinterpret_cast<f32x4*>(rr) + 1);
+          if (sub == 0) {
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = j < ML ? s[j < ML ? j : 0] : 0.f;
+            if (n_pad > 0) w[7] = sp;
+            float* pr = rb + 32 * kD + la * 8;
+            *reinterpret_cast<float4*>(pr) = make_float4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<float4*>(pr + 4) = make_float4(w[4], w[5], w[6], w[7]);
+          }
+        }
       }
+      frag_store(Zp + la * kPS + 8 * sub, split8(z));
     }
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(g.bvec + h * kD + fb + 4 * kq);
-    f32x4 cvec4 = {0.f, 0.f, 0.f, 0.f};
-    if (h == MATCHA_N_HEAD - 1) cvec4 = *reinterpret_cast<const f32x4*>(g.bvec + 8 * kD + fb + 4 * kq);
-    ENC_T(0);
-
-    for (int i = 0; i < ntile; ++i) {
-      const int tile = tile_lo + i;
-      const int4 mc = mnext;
-      const int t0 = mc.x, n_real = mc.y;
-      // what the step behind this one stages: the next tile of this head, or the chunk's first tile for the next head
-      const bool more = (i + 1 < ntile) || (h + 1 < MATCHA_N_HEAD);
-      mnext = meta[i + 1 < ntile ? tile + 1 : tile_lo];
-      __syncthreads();                                // this step's x_hat tiles are staged; the previous step's GEMM2 is done with Zp
-      ENC_T(7);
-      if (more) ENC_GLOAD(mnext);                     // in flight during the GEMMs and the attention
-      // ---- r^T = B'_h x_hat^T + b'_h: lane (c16, kq) ends with token c16 (+ 16), features fb + 4 kq + {0..3} ----
-      {
-        f32x4 acc0 = bias4, acc1 = bias4;
-        const short* xp = Xp + c16 * kPS + 8 * kq;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const Frag3 b0 = frag_row(xp + 32 * s), b1 = frag_row(xp + 16 * kPS + 32 * s);
-          acc0 = mma6(acc0, Bw[s], b0); acc1 = mma6(acc1, Bw[s], b1);
-        }
-        *reinterpret_cast<f32x4*>(&Rs[c16 * kLdF + fb + 4 * kq]) = acc0;
-        *reinterpret_cast<f32x4*>(&Rs[(16 + c16) * kLdF + fb + 4 * kq]) = acc1;
+    ENC_T(2);
+    __syncthreads();
+    ENC_T(7);
+    // ---- phase X ----
+    if (tiA == 0) ENC_LOAD_M(hA);
+    // dyn^T (this head's share) = M'_h z^T, added into Y by the owner of the element; the last head adds c and applies the dropout
+    {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, old0 = acc0, old1 = acc0;
+      float* y0 = g.Y + ((int64_t)t0 + c16) * kD + fb + 4 * kq;
+      float* y1 = y0 + 16 * kD;
+      const bool ok0 = c16 < n_real, ok1 = 16 + c16 < n_real;
+      if (!(ENC_ABL & 16) && hA > 0) {                // the earlier heads' sum: in flight under the MFMAs, added behind them
+        if (ok0) old0 = *reinterpret_cast<const f32x4*>(y0);
+        if (ok1) old1 = *reinterpret_cast<const f32x4*>(y1);
       }
-      ENC_T(1);
-      __syncthreads();
-      ENC_T(7);
-      // ---- attention in x_hat space: 16 lanes per query token ----
-      {
-        V8 z = zero8();
-        if (la < n_real) {
-          const int ia = tinfo[la];
-          const int li0 = ia & 255, k = ia >> 8, pos = la - li0, n_pad = g.L - k;
-          const float padf = (float)n_pad;
-          const V8 r = ld8(&Rs[la * kLdF + 8 * sub]);
-          const V8 xp8 = ld8(&xpad[8 * sub]);
-          V8 xk[ML];
-          float s[ML];
+      if (!(ENC_ABL & 4)) gemm_k128<true>(acc0, acc1, Mw, Zp + c16 * kPS + 8 * kq);
+      acc0 += old0; acc1 += old1;
+      if (hA == MATCHA_N_HEAD - 1) {
+        acc0 += cvec4; acc1 += cvec4;
+        if (g.p_drop > 0.f) {
+          const uint32_t col = (uint32_t)(fb + 4 * kq);
+          if (ok0) {
+            const uint32_t crow = (uint32_t)g.tok_slot[t0 + c16];
 #pragma unroll
-          for (int j = 0; j < ML; ++j) xk[j] = ld8(&Xs[(li0 + (j < k ? j : 0)) * kLdF + 8 * sub]);
-          float mx = -3.4e38f;
-#pragma unroll
-          for (int j = 0; j < ML; ++j) {
-            float v = group_sum16_dpp(dot8(r, xk[j])) * inv_temp;
-            if (j == pos) v = -1e32f;
-            s[j] = v;
-            if (j < k) mx = fmaxf(mx, v);
+            for (int e = 0; e < 4; ++e) acc0[e] = (rng_u32(key, crow, col + e) >= thr) ? acc0[e] * keep_scale : 0.f;
           }
-          float sp = group_sum16_dpp(dot8(r, xp8)) * inv_temp;
-          if (n_pad > 0) mx = fmaxf(mx, sp);
-          float den = 0.f;
+          if (ok1) {
+            const uint32_t crow = (uint32_t)g.tok_slot[t0 + 16 + c16];
 #pragma unroll
-          for (int j = 0; j < ML; ++j) { s[j] = (j < k) ? __expf(s[j] - mx) : 0.f; den += s[j]; }
-          sp = (n_pad > 0) ? __expf(sp - mx) : 0.f;
-          den += padf * sp;
-          const float inv = 1.f / den;
-          sp *= inv;
-          z = scale8(padf * sp, xp8);
-#pragma unroll
-          for (int j = 0; j < ML; ++j) { s[j] *= inv; axpy8(z, s[j], xk[j]); }
-          if (g.rec) {
-            float* rb = g.rec + ((int64_t)tile * MATCHA_N_HEAD + h) * kRec;
-            float* rr = rb + la * kD + 8 * sub;
-            __builtin_nontemporal_store(r.a.x, rr); __builtin_nontemporal_store(r.a.y, rr + 1); __builtin_nontemporal_store(r.b.x, rr + 2);
-            __builtin_nontemporal_store(r.b.y, rr + 3); __builtin_nontemporal_store(r.c.x, rr + 4); __builtin_nontemporal_store(r.c.y, rr + 5);
-            __builtin_nontemporal_store(r.d.x, rr + 6); __builtin_nontemporal_store(r.d.y, rr + 7);
-            if (sub == 0) {
-              float w[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) w[j] = j < ML ? s[j < ML ? j : 0] : 0.f;
-              if (n_pad > 0) w[7] = sp;
-              float* pr = rb + 32 * kD + la * 8;
-              *reinterpret_cast<float4*>(pr) = make_float4(w[0], w[1], w[2], w[3]);
-              *reinterpret_cast<float4*>(pr + 4) = make_float4(w[4], w[5], w[6], w[7]);
-            }
+            for (int e = 0; e < 4; ++e) acc1[e] = (rng_u32(key, crow, col + e) >= thr) ? acc1[e] * keep_scale : 0.f;
           }
         }
-        frag_store(Zp + la * kPS + 8 * sub, split8(z));
       }
-      ENC_T(2);
-      __syncthreads();
-      ENC_T(7);
-      // ---- dyn^T (this head's share) = M'_h z^T, added into Y by the owner of the element; the last head adds c and applies the dropout ----
-      {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        float* y0 = g.Y + ((int64_t)t0 + c16) * kD + fb + 4 * kq;
-        float* y1 = y0 + 16 * kD;
-        const bool ok0 = c16 < n_real, ok1 = 16 + c16 < n_real;
-        if (h > 0) {
-          if (ok0) acc0 = *reinterpret_cast<const f32x4*>(y0);
-          if (ok1) acc1 = *reinterpret_cast<const f32x4*>(y1);
-        }
-        const short* zp = Zp + c16 * kPS + 8 * kq;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const Frag3 b0 = frag_row(zp + 32 * s), b1 = frag_row(zp + 16 * kPS + 32 * s);
-          acc0 = mma6(acc0, Mw[s], b0); acc1 = mma6(acc1, Mw[s], b1);
-        }
-        if (h == MATCHA_N_HEAD - 1) {
-          acc0 += cvec4; acc1 += cvec4;
-          if (g.p_drop > 0.f) {
-            const uint32_t col = (uint32_t)(fb + 4 * kq);
-            if (ok0) {
-              const uint32_t crow = (uint32_t)g.tok_slot[t0 + c16];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc0[e] = (rng_u32(key, crow, col + e) >= thr) ? acc0[e] * keep_scale : 0.f;
-            }
-            if (ok1) {
-              const uint32_t crow = (uint32_t)g.tok_slot[t0 + 16 + c16];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc1[e] = (rng_u32(key, crow, col + e) >= thr) ? acc1[e] * keep_scale : 0.f;
-            }
-          }
-        }
-        if (ok0) *reinterpret_cast<f32x4*>(y0) = acc0;
-        if (ok1) *reinterpret_cast<f32x4*>(y1) = acc1;
-      }
-      // ---- stage the next step's rows: the attention is done with Xs / Xp / tinfo (third barrier above), GEMM2 reads only Zp ----
-      ENC_T(3);
-      if (more) ENC_STAGE(mnext.y);
-      ENC_T(4);
+      if ((!(ENC_ABL & 16) || hA == 7) && ok0) *reinterpret_cast<f32x4*>(y0) = acc0;
+      if ((!(ENC_ABL & 16) || hA == 7) && ok1) *reinterpret_cast<f32x4*>(y1) = acc1;
     }
+    ENC_T(3);
+    if (st + 1 < nsteps) {
+      if (tiB == 0) ENC_LOAD_B(hB);
+      ENC_GEMM1(buf ^ 1);
+    }
+    ENC_T(1);
+    if (!(ENC_ABL & 8) && st + 2 < nsteps) ENC_STAGE(buf, mC.y);         // step st + 2 takes over the buffers step st is done with
+    if (st + 3 < nsteps) { mD = meta[ti3]; ENC_GLOAD(mD); }
+    ENC_T(4);
+    __syncthreads();
+    ENC_T(7);
+    mA = mB; mB = mC; mC = mD;
+    tiA = tiB; hA = hB;
+    ti3 = ti3 + 1 == ntile ? 0 : ti3 + 1;
   }
 #ifdef ENC_TIMING
   if (blockIdx.x == 0 && (tid == 0 || tid == 448))
-    printf("enc128_fwd wg0 wave %d us: weights %.1f gemm1 %.1f attn %.1f gemm2 %.1f stage %.1f barrier-wait %.1f (tiles %d x 8 heads)\n", tid >> 6,
-           tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[7] * 0.01, ntile);
+    printf("enc128_fwd wg0 wave %d us: gemm1 %.1f attn %.1f gemm2 %.1f stage %.1f barrier-wait %.1f (tiles %d x 8 heads)\n", tid >> 6,
+           tph[1] * 0.01, tph[2] * 0.01, tph[3] * 0.01, tph[4] * 0.01, tph[7] * 0.01, ntile);
 #endif
 #undef ENC_GLOAD
 #undef ENC_STAGE
+#undef ENC_LOAD_B
+#undef ENC_LOAD_M
+#undef ENC_GEMM1
 }
 
 // =====================================================================================================================================
