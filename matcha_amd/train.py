@@ -49,6 +49,7 @@ def _barrier():
     if _dist()[1] > 1:
         torch.distributed.barrier()
 
+STATS = {"train_graph_replays": 0}      # captured training graphs replayed by this process (tests: the data-parallel driver does not fall back)
 GRAPH_EPOCHS = os.environ.get("MATCHA_TRAIN_GRAPH", "1") != "0"     # single GPU: the epoch loop replays one captured step (Session.graph_epoch)
 NEG_NUM = 3          # main.py:527
 BATCH_SIZE = 96      # main.py:528 (positives per step)
@@ -170,15 +171,25 @@ class Session:
     # times that.  Everything a step does is already on the device and free of synchronisation, so the step -- positives gathered by a
     # device-side counter, negative sampling, batch assembly, forward, backward, AdamW, the epoch's running sums and its row in the
     # prediction table -- is captured once into a hipGraph and the epoch loop is `graph.replay()` per step.
-    def graph_ok(self, beta: float) -> bool:
+    def graph_ok(self, beta: float, training: bool = True) -> bool:
+        """Whether the epoch loop can replay captured steps.  Data parallel: the gradient exchange sits BETWEEN two graphs (A: selection, negative
+        sampling, forward, backward; collectives, eager; B: AdamW + the epoch's records) -- unless the step has a collective of its own in the
+        middle (adj front end with beta != 0: the reconstruction mean's row count is exchanged between forward and backward), which stays call
+        by call.  A forward-only (evaluation) step has no collective at all."""
         tr = self.trainer
-        return (GRAPH_EPOCHS and self.world == 1 and not tr.force_collectives
-                and (tr.rt.mode == 0 or beta == 0.0 or tr.supports_device_chrom()))
+        if tr.force_collectives and self.world == 1:         # bench.py's one-rank RCCL exercise: call by call
+            return False
+        if self.world > 1 and training and not (tr.rt.mode == 0 or beta == 0.0):
+            return False
+        return GRAPH_EPOCHS and (tr.rt.mode == 0 or beta == 0.0 or tr.supports_device_chrom())
 
-    def graph_epoch(self, e: torch.Tensor, w: torch.Tensor, n_batch: int, P: int, alpha: float, beta: float):
-        """e int64 [>= n_batch * P, L], w float32: the epoch's shuffled positives.  Returns (bce_sum, recon_sum, preds [n_batch, B],
-        labels [B], sizes [n_batch, B]) as device tensors; nothing has synchronised."""
+    def graph_epoch(self, e: torch.Tensor, w: torch.Tensor, n_batch: int, P: int, alpha: float, beta: float, tok_max=None):
+        """e int64 [>= n_batch * P, L], w float32: the epoch's shuffled positives (data parallel: THIS RANK's rows of every global batch, in
+        step order).  Returns (bce_sum, recon_sum, preds [n_batch, B], labels [B], sizes [n_batch, B]) as device tensors; nothing has
+        synchronised.  ``tok_max`` (data parallel): per step the largest real-token count of any rank (host arithmetic of the driver), for
+        the compacted row-sparse exchange."""
         dev, L, B = self.dev, int(e.shape[1]), P * (1 + NEG_NUM)
+        dp = self.world > 1
         # the chromosome of every step's reconstruction branch, drawn exactly as the step-by-step loop draws them (Modules.py:192)
         chroms = np.asarray([self.random_chrom() for _ in range(n_batch)], dtype=np.int32)
         # (a monotonically increasing generation, not id(): CPython reuses the id of a freed Trainer / sampler)
@@ -205,45 +216,84 @@ class Session:
         lib = _lib.load()
         n_rows = n_batch * P
 
-        def one_step():
+        tr = self.trainer
+
+        def part_a(step_i: int):
             # everything that changes from step to step lives on the device: the step counter `it` picks the step's positives, weights
             # and reconstruction chromosome (matcha_step_select) and the row of the epoch's prediction / size buffers (matcha_step_record)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.matcha_step_select(_lib.ptr(st["pos"]), _lib.ptr(st["w"]), n_rows, L, _lib.ptr(st["it"]), P, _lib.ptr(st["x"]),
                                               _lib.ptr(st["ww"]), _lib.ptr(st["chroms"]), n_batch, _lib.ptr(st["cell"]),
-                                              _lib.ptr(self.sampler.seed), _lib.ptr(self.trainer.seed), stream),
+                                              _lib.ptr(self.sampler.seed), _lib.ptr(tr.seed), stream),
                        "matcha_step_select")
             self.sampler.sample_into(st["x"][:P], st["x"][P:], advance_seed=False)
-            self.trainer.seed_advanced_by_caller = True
+            tr.seed_advanced_by_caller = True
             try:
-                bce, recon, logits = self.trainer.step(st["x"], st["y"], st["ww"], alpha=alpha, beta=beta, random_chrom=st["cell"])
+                # (data parallel: a host-side token bound keeps the count exchange -- a collective -- out of the step; the value that
+                # matters is set per step in front of the exchange, below)
+                st["logits"] = tr.forward_backward(st["x"], st["y"], st["ww"], alpha, beta, st["cell"],
+                                                   max_tokens=None if tok_max is None else tok_max[step_i])
             finally:
-                self.trainer.seed_advanced_by_caller = False
-            _lib.check(lib.matcha_step_record(_lib.ptr(logits), _lib.ptr(self.trainer.losses), _lib.ptr(st["x"]), B, L, _lib.ptr(st["it"]),
+                tr.seed_advanced_by_caller = False
+
+        def exchange(step_i: int):
+            if dp:
+                tr._host_max_tokens = None if tok_max is None else int(tok_max[step_i])
+                tr.all_reduce()
+
+        def part_b():
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            tr.optimizer_step()
+            _lib.check(lib.matcha_step_record(_lib.ptr(st["logits"]), _lib.ptr(tr.losses), _lib.ptr(st["x"]), B, L, _lib.ptr(st["it"]),
                                               n_batch, _lib.ptr(st["sums"]), _lib.ptr(st["preds"]), _lib.ptr(st["sizes"]), stream),
                        "matcha_step_record")
 
+        def one_step(step_i: int):
+            part_a(step_i); exchange(step_i); part_b()
+
         done = 0
+        tm = self.__dict__.setdefault("timing", {})
+        tm["graph_replays"] = 0
         if os.environ.get("MATCHA_TRAIN_GRAPH") == "steps":      # development: the same device-side step function, enqueued call by call
-            for _ in range(n_batch):
-                one_step()
+            for i in range(n_batch):
+                one_step(i)
             return st["sums"][0], st["sums"][1], st["preds"], st["y"], st["sizes"]
         if st["graph"] is None:
             # the first steps of the epoch run call by call on a side stream (they ARE steps of the epoch: buffers get allocated,
-            # kernels loaded), then the same function is captured; capturing enqueues nothing
+            # kernels loaded), then the same functions are captured; capturing enqueues nothing
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(min(2, n_batch)):
-                    one_step()
+                    one_step(done)
                     done += 1
             torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                one_step()
-            st["graph"] = g
-        for _ in range(n_batch - done):
-            st["graph"].replay()
+            if dp:
+                # data parallel: the gradient exchange (RCCL all-reduce / all-gather, or gloo on the test box) sits between two graphs
+                ga, gb_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    part_a(min(done, n_batch - 1))
+                with torch.cuda.graph(gb_):
+                    part_b()
+                st["graph"] = (ga, gb_)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one_step(min(done, n_batch - 1))
+                st["graph"] = g
+        if dp:
+            ga, gb_ = st["graph"]
+            for i in range(done, n_batch):
+                ga.replay()
+                exchange(i)
+                gb_.replay()
+                tm["graph_replays"] += 2
+                STATS["train_graph_replays"] += 2
+        else:
+            for _ in range(n_batch - done):
+                st["graph"].replay()
+                tm["graph_replays"] += 1
+                STATS["train_graph_replays"] += 1
         return st["sums"][0], st["sums"][1], st["preds"], st["y"], st["sizes"]
 
 
@@ -325,7 +375,17 @@ def train_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, alpha: fl
     tm = sess.__dict__.setdefault("timing", {})          # wall clock of the epoch's phases (tools/epoch_bench.py reads it)
     t_loop = time.perf_counter()
     if n_batch > 0 and sess.graph_ok(beta):
-        bce_sum, rec_sum, p2, y1, s2 = sess.graph_epoch(e, w, n_batch, batch_size, alpha, beta)
+        if sess.world > 1:
+            # this rank's rows of every global batch (strided shards, as `mine` below), contiguous in step order
+            e_r = e[:n_batch * gb].reshape(n_batch, batch_size, sess.world, -1)[:, :, sess.rank].reshape(n_batch * batch_size, -1).contiguous()
+            w_r = w[:n_batch * gb].reshape(n_batch, batch_size, sess.world)[:, :, sess.rank].reshape(-1).contiguous()
+        else:
+            e_r, w_r = e, w
+        bce_sum, rec_sum, p2, y1, s2 = sess.graph_epoch(e_r, w_r, n_batch, batch_size, alpha, beta, tok_max=tok_max)
+        if sess.world > 1:                                                       # epoch means over all ranks, as in the call-by-call loop
+            both = torch.stack([bce_sum, rec_sum])
+            torch.distributed.all_reduce(both)
+            bce_sum, rec_sum = both[0] / sess.world, both[1] / sess.world
         pred, label, size = p2.reshape(-1), y1.repeat(n_batch), s2.reshape(-1)
         torch.cuda.synchronize(dev)                                              # the epoch's one synchronisation
         tm["loop_s"] = time.perf_counter() - t_loop
@@ -386,7 +446,7 @@ def eval_epoch(sess: Session, edges: np.ndarray, weights: np.ndarray, batch_size
     n_batch = len(e) // batch_size
     tm = sess.__dict__.setdefault("timing", {})
     t_loop = time.perf_counter()
-    if n_batch > 0 and sess.graph_ok(1.0):
+    if n_batch > 0 and sess.graph_ok(1.0, training=False):
         # the forward-only step captured once and replayed per batch (the training epoch's mechanism); metrics as in _epoch_metrics
         bce_t, rec_t, p2, y1, s2 = _graph_eval(sess, e, w, n_batch, batch_size)
         pred, label, size = p2.reshape(-1), y1.repeat(n_batch), s2.reshape(-1)

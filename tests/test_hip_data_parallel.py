@@ -308,6 +308,9 @@ def _run_worker(rank, world, port, tmp, front_end):
     seen = [torch.zeros_like(nxt) for _ in range(world)]
     dist.all_gather(seen, nxt)
     assert torch.equal(seen[0], seen[1]), "the ranks' numpy streams drifted apart"
+    # the epoch loop replayed captured steps on every rank (graph A: sampling + forward + backward; the exchange; graph B: AdamW + records) --
+    # except where the step has a collective of its own in the middle (adj front end, beta != 0), which runs call by call
+    json.dump({"train_graph_replays": T.STATS["train_graph_replays"]}, open(os.path.join(tmp, f"graphs{rank}.json"), "w"))
     if rank == 0:
         assert any("Training" in l for l in logs)
         json.dump({"n_logs": len(logs)}, open(os.path.join(tmp, "rank0.json"), "w"))
@@ -329,6 +332,13 @@ def test_train_run_data_parallel_two_ranks(tmp_path, front_end):
     assert emb.shape == (N, 16) and np.isfinite(emb).all()
     assert os.path.exists(os.path.join(cfg["temp_dir"], "model.chkpt")) and os.path.exists(os.path.join(cfg["temp_dir"], "model2load"))
     assert os.path.exists(os.path.join(tmp_path, "rank0.json"))
+    import json
+    replays = [json.load(open(os.path.join(tmp_path, f"graphs{r}.json")))["train_graph_replays"] for r in (0, 1)]
+    assert replays[0] == replays[1]
+    if front_end == "table":
+        assert replays[0] >= 2 * (1 + 2) * 1                      # three epochs of three steps: two call by call (warm-up + capture), the rest replayed in pairs
+    else:
+        assert replays[0] == 0
 
 
 def test_bench_multi_rank_path_two_ranks_on_one_gpu(tmp_path):
