@@ -57,6 +57,9 @@ GEMM_CLASSES = ("gemm_nt", "gemm_nn", "gemm_tn", "fused_fwd", "fused_bwd", "adj_
 # formulation's ALGORITHMIC flops over the kernel's time -- and `executed_fraction` says what share of them the matrix cores really
 # run (so achieved x executed_fraction is the executed rate, the one bounded by the f32 MFMA peak).
 EXECUTED_FRACTION_MERGED = {"fused_fwd": (8 * 2 + 2) / (8 * 4 + 2.0), "fused_bwd": 4 / 8.0}
+# embed_dim 128 (enc128.hip): the fused attention block alone -- 4 projections per head forward (the two pff GEMMs stay separate launches), 8 GEMMs
+# per head backward; merged heads execute half of each
+EXECUTED_FRACTION_MERGED_128 = {"fused_fwd": 0.5, "fused_bwd": 0.5}
 METRIC = "training hyperedges/sec at k∈{2..5}, embed_dim=64; 1/2/4/8 MI355X"
 
 
@@ -132,6 +135,9 @@ def executed_fraction(lib, kernel_class, dim):
     if dim == 64 and kernel_class in EXECUTED_FRACTION_MERGED and lib.matcha_get_option(b"disable_merged") == 0 \
             and lib.matcha_get_option(b"disable_fused") == 0:
         return EXECUTED_FRACTION_MERGED[kernel_class]
+    if dim == 128 and kernel_class in EXECUTED_FRACTION_MERGED_128 and lib.matcha_get_option(b"disable_merged") == 0 \
+            and lib.matcha_get_option(b"disable_fused") == 0:
+        return EXECUTED_FRACTION_MERGED_128[kernel_class]
     return 1.0
 
 
@@ -139,6 +145,8 @@ def bf16x3_class(lib, kernel_class, dim):
     """Does this kernel class run its products as 3 x bf16 split-operand MFMAs (round 5)?"""
     if dim == 64:
         return kernel_class in ("fused_fwd", "fused_bwd") and lib.matcha_get_option(b"disable_fused") == 0 and lib.matcha_get_option(b"disable_merged") == 0
+    if dim == 128 and kernel_class in ("fused_fwd", "fused_bwd"):
+        return lib.matcha_get_option(b"disable_fused") == 0 and lib.matcha_get_option(b"disable_merged") == 0
     return dim >= 128 and kernel_class in ("gemm_nt", "gemm_nn", "gemm_tn") and lib.matcha_get_option(b"disable_wide_gemm") == 0
 
 
@@ -654,7 +662,8 @@ def main():
                             ("reference_batch_384_rows_adj", dict(layout="hg38_1mb", dim=64, ks=[2, 3, 4, 5], rows=384, front_end="adj")),
                             ("configs3_hg38_100kb_d128", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="table", prof="auto")),
                             # the same configuration in the mode the reference itself would run there (MultipleEmbedding: per-chromosome gather-GEMMs
-                            # over up to 2 491 feature columns + the reconstruction branch); embed_dim 128 takes the unfused adj kernels (adj_frontend.hip)
+                            # over up to 2 491 feature columns + the reconstruction branch); embed_dim 128 takes the unfused adj kernels (adj_frontend.hip) in front of
+                            # the fused attention block (enc128.hip)
                             ("configs3_hg38_100kb_d128_adj", dict(layout="hg38_100kb", dim=128, ks=[2, 3, 4, 5], rows=65536, front_end="adj", prof="auto")),
                             # BASELINE configs[4] at its FULL size: 1 M nodes, 100 M known hyperedges (generated, hashed and CSR-sharded on the
                             # device), k in {2..8}, d = 256.  kernel classes on: the HBM-bound part of this step is the dense AdamW over
@@ -686,7 +695,7 @@ def main():
                     hb = sum(e["class_ms"].get(k, 0.0) for k in ("adamw", "embed_fwd", "embed_scatter", "front_fwd", "front_bwd"))
                     extras[key]["hbm_bound_share"] = round(hb / (e["elapsed"] / 8 * 1e3), 4)
                     extras[key]["roofline_by_kernel_class"] = {k: v for k, v in e["roof_all"].items() if k in ("adamw", "embed_fwd", "embed_scatter", "adj_encode", "adj_recon",
-                                                                                                            "adj_bwd", "gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd")}
+                                                                                                            "adj_bwd", "gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd", "fused_fwd", "fused_bwd")}
             # the reference's DRIVER flow on the clock (main.py:119-197, :261-342; tools/epoch_bench.py): matcha_amd.train running a phase-2
             # epoch at the reference's batch (96 + 288 rows per step) -- DataGenerator, batch assembly, sampler, step, metrics, save_embeddings;
             # a quarter epoch here (250 steps per size), the full 4 x 1000 steps with the CPU estimate in profiles/rNN_epoch_bench.jsonl
