@@ -81,17 +81,8 @@ __device__ __forceinline__ float group_sum(float v) {
 // trip through the LDS crossbar): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i of
 // each 8, which pairs the two quads).  Every lane ends with the group's total.
 __device__ __forceinline__ float group_sum8_dpp(float v) {
-#ifdef MATCHA_DPP_NOPS
-  asm volatile("s_nop 3" : "+v"(v));
-#endif
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-#ifdef MATCHA_DPP_NOPS
-  asm volatile("s_nop 3" : "+v"(v));
-#endif
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-#ifdef MATCHA_DPP_NOPS
-  asm volatile("s_nop 3" : "+v"(v));
-#endif
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
   return v;
 }

@@ -19,12 +19,12 @@
 // the layer-by-layer kernels (attention.hip, gemm_lds.hip), which is what the merged kernels are tested against.
 #include <stdlib.h>
 
+#include "bf16x3.hpp"
 #include "kernels.hpp"
 
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -58,47 +58,12 @@ __device__ __forceinline__ void ln_row16(const float4& v, float& mean, float& rs
 // acc: this lane's running sums {dK_pad, dV_pad} x 8 features.
 // Eight consecutive floats as four packed pairs: dot products and axpys compile to v_pk_mul / v_pk_fma (two flops per lane
 // per instruction) instead of scalar chains the compiler re-packs with extra moves.
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct V8 { f2 a, b, c, d; };
-__device__ __forceinline__ V8 ld8(const float* __restrict__ p) {
-  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-  V8 v;
-  v.a = f2{x.x, x.y}; v.b = f2{x.z, x.w}; v.c = f2{y.x, y.y}; v.d = f2{y.z, y.w};
-  return v;
-}
-__device__ __forceinline__ void st8(float* __restrict__ p, const V8& v) {
-  *reinterpret_cast<float4*>(p) = make_float4(v.a.x, v.a.y, v.b.x, v.b.y);
-  *reinterpret_cast<float4*>(p + 4) = make_float4(v.c.x, v.c.y, v.d.x, v.d.y);
-}
-__device__ __forceinline__ float dot8(const V8& u, const V8& v) {
-  f2 s = u.a * v.a;
-  s = __builtin_elementwise_fma(u.b, v.b, s);
-  s = __builtin_elementwise_fma(u.c, v.c, s);
-  s = __builtin_elementwise_fma(u.d, v.d, s);
-  return s.x + s.y;
-}
-__device__ __forceinline__ V8 scale8(float w, const V8& x) {
-  const f2 ww = {w, w};
-  V8 y;
-  y.a = ww * x.a; y.b = ww * x.b; y.c = ww * x.c; y.d = ww * x.d;
-  return y;
-}
-__device__ __forceinline__ void axpy8(V8& y, float w, const V8& x) {
-  const f2 ww = {w, w};
-  y.a = __builtin_elementwise_fma(ww, x.a, y.a); y.b = __builtin_elementwise_fma(ww, x.b, y.b);
-  y.c = __builtin_elementwise_fma(ww, x.c, y.c); y.d = __builtin_elementwise_fma(ww, x.d, y.d);
-}
-__device__ __forceinline__ V8 zero8() { V8 z; z.a = f2{0.f, 0.f}; z.b = z.a; z.c = z.a; z.d = z.a; return z; }
 
 // The attention rows are STREAMED: one key / value row in use and one in flight.  FB_PIN(addr, x): an empty asm that takes the LDS offset
 // of the NEXT row and the eight registers of the running sum as in / out operands: the load of row j + 1 cannot be issued before the
 // arithmetic on row j - 1 has produced x.  (sched_barrier alone does not do it: instruction selection has already placed the unchained
 // LDS loads of all rows ahead of the arithmetic -- 40 to 80 operand registers -- when the machine scheduler sees the fence.)
-#ifdef FBH_NOPIN
-#define FB_PIN(addr, x) do { } while (0)
-#else
 #define FB_PIN(addr, x) asm volatile("" : "+v"(addr), "+v"((x).a), "+v"((x).b), "+v"((x).c), "+v"((x).d))
-#endif
 // Keys = values (merged heads: both are the x_hat rows, kpad = vpad = the padding token's x_hat): ONE pass over the rows.  With the weights
 // w_j = p_ij (w_pad = n_pad p_i,pad) and d_j = dz_i . x_j:   z_i = sum_j w_j x_j,   sig = sum_j w_j d_j,   A = sum_j (w_j d_j) x_j, and
 //   d r_i = sum_j dS_ij x_j = (A - sig z_i) / temp        (dS_ij = w_j (d_j - sig) / temp; the sums include the padding term),
@@ -136,11 +101,7 @@ __device__ __forceinline__ void attn_row8_kv(const float* __restrict__ Qs, const
       vn2 = ld8(&Xs[ad]);
     }
     axpy8(o, p[j], v);
-#ifdef FBH_NODPP
-    const float d = group_sum<8>(dot8(go, v));
-#else
     const float d = group_sum8_dpp(dot8(go, v));
-#endif
     ds[j] = d;
     const float wd = p[j] * d;
     sig += wd;
@@ -229,82 +190,15 @@ constexpr int kTileH = 32 * kLd;
 // LDS per workgroup (75 KB, two workgroups per CU as before): x_hat f32 (the attention's keys / values) + planes, dDyn planes, RB = r f32 ->
 // dR planes, FB = dZ f32 -> Z planes, G f32.  One set only: the next half tile's rows wait in registers (fetched during the GEMMs) and are
 // staged at the top of the next iteration.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-#ifndef FBH_XBAR
-#define FBH_XBAR 0                      // debugging: extra workgroup barriers (bit i: a second barrier at point i of the half-tile loop)
-#endif
-#define FBH_X(i) do { if (FBH_XBAR & (1 << (i))) __syncthreads(); } while (0)
 constexpr int kPS = 72;                 // bf16 per plane row
 constexpr int kPlane = 32 * kPS;        // bf16 per plane
 constexpr int kPT = 3 * kPlane;         // bf16 per three-plane tile (13 824 B)
-struct Frag3 { u32x4 h, m, l; };
-struct P3 { uint32_t h, m, l; };
-__device__ __forceinline__ P3 split2(float a, float b) {
-  const f2 v = {a, b};
-  const bf16x2 hb = __builtin_convertvector(v, bf16x2);                 // v_cvt_pk_bf16_f32: round to nearest even
-  const f2 r1 = v - __builtin_convertvector(hb, f2);
-  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-  const f2 r2 = r1 - __builtin_convertvector(mb, f2);
-  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-  return P3{__builtin_bit_cast(uint32_t, hb), __builtin_bit_cast(uint32_t, mb), __builtin_bit_cast(uint32_t, lb)};
-}
-__device__ __forceinline__ Frag3 split8(const float* v) {
-  const P3 a = split2(v[0], v[1]), b = split2(v[2], v[3]), c = split2(v[4], v[5]), d = split2(v[6], v[7]);
-  Frag3 f;
-  f.h = (u32x4){a.h, b.h, c.h, d.h}; f.m = (u32x4){a.m, b.m, c.m, d.m}; f.l = (u32x4){a.l, b.l, c.l, d.l};
-  return f;
-}
-__device__ __forceinline__ Frag3 split8(const V8& v) {
-  const float t[8] = {v.a.x, v.a.y, v.b.x, v.b.y, v.c.x, v.c.y, v.d.x, v.d.y};
-  return split8(t);
-}
-// eight consecutive bf16 of a plane-tile row (16-byte aligned) <-> a fragment
-__device__ __forceinline__ Frag3 frag_row(const short* __restrict__ p) {
-  Frag3 f;
-  f.h = *reinterpret_cast<const u32x4*>(p); f.m = *reinterpret_cast<const u32x4*>(p + kPlane); f.l = *reinterpret_cast<const u32x4*>(p + 2 * kPlane);
-  return f;
-}
-__device__ __forceinline__ void frag_store(short* __restrict__ p, const Frag3& f) {
-  *reinterpret_cast<u32x4*>(p) = f.h; *reinterpret_cast<u32x4*>(p + kPlane) = f.m; *reinterpret_cast<u32x4*>(p + 2 * kPlane) = f.l;
-}
-// column fragment: tokens 8 kq .. 8 kq + 7 of ONE column per lane.  p = this lane's block address: row 8 kq + ((lane & 15) >> 2), columns
-// c0 + 4 (lane & 3) of plane h; lane i of the 16-lane group receives column c0 + i (EXEC must be all ones: the GEMM phases are).
-__device__ __forceinline__ u32x4 tr8(const short* __restrict__ p) {
-#ifdef FBH_NOTR
-  // debugging: the same fragment with plain 16-bit reads.  p is THIS lane's block address (row 8 kq + q, column c0 + 4 p'); the lane needs
-  // column c0 + (lane & 15) of rows 8 kq .. 8 kq + 7
-  const int l = threadIdx.x & 15;
-  const short* base = p - ((l >> 2) * kPS + 4 * (l & 3)) + l;
-  uint32_t w[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) w[q] = (uint32_t)(uint16_t)base[(2 * q) * kPS] | ((uint32_t)(uint16_t)base[(2 * q + 1) * kPS] << 16);
-  return (u32x4){w[0], w[1], w[2], w[3]};
-#endif
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * kPS));
-  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
-  return (u32x4){a.x, a.y, b.x, b.y};
-}
-__device__ __forceinline__ Frag3 frag_col(const short* __restrict__ p) {
-  Frag3 f;
-  f.h = tr8(p); f.m = tr8(p + kPlane); f.l = tr8(p + 2 * kPlane);
-  return f;
-}
-#define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (A)), __builtin_bit_cast(bf16x8, (B)), (C), 0, 0, 0)
-// acc += A . B over 32 contraction indices: the six plane products above 2^-26, smallest first
-__device__ __forceinline__ f32x4 mma6(f32x4 acc, const Frag3& a, const Frag3& b) {
-  acc = MFMA16B(a.l, b.h, acc); acc = MFMA16B(a.h, b.l, acc); acc = MFMA16B(a.m, b.m, acc);
-  acc = MFMA16B(a.m, b.h, acc); acc = MFMA16B(a.h, b.m, acc); acc = MFMA16B(a.h, b.h, acc);
-#ifdef FBH_NOPS
-  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
-#endif
-  return acc;
-}
+// column fragments: contraction slot 8 kq + j holds token 8 kq + j -- the lane's block address is row 8 kq + ((lane & 15) >> 2), columns
+// c0 + 4 (lane & 3); lane i of the 16-lane group receives column c0 + i of tokens 8 kq .. 8 kq + 7
+typedef Planes<kPS, 4> PL;
+__device__ __forceinline__ Frag3 frag_row(const short* __restrict__ p) { return PL::row(p); }
+__device__ __forceinline__ void frag_store(short* __restrict__ p, const Frag3& f) { PL::store(p, f); }
+__device__ __forceinline__ Frag3 frag_col(const short* __restrict__ p) { return PL::col(p); }
 
 struct FusedBwdHArgs {
   const float* X; const float* dDyn; const int32_t* count; const int32_t* half_meta; const int32_t* tok_pos;
@@ -315,21 +209,10 @@ struct FusedBwdHArgs {
   float* wslab;                                    // [8][nchunks][kWgSlabM]
   const float* rimg;                               // [nhalves][8][kImgRecH]: r rows (register images) + attention probabilities of the forward
 };
-#ifdef FBH_NOALIAS
-constexpr size_t kBwdLdsBytes = (size_t)4 * kTileH * 4 + (size_t)4 * kPT * 2 + (64 + 256 + 256 + 32) * 4;      // debugging: r and dZ f32 tiles of their own
-#else
-#ifndef FBH_PAD
-#define FBH_PAD 0
-#endif
-constexpr size_t kBwdLdsBytes = (size_t)2 * kTileH * 4 + (size_t)4 * kPT * 2 + (64 + 256 + 256 + 32) * 4 + FBH_PAD;
-#endif
+constexpr size_t kBwdLdsBytes = (size_t)2 * kTileH * 4 + (size_t)4 * kPT * 2 + (64 + 256 + 256 + 32) * 4;
 
 template <int ML>
-#ifdef FBH_NOWPE
-__global__ __launch_bounds__(256) void fused_bwdh_kernel(FusedBwdHArgs g) {
-#else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_bwdh_kernel(FusedBwdHArgs g) {
-#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xs = lds;                                   // x_hat f32 (keys = values of the attention)
   float* Gs = lds + kTileH;                          // attention's gradient into the x_hat rows (keys + values)
@@ -337,15 +220,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   short* Dp = Xp + kPT;                              // dDyn planes
   short* RBp = Dp + kPT;                             // r f32 -> dR planes
   short* FBp = RBp + kPT;                            // dZ f32 -> Z planes
-#ifdef FBH_NOALIAS
-  float* Rs = reinterpret_cast<float*>(FBp + kPT);
-  float* Fs = Rs + kTileH;
-  float* sm = Fs + kTileH;
-#else
   float* Rs = reinterpret_cast<float*>(RBp);
   float* Fs = reinterpret_cast<float*>(FBp);
   float* sm = reinterpret_cast<float*>(FBp + kPT);
-#endif
   float* xpad = sm;
   float* dSs = xpad + 64;             // [32][8]
   float* Ps = dSs + 256;              // [32][8]
@@ -390,9 +267,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // column sums of dDyn (columns sc4 + {0..3} over the rows this thread stages) and of dR (features 8 sub + {0..7} over this lane group's tokens)
   f2 cd0 = {0.f, 0.f}, cd1 = cd0;
   V8 accR = zero8();
-#ifdef FBH_PROBE
-  V8 accR2 = zero8();                                  // debugging: the same column sums taken right behind the row phase
-#endif
 
   const int4* meta = reinterpret_cast<const int4*>(g.half_meta);
   const int4 mzero = make_int4(0, 0, 0, 0);
@@ -469,7 +343,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int t0 = mc.x, n_real = mc.y;
     FB_T(0);
     __syncthreads();                                  // the previous half tile's GEMMs are done with every tile
-    FBH_X(0);
     FB_T(7);
     // ---- stage this half tile (its rows were fetched during the previous one's GEMMs) ----
     {
@@ -480,7 +353,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (tid < 64) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
     }
     __syncthreads();
-    FBH_X(1);
     // per-lane indices re-derived from an opaque copy of the thread id (loop-invariant addresses are hoisted and spilled otherwise)
     int tid_ = tid;
     asm volatile("" : "+v"(tid_));
@@ -504,7 +376,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     FB_T(1);
     __syncthreads();
-    FBH_X(2);
     FB_T(7);
     // ---- attention forward + backward in x_hat space: 8 lanes per token, all 32 rows in one pass ----
     {
@@ -513,13 +384,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const bool acta = la < n_real;
       int ia = 0;
       if (acta) { ia = tinfo[la]; attn_row8_kv<ML>(Rs, Xs, Fs, xpad, Ps, dSs, la, ia & 255, ia >> 8, g.L - (ia >> 8), sub, inv_temp, o0, q0, accK, accV); }
-#ifdef FBH_PROBE
-      if (acta) { accR2.a += q0.a; accR2.b += q0.b; accR2.c += q0.c; accR2.d += q0.d; }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       FB_T(2);
       __syncthreads();
-      FBH_X(3);
       FB_T(7);
       if (acta) {
         attn_col8<ML>(Rs, Fs, Ps, dSs, la, ia & 255, ia >> 8, sub, k0, v0);
@@ -530,7 +397,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       FB_T(3);
       __syncthreads();                                // every column phase is done with the r and dZ rows: they become the dR and Z PLANES
-      FBH_X(4);
       FB_T(7);
       if (!acta) { o0 = zero8(); q0 = zero8(); }      // rows past the tokens: zero planes (they are contraction slots of the weight gradients)
       frag_store(FBp + la * kPS + 8 * sub, split8(o0));
@@ -539,7 +405,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     FB_T(4);
     __syncthreads();
-    FBH_X(5);
     FB_T(7);
     FBH_ROWS_GLOAD(mn);                               // next half tile's rows: in flight during the GEMMs below
     // ---- this head's share of d x_hat = dR B_h + Gs ----
@@ -643,20 +508,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     v += __shfl_xor(v, 32, 64);
     if (lane < 8) (i < 8 ? redp : redr)[wave * 64 + 8 * lane + (i & 7)] = v;
   }
-#ifdef FBH_PROBE
-  {
-    float* redq = lds + 12 * 64;
-    const float v2[8] = {accR2.a.x, accR2.a.y, accR2.b.x, accR2.b.y, accR2.c.x, accR2.c.y, accR2.d.x, accR2.d.y};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = v2[i];
-      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-      if (lane < 8) redq[wave * 64 + 8 * lane + i] = v;
-    }
-    __syncthreads();
-    if (tid < 64) slab[kVecOffM + 192 + tid] = (redq[tid] + redq[64 + tid]) + (redq[128 + tid] + redq[192 + tid]);
-  }
-#endif
   __syncthreads();
   if (tid < 64) {
     slab[kVecOffM + 64 + tid] = (redd[tid] + redd[64 + tid]) + (redd[128 + tid] + redd[192 + tid]);    // d bdyn partial
