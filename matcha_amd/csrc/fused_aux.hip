@@ -25,11 +25,17 @@ struct TailReduceArgs {
   float* partial;     // [kTailSplits][kTailSlab]
   float* dst[12];     // pff1_w, pff0_w, gp, bp, g1, b1, g2, b2, wc, pff1_b, pff0_b, bc
   float4* zero_buf; int64_t zero_n4;     // tail_slab_small_kernel: a buffer to zero in the same launch (the backward kernel's d x_hat)
+  int n_slabs; int rowmajor;             // >= 0: slab count given by the launcher (tail_bwd64_kernel: one per workgroup), matrices row-major
+  int with_mats; uint32_t slot_mask;     // which parts of the slabs are summed: the two matrices, vector slot v (bit v)
 };
 // element i of a summed slab into the gradient tensors: the two weight-gradient matrices arrive in the MFMA accumulator layout
 // [wave][lane][register] (fused_fwd32_tail.hpp), the vectors as they are
 __device__ __forceinline__ void tail_slab_add(const TailReduceArgs& a, int i, float s) {
-  if (i < 8192) {
+  if (i < 8192 && !a.with_mats) return;
+  if (i >= 8192 && ((a.slot_mask >> ((i - kTailVec) >> 6)) & 1u) == 0) return;
+  if (i < 8192 && a.rowmajor) {
+    a.dst[i >> 12][i & 4095] += s;
+  } else if (i < 8192) {
     const int e = i & 4095, wv = e >> 10, ln = (e >> 4) & 63, reg = e & 15;
     const int row = 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), col = 32 * (wv >> 1) + (ln & 31);
     a.dst[i >> 12][row * 64 + col] += s;
@@ -44,7 +50,9 @@ __global__ __launch_bounds__(512) void tail_slab_reduce_kernel(TailReduceArgs a)
   const int c4 = blockIdx.x * 64 + lane, sp = blockIdx.y;
   int nt = a.count[a.count_idx];                       // tiles (or half tiles) planned by ragged.hip: every one of them wrote its slab
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
+  if (a.n_slabs >= 0) nt = a.n_slabs;
   const int lo = (int)((int64_t)nt * sp / kTailSplits), hi = (int)((int64_t)nt * (sp + 1) / kTailSplits);
+  if (!a.with_mats && (blockIdx.x + 1) * 64 <= 8192 / 4) return;     // vector slots only: the matrix columns hold nothing
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0, s6 = s0, s7 = s0;
 #define TSR_ADD(S, V) do { S.x += V.x; S.y += V.y; S.z += V.z; S.w += V.w; } while (0)
   if (c4 < kTailF4) {
@@ -118,12 +126,13 @@ size_t fused_qkv_floats(int64_t B, int L) {          // the training forward's r
 }
 
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& g_, hipStream_t st, bool halves, float* partial, bool small,
-                       float* zero_buf, size_t zero_bytes) {
+                       float* zero_buf, size_t zero_bytes, int n_slabs, bool rowmajor, bool with_mats, uint32_t slot_mask) {
   MATCHA_CHECK_ARG(zero_bytes % 16 == 0 && (uintptr_t)zero_buf % 16 == 0 && (small || !zero_buf), "tail_reduce: zero_buf");
   TailReduceArgs a;
   a.tslab = tslab; a.count = rg.count; a.L = L; a.ntiles_cap = halves ? rg.nhalves : rg.ntiles; a.count_idx = halves ? 3 : 2;
   a.partial = partial;
   a.zero_buf = reinterpret_cast<float4*>(zero_buf); a.zero_n4 = (int64_t)(zero_bytes / 16);
+  a.n_slabs = n_slabs; a.rowmajor = rowmajor ? 1 : 0; a.with_mats = with_mats ? 1 : 0; a.slot_mask = slot_mask;
   float* dst[12] = {g_.pff1_w, g_.pff0_w, g_.pff_ln_g, g_.pff_ln_b, g_.ln1_g, g_.ln1_b, g_.ln2_g, g_.ln2_b, g_.cls_w, g_.pff1_b, g_.pff0_b, g_.cls_b};
   for (int i = 0; i < 12; ++i) a.dst[i] = dst[i];
   if (small) {

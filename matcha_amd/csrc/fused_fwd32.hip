@@ -487,6 +487,7 @@ struct Fwd32Args {
   float p_fc1, p_pff;
   float* ddyn0; float* dXs; float* tslab; float alpha_over_B;
   float* qkv;         // training: the record per (half tile, head) -- this wavefront's own r rows + probabilities, kImgRecH floats (fused_bwdh_kernel)
+  float* tail_dh2;    // single-wave kernel, training: [T][64] dH2 rows -- the tail's backward stops behind its LayerNorms, tail_bwd64_kernel does the convolutions
 };
 
 // Merged per-head matrices (two products per head: r = B_h x + b_h, dyn += M_h z).
@@ -880,8 +881,9 @@ int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, flo
 
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* rimg) {
+                       hipStream_t st, float* ddyn0, float* dXs, float* tslab, float alpha, float* rimg, float* tail_dh2) {
   Fwd32Args g;
+  g.tail_dh2 = nullptr;
   g.X = X; g.row_off = rg.row_off; g.tok_slot = rg.tok_slot; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos;
   g.L = L;
   g.wfrag = reinterpret_cast<const u32x4*>(frag);
@@ -913,6 +915,7 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
     MATCHA_CHECK_LAUNCH("fused_fwd32h_kernel");
     return MATCHA_OK;
   }
+  g.tail_dh2 = g.ddyn0 ? tail_dh2 : nullptr;
   switch (ml) {
     case 2: launch(fused_fwd32_kernel<2>); break;
     case 3: launch(fused_fwd32_kernel<3>); break;

@@ -227,6 +227,12 @@
     for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o, 64);
     if (lane == 0) tsl[kTailVec32 + 9 * 64] = sd;
   }
+  if (g.tail_dh2) {
+    // large batches: the convolutions' backward (dZ1, d dyn, the two weight gradients) is a kernel of its own (tail_bwd.hip) that reads this
+    // row next to the parked Y and H1 rows
+    if (r <= n) fl_store_global(g.tail_dh2 + F32_ROW(), dh2);      // (rows past the tokens: dout = 0 made them zero)
+    return;
+  }
   // the weight stream resumes at conv1^T (the window was not refilled across the end of conv1)
   FF_T(9);
   W32_PRIME_AT(18);

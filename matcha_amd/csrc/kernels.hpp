@@ -138,7 +138,10 @@ size_t fused_tail_slab_floats(int64_t B, int L);
 size_t fused_tail_partial_floats();
 // small: one launch (small batches; another summation order); it can also zero zero_bytes of zero_buf (the backward kernel's d x_hat buffer)
 int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial,
-                       bool small = false, float* zero_buf = nullptr, size_t zero_bytes = 0);
+                       bool small = false, float* zero_buf = nullptr, size_t zero_bytes = 0, int n_slabs = -1, bool rowmajor = false,
+                       bool with_mats = true, uint32_t slot_mask = 0x3FF);
+// (n_slabs >= 0: that many slabs with ROW-MAJOR weight-gradient matrices -- tail_bwd64_kernel's, one per workgroup -- instead of one per half
+// tile; with_mats / slot_mask: which parts of the slabs hold sums -- the two weight-gradient matrices, vector slot v)
 bool fused_small_batch(const Ragged& rg);          // the size rule of the small-batch kernels (fused_fwd32h_kernel, tail_slab_small_kernel)
 
 // fused_fwd32.hip (embed_dim 64): the same forward with ONE wavefront per half tile (<= 31 tokens), weights streamed from L2 in
@@ -153,7 +156,13 @@ MergedView merged_view(const float* merged);
 int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, float* frag, hipStream_t st);     // the three per-step weight forms, one launch
 int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float* frag, const float* X, const Ragged& rg, int64_t B, int L, const float* y,
                        const float* w, float* Y, float* H1, float* H2, float* logits, float* row_loss, const uint64_t* seed, float p_fc1, float p_pff,
-                       hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* rimg = nullptr);
+                       hipStream_t st, float* ddyn0 = nullptr, float* dXs = nullptr, float* tslab = nullptr, float alpha = 0.f, float* rimg = nullptr,
+                       float* tail_dh2 = nullptr);       // tail_dh2 (large batches only): the convolutions' backward is left to launch_tail_bwd64
+// tail_bwd.hip: the backward of pff_n1's two convolutions as its own kernel behind fused_fwd32_kernel (large batches)
+int tail_bwd_grid();
+size_t tail_bwd_slab_floats();
+int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y, const float* H1, const Ragged& rg, const uint64_t* seed, float p_fc1,
+                      float p_pff, float* ddyn0, float* slab, hipStream_t st);
 
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)

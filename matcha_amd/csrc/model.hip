@@ -76,6 +76,7 @@ struct Workspace {
   float* fb_ws;                           // fused backward: workgroup slabs + reduction partials
   float* tslab;                           // training forward: per-tile partials of the tail / pff_n1 parameter gradients
   float* tpart;                           // their two-pass reduction's split partials
+  float* tslab2;                          // large batches: one slab of weight-gradient partials per workgroup of tail_bwd64_kernel
   float* qkv;                             // training forward -> fused backward: Q, K, V tiles of every (tile, head), 384 KB per tile
   float* front_ws;                        // fused front-end backward: workgroup slabs
   void* tg_ws;      size_t tg_ws_bytes;   // table mode: sort scratch of the deterministic table gradient (table_grad.hip)
@@ -136,9 +137,9 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
 // consume records nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so it cannot live in device memory
 // without a synchronisation); bounded, evicted oldest-first, guarded by a mutex.  A backward on a workspace WITHOUT a record is refused.
 static std::mutex g_fwd_mu;
-static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward, bit 2: fused d = 128 attention block
+static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward, bit 2: fused d = 128 attention block, bit 3: the tail's backward ran as tail_bwd64_kernel
 static uint64_t g_fwd_clock = 0;
-static void note_forward(const void* ws, bool merged, bool fused, bool enc = false) {
+static void note_forward(const void* ws, bool merged, bool fused, bool enc = false, bool split_tail = false) {
   std::lock_guard<std::mutex> lk(g_fwd_mu);
   if (g_fwd_state.size() >= 4096 && g_fwd_state.find(ws) == g_fwd_state.end()) {
     auto old = g_fwd_state.begin();
@@ -146,7 +147,7 @@ static void note_forward(const void* ws, bool merged, bool fused, bool enc = fal
       if (it->second.second < old->second.second) old = it;
     g_fwd_state.erase(old);
   }
-  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0) | (enc ? 4 : 0), ++g_fwd_clock);
+  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0) | (enc ? 4 : 0) | (split_tail ? 8 : 0), ++g_fwd_clock);
 }
 static int ws_state(const void* ws) {       // -1: no forward on record for this workspace
   std::lock_guard<std::mutex> lk(g_fwd_mu);
@@ -245,6 +246,7 @@ static size_t carve(const matcha_shape& s, int64_t B, int L, char* base, Workspa
   w.fb_ws = take(s.d == 64 ? fused_bwd_ws_floats(B, L) : 0);
   w.tpart = take(s.d == 64 ? fused_tail_partial_floats() : 0);
   w.tslab = take(s.d == 64 ? fused_tail_slab32_floats(B, L) : 0);   // one slab per HALF tile (>= the four-wave kernel's per-tile need)
+  w.tslab2 = take(s.d == 64 ? tail_bwd_slab_floats() : 0);
   w.qkv = take(s.d == 64 ? fused_qkv_floats(B, L) : 0);        // reserved whatever the option table says: the layout must not depend on a switch read per call
   w.front_ws = take(front_bwd_supported(s.d, s.n_attr) ? front_bwd_ws_floats() : 0);
   w.tg_ws_bytes = (s.mode == 0 && !compact) ? table_grad_ws_bytes(Tn, s.n_nodes) : 0;
@@ -445,12 +447,17 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
-    note_forward(ws, true, true);
+    // large batches: the tail's backward inside the forward kernel stops behind its LayerNorms; pff_n1's two convolutions (dZ1, d dyn, the
+    // weight gradients) are a kernel of their own right behind it (tail_bwd.hip).  Development switch fused_dbg bit 0: all of it in-kernel.
+    const bool split_tail = lif && !fused_small_batch(w.rg) && (options().fused_dbg & 1) == 0;
+    note_forward(ws, true, true, false, split_tail);
     // (with the tail's backward in the forward kernel, Y and H1 are still handed over: the single-wave kernel PARKS the two rows there
     // (and the normalised H2 row in H2's place) between the tail's forward and backward halves instead of holding 96 registers per lane -- fused_fwd32_tail.hpp)
     MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, (save || lif) ? w.Y : nullptr, (save || lif) ? w.H1 : nullptr, (save || lif) ? w.H2 : nullptr,
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
-                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr));
+                                  lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr, split_tail ? w.dH2 : nullptr));
+    if (split_tail)
+      MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, st));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -558,7 +565,7 @@ extern "C" int matcha_debug_layout(const matcha_shape* shp, int64_t B, int32_t L
       {"P", w.P}, {"O_dxh", w.O}, {"Y", w.Y}, {"H1", w.H1}, {"H2", w.H2}, {"row_loss", w.row_loss}, {"logits", w.logits}, {"node", w.node}, {"dH2", w.dH2},
       {"dXs", w.dXs}, {"dZ1", w.dZ1}, {"ddyn0", w.ddyn0}, {"dZ0", w.dZ0}, {"dX0", w.dX0}, {"slab", w.slab}, {"gemm_ws", w.gemm_ws}, {"adj_ws", w.adj_ws},
       {"folded", w.folded}, {"frag", w.frag}, {"merged", w.merged}, {"lwB", w.lwB}, {"lwM", w.lwM}, {"lwdB", w.lwdB}, {"lwdM", w.lwdM}, {"enc", w.enc}, {"fb_ws", w.fb_ws},
-      {"tpart", w.tpart}, {"tslab", w.tslab}, {"qkv_records", w.qkv}, {"front_ws", w.front_ws}, {"tg_ws", w.tg_ws}};
+      {"tpart", w.tpart}, {"tslab", w.tslab}, {"tslab2", w.tslab2}, {"qkv_records", w.qkv}, {"front_ws", w.front_ws}, {"tg_ws", w.tg_ws}};
   size_t n = 0;
   for (const auto& e : f) {
     if (!e.p) continue;
@@ -640,7 +647,13 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // (fused_fwd32.hip).  Small batches: one launch, which also zeroes the buffer the backward kernel's heads add their d x_hat into
     const bool small = fused_small_batch(w.rg);
     dx_zeroed = small && !opts->deterministic && !opts->sparse_table_grad;
-    MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, small, dx_zeroed ? w.dO : nullptr, dx_zeroed ? (size_t)Tn * 64 * sizeof(float) : 0));
+    if ((fwd_state & 8) != 0) {
+      // the half tiles' slabs hold the LayerNorm / classifier vectors only (slots 0-6, 9); the convolutions' gradients (the two matrices, their
+      // biases: slots 7, 8) come in one row-major slab per workgroup of tail_bwd64_kernel
+      MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, false, nullptr, 0, -1, false, false, 0x27Fu));
+      MATCHA_TRY(launch_tail_reduce(w.tslab2, w.rg, L, g_, st, true, w.tpart, false, nullptr, 0, tail_bwd_grid(), true, true, 0x180u));
+    } else
+      MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, small, dx_zeroed ? w.dO : nullptr, dx_zeroed ? (size_t)Tn * 64 * sizeof(float) : 0));
   } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
