@@ -294,6 +294,8 @@ int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y,
   g.dH2 = dH2; g.Y = Y; g.H1 = H1; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_slot = rg.tok_slot; g.nhalves = rg.nhalves;
   g.W0 = p.pff0_w; g.W1 = p.pff1_w; g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   g.ddyn0 = ddyn0; g.slab = slab;
+  // timed with the forward kernel's class (bench.py): the tail's backward was inside that kernel before, its flops were never counted as work
+  ProfScope ps(MATCHA_PROF_FUSED_FWD, 0.0, st);
   auto kfn = tail_bwd64_kernel;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kfn, dim3(tail_bwd_grid()), dim3(256), kLdsBytes, st, g);
