@@ -96,6 +96,7 @@ __global__ __launch_bounds__(512) void tail_slab_small_kernel(TailReduceArgs a) 
     for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < a.zero_n4; i += (int64_t)gridDim.x * 512) a.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int nt = a.count[a.count_idx];
   if (nt > a.ntiles_cap) nt = a.ntiles_cap;
+  if (a.n_slabs >= 0) nt = a.n_slabs;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   if (c4 < kTailF4) {
     const float4* base = reinterpret_cast<const float4*>(a.tslab) + c4;

@@ -183,19 +183,22 @@ constexpr int kTileH = 32 * kLd;
 // instructions); v_mfma_f32_16x16x32_bf16 has its own pipe.  What makes it pay HERE is that every GEMM operand is split ONCE where it is
 // produced and kept in LDS as bf16 planes -- dDyn and x_hat by the staging threads (one split per workgroup, not per wavefront: a 16 x 16
 // output tile reuses a fragment only six times), dR and Z by the attention's write phase, B_h and M_h once per workgroup walk in registers:
-//   plane tile = [32 tokens][72 bf16] x 3 planes (144-byte rows: 16-byte row reads conflict-free to 2-way, transposed reads 2-way)
+//   plane tile = [32 tokens][80 bf16] x 3 planes (160-byte rows: with 144-byte rows a third of the LDS cycles were bank conflicts --
+//     SQ_LDS_BANK_CONFLICT 70 M of SQ_LDS_IDX_ACTIVE 221 M per launch; on 40-dword rows both kinds of read are conflict-free)
 //   row fragment (contraction over FEATURES: dZ^T = M_h^T dDyn^T, d x_hat = dR B_h)   = one ds_read_b128 per plane
 //   column fragment (contraction over TOKENS: dB_h += dR^T x_hat, dM_h += dDyn^T Z)   = two ds_read_b64_tr_b16 per plane -- the hardware
 //     transpose read hands lane i of a 16-lane group column i of a 4 row x 16 column block (MI355X guide T10)
-// LDS per workgroup (75 KB, two workgroups per CU as before): x_hat f32 (the attention's keys / values) + planes, dDyn planes, RB = r f32 ->
+// LDS per workgroup (81 280 B: two workgroups per CU just fit): x_hat f32 (the attention's keys / values) + planes, dDyn planes, RB = r f32 ->
 // dR planes, FB = dZ f32 -> Z planes, G f32.  One set only: the next half tile's rows wait in registers (fetched during the GEMMs) and are
 // staged at the top of the next iteration.
-constexpr int kPS = 72;                 // bf16 per plane row
+constexpr int kPS = 80;                 // bf16 per plane row: 40 dwords -- with the token slots below BOTH fragment reads are conflict-free (bank sets
+                                        // {0,40,16,56,32,8,48,24} + 4 kq for the 16-byte row reads, 8-bank slots 40 r mod 64 for eight consecutive rows)
 constexpr int kPlane = 32 * kPS;        // bf16 per plane
-constexpr int kPT = 3 * kPlane;         // bf16 per three-plane tile (13 824 B)
-// column fragments: contraction slot 8 kq + j holds token 8 kq + j -- the lane's block address is row 8 kq + ((lane & 15) >> 2), columns
-// c0 + 4 (lane & 3); lane i of the 16-lane group receives column c0 + i of tokens 8 kq .. 8 kq + 7
-typedef Planes<kPS, 4> PL;
+constexpr int kPT = 3 * kPlane;         // bf16 per three-plane tile (15 360 B)
+// column fragments: contraction slot 8 kq + j holds token 4 kq + j (j < 4) or 16 + 4 kq + (j - 4) -- free, both operands of a product use the
+// same map -- so that a 32-lane half reads EIGHT CONSECUTIVE rows per transposed read.  The lane's block address: row 4 kq + ((lane & 15) >> 2),
+// columns c0 + 4 (lane & 3); lane i of the 16-lane group receives column c0 + i
+typedef Planes<kPS, 16> PL;
 __device__ __forceinline__ Frag3 frag_row(const short* __restrict__ p) { return PL::row(p); }
 __device__ __forceinline__ void frag_store(short* __restrict__ p, const Frag3& f) { PL::store(p, f); }
 __device__ __forceinline__ Frag3 frag_col(const short* __restrict__ p) { return PL::col(p); }
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tile + 1 < tile_hi) FBH_RIMG_GLOAD(tile + 1);     // next half tile's r rows and probabilities: in flight during the weight-gradient GEMMs
     // ---- weight gradients: dB[a][b] += sum_t dR[t][a] x_hat[t][b];  dM[n][m] += sum_t dDyn[t][n] Z[t][m]: ONE 32-token step, column fragments ----
     {
-      const int blk = ((8 * kq + ((lane & 15) >> 2)) * kPS) + 4 * (lane & 3);      // this lane's address inside a 4 x 16 transpose block
+      const int blk = ((4 * kq + ((lane & 15) >> 2)) * kPS) + 4 * (lane & 3);      // this lane's address inside a 4 x 16 transpose block
       const Frag3 xb = frag_col(Xp + blk + fb), zb = frag_col(FBp + blk + fb);
       {
         const Frag3 r0 = frag_col(RBp + blk), r1 = frag_col(RBp + blk + 16);

@@ -651,7 +651,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
       // the half tiles' slabs hold the LayerNorm / classifier vectors only (slots 0-6, 9); the convolutions' gradients (the two matrices, their
       // biases: slots 7, 8) come in one row-major slab per workgroup of tail_bwd64_kernel
       MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, false, nullptr, 0, -1, false, false, 0x27Fu));
-      MATCHA_TRY(launch_tail_reduce(w.tslab2, w.rg, L, g_, st, true, w.tpart, false, nullptr, 0, tail_bwd_grid(), true, true, 0x180u));
+      MATCHA_TRY(launch_tail_reduce(w.tslab2, w.rg, L, g_, st, true, w.tpart, true, nullptr, 0, tail_bwd_grid(), true, true, 0x180u));      // 512 slabs: the one-pass kernel
     } else
       MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, small, dx_zeroed ? w.dO : nullptr, dx_zeroed ? (size_t)Tn * 64 * sizeof(float) : 0));
   } else {

@@ -29,13 +29,13 @@ namespace {
 
 constexpr int kLd = 68;
 constexpr int kTileF = 32 * kLd;
-constexpr int kPS = 72;
+constexpr int kPS = 80;                 // 40-dword plane rows: conflict-free row and transposed reads (fused_bwd.hip)
 constexpr int kPlane = 32 * kPS;
 constexpr int kPT = 3 * kPlane;
 constexpr float kEps = 1e-5f;
 constexpr int kSlab = 2 * 4096 + 10 * 64;          // dW1 | dW0 (row-major [out][in]) | gp bp g1 b1 g2 b2 wc pff1_b pff0_b bc  (tail_slab_reduce's vector order)
 constexpr int kVec = 2 * 4096;
-typedef Planes<kPS, 4> PL;
+typedef Planes<kPS, 16> PL;
 
 struct TailBwdArgs {
   const float* dH2; const float* Y; const float* H1;  // [T][64] rows left by the forward kernel
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // ---- weight gradients: dW1[n][k] += sum_t dH2[t][n] H1[t][k];  dW0[n][k] += sum_t dZ1[t][n] Y[t][k]  (one 32-token step) ----
     {
-      const int blk = ((8 * kq + ((lane & 15) >> 2)) * kPS) + 4 * (lane & 3);
+      const int blk = ((4 * kq + ((lane & 15) >> 2)) * kPS) + 4 * (lane & 3);
       const Frag3 hb = PL::col(Hp + blk + fb), yb = PL::col(Yp + blk + fb);
 #pragma unroll
       for (int i = 0; i < 4; ++i) aw1[i] = mma6(aw1[i], PL::col(Dp + blk + 16 * i), hb);
