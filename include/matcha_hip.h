@@ -76,11 +76,12 @@ int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
 
 /* A/B switches for tests and profiling.  Each option is read from the environment variable MATCHA_<NAME> (upper case) ONCE,
  * when the library is loaded, and can be changed afterwards only through matcha_set_option -- no entry point reads the
- * environment per call.  FOUR switches: "disable_fused" (1 = layer-by-layer kernels at every embed_dim; 2 = only the front end as
- * separate kernels, the encoder stays fused), "disable_merged" (the reference's four products per attention head instead of the
+ * environment per call.  FOUR switches: "disable_fused" (1 = layer-by-layer kernels at every embed_dim, also instead of the fused
+ * attention block of embed_dim 128; 2 = only the front end as separate kernels, the encoder stays fused), "disable_merged" (the reference's four products per attention head instead of the
  * merged two; they live on the layer-by-layer kernels, so at embed_dim 64 this implies disable_fused), "disable_small_batch" (the
  * large-batch forward and plan kernels at every size), "disable_wide_gemm" (embed_dim >= 128: the 64-wide GEMM / attention kernels
- * instead of the 128 x 128 ones); development: "debug_nan", "fused_dbg".  (Whether the tail's backward runs inside the forward
+ * instead of the 128 x 128 ones); development: "debug_nan", "fused_dbg" (bit 0: the backward of
+ * pff_n1's convolutions inside the forward kernel at every batch size, instead of tail_bwd64_kernel for large batches).  (Whether the tail's backward runs inside the forward
  * kernel is a per-call choice: matcha_step_opts.loss_in_forward.)  Returns MATCHA_EINVAL for an unknown name;
  * matcha_get_option returns -1 for one.
  * Process-global: flip them only while no call is in flight. */
