@@ -630,6 +630,43 @@ def test_merged_layerwise_heads_match_the_four_product_formulation(d):
         assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("mode", ["table", "adj"])
+def test_split_tail_kernel_matches_the_in_kernel_tail(mode):
+    """Large batches: the backward of pff_n1's two convolutions as tail_bwd64_kernel behind the fused forward (persistent workgroups, weight
+    gradients in MFMA accumulators, one slab per workgroup) against the same backward inside the forward kernel (development switch
+    fused_dbg bit 0): dropout on, same masks -- logits bitwise (the forward halves are the same code), every gradient within 2e-6 of its
+    tensor's scale; two runs of the split path are bitwise equal (table front end)."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(_big_batch(N, 8192, rng)).cuda()
+    x[11] = 0                                           # a row of padding only
+    y = (torch.rand(len(x), device="cuda") < 0.25).float()
+    w = torch.rand(len(x), device="cuda") + 0.5
+    out = []
+    for flag in (0, 0, 1):
+        _lib.set_option("fused_dbg", flag)
+        try:
+            clf, _ = hip_model(num, 64, mode, 13)
+            clf.train()
+            tr = Trainer(clf, lr=1e-3, base_seed=6, deterministic=True)
+            lg = tr.forward_backward(x, y, w, 1.0, 0.001, 1).clone()
+            torch.cuda.synchronize()
+            out.append((lg, tr.gflat.clone(), tr))
+        finally:
+            _lib.set_option("fused_dbg", 0)
+    assert torch.equal(out[0][0], out[1][0])
+    if mode == "table":                                 # (the adj front end adds its per-chromosome weight gradients with float atomics)
+        assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[2][0])
+    assert not torch.equal(out[0][1], out[2][1])        # the two backward paths really ran (they round differently)
+    rt = out[0][2].rt
+    for p_, o in zip(rt.live, rt.seg_off_list[:-1]):
+        ga, gb = out[0][1][o:o + p_.numel()], out[2][1][o:o + p_.numel()]
+        assert float((ga - gb).abs().max()) <= 2e-6 * max(float(gb.abs().max()), 1e-3)
+
+
 @pytest.mark.parametrize("ks,L,n", [((2, 3, 4, 5), 5, 300), ((2, 5), 5, 4000), ((2, 3, 6, 8), 8, 500), ((2,), 2, 64)])
 def test_fused_d128_attention_block_matches_the_layerwise_kernels(ks, L, n):
     """embed_dim 128: the attention block as one forward / one backward kernel in x_hat space with the LayerNorm affines folded into the merged
