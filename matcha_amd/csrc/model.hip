@@ -457,7 +457,7 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr, split_tail ? w.dH2 : nullptr));
     if (split_tail)
-      MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, st));
+      MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, w.tslab, st));
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -648,10 +648,9 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     const bool small = fused_small_batch(w.rg);
     dx_zeroed = small && !opts->deterministic && !opts->sparse_table_grad;
     if ((fwd_state & 8) != 0) {
-      // the half tiles' slabs hold the LayerNorm / classifier vectors only (slots 0-6, 9); the convolutions' gradients (the two matrices, their
-      // biases: slots 7, 8) come in one row-major slab per workgroup of tail_bwd64_kernel
-      MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, false, nullptr, 0, -1, false, false, 0x27Fu));
-      MATCHA_TRY(launch_tail_reduce(w.tslab2, w.rg, L, g_, st, true, w.tpart, true, nullptr, 0, tail_bwd_grid(), true, true, 0x180u));      // 512 slabs: the one-pass kernel
+      // one row-major slab per workgroup of tail_bwd64_kernel: the convolutions' gradients and the half tiles' LayerNorm / classifier vectors
+      // (summed along its walk): 512 slabs, the one-pass reduction
+      MATCHA_TRY(launch_tail_reduce(w.tslab2, w.rg, L, g_, st, true, w.tpart, true, nullptr, 0, tail_bwd_grid(), true));
     } else
       MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, small, dx_zeroed ? w.dO : nullptr, dx_zeroed ? (size_t)Tn * 64 * sizeof(float) : 0));
   } else {

@@ -43,7 +43,9 @@ struct TailBwdArgs {
   int nhalves;
   const float* W0; const float* W1;                 // pff_n1 conv0 / conv1 weights [64 out][64 in]
   const uint64_t* seed; float p_fc1, p_pff;
-  float* ddyn0; float* slab;                        // slab [gridDim.x][kSlab]: dW1 | dW0 | ... pff1_b (slot 7), pff0_b (slot 8)
+  float* ddyn0; float* slab;                        // slab [gridDim.x][kSlab]: dW1 | dW0 | the ten vector slots
+  const float* vslab;                               // the forward kernel's per-half-tile slabs: their vector slots 0-6 and 9 (LayerNorm / classifier
+                                                    // gradients) are summed along the walk into this workgroup's slab -- ONE reduction over 512 slabs behind it
 };
 constexpr size_t kLdsBytes = (size_t)2 * kTileF * 4 + (size_t)4 * kPT * 2;
 
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 aw1[4], aw0[4];                              // dW1 / dW0: rows 16 i + 4 kq + reg, column fb + c16
 #pragma unroll
   for (int i = 0; i < 4; ++i) { aw1[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw0[i] = aw1[i]; }
+  float va0 = 0.f, va1 = 0.f, va2 = 0.f;            // vector slots of the forward's slabs: elements tid, tid + 256, and d bc (slot 9) in thread 64
   V8 a_c1 = zero8();                                 // column sums of dH2 (conv1's bias gradient), this thread's 8 features of its staging row
   f32x4 a_c0 = {0.f, 0.f, 0.f, 0.f};                 // column sums of dZ1 in the GEMM's output layout (features fb + 4 kq + {0..3})
 
@@ -130,6 +133,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int4 mnn = tile + 2 < tile_hi ? meta[tile + 2] : mzero;
     const int t0 = mc.x, n_real = mc.y;
+    const float* vs = g.vslab + (int64_t)tile * kSlab + kVec;          // (added at the end of the trip: in flight during the tile's work)
+    const float vl0 = vs[tid], vl1 = vs[tid + 256], vl2 = tid == 64 ? vs[9 * 64] : 0.f;      // slots 0-3, 4-7, the scalar of slot 9
     int tid_ = tid;
     asm volatile("" : "+v"(tid_));
     const int lane = tid_ & 63, wave = tid_ >> 6;
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < 4; ++i) aw0[i] = mma6(aw0[i], PL::col(Zp + blk + 16 * i), yb);
     }
     __syncthreads();                                  // the GEMMs are done with every tile
+    va0 += vl0; va1 += vl1; va2 += vl2;
     mc = mn; mn = mnn;
   }
 #undef TB_GLOAD
@@ -265,6 +271,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (c16 == 0) slab[kVec + 8 * 64 + fb + 4 * kq + e] = x;
     }
   }
+  // the forward's vector slots (element e of [10][64]; slots 7 and 8 are this kernel's own, written around this)
+  {
+    slab[kVec + tid] = va0;                                              // slots 0-3
+    if (tid < 192) slab[kVec + 256 + tid] = va1;                          // slots 4-6 (7 is this kernel's)
+    if (tid == 64) slab[kVec + 9 * 64] = va2;                             // d bc
+  }
   __syncthreads();
   if (tid < 64) slab[kVec + 7 * 64 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
 }
@@ -286,11 +298,12 @@ int tail_bwd_grid() {
 size_t tail_bwd_slab_floats() { return (size_t)tail_bwd_grid() * kSlab; }
 
 // After a training forward that ran fused_fwd32_kernel with `tail_split` set (it stopped behind the LayerNorm backward and left dH2 rows):
-// ddyn0 and one slab of weight-gradient partials per workgroup (tail_bwd_slab_floats() floats at `slab`; summed by
-// launch_tail_reduce(..., n_slabs = tail_bwd_grid(), rowmajor, slots 7 and 8 only)
+// ddyn0 and one slab of parameter-gradient partials per workgroup (tail_bwd_slab_floats() floats at `slab`: the convolutions' gradients + the
+// forward's per-half-tile vector slots of `vslab` summed along the walk; launch_tail_reduce(..., n_slabs = tail_bwd_grid(), rowmajor) sums them)
 int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y, const float* H1, const Ragged& rg, const uint64_t* seed, float p_fc1,
-                      float p_pff, float* ddyn0, float* slab, hipStream_t st) {
+                      float p_pff, float* ddyn0, float* slab, const float* vslab, hipStream_t st) {
   TailBwdArgs g;
+  g.vslab = vslab;
   g.dH2 = dH2; g.Y = Y; g.H1 = H1; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_slot = rg.tok_slot; g.nhalves = rg.nhalves;
   g.W0 = p.pff0_w; g.W1 = p.pff1_w; g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   g.ddyn0 = ddyn0; g.slab = slab;
