@@ -457,7 +457,8 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
                                   lg_out, w.row_loss, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, st,
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr, split_tail ? w.dH2 : nullptr));
     if (split_tail)
-      MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, w.tslab, st));
+      MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, w.tslab,
+                                   (!opts->deterministic && !opts->sparse_table_grad) ? w.dO : nullptr, st));      // ... and zeroes the backward's d x_hat rows
     if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
@@ -646,7 +647,7 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // ddyn0 and dXs were produced by matcha_forward; only the per-half-tile parameter-gradient partials remain to be summed
     // (fused_fwd32.hip).  Small batches: one launch, which also zeroes the buffer the backward kernel's heads add their d x_hat into
     const bool small = fused_small_batch(w.rg);
-    dx_zeroed = small && !opts->deterministic && !opts->sparse_table_grad;
+    dx_zeroed = (small || (fwd_state & 8) != 0) && !opts->deterministic && !opts->sparse_table_grad;      // (split tail: tail_bwd64_kernel zeroed the rows)
     if ((fwd_state & 8) != 0) {
       // one row-major slab per workgroup of tail_bwd64_kernel: the convolutions' gradients and the half tiles' LayerNorm / classifier vectors
       // (summed along its walk): 512 slabs, the one-pass reduction

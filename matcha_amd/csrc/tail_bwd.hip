@@ -44,6 +44,8 @@ struct TailBwdArgs {
   const float* W0; const float* W1;                 // pff_n1 conv0 / conv1 weights [64 out][64 in]
   const uint64_t* seed; float p_fc1, p_pff;
   float* ddyn0; float* slab;                        // slab [gridDim.x][kSlab]: dW1 | dW0 | the ten vector slots
+  float* zero_rows;                                 // [T][64] or null: the buffer the attention block's backward adds its d x_hat into with float atomics --
+                                                    // zeroed here row by row (a 13 us launch of its own otherwise)
   const float* vslab;                               // the forward kernel's per-half-tile slabs: their vector slots 0-6 and 9 (LayerNorm / classifier
                                                     // gradients) are summed along the walk into this workgroup's slab -- ONE reduction over 512 slabs behind it
 };
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- stage: this thread's 8 features of its row -> planes (rows past the tokens: zero gradient rows) ----
     {
       const V8 dh2 = scale8(row < n_real ? 1.f : 0.f, dn);
+      if (g.zero_rows && row < n_real) st8(g.zero_rows + ((int64_t)t0 + row) * 64 + 8 * sub, zero8());
       add8(a_c1, dh2);
       st8(&Ds[row * kLd + 8 * sub], dh2);
       st8(&Hs[row * kLd + 8 * sub], hn);
@@ -301,9 +304,9 @@ size_t tail_bwd_slab_floats() { return (size_t)tail_bwd_grid() * kSlab; }
 // ddyn0 and one slab of parameter-gradient partials per workgroup (tail_bwd_slab_floats() floats at `slab`: the convolutions' gradients + the
 // forward's per-half-tile vector slots of `vslab` summed along the walk; launch_tail_reduce(..., n_slabs = tail_bwd_grid(), rowmajor) sums them)
 int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y, const float* H1, const Ragged& rg, const uint64_t* seed, float p_fc1,
-                      float p_pff, float* ddyn0, float* slab, const float* vslab, hipStream_t st) {
+                      float p_pff, float* ddyn0, float* slab, const float* vslab, float* zero_rows, hipStream_t st) {
   TailBwdArgs g;
-  g.vslab = vslab;
+  g.vslab = vslab; g.zero_rows = zero_rows;
   g.dH2 = dH2; g.Y = Y; g.H1 = H1; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_slot = rg.tok_slot; g.nhalves = rg.nhalves;
   g.W0 = p.pff0_w; g.W1 = p.pff1_w; g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
   g.ddyn0 = ddyn0; g.slab = slab;
