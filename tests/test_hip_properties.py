@@ -716,6 +716,84 @@ def test_fused_d128_attention_block_matches_the_layerwise_kernels(ks, L, n):
         assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-8, (nme, float((a - b).abs().max()), scale)
 
 
+def _perturb_layer_norms(clf):
+    with torch.no_grad():
+        for nme, p_ in clf.named_parameters():
+            if "layer_norm" in nme:
+                p_.add_(0.2 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(len(nme))).to(p_.device))
+
+
+@pytest.mark.parametrize("mode", ["table", "adj"])
+@pytest.mark.parametrize("ks,n", [([2, 3, 4, 5], 300), ([3], 37)])
+def test_fused_d128_attention_block_in_eval_mode(mode, ks, n):
+    """embed_dim 128, forward only (no records, no dropout: the path Classifier.forward / predict take): enc128.hip against the
+    layer-by-layer kernels on the same weights, both front ends -- probabilities agree to rounding and really come from two kernels."""
+    num = synth.LAYOUTS["c1"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(41)
+    x = _mixed_batch(N, ks, n, rng)
+    x[3] = 0
+    x[4, 1:] = 0
+    clf, _ = hip_model(num, 128, mode, 23)
+    _perturb_layer_norms(clf)
+    clf.eval()
+    out = []
+    for fused_off in (0, 1):
+        _lib.set_option("disable_fused", fused_off)
+        try:
+            with torch.no_grad():
+                out.append(clf(x).clone())
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("disable_fused", 0)
+    assert torch.isfinite(out[0]).all()
+    assert not torch.equal(out[0], out[1])
+    assert float((out[0] - out[1]).abs().max()) <= 2e-5 * max(1.0, float(out[1].abs().max()))
+
+
+def test_captured_step_replays_like_eager_steps_at_embed_dim_128():
+    """Trainer.capture() over the embed_dim-128 step (enc128 forward + backward, their workspace and record buffers inside the hipGraph):
+    two eager steps + three replays against five eager steps on the same batch.  The d x_hat rows and the table gradient go through float
+    atomics on this path, so the comparison is to rounding, not bitwise; the BCE of the last step agrees to 1e-5."""
+    from matcha_amd.engine import Trainer
+    num = synth.LAYOUTS["c1"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(12)
+    x = _mixed_batch(N, [2, 3, 4, 5], 256, rng)
+    y = (torch.rand(len(x), device="cuda") < 0.25).float()
+    w = torch.ones(len(x), device="cuda")
+    res = []
+    for graph in (False, True):
+        clf, _ = hip_model(num, 128, "table", 6)
+        clf.train()
+        init = {n: p.detach().clone() for n, p in clf.named_parameters()}
+        tr = Trainer(clf, base_seed=3)
+        losses = []
+        if graph:
+            replay = tr.capture(x, y, w, alpha=1.0, beta=0.0)
+            for _ in range(3):
+                losses.append(float(replay()[0]))
+        else:
+            for i in range(5):
+                bce = float(tr.step(x, y, w, alpha=1.0, beta=0.0)[0])
+                if i >= 2:
+                    losses.append(bce)
+        torch.cuda.synchronize()
+        res.append((losses, init, {n: p.detach().clone() for n, p in clf.named_parameters()}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (res[0][0], res[1][0])
+    assert res[0][0][0] != res[0][0][2]                                     # the steps moved the model
+    for n in res[0][2]:
+        # AdamW normalises every element's update, so an element whose gradient is rounding noise (a few exist: zero by construction) moves
+        # by a run-dependent 1e-5; compare the distance between the two runs with the distance either of them travelled
+        a, b, a0 = res[0][2][n], res[1][2][n], res[0][1][n]
+        assert torch.equal(a0, res[1][1][n])
+        moved = float((a - a0).norm())
+        if n == GAUGE or moved == 0.0:
+            continue
+        assert float((a - b).norm()) <= 1e-2 * moved, (n, float((a - b).norm()), moved)
+
+
 def test_trainer_step_with_empty_rows_half_tile_backward():
     """The Trainer's default d = 64 step (merged heads, half-tile backward, heads' d x_hat through float atomics) on a batch with 300
     all-padding rows in the middle and k = 1 rows (a half tile then holds more than 31 hyperedges, some with no token at all), against
