@@ -15,8 +15,11 @@
 // 8 partials (2 KB), X, dXs, x0 (768 B), the id and its attribute row, and dZ0 / dX0 never reach HBM (table mode).
 // Persistent workgroups walk 64-token tiles; next_w stays in LDS, the two weight gradients in MFMA accumulators; one slab
 // per workgroup, summed in a fixed order by front_slab_reduce_kernel.  LDS 78 KB -> two workgroups per CU.
+#include <string.h>
+
 #include "attr_src.hpp"
 #include "kernels.hpp"
+#include "prep_heads.hpp"
 
 namespace matcha {
 
@@ -210,10 +213,20 @@ struct FrontFwdArgs {
   const float* Wa; const float* ba; const float* Wn; const float* bn;
   const int32_t* count;
   float* x0; float* X;
+  int nprep; PrepArgs prep;      // the first nprep blocks build the step's weight forms instead (prep_heads.hpp): they depend on the parameters only
 };
 
 __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // Block roles: the per-step weight forms of the encoder kernels (B_h, M_h, the fragment stream) are independent of the batch, the front end is
+  // independent of them -- their 72 blocks ride in front of this launch instead of being a launch of their own between the front end and the
+  // encoder (11 us of every step, a quarter of this kernel's own time at 65 536 rows and more than all of it at 384).
+  if ((int)blockIdx.x < g.nprep) {
+    const int b = blockIdx.x;
+    prep_heads_role(g.prep, b % kPrepGridX, (b / kPrepGridX) % kPrepGridY, b / (kPrepGridX * kPrepGridY), lds);
+    return;
+  }
+  const int bid = (int)blockIdx.x - g.nprep, stride = (int)gridDim.x - g.nprep;
   // The two weight matrices live in REGISTERS as MFMA operand fragments (32 + 16 per lane) instead of LDS tiles: 44 KB of LDS per
   // workgroup instead of 70, i.e. three workgroups per CU gathering rows -- this kernel is a gather, bytes in flight are what it needs
   float* Es = lds;                                // node rows, then x0 in place
@@ -272,9 +285,8 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
       pa[j__] = make_float4(v__.x * amask, v__.y * amask, v__.z * amask, v__.w * amask);                 \
     }                                                                                                    \
   } while (0)
-  const int stride = (int)gridDim.x;
   {
-    const int first = blockIdx.x;
+    const int first = bid;
     FF_IDS_GLOAD(first);
     FF_ROWS_GLOAD(first);
 #pragma unroll
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
     for (int i = 0; i < 4; ++i) { const float4 t = pe[i]; pe[i] = qe[i]; qe[i] = t; }
     { const float4 t0 = pa[0], t1 = pa[1]; pa[0] = qa[0]; pa[1] = qa[1]; qa[0] = t0; qa[1] = t1; }
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = bid; tile < ntiles; tile += stride) {
     const int64_t t_base = (int64_t)tile * 64;
     __syncthreads();
     // ---- the prefetched node rows (16 lanes x float4 per 256-B row) and attribute rows -> LDS; next tile's rows, the one after's ids ----
@@ -420,7 +432,7 @@ int front_grid() {
 }  // namespace
 
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const matcha_frozen& f, int n_attr,
-                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st) {
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st, const PrepSpec* prep) {
   // the fused front end GATHERS attribute rows (rows padded to one 128-byte unit when the caller padded them, attr_ld): its row pieces are
   // loaded by eight threads per row inside a register prefetch pipeline; rebuilding them from the node id there (attr_mode 1) put a branch
   // around the loads and cost 20 % of front_bwd_kernel -- embed_fwd_kernel and the fused adj forward, one thread / one lane pair per row, do rebuild
@@ -432,6 +444,15 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   const int64_t max_tiles = cdiv(tcap, 64);
   if (grid > max_tiles) grid = (int)max_tiles;
   const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
+  static_assert(((size_t)2 * kTile + 64 * kLdA) >= (size_t)kPrepLdsFloats, "the weight-form role needs its LDS inside the front end's");
+  g.nprep = 0;
+  if (prep) {
+    prep_heads_args(*prep->p, prep->folded, prep->merged, prep->frag, g.prep);
+    g.nprep = kPrepBlocks;
+    grid += kPrepBlocks;
+  } else {
+    memset(&g.prep, 0, sizeof(g.prep));
+  }
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read (attr_mode 1: rebuilt from the id, nothing read); x0 and X rows
   // written (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
   ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + (g.attr.mode == 1 ? 0.0 : 4.0 * n_attr) + (x0 ? 512.0 : 256.0)), st);

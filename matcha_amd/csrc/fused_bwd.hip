@@ -18,9 +18,11 @@
 // The reference's own four-product formulation (Q, K, V, fc1 per head) is NOT in this file any more: option disable_merged runs it on
 // the layer-by-layer kernels (attention.hip, gemm_lds.hip), which is what the merged kernels are tested against.
 #include <stdlib.h>
+#include <string.h>
 
 #include "bf16x3.hpp"
 #include "kernels.hpp"
+#include "tail_reduce.hpp"
 
 namespace matcha {
 
@@ -532,9 +534,19 @@ struct ChainArgs {
   float* out;                                // [8][kWgSlab]
   float* dxpad;                              // [64]
 };
-// chunk sums of every slab element in chunk order; dxpad = the sum over heads and chunks of the padding token's share
-__global__ __launch_bounds__(256) void fbm_reduce_kernel(ChainArgs a) {
-  const int head = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+// chunk sums of every slab element in chunk order; dxpad = the sum over heads and chunks of the padding token's share.
+// Block roles: blocks [0, kFbmReduceBlocks) sum the backward kernel's slabs; the blocks behind them sum the slabs of the TAIL's parameter
+// gradients that the forward left (tail_reduce.hpp) -- independent sums that used to be two launches, one in front of the backward kernel and
+// one behind it.
+constexpr int kFbmReduceX = (kWgSlabM + 255) / 256;
+constexpr int kFbmReduceBlocks = kFbmReduceX * MATCHA_N_HEAD;
+__global__ __launch_bounds__(256) void fbm_reduce_kernel(ChainArgs a, TailReduceArgs tl, int tail_blocks) {
+  __shared__ float4 part[8 * 32];
+  if ((int)blockIdx.x >= kFbmReduceBlocks) {
+    tail_reduce_role(tl, (int)blockIdx.x - kFbmReduceBlocks, part);
+    return;
+  }
+  const int head = blockIdx.x / kFbmReduceX, i = (blockIdx.x % kFbmReduceX) * 256 + threadIdx.x;
   if (i >= kWgSlabM) return;
   const float* base = a.wslab + (int64_t)head * a.nchunks * kWgSlabM + i;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
@@ -778,7 +790,7 @@ size_t fused_bwd_ws_floats(int64_t B, int L) {
 // merged heads: fused_bwdh_kernel -> fbm_chain_kernel -> the LayerNorm un-folding of launch_fused_bwd (one slab per head)
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool dx_zeroed) {
+                            bool dx_atomic, bool dx_zeroed, const TailReduceArgs* tail) {
   const int64_t tcap = B * L + 1;
   if (dx_atomic && !dx_zeroed) MATCHA_TRY(zero_async(dxh, (size_t)tcap * 64 * sizeof(float), st));
   int nchunks = 2 * chunks_for(rg.nhalves);                  // two four-wave workgroups per CU
@@ -824,7 +836,10 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
     c.wslab = wslab; c.nchunks = nchunks; c.red = chain + (size_t)MATCHA_N_HEAD * kWgSlab;
     c.wq = folded; c.wk = folded + wsz; c.wv = folded + 2 * wsz; c.cq = folded + 3 * wsz; c.cv = c.cq + 2 * csz;
     c.fc1_w = p.fc1_w; c.out = chain; c.dxpad = dxpad;
-    hipLaunchKernelGGL(fbm_reduce_kernel, dim3((unsigned)cdiv(kWgSlabM, 256), MATCHA_N_HEAD), dim3(256), 0, st, c);
+    TailReduceArgs tl;
+    if (tail) tl = *tail; else memset(&tl, 0, sizeof(tl));
+    const int tail_blocks = tail ? kTailRoleBlocks : 0;
+    hipLaunchKernelGGL(fbm_reduce_kernel, dim3((unsigned)(kFbmReduceBlocks + tail_blocks)), dim3(256), 0, st, c, tl, tail_blocks);
     MATCHA_CHECK_LAUNCH("fbm_reduce_kernel");
     hipLaunchKernelGGL(fbm_chain_kernel, dim3(4, 4, MATCHA_N_HEAD), dim3(256), 0, st, c);
     MATCHA_CHECK_LAUNCH("fbm_chain_kernel");

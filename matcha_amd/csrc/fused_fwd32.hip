@@ -25,6 +25,7 @@
 //
 // fused_fwd32h_kernel (below) is the same forward for small batches: eight wavefronts per half tile, one per head.
 #include "kernels.hpp"
+#include "prep_heads.hpp"
 
 #ifndef F32_ABL
 #define F32_ABL 0                     // timing ablations (tools/debug/abl_fwd32.sh; results are wrong on purpose): 1 no attention pieces, 2 no record stores,
@@ -34,15 +35,12 @@
 namespace matcha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int kLdH = 68;                  // LDS row stride (floats)
 constexpr int kHT = 32 * kLdH;            // one half tile [32 rows][68]
 constexpr float kEps32 = 1e-5f;
-constexpr int kNMat = 20;                 // R_0 | R_{h+1} M_h (h = 0..6) | M_7 | conv0, conv1, conv1^T, conv0^T -- in consumption order (prep_heads_kernel)
 constexpr int kTailVec32 = 2 * 4096;      // same slab format as fused_fwd.hip (tail_slab_reduce_kernel reads both)
 constexpr int kTailSlab32 = 2 * 4096 + 10 * 64;
 
@@ -191,28 +189,12 @@ __device__ __forceinline__ FL fl_unpark_lds(const float* __restrict__ base, int 
 // f32 vectors added to the accumulator (kBias*: b_0..b_7, the merged fc1 bias, conv0, conv1), not part of the stream.
 // The window W_[0..5] holds the six fragments of the current chunk; every consumed step refills its three slots with the fragments six
 // ahead (`wp`, wave-uniform, points at the PREFETCH position), pinned there by a scheduling barrier.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_BF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)), __builtin_bit_cast(bf16x8, (B)), (C), 0, 0, 0)
 #ifndef F32_WIN
 #define F32_WIN 6                     // fragments in flight ahead of the product (divides 24)
 #endif
-constexpr int kFragPerMat = 24;
-constexpr int kFragU4 = kFragPerMat * 64;       // u32x4 per matrix
-constexpr int kBiasR = 0, kBiasDyn = 8, kBiasConv0 = 9, kBiasConv1 = 10, kNBias = 11;    // rows of the f32 bias table behind the stream
 
 struct B3 { u32x4 h, m, l; };                   // eight f32 values as three bf16 planes
-struct P3 { uint32_t h, m, l; };                // two f32 values as three packed bf16 pairs
-__device__ __forceinline__ P3 split2(float a, float b) {
-  const f2 v = {a, b};
-  const bf16x2 hb = __builtin_convertvector(v, bf16x2);                 // v_cvt_pk_bf16_f32: round to nearest even
-  const f2 r1 = v - __builtin_convertvector(hb, f2);
-  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-  const f2 r2 = r1 - __builtin_convertvector(mb, f2);
-  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-  return P3{__builtin_bit_cast(uint32_t, hb), __builtin_bit_cast(uint32_t, mb), __builtin_bit_cast(uint32_t, lb)};
-}
 // register 8 C + J of an FL row (C = 0..3 compile-time): features 16 C + 8 (J >> 2) + 4 hf + (J & 3)
 #define FL_CHUNK(V, C, J) ((C) < 2 ? (V).lo[8 * ((C) & 1) + (J)] : (V).hi[8 * ((C) & 1) + (J)])
 #define FL_SPLIT(OUT, V, C)                                                                              \
@@ -288,190 +270,10 @@ __device__ __forceinline__ FL fl_zero() {
 //            dyn += Wfc1_h O_i                                   ->  z_i = sum_j p_ij x_j,  dyn += M_h z_i,   M_h = Wfc1_h W'v_h
 // (x = the LayerNorm-normalised row, the same for every head: it is the key AND the value of every head, written to LDS once per tile.)
 // The constants Wfc1_h cv_h join the fc1 bias.  prep_heads_kernel builds B_h, b_h, M_h and that bias once per step.
-// ---- the per-step weight forms in ONE launch (rounds 1-3: fold_ln_kernel -> merge_heads_kernel -> fold_frag_kernel, 23 us of dependent
-// latency in front of every forward; now 12) ------------------------------------------------------------------------------------------
-//   fold:      W' = W * g, c = W . b for the three LayerNorm affines in front of Q / K / V (Modules.py:519-529); the fold happens on the way
-//              into LDS and is written out for the backward's chain rule (fbm_chain_kernel reads W'q, W'k, W'v, cq, cv)
-//   merge:     B_h = W'k^T W'q, b_h = W'k^T cq, M_h = Wfc1_h W'v, merged fc1 bias = fc1_b + Wfc1 cv   (16 products of 64^3 on MFMA tiles)
-//   fragments: every matrix the forward streams, in MFMA-fragment order, in consumption order (R_0 | R_{h+1} M_h | M_7 | conv0 conv1
-//              conv1^T conv0^T | one matrix of zeros): per 64 x 64 matrix 18 fragments of one float4 per lane, [wc][c = 0..7 | bias][lane],
-//              lane (r, h) holds W[32 wc + r][8 c + 4 h .. + 3]; the bias fragment enters the accumulator as one more MFMA against 1
-// grid (4 row slices of 16, 2 matrices, 8 heads + 1): block (slice, y, hd) computes 16 rows of B_hd (y = 0) or M_hd (y = 1) and writes them
-// row-major (for the backward) and as fragments; slice 0 also computes the bias vector(s) it needs; z = 8: the conv fragments.
-struct PrepArgs {
-  const float* Wq; const float* Wk; const float* Wv;      // [512][64] as the reference holds them
-  const float* gq; const float* gk; const float* gv; const float* bq; const float* bv;   // LayerNorm affines in front of them [64]
-  const float* fc1_w; const float* fc1_b;
-  const float* p0w; const float* p0b; const float* p1w; const float* p1b;
-  float* fwq; float* fwk; float* fwv; float* fcq; float* fcv;          // folded forms (read by fbm_chain_kernel)
-  float* B; float* M; float* bvec; float* bdyn;                        // merged forms (read by fused_bwdh_kernel / fbm_chain_kernel)
-  u32x4* frag;                                                         // [kNMat + 1][kFragU4] bf16 planes, then the f32 bias table [kNBias][64]
-};
-// eight f32 values of one lane's contraction slots -> the three bf16 planes of fragment (c, wc) of matrix m, lane ln
-__device__ __forceinline__ void frag_put8(u32x4* frag, int m, int c, int wc, int ln, const float* v8) {
-  B3 b;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const P3 t = split2(v8[2 * q], v8[2 * q + 1]);
-    b.h[q] = t.h; b.m[q] = t.m; b.l[q] = t.l;
-  }
-  u32x4* d = frag + (int64_t)m * kFragU4 + ((2 * c + wc) * 3) * 64 + ln;
-  d[0] = b.h; d[64] = b.m; d[128] = b.l;
-}
+// ---- the per-step weight forms (prep_heads.hpp): stand-alone launch for the paths whose front end is not front_fwd_kernel ----------------
 __global__ __launch_bounds__(256) void prep_heads_kernel(PrepArgs a) {
-  __shared__ float As[16 * 65];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * 68];
-  __shared__ __attribute__((aligned(16))) float cs[512];               // cq of this head (y = 0) / cv of this head or of all heads (y = 1, head 0)
-  __shared__ float bs[64];                                             // b_h or the merged fc1 bias
-  const int slice = blockIdx.x, hd = blockIdx.z, tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  if (hd == MATCHA_N_HEAD) {
-    // conv0, conv1, conv1^T, conv0^T (matrices 16..19), one matrix of zeros behind the stream, and the two conv biases of the bias table
-    const int id = blockIdx.x + 4 * blockIdx.y;
-    if (id > 4) return;
-    for (int idx = tid; idx < 8 * 64; idx += 256) {       // (chunk c, block wc) x lane: one lane's eight slots, all three planes
-      const int cw = idx >> 6, c = cw >> 1, wc = cw & 1, ln = idx & 63, r = ln & 31, hf = ln >> 5;
-      const int n = 32 * wc + r;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 16 * c + 8 * (j >> 2) + 4 * hf + (j & 3);
-        v[j] = id == 0 ? a.p0w[n * 64 + k] : id == 1 ? a.p1w[n * 64 + k] : id == 2 ? a.p1w[k * 64 + n] : id == 3 ? a.p0w[k * 64 + n] : 0.f;
-      }
-      frag_put8(a.frag, 16 + id, c, wc, ln, v);
-    }
-    float* bias = reinterpret_cast<float*>(a.frag + (int64_t)(kNMat + 1) * kFragU4);
-    if (id < 2 && tid < 64) bias[(kBiasConv0 + id) * 64 + tid] = id == 0 ? a.p0b[tid] : a.p1b[tid];
-    return;
-  }
-  const bool isB = blockIdx.y == 0;
-  const int64_t ho = (int64_t)hd * 4096;
-  const float* Braw = (isB ? a.Wq : a.Wv) + ho;
-  const float* gB = isB ? a.gq : a.gv;
-  float* Bfold = (isB ? a.fwq : a.fwv) + ho;
-  float* out = (isB ? a.B : a.M) + ho;
-  const int mat = isB ? (hd == 0 ? 0 : 2 * hd - 1) : (hd < 7 ? 2 * hd + 2 : 15);     // position in the fragment stream
-  {
-    // the 16 x 64 left operand.  B_h: A(i, x) = W'k[x][16 slice + i] = Wk[x][16 slice + i] * gk[16 slice + i] (folded here, written out for
-    // the backward); M_h: A(i, x) = Wfc1[16 slice + i][hd 64 + x]
-    float av[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = tid + 256 * t;
-      if (isB) av[t] = a.Wk[ho + (int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)] * a.gk[16 * slice + (i & 15)];
-      else av[t] = a.fc1_w[(int64_t)(16 * slice + (i >> 6)) * 512 + hd * 64 + (i & 63)];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = tid + 256 * t;
-      As[isB ? (i & 15) * 65 + (i >> 4) : (i >> 6) * 65 + (i & 63)] = av[t];
-      if (isB) a.fwk[ho + (int64_t)(i >> 4) * 64 + 16 * slice + (i & 15)] = av[t];
-    }
-  }
-  {
-    // the 64 x 64 right operand W'q_h / W'v_h = W * g (column scale), four float4 per thread in flight
-    f32x4 bvv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bvv[u] = reinterpret_cast<const f32x4*>(Braw)[tid + 256 * u];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int f = (tid + 256 * u) * 4;
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(gB + (f & 63));
-      f32x4 w = bvv[u];
-      w.x *= gg.x; w.y *= gg.y; w.z *= gg.z; w.w *= gg.w;
-      *reinterpret_cast<f32x4*>(&Bs[(f >> 6) * 68 + (f & 63)]) = w;
-      if (slice == 0) reinterpret_cast<f32x4*>(Bfold)[tid + 256 * u] = w;
-    }
-  }
-  __syncthreads();
-  {
-    const int c16 = lane & 15, kq = lane >> 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[c16 * 65 + 4 * kk + kq], Bs[(4 * kk + kq) * 68 + 16 * wave + c16], acc, 0, 0, 0);
-    __syncthreads();                                  // every wavefront is done reading As: it now takes the 16 x 64 result tile
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int n = 16 * slice + 4 * kq + reg, k = 16 * wave + c16;
-      out[n * 64 + k] = acc[reg];
-      As[(4 * kq + reg) * 65 + k] = acc[reg];
-    }
-    __syncthreads();
-    if (tid < 128) {
-      // fragments: thread -> (row i of the tile, chunk c, lane half hf): eight contraction slots, three planes, 16-byte stores
-      const int i = tid & 15, c = (tid >> 4) & 3, hf = tid >> 6;
-      const int n = 16 * slice + i, wc = n >> 5, r = n & 31;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = As[i * 65 + 16 * c + 8 * (j >> 2) + 4 * hf + (j & 3)];
-      frag_put8(a.frag, mat, c, wc, r + 32 * hf, v);
-    }
-  }
-  if (slice != 0) return;
-  // ---- slice 0 of every (matrix, head): the folded bias vector(s) it needs, the merged bias, the bias fragment -------------------------
-  {
-    // c[m] = sum_k W[m][k] b[k] (one xor tree over the 64 lanes per row).  y = 0: cq of this head;
-    // y = 1: cv of this head -- of ALL heads for head 0, whose block builds the merged fc1 bias from them
-    const float* Wraw = isB ? a.Wq : a.Wv;
-    const float* bb = isB ? a.bq : a.bv;
-    const int row0 = (!isB && hd == 0) ? 0 : hd * 64, nrow = (!isB && hd == 0) ? 512 : 64;
-    const float bk = bb[lane];
-    // 64 rows per wavefront and trip, lane = column: the 64 x 64 products are summed over the lanes by a TRANSPOSING butterfly -- at
-    // offset o a lane keeps the rows whose index has bit o like its own lane id and hands the others to its partner -- 63 shuffles for 64
-    // rows instead of 384, the same additions in the same order as group_sum<64> row by row (both partners of a butterfly step
-    // compute the same sum), and lane l ends with row l
-#pragma unroll 1
-    for (int m0 = 64 * wave; m0 < nrow; m0 += 256) {
-      float v[64];
-#pragma unroll
-      for (int j = 0; j < 64; ++j) v[j] = Wraw[(int64_t)(row0 + m0 + j) * 64 + lane];
-#pragma unroll
-      for (int j = 0; j < 64; ++j) v[j] *= bk;
-#pragma unroll
-      for (int half = 32; half >= 1; half >>= 1) {
-        const bool up = (lane & half) != 0;
-#pragma unroll
-        for (int j = 0; j < half; ++j) {
-          const float keep = up ? v[j + half] : v[j];
-          const float send = up ? v[j] : v[j + half];
-          v[j] = keep + __shfl_xor(send, half, 64);
-        }
-      }
-      cs[m0 + lane] = v[0];
-    }
-  }
-  __syncthreads();
-  if (tid < 64) (isB ? a.fcq : a.fcv)[hd * 64 + tid] = cs[tid];        // (head 0 of y = 1 holds all 512 but writes its own 64: the others write theirs)
-  {
-    const int o = tid >> 2, part = tid & 3;
-    if (isB) {
-      // b_h[o] = sum_m W'k[m][o] cq[m]
-      float s_ = 0.f;
-      for (int m = 16 * part; m < 16 * part + 16; ++m) s_ += (a.Wk[ho + m * 64 + o] * a.gk[o]) * cs[m];
-      s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64);
-      if (part == 0) { a.bvec[hd * 64 + o] = s_; bs[o] = s_; }
-    } else if (hd == 0) {
-      const float4* wrow = reinterpret_cast<const float4*>(a.fc1_w + o * 512 + 128 * part);
-      const float4* cvp = reinterpret_cast<const float4*>(cs + 128 * part);
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-      for (int m = 0; m < 32; m += 2) {
-        const float4 w0 = wrow[m], c0 = cvp[m], w1 = wrow[m + 1], c1 = cvp[m + 1];
-        s0 += (w0.x * c0.x + w0.y * c0.y) + (w0.z * c0.z + w0.w * c0.w);
-        s1 += (w1.x * c1.x + w1.y * c1.y) + (w1.z * c1.z + w1.w * c1.w);
-      }
-      float s_ = s0 + s1;
-      s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64);
-      if (part == 0) { const float v = a.fc1_b[o] + s_; a.bdyn[o] = v; bs[o] = v; }
-    } else if (part == 0) {
-      bs[o] = 0.f;                                                     // the merged fc1 bias enters dyn once, with head 0
-    }
-  }
-  __syncthreads();
-  // the f32 bias table behind the stream: b_h (row hd) and, from head 0's M block, the merged fc1 bias (row kBiasDyn)
-  if (tid < 64 && (isB || hd == 0))
-    reinterpret_cast<float*>(a.frag + (int64_t)(kNMat + 1) * kFragU4)[(isB ? kBiasR + hd : kBiasDyn) * 64 + tid] = bs[tid];
+  __shared__ __attribute__((aligned(16))) float sm[kPrepLdsFloats];
+  prep_heads_role(a, blockIdx.x, blockIdx.y, blockIdx.z, sm);
 }
 
 struct Fwd32Args {
@@ -864,8 +666,7 @@ MergedView merged_view(const float* m) {
   return MergedView{m, m + (size_t)MATCHA_N_HEAD * 4096, m + (size_t)2 * MATCHA_N_HEAD * 4096, m + (size_t)2 * MATCHA_N_HEAD * 4096 + MATCHA_N_HEAD * 64};
 }
 // the per-step weight forms (prep_heads_kernel): `folded` = fused_fold_floats() floats, `merged` = fused_merged_floats()
-int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, float* frag, hipStream_t st) {
-  PrepArgs a;
+void prep_heads_args(const matcha_tensors& p, float* folded, float* merged, float* frag, PrepArgs& a) {
   const size_t wsz = (size_t)MATCHA_N_HEAD * 64 * 64, csz = (size_t)MATCHA_N_HEAD * 64;
   a.Wq = p.w_q; a.Wk = p.w_k; a.Wv = p.w_v;
   a.gq = p.ln_q_g; a.gk = p.ln_k_g; a.gv = p.ln_v_g; a.bq = p.ln_q_b; a.bv = p.ln_v_b;
@@ -874,7 +675,11 @@ int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, flo
   const MergedView v = merged_view(merged);
   a.B = const_cast<float*>(v.B); a.M = const_cast<float*>(v.M); a.bvec = const_cast<float*>(v.bvec); a.bdyn = const_cast<float*>(v.bdyn);
   a.frag = reinterpret_cast<u32x4*>(frag);
-  hipLaunchKernelGGL(prep_heads_kernel, dim3(4, 2, MATCHA_N_HEAD + 1), dim3(256), 0, st, a);
+}
+int launch_prep_heads(const matcha_tensors& p, float* folded, float* merged, float* frag, hipStream_t st) {
+  PrepArgs a;
+  prep_heads_args(p, folded, merged, frag, a);
+  hipLaunchKernelGGL(prep_heads_kernel, dim3(kPrepGridX, kPrepGridY, kPrepGridZ), dim3(256), 0, st, a);
   MATCHA_CHECK_LAUNCH("prep_heads_kernel");
   return MATCHA_OK;
 }

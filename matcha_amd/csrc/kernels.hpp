@@ -130,19 +130,17 @@ int launch_head_bwd(const int32_t* row_off, const float* H2, const float* X, int
                     const float* y, const float* w, const float* logits, const float* dlogits, float alpha, float* dH2,
                     float* dXs, float* slab, const HeadParams& ghp, hipStream_t st);
 size_t colsum_slab_bytes(int64_t n, int nv, int d);
-int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon = false);   // zero_recon: losses[1..2] = 0 too
+int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon = false,     // zero_recon: losses[1..2] = 0 too
+                       float* zero_buf = nullptr, size_t zero_bytes = 0);                                               // a buffer zeroed by extra blocks of the launch
 
 // fused_aux.hip (embed_dim 64): per-step weight folding, reduction of the training forward's parameter-gradient slabs
 size_t fused_fold_floats();
 size_t fused_tail_slab_floats(int64_t B, int L);
 size_t fused_tail_partial_floats();
-// small: one launch (small batches; another summation order); it can also zero zero_bytes of zero_buf (the backward kernel's d x_hat buffer)
-int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial,
-                       bool small = false, float* zero_buf = nullptr, size_t zero_bytes = 0, int n_slabs = -1, bool rowmajor = false,
-                       bool with_mats = true, uint32_t slot_mask = 0x3FF);
-// (n_slabs >= 0: that many slabs with ROW-MAJOR weight-gradient matrices -- tail_bwd64_kernel's, one per workgroup -- instead of one per half
-// tile; with_mats / slot_mask: which parts of the slabs hold sums -- the two weight-gradient matrices, vector slot v)
-bool fused_small_batch(const Ragged& rg);          // the size rule of the small-batch kernels (fused_fwd32h_kernel, tail_slab_small_kernel)
+// two passes over one slab per (half) tile (the forward with its tail's backward in-kernel at a large batch); small batches and the split tail
+// are summed by blocks of fbm_reduce_kernel's launch (tail_reduce.hpp, launch_fused_bwd_merged)
+int launch_tail_reduce(const float* tslab, const Ragged& rg, int L, matcha_tensors& grads, hipStream_t st, bool halves, float* partial);
+bool fused_small_batch(const Ragged& rg);          // the size rule of the small-batch kernels (fused_fwd32h_kernel)
 
 // fused_fwd32.hip (embed_dim 64): the same forward with ONE wavefront per half tile (<= 31 tokens), weights streamed from L2 in
 // MFMA-fragment order (launch_prep_heads rewrites them once per step), no workgroup barriers
@@ -167,9 +165,11 @@ int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y,
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)
 size_t fused_bwd_ws_floats(int64_t B, int L);
+struct TailReduceArgs;
 int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const float* merged, const float* X, const float* dDyn, const float* dXs,
                             const Ragged& rg, int64_t B, int L, float* dxh, float* ws, matcha_tensors& grads, float* dZ0, hipStream_t st, const float* rimg,
-                            bool dx_atomic, bool dx_zeroed = false);   // dx_zeroed: the caller already zeroed dxh[(B L + 1) x 64] on this stream
+                            bool dx_atomic, bool dx_zeroed = false,    // dx_zeroed: the caller already zeroed dxh[(B L + 1) x 64] on this stream
+                            const struct TailReduceArgs* tail = nullptr);   // tail != null: the launch that sums this kernel's slabs also sums the forward's tail slabs (tail_reduce.hpp)
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (half tile, head):
 constexpr int kImgRecH = 2048 + 256;               // 32 r rows (r = B_h x_hat + b_h; register images) + their attention probabilities [32][8]
 
@@ -190,8 +190,10 @@ int launch_enc128_bwd(const matcha_tensors& p, const float* lwB, const float* lw
 // backward = LayerNorm backward of the summed d x_hat partials, next_w and attribute_nn
 // backward, embedding scatter (dtable != null) or dX0 output (adj front end) in one kernel
 bool front_bwd_supported(int d, int n_attr);
+// prep != null: the launch also builds the encoder's per-step weight forms (what launch_prep_heads does) in blocks of their own
+struct PrepSpec { const matcha_tensors* p; float* folded; float* merged; float* frag; };
 int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* table, const float* dense, const matcha_frozen& f, int n_attr,
-                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st);
+                     const Ragged& rg, int64_t tcap, float* x0, float* X, hipStream_t st, const PrepSpec* prep = nullptr);
 size_t front_bwd_ws_floats();
 int launch_front_bwd(const matcha_tensors& p, const float* X, const float* dxh, int nslab, int64_t tcap, const float* dxpad, const float* dXs, const float* x0,
                      const int64_t* ids, const matcha_frozen& f, int n_attr, const Ragged& rg, float* dX0, float* dtable, float* ws,

@@ -12,6 +12,7 @@
 #include <unordered_map>
 
 #include "kernels.hpp"
+#include "tail_reduce.hpp"
 
 namespace matcha {
 
@@ -137,9 +138,9 @@ static bool loss_in_forward(const matcha_shape& s, const matcha_step_opts& o, co
 // consume records nobody wrote.  Host-side record per workspace pointer (the decision picks a kernel, so it cannot live in device memory
 // without a synchronisation); bounded, evicted oldest-first, guarded by a mutex.  A backward on a workspace WITHOUT a record is refused.
 static std::mutex g_fwd_mu;
-static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward, bit 2: fused d = 128 attention block, bit 3: the tail's backward ran as tail_bwd64_kernel
+static std::unordered_map<const void*, std::pair<int, uint64_t>> g_fwd_state;     // ws -> (bits, age); bit 0: merged heads, bit 1: fused d = 64 forward, bit 2: fused d = 128 attention block, bit 3: the tail's backward ran as tail_bwd64_kernel, bit 4: the forward zeroed the d x_hat rows of the backward kernel
 static uint64_t g_fwd_clock = 0;
-static void note_forward(const void* ws, bool merged, bool fused, bool enc = false, bool split_tail = false) {
+static void note_forward(const void* ws, bool merged, bool fused, bool enc = false, bool split_tail = false, bool dx_zeroed = false) {
   std::lock_guard<std::mutex> lk(g_fwd_mu);
   if (g_fwd_state.size() >= 4096 && g_fwd_state.find(ws) == g_fwd_state.end()) {
     auto old = g_fwd_state.begin();
@@ -147,7 +148,7 @@ static void note_forward(const void* ws, bool merged, bool fused, bool enc = fal
       if (it->second.second < old->second.second) old = it;
     g_fwd_state.erase(old);
   }
-  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0) | (enc ? 4 : 0) | (split_tail ? 8 : 0), ++g_fwd_clock);
+  g_fwd_state[ws] = std::make_pair((merged ? 1 : 0) | (fused ? 2 : 0) | (enc ? 4 : 0) | (split_tail ? 8 : 0) | (dx_zeroed ? 16 : 0), ++g_fwd_clock);
 }
 static int ws_state(const void* ws) {       // -1: no forward on record for this workspace
   std::lock_guard<std::mutex> lk(g_fwd_mu);
@@ -425,12 +426,16 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   } else {
     MATCHA_TRY(adj_forward(s, p, *frozen, *opts, ids, Tn, w.node, recon_out, w.adj_ws, w.adj_ws_bytes, st, cnt, w.rg.tok_slot));
   }
+  bool prep_in_front = false;
   if (adj_fused) {
     // x0 and X are already there
   } else if (front) {
     // gather (or the adj front end's rows) + attribute path + add + next_w + tanh in one kernel (Modules.py:263-270)
+    // (fused encoder behind it: the launch also builds the step's weight forms -- folded / merged / fragment-order -- in blocks of their own)
+    const PrepSpec prep = {&p, w.folded, w.merged, w.frag};
+    prep_in_front = fused_path;
     MATCHA_TRY(launch_front_fwd(p, ids, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, *frozen, s.n_attr, w.rg, Tn,
-                                opts->forward_only ? nullptr : w.x0, w.X, st));     // x0 (pre-activation) is only read by the backward pass
+                                opts->forward_only ? nullptr : w.x0, w.X, st, prep_in_front ? &prep : nullptr));     // x0 (pre-activation) is only read by the backward pass
   } else {
     MATCHA_TRY(launch_embed_fwd(ids, Tn, d, s.mode == 0 ? p.table : nullptr, s.mode == 0 ? nullptr : w.node, *frozen, s.n_attr, p.attr_w,
                                 p.attr_b, w.x0, st, cnt));
@@ -443,14 +448,17 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
     // everything from X to the logits in one kernel; a forward that will be differentiated saves Y, H1, H2 (768 B per
     // token); every training forward also leaves its Q/K/V tiles and attention probabilities for the fused backward (w.qkv)
     const bool save = !opts->forward_only && !lif;
-    MATCHA_TRY(launch_prep_heads(p, w.folded, w.merged, w.frag, st));      // folded / merged / fragment-order weights of this step
+    if (!prep_in_front) MATCHA_TRY(launch_prep_heads(p, w.folded, w.merged, w.frag, st));      // folded / merged / fragment-order weights of this step
     // the logits go straight to the caller's buffer when no later kernel reads them from the workspace (a differentiated forward
     // keeps them there for head_bwd): one device-to-device copy less per step / per inference call
     float* lg_out = (logits && !save) ? logits : w.logits;
     // large batches: the tail's backward inside the forward kernel stops behind its LayerNorms; pff_n1's two convolutions (dZ1, d dyn, the
     // weight gradients) are a kernel of their own right behind it (tail_bwd.hip).  Development switch fused_dbg bit 0: all of it in-kernel.
     const bool split_tail = lif && !fused_small_batch(w.rg) && (options().fused_dbg & 1) == 0;
-    note_forward(ws, true, true, false, split_tail);
+    // the backward kernel's heads ADD their d x_hat rows (float atomics) unless the sum has to be reproducible: the rows are zeroed by a launch
+    // that runs anyway -- tail_bwd64_kernel, or for small batches the loss reduction's -- and the record says so
+    const bool zero_dx = lif && !opts->deterministic && !opts->sparse_table_grad && (split_tail || fused_small_batch(w.rg)) && y && w_bce && losses;
+    note_forward(ws, true, true, false, split_tail, zero_dx);
     // (with the tail's backward in the forward kernel, Y and H1 are still handed over: the single-wave kernel PARKS the two rows there
     // (and the normalised H2 row in H2's place) between the tail's forward and backward halves instead of holding 96 registers per lane -- fused_fwd32_tail.hpp)
     MATCHA_TRY(launch_fused_fwd32(p, w.folded, w.frag, w.X, w.rg, B, L, y, w_bce, (save || lif) ? w.Y : nullptr, (save || lif) ? w.H1 : nullptr, (save || lif) ? w.H2 : nullptr,
@@ -458,8 +466,10 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr, split_tail ? w.dH2 : nullptr));
     if (split_tail)
       MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, w.tslab,
-                                   (!opts->deterministic && !opts->sparse_table_grad) ? w.dO : nullptr, st));      // ... and zeroes the backward's d x_hat rows
-    if (y && w_bce && losses) MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss));
+                                   zero_dx ? w.dO : nullptr, st));      // ... and zeroes the backward's d x_hat rows
+    const bool zero_in_loss = zero_dx && !split_tail;
+    if (y && w_bce && losses)
+      MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss, zero_in_loss ? w.dO : nullptr, zero_in_loss ? (size_t)Tn * 64 * sizeof(float) : 0));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;
     }
@@ -642,18 +652,23 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
   const bool fused_fwd = (fwd_state & 2) != 0;          // which kernels the forward ran is what decides, not the option table now
   const bool lif = fused_fwd && loss_in_forward(s, *opts, y, w_bce);
   MATCHA_CHECK_ARG(!(lif && dlogits), "matcha_backward: opts->loss_in_forward excludes an explicit dlogits");
-  bool dx_zeroed = false;
+  bool dx_zeroed = false, tail_in_bwd = false;
+  TailReduceArgs tail_args;
   if (lif) {
     // ddyn0 and dXs were produced by matcha_forward; only the per-half-tile parameter-gradient partials remain to be summed
     // (fused_fwd32.hip).  Small batches: one launch, which also zeroes the buffer the backward kernel's heads add their d x_hat into
     const bool small = fused_small_batch(w.rg);
-    dx_zeroed = (small || (fwd_state & 8) != 0) && !opts->deterministic && !opts->sparse_table_grad;      // (split tail: tail_bwd64_kernel zeroed the rows)
+    dx_zeroed = (fwd_state & 16) != 0 && !opts->deterministic && !opts->sparse_table_grad;      // tail_bwd64_kernel / the loss reduction zeroed the rows
     if ((fwd_state & 8) != 0) {
       // one row-major slab per workgroup of tail_bwd64_kernel: the convolutions' gradients and the half tiles' LayerNorm / classifier vectors
-      // (summed along its walk): 512 slabs, the one-pass reduction
-      MATCHA_TRY(launch_tail_reduce(w.tslab2, w.rg, L, g_, st, true, w.tpart, true, nullptr, 0, tail_bwd_grid(), true));
+      // (summed along its walk): 512 slabs.  Summed by blocks of the launch that sums the backward kernel's slabs (fused_bwd.hip)
+      tail_reduce_args(w.tslab2, w.rg, L, g_, true, tail_bwd_grid(), true, tail_args);
+      tail_in_bwd = true;
+    } else if (small) {
+      tail_reduce_args(w.tslab, w.rg, L, g_, true, -1, false, tail_args);     // one slab per half tile (a few dozen)
+      tail_in_bwd = true;
     } else
-      MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart, small, dx_zeroed ? w.dO : nullptr, dx_zeroed ? (size_t)Tn * 64 * sizeof(float) : 0));
+      MATCHA_TRY(launch_tail_reduce(w.tslab, w.rg, L, g_, st, true, w.tpart));
   } else {
   // tail: dH2, dXs and the gradients of pff_n1.layer_norm, layer_norm1/2, pff_classifier
   HeadParams hp = {p.pff_ln_g, p.pff_ln_b, p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b, p.cls_w, p.cls_b};
@@ -684,7 +699,8 @@ extern "C" int matcha_backward(const matcha_shape* shp, const matcha_tensors* pa
     // and read back).  `deterministic` and the row-sparse table gradient (whose sum is bitwise reproducible) keep the slabs and their
     // fixed summation order
     const bool dx_atomic = !opts->deterministic && !opts->sparse_table_grad;
-    MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic, dx_zeroed));
+    MATCHA_TRY(launch_fused_bwd_merged(p, w.folded, w.merged, w.X, w.ddyn0, w.dXs, w.rg, B, L, w.dO, w.fb_ws, g_, front ? nullptr : w.dZ0, st, w.qkv, dx_atomic, dx_zeroed,
+                                       tail_in_bwd ? &tail_args : nullptr));
     MATCHA_TRY(encoder_done(*opts, st));
     if (front) {
       // LayerNorm backward of the summed partials + next_w + attribute_nn backward + embedding scatter in one kernel

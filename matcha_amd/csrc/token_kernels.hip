@@ -611,8 +611,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const int32_t* __restrict
 }
 
 // sum of row losses / B in a fixed order (one block): losses[0] = bce
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out, int zero_recon) {
+// Blocks behind the first: a buffer to zero in the same launch (small batches: the d x_hat rows the backward kernel's heads add into -- the
+// one-pass tail reduction used to zero them in front of the backward kernel; it now rides in the launch BEHIND that kernel, fused_bwd.hip).
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int64_t B, float* __restrict__ out, int zero_recon,
+                                                           float4* __restrict__ zero_buf, int64_t zero_n4) {
   __shared__ float red[16];
+  if (blockIdx.x > 0) {
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n4; i += (int64_t)(gridDim.x - 1) * 1024) zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   // fixed order: thread t sums rows t, t + 1024, ... (eight loads in flight), xor tree inside the wavefront, the sixteen wavefronts in order
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
   const int64_t B4 = ((uintptr_t)row_loss % 16 == 0) ? B / 4 : 0;           // float4 part (the workspace buffer is 256-byte aligned)
@@ -787,8 +794,12 @@ int launch_ln3_bwd(const float* X, const float* dqin, const float* dkin, const f
   return MATCHA_OK;
 }
 
-int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, row_loss, B, bce_out, zero_recon ? 1 : 0);
+int launch_loss_reduce(const float* row_loss, int64_t B, float* bce_out, hipStream_t st, bool zero_recon, float* zero_buf, size_t zero_bytes) {
+  MATCHA_CHECK_ARG(zero_bytes % 16 == 0 && (uintptr_t)zero_buf % 16 == 0, "loss_reduce: zero_buf");
+  const int64_t n4 = zero_buf ? (int64_t)(zero_bytes / 16) : 0;
+  int zb = (int)cdiv(n4, 4096);                           // four float4 per thread
+  if (zb > 64) zb = 64;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1 + zb), dim3(1024), 0, st, row_loss, B, bce_out, zero_recon ? 1 : 0, reinterpret_cast<float4*>(zero_buf), n4);
   MATCHA_CHECK_LAUNCH("loss_reduce_kernel");
   return MATCHA_OK;
 }
@@ -801,7 +812,7 @@ int launch_head_fwd(const int32_t* row_off, const float* H2, const float* X, int
   DISPATCH_NCH(d, hipLaunchKernelGGL((head_fwd_kernel<NCH>), dim3((unsigned)cdiv(B, 16)), dim3(256), 0, st, row_off, H2, X, B, L, d, hp, y, w, logits, rl));
   MATCHA_CHECK_LAUNCH("head_fwd_kernel");
   if (rl && bce_out) {
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rl, B, bce_out, 0);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rl, B, bce_out, 0, (float4*)nullptr, (int64_t)0);
     MATCHA_CHECK_LAUNCH("loss_reduce_kernel");
   }
   return MATCHA_OK;
