@@ -214,19 +214,25 @@ struct FrontFwdArgs {
   const int32_t* count;
   float* x0; float* X;
   int nprep; PrepArgs prep;      // the first nprep blocks build the step's weight forms instead (prep_heads.hpp): they depend on the parameters only
+  int prep_walks;                // ... and then walk tiles like the other blocks (the launch has one block per slot of the chip) or leave
 };
 
 __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // Block roles: the per-step weight forms of the encoder kernels (B_h, M_h, the fragment stream) are independent of the batch, the front end is
-  // independent of them -- their 72 blocks ride in front of this launch instead of being a launch of their own between the front end and the
-  // encoder (11 us of every step, a quarter of this kernel's own time at 65 536 rows and more than all of it at 384).
-  if ((int)blockIdx.x < g.nprep) {
+  // Block roles.  The per-step weight forms of the encoder kernels (B_h, M_h, the fragment stream) depend on the parameters only, this kernel on
+  // the batch only: their 72 blocks ride in this launch instead of being a launch of their own between the front end and the encoder (11 us
+  // of every step).  Large batches: the launch still has ONE block per slot of the chip -- 72 blocks on top of a full grid start the last
+  // front-end blocks late and stretch the kernel by what they took --, so the role blocks build weight forms and THEN walk tiles like the
+  // others, and the last (partial) round of tiles goes to the blocks without a role first.
+  const int nprep = g.nprep;
+  if ((int)blockIdx.x < nprep) {
     const int b = blockIdx.x;
     prep_heads_role(g.prep, b % kPrepGridX, (b / kPrepGridX) % kPrepGridY, b / (kPrepGridX * kPrepGridY), lds);
-    return;
+    if (!g.prep_walks) return;
+    __syncthreads();
   }
-  const int bid = (int)blockIdx.x - g.nprep, stride = (int)gridDim.x - g.nprep;
+  const int nlate = g.prep_walks ? nprep : 0;           // front-end blocks that start late
+  const int vb = (int)blockIdx.x - (nprep - nlate), Gf = (int)gridDim.x - (nprep - nlate);
   // The two weight matrices live in REGISTERS as MFMA operand fragments (32 + 16 per lane) instead of LDS tiles: 44 KB of LDS per
   // workgroup instead of 70, i.e. three workgroups per CU gathering rows -- this kernel is a gather, bytes in flight are what it needs
   float* Es = lds;                                // node rows, then x0 in place
@@ -237,6 +243,11 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;
   const int T = g.count[0];
   const int ntiles = (T + 63) / 64;
+  // tiles of this block: vb + it Gf in the full rounds it < q; the r tiles of the last round go to the blocks vb = nlate, nlate + 1, ... (mod Gf)
+  const int q = ntiles / Gf, r_last = ntiles - q * Gf;
+  const int last_slot = vb >= nlate ? vb - nlate : vb - nlate + Gf;
+  const int tile_last = last_slot < r_last ? q * Gf + last_slot : 0x3FFFFFF;
+#define FF_TILE(IT) ((IT) < q ? vb + (IT) * Gf : ((IT) == q ? tile_last : 0x3FFFFFF))
   float4 wn[8], wa[kAttrCols / 8];                // B fragments: next_w[32 wc + r][8 c + 4 h ..], attribute_nn.weight[32 wc + r][8 c + 4 h ..]
 #pragma unroll
   for (int c = 0; c < 8; ++c) wn[c] = *reinterpret_cast<const float4*>(g.Wn + (32 * wc + r) * 64 + 8 * c + 4 * h);
@@ -286,21 +297,22 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
     }                                                                                                    \
   } while (0)
   {
-    const int first = bid;
-    FF_IDS_GLOAD(first);
-    FF_ROWS_GLOAD(first);
+    FF_IDS_GLOAD(FF_TILE(0));
+    FF_ROWS_GLOAD(FF_TILE(0));
 #pragma unroll
     for (int i = 0; i < 4; ++i) qe[i] = pe[i];
     qa[0] = pa[0]; qa[1] = pa[1];
-    // (qe, qa) = tile `first`; now tile first + stride into (pe, pa) ... rotated below so that (pe, pa) is always the tile about to be used
-    FF_IDS_GLOAD(first + stride);
-    FF_ROWS_GLOAD(first + stride);
-    FF_IDS_GLOAD(first + 2 * stride);
+    // (qe, qa) = the first tile; now the second into (pe, pa) ... rotated below so that (pe, pa) is always the tile about to be used
+    FF_IDS_GLOAD(FF_TILE(1));
+    FF_ROWS_GLOAD(FF_TILE(1));
+    FF_IDS_GLOAD(FF_TILE(2));
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float4 t = pe[i]; pe[i] = qe[i]; qe[i] = t; }
     { const float4 t0 = pa[0], t1 = pa[1]; pa[0] = qa[0]; pa[1] = qa[1]; qa[0] = t0; qa[1] = t1; }
   }
-  for (int tile = bid; tile < ntiles; tile += stride) {
+  for (int it = 0;; ++it) {
+    const int tile = FF_TILE(it);
+    if (tile >= ntiles) break;
     const int64_t t_base = (int64_t)tile * 64;
     __syncthreads();
     // ---- the prefetched node rows (16 lanes x float4 per 256-B row) and attribute rows -> LDS; next tile's rows, the one after's ids ----
@@ -317,12 +329,12 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) se[i] = pe[i];
       sa[0] = pa[0]; sa[1] = pa[1];
-      FF_ROWS_GLOAD(tile + 2 * stride);               // into (pe, pa) ...
+      FF_ROWS_GLOAD(FF_TILE(it + 2));                 // into (pe, pa) ...
 #pragma unroll
       for (int i = 0; i < 4; ++i) { qe[i] = pe[i]; pe[i] = se[i]; }     // ... which become (qe, qa); (pe, pa) = the next tile again
       qa[0] = pa[0]; qa[1] = pa[1]; pa[0] = sa[0]; pa[1] = sa[1];
     }
-    FF_IDS_GLOAD(tile + 3 * stride);
+    FF_IDS_GLOAD(FF_TILE(it + 3));
     __syncthreads();
     // ---- x0 = node_row + attr . Wa^T + ba   (K = 32) ----
     {
@@ -440,23 +452,25 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   FrontFwdArgs g;
   g.ids = ids; g.table = table; g.dense = dense; g.attr = attr_src_table_first(f, n_attr); g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
-  int grid = front_grid() / 2 * 3;                      // three workgroups per CU (44 KB of LDS each)
+  const int slots = front_grid() / 2 * 3;               // three workgroups per CU (44 KB of LDS each)
   const int64_t max_tiles = cdiv(tcap, 64);
-  if (grid > max_tiles) grid = (int)max_tiles;
   const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
   static_assert(((size_t)2 * kTile + 64 * kLdA) >= (size_t)kPrepLdsFloats, "the weight-form role needs its LDS inside the front end's");
   g.nprep = 0;
   if (prep) {
     prep_heads_args(*prep->p, prep->folded, prep->merged, prep->frag, g.prep);
     g.nprep = kPrepBlocks;
-    grid += kPrepBlocks;
   } else {
     memset(&g.prep, 0, sizeof(g.prep));
   }
+  // large batches: one block per slot of the chip, the role blocks among them; small ones: the role blocks + one block per tile
+  g.prep_walks = (g.nprep > 0 && max_tiles + g.nprep > slots) ? 1 : 0;      // (measured against 72 blocks on top of a full grid: 5 us per 65 536-row step)
+  int64_t grid = g.prep_walks ? slots : g.nprep + (max_tiles < slots ? max_tiles : slots);
+  if (grid < g.nprep + 1) grid = g.nprep + 1;
   // algorithmic bytes per token: id 8 + node row 256 + attribute row read (attr_mode 1: rebuilt from the id, nothing read); x0 and X rows
   // written (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
   ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + (g.attr.mode == 1 ? 0.0 : 4.0 * n_attr) + (x0 ? 512.0 : 256.0)), st);
-  hipLaunchKernelGGL(front_fwd_kernel, dim3(grid), dim3(256), lds, st, g);
+  hipLaunchKernelGGL(front_fwd_kernel, dim3((unsigned)grid), dim3(256), lds, st, g);
   MATCHA_CHECK_LAUNCH("front_fwd_kernel");
   return MATCHA_OK;
 }

@@ -260,21 +260,36 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(CompactArgs a, int n
   const int total = carry < ntiles_cap ? carry : ntiles_cap;
   if (threadIdx.x == 0) count[2 + which] = total;
   __syncthreads();                                     // sb_cnt (now offsets) written by this block: visible after the barrier
-  const int4* src = reinterpret_cast<const int4*>(sb_tiles);
-  int4* dst = reinterpret_cast<int4*>(meta);
-  // one wavefront per superblock: its (few) tiles move as consecutive int4 (a flat loop over nsb * cap_per_sb slots spent a division and two
-  // dependent loads per slot, most of them empty)
-  __shared__ int offs[1025];                          // the offsets of up to 1024 superblocks: one parallel round of loads instead of two
-  const bool staged = nsb <= 1024;                     // dependent ones per superblock and wavefront
-  if (staged) {
-    if ((int)threadIdx.x < nsb) offs[threadIdx.x] = sb_cnt[threadIdx.x];
+  const int4* __restrict__ src = reinterpret_cast<const int4*>(sb_tiles);
+  int4* __restrict__ dst = reinterpret_cast<int4*>(meta);
+  __shared__ int offs[1025];
+  if (nsb <= 1024) {
+    // the offsets of the superblocks in LDS; every thread then moves tiles i = tid, tid + 1024, ... of the COMPACT list, finding each one's
+    // superblock by bisection over the offsets -- independent loads, four in flight per thread (a wavefront per superblock was a chain of
+    // nsb / 16 dependent round trips)
+    for (int i = threadIdx.x; i < nsb; i += 1024) offs[i] = sb_cnt[i];
     if (threadIdx.x == 0) offs[nsb] = total;
     __syncthreads();
-  }
-  for (int s = wave; s < nsb; s += 16) {
-    const int lo = staged ? offs[s] : sb_cnt[s], hi = staged ? offs[s + 1] : ((s + 1 < nsb) ? sb_cnt[s + 1] : total);
-    for (int j = lane; lo + j < hi && j < cap_per_sb; j += 64)
-      if (lo + j < ntiles_cap) dst[lo + j] = src[(int64_t)s * cap_per_sb + j];
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 1024) {
+      int4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 1024 < total ? i0 + u * 1024 : total - 1;
+        int lo = 0, hi = nsb;                          // the last superblock whose offset is <= i (empty ones in front of it share the offset)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid; }
+        v[u] = src[(int64_t)lo * cap_per_sb + (i - offs[lo])];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * 1024 < total) dst[i0 + u * 1024] = v[u];
+    }
+  } else {
+    // one wavefront per superblock: its (few) tiles move as consecutive int4
+    for (int s = wave; s < nsb; s += 16) {
+      const int lo = sb_cnt[s], hi = (s + 1 < nsb) ? sb_cnt[s + 1] : total;
+      for (int j = lane; lo + j < hi && j < cap_per_sb; j += 64)
+        if (lo + j < ntiles_cap) dst[lo + j] = src[(int64_t)s * cap_per_sb + j];
+    }
   }
   for (int i = total + threadIdx.x; i < ntiles_cap + 2; i += 1024) dst[i] = make_int4(0, 0, 0, 0);
 }
