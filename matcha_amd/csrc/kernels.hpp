@@ -160,7 +160,8 @@ int launch_fused_fwd32(const matcha_tensors& p, const float* folded, const float
 int tail_bwd_grid();
 size_t tail_bwd_slab_floats();
 int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y, const float* H1, const Ragged& rg, const uint64_t* seed, float p_fc1,
-                      float p_pff, float* ddyn0, float* slab, const float* vslab, float* zero_rows, hipStream_t st);
+                      float p_pff, float* ddyn0, float* slab, const float* vslab, float* zero_rows, hipStream_t st,
+                      const float* row_loss = nullptr, int64_t B = 0, float* losses = nullptr, bool zero_recon = false);   // losses != null: launch_loss_reduce's work in one extra block
 
 // fused_bwd.hip (embed_dim 64): attention-block backward from X and dDyn; accumulates the gradients of w_q/w_k/w_v, the
 // three LayerNorm affines in front of them, fc1 (weight + bias) and writes dZ0 (gradient at the next_w pre-activation)

@@ -466,9 +466,9 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
                                   lif ? w.ddyn0 : nullptr, w.dXs, w.tslab, opts->alpha, keep_rimg ? w.qkv : nullptr, split_tail ? w.dH2 : nullptr));
     if (split_tail)
       MATCHA_TRY(launch_tail_bwd64(p, w.dH2, w.Y, w.H1, w.rg, opts->seed, train ? opts->p_drop_fc1 : 0.f, train ? opts->p_drop_pff : 0.f, w.ddyn0, w.tslab2, w.tslab,
-                                   zero_dx ? w.dO : nullptr, st));      // ... and zeroes the backward's d x_hat rows
+                                   zero_dx ? w.dO : nullptr, st, w.row_loss, B, (y && w_bce) ? losses : nullptr, recon_zero_in_loss));      // ... zeroes the backward's d x_hat rows, reduces the loss
     const bool zero_in_loss = zero_dx && !split_tail;
-    if (y && w_bce && losses)
+    if (y && w_bce && losses && !split_tail)
       MATCHA_TRY(launch_loss_reduce(w.row_loss, B, losses, st, recon_zero_in_loss, zero_in_loss ? w.dO : nullptr, zero_in_loss ? (size_t)Tn * 64 * sizeof(float) : 0));
     if (logits && lg_out != logits && hipMemcpyAsync(logits, w.logits, B * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
       set_error("logits copy failed"); return MATCHA_EHIP;

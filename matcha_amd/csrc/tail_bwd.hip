@@ -22,6 +22,7 @@
 // The small-batch step keeps the whole tail in the forward kernel (fused_fwd32h_kernel): there the forward is one wave of workgroups anyway.
 #include "bf16x3.hpp"
 #include "kernels.hpp"
+#include "loss_reduce.hpp"
 
 namespace matcha {
 
@@ -46,6 +47,8 @@ struct TailBwdArgs {
   float* ddyn0; float* slab;                        // slab [gridDim.x][kSlab]: dW1 | dW0 | the ten vector slots
   float* zero_rows;                                 // [T][64] or null: the buffer the attention block's backward adds its d x_hat into with float atomics --
                                                     // zeroed here row by row (a 13 us launch of its own otherwise)
+  const float* row_loss; int64_t B; float* losses; int zero_recon;     // losses != null: ONE extra block (the last) reduces the forward's per-hyperedge losses
+                                                    // to their mean (loss_reduce.hpp) -- a 7 us launch of its own otherwise
   const float* vslab;                               // the forward kernel's per-half-tile slabs: their vector slots 0-6 and 9 (LayerNorm / classifier
                                                     // gradients) are summed along the walk into this workgroup's slab -- ONE reduction over 512 slabs behind it
 };
@@ -61,10 +64,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   short* Zp = Yp + kPT;                              // dZ1 planes
 
   const int tid = threadIdx.x;
+  const int nwg = (int)gridDim.x - (g.losses ? 1 : 0);
+  if ((int)blockIdx.x == nwg) {
+    loss_reduce_role<256>(g.row_loss, g.B, g.losses, g.zero_recon, lds);
+    return;
+  }
   const int tr = g.count[1];
   int nh = g.count[3];
   if (nh > g.nhalves) nh = g.nhalves;
-  const int per = (nh + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int per = (nh + nwg - 1) / nwg;
   const int tile_lo = blockIdx.x * per;
   const int tile_hi = tile_lo + per < nh ? tile_lo + per : nh;
 
@@ -304,8 +312,10 @@ size_t tail_bwd_slab_floats() { return (size_t)tail_bwd_grid() * kSlab; }
 // ddyn0 and one slab of parameter-gradient partials per workgroup (tail_bwd_slab_floats() floats at `slab`: the convolutions' gradients + the
 // forward's per-half-tile vector slots of `vslab` summed along the walk; launch_tail_reduce(..., n_slabs = tail_bwd_grid(), rowmajor) sums them)
 int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y, const float* H1, const Ragged& rg, const uint64_t* seed, float p_fc1,
-                      float p_pff, float* ddyn0, float* slab, const float* vslab, float* zero_rows, hipStream_t st) {
+                      float p_pff, float* ddyn0, float* slab, const float* vslab, float* zero_rows, hipStream_t st, const float* row_loss, int64_t B,
+                      float* losses, bool zero_recon) {
   TailBwdArgs g;
+  g.row_loss = row_loss; g.B = B; g.losses = losses; g.zero_recon = zero_recon ? 1 : 0;
   g.vslab = vslab; g.zero_rows = zero_rows;
   g.dH2 = dH2; g.Y = Y; g.H1 = H1; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_slot = rg.tok_slot; g.nhalves = rg.nhalves;
   g.W0 = p.pff0_w; g.W1 = p.pff1_w; g.seed = seed; g.p_fc1 = p_fc1; g.p_pff = p_pff;
@@ -314,7 +324,7 @@ int launch_tail_bwd64(const matcha_tensors& p, const float* dH2, const float* Y,
   ProfScope ps(MATCHA_PROF_FUSED_FWD, 0.0, st);
   auto kfn = tail_bwd64_kernel;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(kfn, dim3(tail_bwd_grid()), dim3(256), kLdsBytes, st, g);
+  hipLaunchKernelGGL(kfn, dim3(tail_bwd_grid() + (losses ? 1 : 0)), dim3(256), kLdsBytes, st, g);
   MATCHA_CHECK_LAUNCH("tail_bwd64_kernel");
   return MATCHA_OK;
 }

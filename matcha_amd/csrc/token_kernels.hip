@@ -9,6 +9,7 @@
 
 #include "attr_src.hpp"
 #include "kernels.hpp"
+#include "loss_reduce.hpp"
 
 namespace matcha {
 
@@ -620,30 +621,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
     for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n4; i += (int64_t)(gridDim.x - 1) * 1024) zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  // fixed order: thread t sums rows t, t + 1024, ... (eight loads in flight), xor tree inside the wavefront, the sixteen wavefronts in order
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-  const int64_t B4 = ((uintptr_t)row_loss % 16 == 0) ? B / 4 : 0;           // float4 part (the workspace buffer is 256-byte aligned)
-  const float4* r4 = reinterpret_cast<const float4*>(row_loss);
-  int64_t i = threadIdx.x;
-  for (; i + 3072 < B4; i += 4096) {
-    const float4 v0 = r4[i], v1 = r4[i + 1024], v2 = r4[i + 2048], v3 = r4[i + 3072];
-    a0 += v0.x + v0.y; a1 += v0.z + v0.w; a2 += v1.x + v1.y; a3 += v1.z + v1.w;
-    a4 += v2.x + v2.y; a5 += v2.z + v2.w; a6 += v3.x + v3.y; a7 += v3.z + v3.w;
-  }
-  for (; i < B4; i += 1024) { const float4 v = r4[i]; a0 += v.x + v.y; a1 += v.z + v.w; }
-  for (int64_t j = 4 * B4 + threadIdx.x; j < B; j += 1024) a2 += row_loss[j];
-  float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) t += red[w];
-    out[0] = t / (float)B;
-    if (zero_recon) { out[1] = 0.f; out[2] = 0.f; }   // table front end: no reconstruction loss (instead of a memset in front of the forward)
-  }
+  loss_reduce_role<1024>(row_loss, B, out, zero_recon, red);
 }
 
 // dst[v][j] += sum_blk slab[blk][v][j]   (v < nv, j < d), blocks ascending; dst pointers per v
