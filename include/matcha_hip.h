@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MATCHA_ABI_VERSION 6
+#define MATCHA_ABI_VERSION 7
 
 #define MATCHA_OK 0
 #define MATCHA_EINVAL (-22) /* bad argument (shape, alignment, null pointer) */
@@ -73,6 +73,14 @@ int matcha_device_count(void);
                                       of uniformly drawn node ids: a token's feature row has sum_i n_i^2 / N columns on average         */
 int matcha_profile_select(int32_t kernel_class);
 int matcha_profile_read(double* total_ms, int64_t* launches, double* work);
+
+/* Launch log (ABI 7): which kernels did a call run?  matcha_launch_log(1) clears the log and starts counting every kernel launch the
+ * library makes (by the kernel's name, template instances together), matcha_launch_log(0) stops; matcha_launch_log_read writes one
+ * "kernel_name count\n" line per kernel seen (MATCHA_ENOMEM if `cap` is too small).  The parity tests assert the kernel set with
+ * it: the library picks kernels by batch size and embed_dim, and a test that is "about" a kernel must fail when a size rule moves
+ * it onto another one.  A captured graph counts at capture time, not per replay.  Process-global, single-threaded use. */
+int matcha_launch_log(int32_t on);
+int matcha_launch_log_read(char* out, size_t cap);
 
 /* A/B switches for tests and profiling.  Each option is read from the environment variable MATCHA_<NAME> (upper case) ONCE,
  * when the library is loaded, and can be changed afterwards only through matcha_set_option -- no entry point reads the

@@ -397,6 +397,7 @@ class _Runtime:
         self.attr_table = attr_mod.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
         # the kernels work on a (padded) COPY of this frozen table and on structure decided from it once: remember which tensor state that was
         self._attr_src = attr_mod.weight
+        self._attr_ref = self.attr_table                      # the unpadded device copy the structure decision was taken from
         self._attr_src_state = (attr_mod.weight.data_ptr(), attr_mod.weight._version)
         self._keep = [self.attr_table]
         self.frozen = _lib.Frozen()
@@ -475,8 +476,14 @@ class _Runtime:
         """The live parameters still sit where the kernels were told, and the frozen attribute table has not been rewritten in place
         (load_state_dict after the first forward: the runtime holds a padded copy and a cached structure decision) -- otherwise the
         owner rebuilds the runtime."""
-        if (self._attr_src.data_ptr(), self._attr_src._version) != self._attr_src_state:
-            return False
+        state = (self._attr_src.data_ptr(), self._attr_src._version)
+        if state != self._attr_src_state:
+            # a version bump alone is not a change: train() ends every phase with load_state_dict(model_link), which copy_()s the same bytes
+            # into the frozen table (ADVICE r05).  Compare ONCE per bump (one synchronising device compare) and accept an identical table.
+            src = self._attr_src.detach()
+            if tuple(src.shape) != tuple(self._attr_ref.shape) or not torch.equal(src.to(device=self.device, dtype=torch.float32), self._attr_ref):
+                return False
+            self._attr_src_state = state
         return all(p.data_ptr() == e for p, e in zip(self.live, self.expected_ptrs))
 
     def workspace(self, B: int, L: int, forward_only: bool = False) -> torch.Tensor:

@@ -71,6 +71,8 @@ SIGNATURES = {
     "matcha_device_count": (C.c_int, []),
     "matcha_profile_select": (C.c_int, [_I32]),
     "matcha_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "matcha_launch_log": (C.c_int, [_I32]),
+    "matcha_launch_log_read": (C.c_int, [C.c_char_p, _SZ]),
     "matcha_workspace_bytes": (_SZ, [C.POINTER(Shape), _I64, _I32]),
     "matcha_workspace_bytes_forward": (_SZ, [C.POINTER(Shape), _I64, _I32]),
     "matcha_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Tensors), C.POINTER(Frozen), C.POINTER(StepOpts), _fp, _I64,
@@ -115,7 +117,7 @@ SIGNATURES = {
 }
 
 FEAT_ROW_PAD = 64           # adj front end: feature rows padded to this many floats (matcha_frozen.feat_row_pad)
-ABI_VERSION = 6             # MATCHA_ABI_VERSION of include/matcha_hip.h
+ABI_VERSION = 7             # MATCHA_ABI_VERSION of include/matcha_hip.h
 
 _lib = None
 
@@ -178,6 +180,25 @@ class option:
 
     def __exit__(self, *a):
         set_option(self.name, self.old)
+
+
+class launch_log:
+    """``with _lib.launch_log() as log: ...; log.counts`` -- {kernel name: launches} of every kernel the library launched inside
+    the block (matcha_launch_log).  The parity tests assert the kernel set with it."""
+
+    def __enter__(self):
+        self.counts = {}
+        check(load().matcha_launch_log(1), "matcha_launch_log")
+        return self
+
+    def __exit__(self, *a):
+        lib = load()
+        lib.matcha_launch_log(0)
+        buf = C.create_string_buffer(1 << 14)
+        check(lib.matcha_launch_log_read(buf, len(buf)), "matcha_launch_log_read")
+        for line in buf.value.decode().splitlines():
+            name, n = line.rsplit(" ", 1)
+            self.counts[name] = int(n)
 
 
 def raise_on_status(status_host, what: str):

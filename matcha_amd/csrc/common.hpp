@@ -21,8 +21,14 @@ void set_error(const char* fmt, ...);
     }                                            \
   } while (0)
 
+// Launch log (matcha_launch_log / matcha_launch_log_read): every launch site names its kernel here, so a test can assert WHICH
+// kernels an entry point ran -- a size rule must not move a parity test onto another kernel unnoticed.  Off: one branch.
+extern int g_launch_log;
+void note_launch(const char* name);
+
 #define MATCHA_CHECK_LAUNCH(name)                                                       \
   do {                                                                                  \
+    if (::matcha::g_launch_log) ::matcha::note_launch(name);                            \
     hipError_t e__ = hipGetLastError();                                                 \
     if (e__ != hipSuccess) {                                                            \
       ::matcha::set_error("launch of %s failed: %s", name, hipGetErrorString(e__));     \
@@ -46,6 +52,10 @@ struct ProfScope {
   ProfScope(int cls, double work, hipStream_t s) : on(cls == g_prof_class), st(s) { if (on) prof_record(true, work, st); }
   ~ProfScope() { if (on) prof_record(false, 0.0, st); }
 };
+
+// Compute units of the CURRENT device (hipGetDevice), cached per device id: grids and slab counts of the persistent kernels are sized from
+// it, and a process may drive more than one device (the per-file function-static caches kept the first device's count).
+int device_cu_count();
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -866,18 +866,7 @@ __global__ __launch_bounds__(256) void enc128_lnhat_bwd_kernel(const float* __re
 }
 
 int ml_of(int L) { return L <= 2 ? 2 : (L <= 6 ? L : 8); }
-int cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    cus = n;
-  }
-  return cus;
-}
+int cu_count() { return device_cu_count(); }
 
 struct WsView { float* fold; float* bvec; u32x4* frag; float* wslab; float* red; float* colpart; float* dc; };
 WsView ws_view(float* ws) {

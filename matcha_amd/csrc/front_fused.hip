@@ -428,17 +428,8 @@ __global__ __launch_bounds__(1024) void front_slab_reduce_kernel(FrontReduceArgs
 }
 
 int front_grid() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    n = 2 * cus;
-    if (n > 1024) n = 1024;
-  }
-  return n;
+  const int n = 2 * device_cu_count();
+  return n > 1024 ? 1024 : n;
 }
 
 }  // namespace

@@ -763,15 +763,7 @@ __global__ __launch_bounds__(256) void lnhat_bwd_kernel(const float* __restrict_
 }
 
 int chunks_for(int ntiles) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    cus = n;
-  }
+  const int cus = device_cu_count();
   int c = cus / MATCHA_N_HEAD;
   if (c > kMaxChunks) c = kMaxChunks;
   if (c > ntiles) c = ntiles;

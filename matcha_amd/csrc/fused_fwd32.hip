@@ -643,18 +643,7 @@ __global__ __launch_bounds__(512) void fused_fwd32h_kernel(Fwd32Args g) {
 #endif
 }
 
-static int fwd32h_max_halves() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    n = 2 * cus;
-  }
-  return n;
-}
+static int fwd32h_max_halves() { return 2 * device_cu_count(); }
 
 bool fused_small_batch(const Ragged& rg) { return rg.nhalves <= fwd32h_max_halves() && !options().disable_small_batch; }
 

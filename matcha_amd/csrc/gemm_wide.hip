@@ -77,6 +77,12 @@ struct Epi {
 // not once per 256 MFMAs (at K = 128 a tile is only four chunks: the one-tile-per-workgroup version sat at 75 TFLOP/s).
 // XCD-aware order: workgroup ids b, b + 8, ... run on one XCD; each XCD gets a contiguous range of the tile list, so the
 // workgroups that share an activation row tile hit the same L2.
+// in-situ ablations (wrong results on purpose; bit 0 no epilogue, bit 1 no MFMAs, bit 2 no prefetch): a COMPILE-time switch (-DWIDE_ABL=n, like
+// ENC_ABL / F32_ABL) -- it used to be the run-time option fused_dbg, whose bit 0 has a documented meaning elsewhere
+#ifndef WIDE_ABL
+#define WIDE_ABL 0
+#endif
+constexpr int kWideAbl = WIDE_ABL;
 template <bool B_KN, int FLAGS>
 __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g, int64_t nx, int64_t ny, int ntpb, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -292,7 +298,7 @@ void launch_wide_one(const GemmArgs& g, hipStream_t st) {
   if (ntpb > 8) ntpb = 8;
   if (ntpb < 1) ntpb = 1;
   const int64_t nwg = cdiv(nx * ny, ntpb);
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(cdiv(nwg, 8) * 8), (unsigned)g.batch), dim3(256), lds, st, g, nx, ny, (int)ntpb, options().fused_dbg);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(cdiv(nwg, 8) * 8), (unsigned)g.batch), dim3(256), lds, st, g, nx, ny, (int)ntpb, kWideAbl);
 }
 
 // ---- TN: C[M,N] partial of one token partition = A[rows, M]^T . B[rows, N] -----------------------------------------------------

@@ -24,6 +24,17 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int device_cu_count() {
+  static int cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 64) cache[dev] = n;
+  return n;
+}
+
 // ---- per-kernel-class event timing -------------------------------------------------------------------
 int g_prof_class = 0;
 static hipEvent_t* g_prof_ev = nullptr;     // pairs (start, stop)
@@ -46,6 +57,20 @@ void prof_record(bool start, double work, hipStream_t st) {
     (void)hipEventRecord(g_prof_ev[g_prof_used + 1], st);
     g_prof_used += 2;
   }
+}
+
+// ---- launch log: kernel name -> number of launches since matcha_launch_log(1) -------------------------
+int g_launch_log = 0;
+namespace {
+struct LaunchCount { const char* name; int64_t n; };
+constexpr int kLaunchNames = 128;
+LaunchCount g_launches[kLaunchNames];
+int g_launch_names = 0;
+}  // namespace
+void note_launch(const char* name) {
+  for (int i = 0; i < g_launch_names; ++i)
+    if (g_launches[i].name == name || strcmp(g_launches[i].name, name) == 0) { ++g_launches[i].n; return; }
+  if (g_launch_names < kLaunchNames) g_launches[g_launch_names++] = LaunchCount{name, 1};
 }
 
 // adj_frontend.hip
@@ -342,6 +367,24 @@ extern "C" int matcha_profile_select(int32_t kernel_class) {
   return MATCHA_OK;
 }
 
+extern "C" int matcha_launch_log(int32_t on) {
+  if (on) g_launch_names = 0;
+  g_launch_log = on ? 1 : 0;
+  return MATCHA_OK;
+}
+
+extern "C" int matcha_launch_log_read(char* out, size_t cap) {
+  MATCHA_CHECK_ARG(out && cap > 0, "matcha_launch_log_read: null buffer");
+  size_t n = 0;
+  out[0] = 0;
+  for (int i = 0; i < g_launch_names; ++i) {
+    const int k = snprintf(out + n, cap - n, "%s %lld\n", g_launches[i].name, (long long)g_launches[i].n);
+    if (k < 0 || (size_t)k >= cap - n) { set_error("matcha_launch_log_read: buffer too small"); return MATCHA_ENOMEM; }
+    n += (size_t)k;
+  }
+  return MATCHA_OK;
+}
+
 extern "C" int matcha_profile_read(double* total_ms, int64_t* launches, double* work) {
   double ms = 0.0;
   for (int i = 0; i + 1 < g_prof_used; i += 2) {
@@ -407,7 +450,10 @@ static int forward_impl(const matcha_shape* shp, const matcha_tensors* params, c
   const bool keep_rimg = !opts->forward_only;
   // CSR plan: real tokens + one shared padding token; the fused kernels walk the HALF tiles (level 1: no 64-row tile list, no token -> tile
   // map -- matcha_ragged_plan still builds those for callers that ask)
-  const bool enc = !force_layerwise && enc128_enabled(s, *opts);      // embed_dim 128: the attention block as one kernel (enc128.hip)
+  // embed_dim 128: the attention block as one kernel (enc128.hip) -- when a training forward's records fit where the layer-wise path keeps
+  // Q / K / V / P / O: the records are sized per HALF TILE (at least two, 8 x 4352 floats each), so a batch of one to three rows does not
+  // fit and runs layer by layer (it used to fail with MATCHA_ENOMEM)
+  const bool enc = !force_layerwise && enc128_enabled(s, *opts) && (opts->forward_only || enc128_rec_floats(w.rg) <= w.enc_rec_floats);
   const int plan_level = (fused_enabled(s) || enc) ? 1 : 0;
   MATCHA_TRY(launch_ragged_plan(x, B, L, s.n_nodes, opts->status, w.rg, st, plan_level));
   // front end: node rows (K1) + attribute path (K6) + add (Modules.py:263-269)

@@ -294,18 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-int tail_bwd_grid() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    n = 2 * cus;
-  }
-  return n;
-}
+int tail_bwd_grid() { return 2 * device_cu_count(); }
 size_t tail_bwd_slab_floats() { return (size_t)tail_bwd_grid() * kSlab; }
 
 // After a training forward that ran fused_fwd32_kernel with `tail_split` set (it stopped behind the LayerNorm backward and left dH2 rows):

@@ -310,6 +310,9 @@ def _graph_eval(sess: Session, e: torch.Tensor, w: torch.Tensor, n_batch: int, P
         chroms = np.zeros(n_batch, dtype=np.int32)
     key = (n_batch, P, L, sess._generation)
     st = sess.__dict__.get("_eval_state")
+    if st is not None and not sess.trainer.rt.still_packed():
+        # parameters moved since the capture (model.to(), a rebuilt runtime): a replay would evaluate the old buffers (as graph_epoch refuses to)
+        raise _lib.MatchaHipError("model parameters moved after the evaluation step was captured; create a new Session / Trainer")
     if st is None or st["key"] != key:
         st = dict(key=key, graph=None,
                   pos=torch.empty((n_batch * P, L), dtype=torch.long, device=dev), w=torch.empty(n_batch * P, dtype=torch.float32, device=dev),
@@ -328,8 +331,8 @@ def _graph_eval(sess: Session, e: torch.Tensor, w: torch.Tensor, n_batch: int, P
     def one_step():
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.matcha_step_select(_lib.ptr(st["pos"]), _lib.ptr(st["w"]), n_rows, L, _lib.ptr(st["it"]), P, _lib.ptr(st["x"]), _lib.ptr(st["ww"]),
-                                          _lib.ptr(st["chroms"]), n_batch, _lib.ptr(st["cell"]), _lib.ptr(sess.sampler.seed), _lib.ptr(tr.seed), stream),
-                   "matcha_step_select")
+                                          _lib.ptr(st["chroms"]), n_batch, _lib.ptr(st["cell"]), _lib.ptr(sess.sampler.seed), None, stream),
+                   "matcha_step_select")          # (no dropout in a forward-only step: the trainer's dropout seed stays where the call-by-call loop leaves it)
         sess.sampler.sample_into(st["x"][:P], st["x"][P:], advance_seed=False)
         logits = tr.eval_forward(st["x"], st["y"], st["ww"], random_chrom=st["cell"])
         _lib.check(lib.matcha_step_record(_lib.ptr(logits), _lib.ptr(tr.losses), _lib.ptr(st["x"]), B, L, _lib.ptr(st["it"]), n_batch, _lib.ptr(st["sums"]),

@@ -644,11 +644,104 @@ def round4(M):
     g3_long(M, "c23_adj_d64", synth.LAYOUTS["c23"], 64, "adj", 49)
 
 
+def g3_big(M, name, num, d, mode, seed, ks, rows_per_k, n_eval=64):
+    """Round 6 fixture g3big_*: ONE dropout-free training step of the real reference on a batch large enough for the kernels the
+    library picks at bench sizes (d = 64: more than 512 half tiles -> fused_fwd32_kernel + tail_bwd64_kernel + fused_bwdh_kernel on a
+    full grid; d = 128: enc128 at thousands of rows; d = 256 / k up to 8: the wide layer-wise kernels and the ML = 8 instances).
+    Stored: the batch (node ids in the narrowest integer type), logits, losses, every gradient tensor -- in full up to 32 768
+    elements, every s-th element above (key grad0s<s>/name) --, which tensors have grad None, and eval-mode logits of the first
+    `n_eval` rows evaluated as their own batch at the same width L (the forward-only kernels; Modules.py:278-318)."""
+    clf, attr, feats, inter_z, sd = build_ref(M, num, d, mode, seed)
+    C, N = len(num), int(np.sum(num))
+    set_dropout(clf, 0.0)
+    clf.train()
+    out = {}
+    chrom = predraw_chroms(C, 1, 4321)
+    out["chroms"] = np.asarray(chrom, dtype=np.int64)
+    x, y, w = synth.make_batch(np.random.default_rng(seed + 5), N, list(ks), rows_per_k)
+    out["x0"] = x.astype(np.int16 if N < 32767 else np.int32)
+    out["y0"], out["w0"] = y, w
+    pred, recon = clf(torch.from_numpy(x), return_recon=True)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.from_numpy(y), weight=torch.from_numpy(w))
+    (bce * 1.0 + recon * 0.001).backward()
+    out["bce0"], out["recon0"], out["logits0"] = bce.detach().numpy().copy(), recon.detach().numpy().copy(), pred.detach().numpy().copy()
+    none = []
+    for n_, p in clf.named_parameters():
+        if p.grad is None:
+            none.append(n_)
+            continue
+        gnp = p.grad.numpy().reshape(-1)
+        stride = -(-gnp.size // 32768)
+        if stride == 1:
+            out["grad0/" + n_] = p.grad.numpy().copy()
+        else:
+            out[f"grad0s{stride}/" + n_] = gnp[::stride].copy()
+    out["grad_none"] = np.asarray(none)
+    clf.eval()
+    np.random.seed(7)
+    with torch.no_grad():
+        lg, rc = clf(torch.from_numpy(x[:n_eval]), return_recon=True)
+    out["logits_eval"], out["recon_eval"], out["chrom_eval"] = lg.numpy().copy(), rc.numpy().copy(), np.int64(predraw_chroms(C, 1, 7)[0])
+    np.savez_compressed(os.path.join(HERE, f"g3big_{name}.npz"), **out)
+    print("G3big", name, "rows", len(x), "L", x.shape[1], "bce0", out["bce0"], "recon0", out["recon0"], "tensors", sum(k.startswith("grad0") for k in out))
+
+
+def g10_host_streams(M, U):
+    """Round 6 fixture g10: the reference's INTEGER host work under fixed seeds -- DataGenerator.__init__ / next_iter
+    (Modules.py:620-681) on uniform-k inputs (np.random.seed drives its permutations) and sync_shuffle (utils.py:142-149; torch's
+    global generator drives randperm).  Inputs are regenerated by the test from the same default_rng seeds; outputs are stored."""
+    out = {}
+    rng = np.random.default_rng(1010)
+    for k, m in ((2, 700), (3, 1300)):
+        edges = synth.make_edges(rng, 300, k, m)
+        weight = rng.uniform(0.1, 3.0, size=m).astype(np.float32)
+        out[f"edges_k{k}"], out[f"weight_k{k}"] = edges, weight
+        for bs, nb in ((96, 10), (250, 3), (96, 2)):
+            np.random.seed(77 + k)
+            with redirect_stdout(io.StringIO()):
+                dg = M.DataGenerator(edges.copy(), weight.copy(), bs, nb, min_size=k, max_size=k, flag=(bs == 250))
+            tag = f"k{k}_b{bs}_n{nb}"
+            out[f"dg_len_{tag}"] = np.int64(len(dg.edges[k]))
+            for it in range(5):
+                with redirect_stdout(io.StringIO()):
+                    e, wv = dg.next_iter()
+                out[f"dg_e_{tag}_{it}"] = np.asarray(e)
+                out[f"dg_w_{tag}_{it}"] = np.asarray(wv)
+    for n in (1, 7, 384, 1000):
+        a = np.arange(n, dtype=np.int64) * 3 + 1
+        b = rng.random(n).astype(np.float32)
+        torch.manual_seed(5 + n)
+        sa, sb = U.sync_shuffle([torch.from_numpy(a), torch.from_numpy(b)])
+        out[f"ss_in_b_{n}"] = b
+        out[f"ss_a_{n}"], out[f"ss_b_{n}"] = sa.numpy().copy(), sb.numpy().copy()
+        torch.manual_seed(5 + n)
+        sa2, = U.sync_shuffle([torch.from_numpy(a)], min(n, 10))
+        out[f"ss_a10_{n}"] = sa2.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g10_host_streams.npz"), **out)
+    print("G10", len(out), "arrays")
+
+
+def round6(M, U):
+    K5, K8 = (2, 3, 4, 5), (2, 3, 4, 5, 6, 7, 8)
+    g3_big(M, "hg38_table_d64_k5", synth.LAYOUTS["hg38_1mb"], 64, "table", 61, K5, 2304)     # 9 216 rows: ~1 100 half tiles
+    g3_big(M, "hg38_adj_d64_k5", synth.LAYOUTS["hg38_1mb"], 64, "adj", 62, K5, 2304)
+    g3_big(M, "c1_table_d64_k8", synth.LAYOUTS["c1"], 64, "table", 63, K8, 1320)             # 9 240 rows, L = 8
+    g3_big(M, "c1_table_d128_k5", synth.LAYOUTS["c1"], 128, "table", 64, K5, 1024)           # 4 096 rows (enc128)
+    g3_big(M, "c1_adj_d128_k5", synth.LAYOUTS["c1"], 128, "adj", 65, K5, 1024)
+    g3_big(M, "c1_table_d128_k8", synth.LAYOUTS["c1"], 128, "table", 66, K8, 600)            # 4 200 rows, L = 8
+    g3_big(M, "c1_table_d256_k8", synth.LAYOUTS["c1"], 256, "table", 67, K8, 300)            # 2 100 rows, L = 8 (configs[4]'s shape)
+    g3_big(M, "c1_table_d64_k8_small", synth.LAYOUTS["c1"], 64, "table", 68, K8, 16)         # 112 rows: the small-batch kernels at ML = 8
+    g10_host_streams(M, U)
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
     if "--round4" in sys.argv:       # only the fixtures round 4 added (the others are unchanged)
         round4(M)
+        return
+    if "--round6" in sys.argv:       # only the fixtures round 6 added
+        round6(M, U)
         return
     g1_g5(M)
     g2_eval(M, "tiny_adj", synth.LAYOUTS["tiny"], 16, "adj", 21)
@@ -672,6 +765,7 @@ def main():
     g8_positives(M, U)
     g9_process(M, U)
     round4(M)
+    round6(M, U)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,30 @@ def gold(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
 
+# Round 6 fixtures g3big_* (tests/golden/make_golden.py::g3_big): name -> (layout, embed_dim, front end, weight seed).  One dropout-free
+# training step of the REAL reference on batches large enough for the kernels the library picks at bench sizes.
+G3BIG = {
+    "hg38_table_d64_k5": ("hg38_1mb", 64, "table", 61), "hg38_adj_d64_k5": ("hg38_1mb", 64, "adj", 62),
+    "c1_table_d64_k8": ("c1", 64, "table", 63), "c1_table_d128_k5": ("c1", 128, "table", 64), "c1_adj_d128_k5": ("c1", 128, "adj", 65),
+    "c1_table_d128_k8": ("c1", 128, "table", 66), "c1_table_d256_k8": ("c1", 256, "table", 67), "c1_table_d64_k8_small": ("c1", 64, "table", 68),
+}
+
+
+def g3big_batch(g):
+    """(x int64 [B, L], y, w float32 [B, 1]) of a g3big fixture (node ids are stored in a narrow integer type)."""
+    return torch.from_numpy(g["x0"].astype(np.int64)), torch.from_numpy(g["y0"]), torch.from_numpy(g["w0"])
+
+
+def g3big_grad_ref(g, name):
+    """(stride, reference gradient) of one tensor: stored in full (stride 1) or every stride-th element of the flattened tensor."""
+    if ("grad0/" + name) in g.files:
+        return 1, g["grad0/" + name].reshape(-1)
+    for key in g.files:
+        if key.startswith("grad0s") and key.split("/", 1)[1] == name:
+            return int(key.split("/", 1)[0][len("grad0s"):]), g[key]
+    raise KeyError(name)
+
+
 def oracle_state(num, d, mode, seed, requires_grad=False):
     """(P, fe, sd_numpy): the same deterministic weights/features make_golden.py loaded into the reference."""
     attr = O.attribute_table(num)

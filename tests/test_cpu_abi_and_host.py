@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libmatcha_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding missing for {name}"
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.matcha_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.matcha_abi_version() == _lib.ABI_VERSION == 7
     assert lib.matcha_device_count() >= 0
 
 
@@ -156,6 +156,43 @@ def test_data_generator_contract():
         lut = {tuple(r.tolist()): i for i, r in enumerate(edges)}
         for row, wi in zip(e, ww):
             assert lut[tuple(row[row != 0].tolist())] == int(wi)
+
+
+def test_g10_data_generator_and_sync_shuffle_bit_exact_vs_reference():
+    """Round 6 fixture g10 (make_golden.py::g10_host_streams): the reference's DataGenerator.__init__ / next_iter (Modules.py:620-681)
+    under np.random.seed and sync_shuffle (utils.py:142-149) under torch.manual_seed, uniform-k inputs -- integer work, so the host
+    mirror must return the SAME rows in the SAME order, bit for bit (the duplication rule, the permutation calls and their order,
+    the wrap-around with its reshuffle)."""
+    import Modules as M
+    from matcha_amd import utils as U
+    g = gold_g10()
+    rng = np.random.default_rng(1010)
+    for k, m in ((2, 700), (3, 1300)):
+        edges = synth.make_edges(rng, 300, k, m)
+        weight = rng.uniform(0.1, 3.0, size=m).astype(np.float32)
+        assert np.array_equal(edges, g[f"edges_k{k}"]) and np.array_equal(weight, g[f"weight_k{k}"])   # (the generator's inputs)
+        for bs, nb in ((96, 10), (250, 3), (96, 2)):
+            np.random.seed(77 + k)
+            dg = M.DataGenerator(edges.copy(), weight.copy(), bs, nb, min_size=k, max_size=k, flag=(bs == 250))
+            tag = f"k{k}_b{bs}_n{nb}"
+            assert len(dg.edges[k]) == int(g[f"dg_len_{tag}"])
+            for it in range(5):
+                e, w = dg.next_iter()
+                assert np.array_equal(e, g[f"dg_e_{tag}_{it}"]), (tag, it)
+                assert np.array_equal(w, g[f"dg_w_{tag}_{it}"]), (tag, it)
+    for n in (1, 7, 384, 1000):
+        a = np.arange(n, dtype=np.int64) * 3 + 1
+        b = g[f"ss_in_b_{n}"]
+        torch.manual_seed(5 + n)
+        sa, sb = U.sync_shuffle([torch.from_numpy(a), torch.from_numpy(b)])
+        assert np.array_equal(sa.numpy(), g[f"ss_a_{n}"]) and np.array_equal(sb.numpy(), g[f"ss_b_{n}"])
+        torch.manual_seed(5 + n)
+        sa10, = U.sync_shuffle([torch.from_numpy(a)], min(n, 10))
+        assert np.array_equal(sa10.numpy(), g[f"ss_a10_{n}"])
+
+
+def gold_g10():
+    return np.load(os.path.join(ROOT, "tests", "golden", "g10_host_streams.npz"), allow_pickle=False)
 
 
 def test_rng_spec_is_stable():

@@ -363,3 +363,10 @@ def test_bench_multi_rank_path_two_ranks_on_one_gpu(tmp_path):
     assert abs(rec["value"] - 16384 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-3 * rec["value"]
     assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None          # rank 0 at N = 1 only
     assert rec["roofline"] is not None and 0.0 < rec["last_bce"] < 5.0
+    # the line diagnoses a multi-rank run by itself (the first real 8-GPU run must not need a second one to be understood): every rank
+    # reports the process group it saw, the device it ran on and its per-collective time
+    coll = rec["config"]["collectives"]
+    assert coll["world_size_seen_by_rank"] == [2, 2] and coll["device_by_rank"] == [0, 0] and coll["backend"] == "gloo"
+    per_call = coll["collective_us_per_call_by_rank"]
+    assert per_call and all(len(v) == 2 and all(t > 0.0 for t in v) for v in per_call.values()), per_call
+    assert rec["config"]["collective_payload_bytes_per_step"] and all(b > 0 for b in rec["config"]["collective_payload_bytes_per_step"].values())

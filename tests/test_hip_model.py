@@ -12,7 +12,7 @@ import torch
 from matcha_amd import synth, _lib
 from oracle import hypersagnn as O
 from oracle import rng as R
-from tests.helpers import GOLD, gold, oracle_state, logit_err, rel_err, front_end
+from tests.helpers import GOLD, gold, oracle_state, logit_err, rel_err, front_end, G3BIG, g3big_batch, g3big_grad_ref
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4     # north_star: <= 1e-4 rel fp32
@@ -334,6 +334,35 @@ def test_backward_matches_oracle_other_dims(d, layout):
         assert np.abs(p.grad.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
 
 
+@pytest.mark.parametrize("B,ks", [(1, [5]), (2, [5]), (3, [5]), (1, [8]), (4, [2]), (7, [2])])
+def test_tiny_batches_at_embed_dim_128_run_and_match_oracle(B, ks):
+    """a differentiated forward on one to three rows at embed_dim 128 failed with MATCHA_ENOMEM (the fused attention
+    block's records are sized per half tile and did not fit where the layer-wise path keeps Q / K / V / P / O); such batches now run on
+    the layer-by-layer kernels.  model(x) in train mode + backward against the oracle; the launch log says which path ran."""
+    num = synth.LAYOUTS["c1"]
+    clf, _ = hip_model(num, 128, "table", 78)
+    P, fe, _ = oracle_state(num, 128, "table", 78, requires_grad=True)
+    for m in clf.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    clf.train()
+    x, y, w = synth.make_batch(np.random.default_rng(9), int(np.sum(num)), ks, B)
+    xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
+    loss, bce, recon, logits, grads = O.loss_and_grads(P, fe, xt, yt, wt, 1.0, 0.0)
+    with _lib.launch_log() as log:
+        lg = clf(xt)
+        torch.nn.functional.binary_cross_entropy_with_logits(lg, yt.cuda(), weight=wt.cuda()).backward()
+        torch.cuda.synchronize()
+    ran = {k for k, n in log.counts.items() if n > 0}
+    assert ("enc128_fwd_kernel" in ran) == ("enc128_bwd_kernel" in ran), sorted(ran)        # forward and backward agree on the path
+    assert logit_err(lg.detach().cpu().numpy(), logits.numpy()) < TOL
+    for n, p in clf.named_parameters():
+        if grads.get(n) is None or n == GAUGE:
+            continue
+        ref = grads[n].numpy()
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
+
+
 def test_training_dropout_masks_match_oracle_rng():
     """Train-mode forward: the kernels' dropout masks are the counter-RNG of oracle/rng.py, bit for bit, so the
     oracle with the same (injected) masks reproduces the logits."""
@@ -449,6 +478,73 @@ def test_g3g_elementwise_gradients_at_the_hg38_layout(name, mode, seed):
         assert np.abs(got - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3), n
         checked += 1
     assert checked >= 25
+
+
+# kernels a g3big case MUST run / must NOT run (matcha_launch_log): the library picks kernels by batch size and embed_dim, and these
+# tests are about the ones it picks at bench sizes -- if a size rule moves a case onto another kernel, the case fails instead of
+# silently testing something else (round-5 review: the "bench configuration" test had moved onto the small-batch forward).
+_BIG64 = ({"fused_fwd32_kernel", "tail_bwd64_kernel", "fused_bwdh_kernel", "fbm_reduce_kernel", "fbm_chain_kernel"}, {"fused_fwd32h_kernel", "plan_small_kernel"})
+G3BIG_KERNELS = {
+    "hg38_table_d64_k5": (_BIG64[0] | {"front_fwd_kernel", "front_bwd_kernel"}, _BIG64[1] | {"embed_fwd_kernel"}),
+    "hg38_adj_d64_k5": (_BIG64[0] | {"adj_fused_fwd_kernel", "adj_recon_kernel", "adj_fused_bwd_kernel"}, _BIG64[1] | {"adj_encode_fwd_kernel"}),
+    "c1_table_d64_k8": (_BIG64[0] | {"front_fwd_kernel", "front_bwd_kernel"}, _BIG64[1]),
+    "c1_table_d64_k8_small": ({"fused_fwd32h_kernel", "plan_small_kernel", "fused_bwdh_kernel", "front_fwd_kernel"}, {"fused_fwd32_kernel", "tail_bwd64_kernel"}),
+    "c1_table_d128_k5": ({"enc128_fwd_kernel", "enc128_bwd_kernel", "enc128_unfold_kernel"}, {"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"}),
+    "c1_adj_d128_k5": ({"enc128_fwd_kernel", "enc128_bwd_kernel"}, {"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"}),
+    "c1_table_d128_k8": ({"enc128_fwd_kernel", "enc128_bwd_kernel"}, {"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"}),
+    "c1_table_d256_k8": ({"gemm_wide_kernel", "gemm_tn_wide_kernel", "attn_fwd_wide_kernel", "attn_bwd_wide_kernel"}, {"enc128_fwd_kernel", "fused_fwd32_kernel"}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(G3BIG))
+def test_g3big_bench_sized_step_vs_reference(name):
+    """Round 6 fixtures g3big_*: one dropout-free training step of the REAL reference on 2 100 - 9 240 rows against the Trainer path
+    (the bench's kernels), element by element at the north-star tolerance: logits, losses, which tensors have grad None, every stored
+    gradient element; then eval-mode logits of the first rows through model(x) (the forward-only kernels).  The launch log asserts
+    WHICH kernels ran: embed_dim 64 at > 512 half tiles = fused_fwd32_kernel + tail_bwd64_kernel + fused_bwdh_kernel on a full grid
+    (the headline's kernel set, 31 % + 50 % of the bench step), embed_dim 128 = the fused attention block at thousands of rows,
+    embed_dim 256 / k <= 8 = the wide layer-wise kernels (main.py:164-183, Modules.py:278-318)."""
+    from matcha_amd.engine import Trainer
+    layout, d, mode, seed = G3BIG[name]
+    g = gold(f"g3big_{name}.npz")
+    clf, _ = hip_model(synth.LAYOUTS[layout], d, mode, seed)
+    for m in clf.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    clf.train()
+    tr = Trainer(clf, lr=1e-3)
+    x, y, w = (t.cuda() for t in g3big_batch(g))
+    with _lib.launch_log() as log:
+        logits = tr.forward_backward(x.contiguous(), y.reshape(-1).contiguous(), w.reshape(-1).contiguous(), 1.0, 0.001, int(g["chroms"][0]))
+        torch.cuda.synchronize()
+    must, must_not = G3BIG_KERNELS[name]
+    ran = {k for k, n in log.counts.items() if n > 0}
+    assert must <= ran, (name, sorted(must - ran), sorted(ran))
+    assert not (must_not & ran), (name, sorted(must_not & ran))
+    assert logit_err(logits.cpu().numpy(), g["logits0"]) < TOL
+    assert abs(float(tr.losses[0]) - float(g["bce0"])) < TOL * max(1.0, abs(float(g["bce0"])))
+    assert abs(float(tr.losses[1]) - float(g["recon0"][0])) < TOL * max(1.0, abs(float(g["recon0"][0])))
+    grads = _trainer_grads(tr, clf)
+    assert {n for n, v in grads.items() if v is None} - {"attribute_dict_embedding.weight"} == set(g["grad_none"].tolist()) - {"attribute_dict_embedding.weight"}
+    checked, worst = 0, 0.0
+    for n, v in grads.items():
+        if v is None or n == GAUGE:
+            continue
+        stride, ref = g3big_grad_ref(g, n)
+        got = v.cpu().numpy().reshape(-1)[::stride]
+        e = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-3)
+        worst = max(worst, e)
+        assert e <= TOL, (n, e)
+        checked += 1
+    assert checked >= 25
+    clf.eval()
+    n_eval = len(g["logits_eval"])
+    np.random.seed(7)                      # adj front end: Classifier.forward draws random_chrom like the reference (= chrom_eval)
+    with torch.no_grad():
+        lg = clf(x[:n_eval].contiguous())
+    e_eval = logit_err(lg.cpu().numpy(), g["logits_eval"])
+    assert e_eval < TOL
+    print(f"g3big {name}: logits {logit_err(logits.cpu().numpy(), g['logits0']):.1e}, worst gradient {worst:.1e}, eval logits {e_eval:.1e}; kernels {sorted(ran)}")
 
 
 @pytest.mark.parametrize("name,mode,seed", [("c23_table_d64", "table", 48), ("c23_adj_d64", "adj", 49)])

@@ -491,16 +491,22 @@ def test_forward_only_workspace_is_compact_and_equivalent(mode):
     assert rc_ != 0 and b"workspace" in rt.lib.matcha_last_error()
 
 
-@pytest.mark.parametrize("mode,layout,rows_per_k", [("table", "hg38_1mb", 1024), ("adj", "c23", 1024)])
-def test_trainer_fused_step_vs_oracle_4096_rows_dropout(mode, layout, rows_per_k):
-    """The bench's kernel configuration (Trainer: loss inside the fused forward, saved-Q/K/V fused backward, fused front end)
-    against the oracle ELEMENT BY ELEMENT on 4 096 mixed-k rows with dropout ON: the kernels' masks are the counter RNG of
-    oracle/rng.py, so the oracle with the same injected masks must reproduce logits, loss and every gradient (main.py:164-183)."""
+@pytest.mark.parametrize("mode,layout,d,rows_per_k,expect", [("table", "hg38_1mb", 64, 2304, "large64"), ("adj", "c23", 64, 2304, "large64"),
+                                                           ("table", "hg38_1mb", 64, 1024, "small64"), ("adj", "c23", 64, 1024, "small64"),
+                                                           ("table", "c1", 128, 1024, "enc128"), ("adj", "c23", 128, 1024, "enc128")])
+def test_trainer_fused_step_vs_oracle_bench_kernels_dropout(mode, layout, d, rows_per_k, expect):
+    """The bench's kernel configuration (Trainer: loss inside the fused forward, fused backward, fused front end) against the oracle
+    ELEMENT BY ELEMENT with dropout ON: the kernels' masks are the counter RNG of oracle/rng.py, so the oracle with the same injected
+    masks must reproduce logits, loss and every gradient (main.py:164-183).  Two sizes, and the launch log asserts which forward
+    each one runs: 9 216 mixed-k rows = ~1 100 half tiles > 2 x CUs -> fused_fwd32_kernel (one wavefront per half tile) +
+    tail_bwd64_kernel, the kernels of the 65 536-row bench step; 4 096 rows = 487 half tiles -> the eight-wave fused_fwd32h_kernel
+    with the tail in-kernel (the round-5 review found that the one size tested then had silently moved onto the latter).  embed_dim
+    128: the fused attention block (enc128_fwd / enc128_bwd) at 4 096 rows, both front ends."""
     from matcha_amd.engine import Trainer
     from oracle import rng as R
     from tests.test_hip_model import _trainer_grads
     num = synth.LAYOUTS[layout]
-    N, d = int(np.sum(num)), 64
+    N = int(np.sum(num))
     clf, _ = hip_model(num, d, mode, 17)
     P, fe, _ = oracle_state(num, d, mode, 17, requires_grad=True)
     clf.train()
@@ -513,8 +519,18 @@ def test_trainer_fused_step_vs_oracle_4096_rows_dropout(mode, layout, rows_per_k
     xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
     base_seed, chrom, alpha, beta = 4242, 3, 1.0, 0.05
     tr = Trainer(clf, base_seed=base_seed)
-    logits = tr.forward_backward(xt.cuda(), yt.cuda().reshape(-1), wt.cuda().reshape(-1), alpha, beta, chrom)
-    torch.cuda.synchronize()
+    with _lib.launch_log() as log:
+        logits = tr.forward_backward(xt.cuda(), yt.cuda().reshape(-1), wt.cuda().reshape(-1), alpha, beta, chrom)
+        torch.cuda.synchronize()
+    ran = {k for k, n in log.counts.items() if n > 0}
+    if expect == "large64":
+        assert {"fused_fwd32_kernel", "tail_bwd64_kernel", "fused_bwdh_kernel"} <= ran and "fused_fwd32h_kernel" not in ran, sorted(ran)
+    elif expect == "small64":
+        assert {"fused_fwd32h_kernel", "fused_bwdh_kernel"} <= ran and not ({"fused_fwd32_kernel", "tail_bwd64_kernel"} & ran), sorted(ran)
+    else:
+        assert {"enc128_fwd_kernel", "enc128_bwd_kernel"} <= ran and not ({"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"} & ran), sorted(ran)
+    if d == 64:
+        assert ("front_fwd_kernel" in ran) if mode == "table" else ({"adj_fused_fwd_kernel", "adj_recon_kernel", "adj_fused_bwd_kernel"} <= ran), sorted(ran)
     seed = base_seed + 1                       # Trainer advances the device seed before every step
     T = x.size
     masks = {"fc1": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_FC1, O.P_DROP_FC1, T, d)),
