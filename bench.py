@@ -42,11 +42,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: measured float4 copy (read + write)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA peak (no xf32/TF32 on gfx950)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
-# Round 5: the fused embed_dim-64 kernels and the wide GEMMs of embed_dim >= 128 compute every f32 product as SIX bf16 MFMAs over three bf16
-# planes per operand (v = h + m + l to 2^-27, f32 accumulate: fp32-accurate, DESIGN.md §4.0) -- 6 x 32 cycles on the matrix pipe instead of
-# 8 x 64 on the vector ALUs.  `achieved` / `frac` stay what the contract defines (the reference formulation's ALGORITHMIC f32 flops over the
-# kernel's time, against the f32 MFMA peak the dtype names) and may now exceed 1; `frac_bf16_pipe` is what the silicon's matrix pipe does:
-# executed plane-product flops (6 per executed f32 flop) against the dense bf16 peak.
+# Round 5: the fused embed_dim-64 / 128 kernels and the wide GEMMs of embed_dim >= 128 compute every f32 product as SIX bf16 MFMAs over three bf16
+# planes per operand (v = h + m + l to 2^-27, f32 accumulate: fp32-accurate, DESIGN.md 4.0) -- 6 x 32 cycles on the matrix pipe instead of
+# 8 x 64 on the vector ALUs.  Round 6: a roofline `frac` is EXECUTED work over the peak of the pipe that executes it (mfma_roofline below):
+# plane-product flops (6 per executed f32 flop) against the dense bf16 peak for these classes; the contract's algorithmic figure (the reference
+# formulation's f32 flops / time / the f32 MFMA peak) is reported beside it as frac_reference_f32 and may exceed 1.
 BF16X3_FLOPS_PER_F32_FLOP = 6.0
 # MFMA-bound kernel classes.  The fused kernels count ALGORITHMIC GEMM flops only: fused_fwd 4 projections per
 # head + the two pff GEMMs; fused_bwd 8 GEMMs per head (dO, dWfc1, 3 dW', 3 d x_hat terms) -- the Q/K/V recompute of the
@@ -148,6 +148,35 @@ def bf16x3_class(lib, kernel_class, dim):
     if dim == 128 and kernel_class in ("fused_fwd", "fused_bwd"):
         return lib.matcha_get_option(b"disable_fused") == 0 and lib.matcha_get_option(b"disable_merged") == 0
     return dim >= 128 and kernel_class in ("gemm_nt", "gemm_nn", "gemm_tn") and lib.matcha_get_option(b"disable_wide_gemm") == 0
+
+
+def mfma_roofline(lib, kernel_class, dim, ach_ref_tflops):
+    """The roofline entry of an MFMA-bound kernel class.  `ach_ref_tflops` = the reference formulation's ALGORITHMIC f32 flops (SURVEY.md
+    §8 d4) over the kernel's time.  `frac` is EXECUTED work over the peak of the pipe that executes it (round-5 review: the algorithmic
+    figure over the f32 MFMA peak exceeded 1 once the products had left that pipe, and a fraction above 1 is not a roofline fraction):
+      * bf16x3 classes (the fused embed_dim 64 / 128 kernels, the wide GEMMs): merged heads execute `executed_fraction` of the reference's
+        products, each as SIX bf16 plane products (3 planes per f32 operand, f32 accumulate) -> achieved = plane-product TFLOP/s against the
+        dense bf16 MFMA peak;
+      * f32-MFMA classes: executed f32 TFLOP/s against the f32 MFMA peak.
+    The contract's figure stays beside it as achieved_reference_f32 / frac_reference_f32 (it may exceed 1 for the bf16x3 classes)."""
+    ex = executed_fraction(lib, kernel_class, dim)
+    out = dict(bound="mfma", kernel=kernel_class)
+    if bf16x3_class(lib, kernel_class, dim):
+        a = ach_ref_tflops * ex * BF16X3_FLOPS_PER_F32_FLOP
+        out.update(achieved=round(a, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(a / MFMA_BF16_PEAK_TFLOPS, 4),
+                   peak_is="dense bf16 MFMA (the pipe that executes the products: 3 bf16 planes per f32 operand, 6 plane products per f32 product, "
+                           "f32 accumulate -- fp32-accurate, DESIGN.md 4.0)",
+                   achieved_is="executed bf16 plane-product flops / kernel time")
+    else:
+        a = ach_ref_tflops * ex
+        out.update(achieved=round(a, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(a / MFMA_F32_PEAK_TFLOPS, 4),
+                   peak_is="f32 MFMA", achieved_is="executed f32 flops / kernel time")
+    out.update(executed_fraction=round(ex, 4), achieved_reference_f32=round(ach_ref_tflops, 3), peak_reference_f32=MFMA_F32_PEAK_TFLOPS,
+               frac_reference_f32=round(ach_ref_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+               reference_note="achieved_reference_f32 = the reference formulation's algorithmic f32 flops (SURVEY.md 8 d4) / kernel time -- the contract's "
+                              "`achieved`; over the f32 MFMA peak it can exceed 1 where the products run on the bf16 pipe",
+               pmc=None)
+    return out
 
 
 def csrc_sha16():
@@ -333,29 +362,8 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             per_launch_ms = ms.value / n.value
             if prof_cls in GEMM_CLASSES:
                 ach = wk.value / (ms.value * 1e-3) / 1e12
-                roof = dict(bound="mfma", kernel=prof_cls, achieved=round(ach, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches_per_step=n.value / steps_timed,
-                            avg_launch_ms=round(per_launch_ms, 5), work_per_launch=wk.value / n.value)
-                ex = executed_fraction(lib, prof_cls, dim)
-                # frac = the contract's figure (SURVEY d4's ALGORITHMIC flops of the reference formulation / time / peak);
-                # frac_executed = the flops the kernel really issues / time / peak (merged heads execute half of the reference's
-                # products) -- the number the hardware bounds; mfma_util_pmc = the matrix pipe's busy share from the PMC pass
-                roof["executed_fraction"] = round(ex, 4)
-                roof["executed_tflops"] = round(ach * ex, 3)
-                roof["frac_executed"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
-                roof["mfma_util_pmc"] = None
-                if bf16x3_class(lib, prof_cls, dim):
-                    roof["matrix_pipe"] = "bf16, 3 planes per f32 operand, 6 plane products per f32 product, f32 accumulate (fp32-accurate)"
-                    roof["executed_bf16_tflops"] = round(ach * ex * BF16X3_FLOPS_PER_F32_FLOP, 2)
-                    roof["peak_bf16_dense"] = MFMA_BF16_PEAK_TFLOPS
-                    roof["frac_bf16_pipe"] = round(ach * ex * BF16X3_FLOPS_PER_F32_FLOP / MFMA_BF16_PEAK_TFLOPS, 4)
-                    roof["note"] = ("frac = the reference formulation's algorithmic f32 flops / time / the f32 MFMA peak (the contract's figure; it can exceed 1: "
-                                    "the products no longer run on the f32 pipe); merged heads execute executed_fraction of those products, each as 6 bf16 "
-                                    "MFMAs: frac_bf16_pipe = executed plane-product flops / time / the dense bf16 peak is what the matrix pipe does -- the "
-                                    "kernel is bound by its vector work (attention, operand splits), not by the matrix pipe (DESIGN.md §4.0, §5)")
-                elif ex < 1.0:
-                    roof["note"] = ("frac = the reference formulation's algorithmic flops / time / peak; merged heads execute "
-                                    "executed_fraction of them: frac_executed is what the silicon does (DESIGN.md §4.1)")
+                roof = mfma_roofline(lib, prof_cls, dim, ach)
+                roof.update(traffic=None, launches_per_step=n.value / steps_timed, avg_launch_ms=round(per_launch_ms, 5), work_per_launch=wk.value / n.value)
             else:
                 ach = wk.value / (ms.value * 1e-3) / 1e9
                 roof = dict(bound="hbm", kernel=prof_cls, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -375,12 +383,14 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
                         roof["traffic"] = round(c["hbm_bytes_per_launch"], 1)
                         roof["traffic_source"] = os.path.basename(f)
                     mf = os.path.join(os.path.dirname(f), os.path.basename(f).replace("pmc_traffic", "pmc_mfma"))
-                    if "mfma_util_pmc" in roof and os.path.exists(mf):
+                    if "pmc" in roof and os.path.exists(mf):
+                        # pipe occupancy of the same kernel from the committed counter passes (tools/summarize_profiles.py): matrix pipe, vector
+                        # ALUs, their co-execution, LDS -- what says WHICH resource a kernel below its roof is waiting on
                         with open(mf) as fh2:
                             mm = json.load(fh2)
                         if mm.get("csrc_sha16") == csrc_sha16():
-                            mu = mm.get("kernels", {}).get(prof_cls, {}).get("MfmaUtil_percent")
-                            roof["mfma_util_pmc"] = None if mu is None else round(mu / 100.0, 4)
+                            k_ = mm.get("kernels", {}).get(prof_cls, {})
+                            roof["pmc"] = dict(k_.get("derived", {}), source=os.path.basename(mf)) if k_ else None
                     break
             except (OSError, ValueError, KeyError):
                 pass
@@ -422,15 +432,22 @@ def run_workload(dist, *, layout, dim, ks, rows, front_end, steps, warmup, prof=
             continue
         if name in GEMM_CLASSES:
             ach = work / (ms_step * 1e-3) / 1e12
-            roof_all[name] = dict(bound="mfma", ms_per_step=round(ms_step, 4), achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
-            ex = executed_fraction(lib, name, dim)
-            if bf16x3_class(lib, name, dim):
-                roof_all[name]["frac_bf16_pipe"] = round(ach * ex * BF16X3_FLOPS_PER_F32_FLOP / MFMA_BF16_PEAK_TFLOPS, 4)
-            elif ex < 1.0:
-                roof_all[name]["executed_frac_of_peak"] = round(ach * ex / MFMA_F32_PEAK_TFLOPS, 4)
+            r_ = mfma_roofline(lib, name, dim, ach)
+            roof_all[name] = dict(bound="mfma", ms_per_step=round(ms_step, 4), achieved=r_["achieved"], unit="TFLOP/s", peak=r_["peak"], frac=r_["frac"],
+                                  pipe="bf16 x3 planes" if r_["peak"] == MFMA_BF16_PEAK_TFLOPS else "f32", executed_fraction=r_["executed_fraction"],
+                                  frac_reference_f32=r_["frac_reference_f32"])
         else:
             ach = work / (ms_step * 1e-3) / 1e9
             roof_all[name] = dict(bound="hbm", ms_per_step=round(ms_step, 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+            # SURVEY.md 8 d4 prices the gather at k (4 d + 8) READ bytes per row and the backward scatter at k 4 d bytes added; the fused front-end
+            # kernels also write X (+ the pre-activation rows) / read the d x_hat, dXs, x0 rows, which `frac` counts: both figures, labelled
+            tok = wpl / (B * L + 1.0)
+            if name == "front_fwd" and tok > 0:
+                roof_all[name]["frac_is"] = "bytes read + written per token (ids, table row, attribute row, X [, x0]) / time / 8 TB/s"
+                roof_all[name]["frac_d4_read_bytes"] = round(ach * (4.0 * dim + 8.0) / tok / HBM_PEAK_GBS, 4)
+            if name == "front_bwd" and tok > 0:
+                roof_all[name]["frac_is"] = "bytes read + written per token (d x_hat slabs, dXs, x0, X, ids, attribute row, gradient row) / time / 8 TB/s"
+                roof_all[name]["frac_d4_scatter_bytes"] = round(ach * (4.0 * dim) / tok / HBM_PEAK_GBS, 4)
             if name == "adamw":
                 # SURVEY §8 d4 prices the update at 28 B per element (p, g, m, v read; p, m, v written); the kernel also zeroes g (zero_grad): 32 B moved
                 roof_all[name]["frac_incl_grad_zeroing_32B"] = round(ach * 32.0 / 28.0 / HBM_PEAK_GBS, 4)
@@ -574,6 +591,8 @@ def front_gather_roofline(device):
         rec = dict(table=name, d=d, tokens_per_launch=tokens, resident="hbm", bound="hbm", kernel=cls, avg_launch_ms=round(t * 1e3, 4),
                    achieved=round(read / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(read / t / 1e9 / HBM_PEAK_GBS, 4),
                    read_bytes_per_token=8 + 4 * d + attr_read, written_bytes_per_token=4 * d,
+                   # SURVEY.md 8 d4's own figure: k (4 d + 8) read bytes per row = (4 d + 8) per token -- the node row and its int64 id only
+                   frac_d4_read_bytes=round(tokens * (4.0 * d + 8.0) / t / 1e9 / HBM_PEAK_GBS, 4),
                    read_plus_write_gbs=round((read + written) / t / 1e9, 1),
                    # the kernel moves as many bytes out as in: the measured copy ceiling (6.29 TB/s read + write) is its HBM bound,
                    # i.e. frac <= ~0.39-0.40 whatever the access pattern

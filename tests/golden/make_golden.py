@@ -725,7 +725,7 @@ def round6(M, U):
     K5, K8 = (2, 3, 4, 5), (2, 3, 4, 5, 6, 7, 8)
     g3_big(M, "hg38_table_d64_k5", synth.LAYOUTS["hg38_1mb"], 64, "table", 61, K5, 2304)     # 9 216 rows: ~1 100 half tiles
     g3_big(M, "hg38_adj_d64_k5", synth.LAYOUTS["hg38_1mb"], 64, "adj", 62, K5, 2304)
-    g3_big(M, "c1_table_d64_k8", synth.LAYOUTS["c1"], 64, "table", 63, K8, 1320)             # 9 240 rows, L = 8
+    g3_big(M, "c23_table_d64_k8", synth.LAYOUTS["c23"], 64, "table", 63, K8, 1320)           # 9 240 rows, L = 8 (n_attr = 24: the fused front end)
     g3_big(M, "c1_table_d128_k5", synth.LAYOUTS["c1"], 128, "table", 64, K5, 1024)           # 4 096 rows (enc128)
     g3_big(M, "c1_adj_d128_k5", synth.LAYOUTS["c1"], 128, "adj", 65, K5, 1024)
     g3_big(M, "c1_table_d128_k8", synth.LAYOUTS["c1"], 128, "table", 66, K8, 600)            # 4 200 rows, L = 8

@@ -18,7 +18,7 @@ def gold(name):
 # training step of the REAL reference on batches large enough for the kernels the library picks at bench sizes.
 G3BIG = {
     "hg38_table_d64_k5": ("hg38_1mb", 64, "table", 61), "hg38_adj_d64_k5": ("hg38_1mb", 64, "adj", 62),
-    "c1_table_d64_k8": ("c1", 64, "table", 63), "c1_table_d128_k5": ("c1", 128, "table", 64), "c1_adj_d128_k5": ("c1", 128, "adj", 65),
+    "c23_table_d64_k8": ("c23", 64, "table", 63), "c1_table_d128_k5": ("c1", 128, "table", 64), "c1_adj_d128_k5": ("c1", 128, "adj", 65),
     "c1_table_d128_k8": ("c1", 128, "table", 66), "c1_table_d256_k8": ("c1", 256, "table", 67), "c1_table_d64_k8_small": ("c1", 64, "table", 68),
 }
 

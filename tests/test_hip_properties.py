@@ -492,15 +492,16 @@ def test_forward_only_workspace_is_compact_and_equivalent(mode):
 
 
 @pytest.mark.parametrize("mode,layout,d,rows_per_k,expect", [("table", "hg38_1mb", 64, 2304, "large64"), ("adj", "c23", 64, 2304, "large64"),
-                                                           ("table", "hg38_1mb", 64, 1024, "small64"), ("adj", "c23", 64, 1024, "small64"),
+                                                           ("table", "hg38_1mb", 64, 512, "small64"), ("adj", "c23", 64, 512, "small64"),
                                                            ("table", "c1", 128, 1024, "enc128"), ("adj", "c23", 128, 1024, "enc128")])
 def test_trainer_fused_step_vs_oracle_bench_kernels_dropout(mode, layout, d, rows_per_k, expect):
     """The bench's kernel configuration (Trainer: loss inside the fused forward, fused backward, fused front end) against the oracle
     ELEMENT BY ELEMENT with dropout ON: the kernels' masks are the counter RNG of oracle/rng.py, so the oracle with the same injected
     masks must reproduce logits, loss and every gradient (main.py:164-183).  Two sizes, and the launch log asserts which forward
     each one runs: 9 216 mixed-k rows = ~1 100 half tiles > 2 x CUs -> fused_fwd32_kernel (one wavefront per half tile) +
-    tail_bwd64_kernel, the kernels of the 65 536-row bench step; 4 096 rows = 487 half tiles -> the eight-wave fused_fwd32h_kernel
-    with the tail in-kernel (the round-5 review found that the one size tested then had silently moved onto the latter).  embed_dim
+    tail_bwd64_kernel, the kernels of the 65 536-row bench step; 2 048 rows -> the eight-wave fused_fwd32h_kernel with the tail in-kernel
+    (the library picks by the plan's half-tile CAPACITY, ceil((B L + 1) / (32 - L)) <= 2 x CUs, known on the host -- not by the
+    batch's actual half tiles, which only the device knows).  embed_dim
     128: the fused attention block (enc128_fwd / enc128_bwd) at 4 096 rows, both front ends."""
     from matcha_amd.engine import Trainer
     from oracle import rng as R

@@ -10,6 +10,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -- python $R/bench.py --steps 2 --warmup 1 --prof none --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_mfma1 -- python $R/bench.py --steps 2 --warmup 1 --prof none --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/${TAG}_mfma1.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_mfma2 -- python $R/bench.py --steps 2 --warmup 1 --prof none --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/${TAG}_mfma2.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_mfma3 -- python $R/bench.py --steps 2 --warmup 1 --prof none --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/${TAG}_mfma3.log 2>&1
 echo "collected $TAG"
 # the embedding gather alone (roofline_gather of the bench line): kernel stats + the two HBM-traffic passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_gather_stats -- python $R/tools/gather_bench.py > $R/gpurun_out/${TAG}_gather.log 2>&1

@@ -110,8 +110,33 @@ if glob.glob(f"gpurun_out/{tag}_mfma1/*/*_counter_collection.csv"):
                 if start <= i < stop and c in ("fused_fwd", "fused_bwd", "front_fwd", "front_bwd"):
                     res.setdefault(c, collections.OrderedDict())
                     res[c][name] = res[c].get(name, 0.0) + vals[i][1]
+    # third pass (round 6): LDS occupancy and bank conflicts
+    if glob.glob(f"gpurun_out/{tag}_mfma3/*/*_counter_collection.csv"):
+        for name in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"):
+            vals = load("mfma3", name)
+            ids = sorted(vals)
+            start = max(i for i in ids if "neg_sample" in vals[i][0])
+            plans = [i for i in ids if i > start and "row_count_kernel" in vals[i][0]]
+            stop = plans[1] if len(plans) > 1 else ids[-1] + 1
+            for i in ids:
+                c = cls(vals[i][0])
+                if start <= i < stop and c in res:
+                    res[c][name] = res[c].get(name, 0.0) + vals[i][1]
     for c, v in res.items():
         v["MfmaUtil_percent"] = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 1)
+        # pipe occupancy as shares of the kernel's SIMD time (cycles = GRBM_GUI_ACTIVE / 8 XCDs; 1024 SIMDs, 256 CUs): a vector instruction
+        # holds its SIMD's issue port for 4 cycles (64 lanes on 16-wide ALUs); co-execution as a share of the matrix pipe's busy time
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        d_ = {"mfma_busy": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), 4)}
+        if "SQ_ACTIVE_INST_VALU" in v:
+            d_["valu_busy"] = round(4.0 * v["SQ_ACTIVE_INST_VALU"] / (cyc * 1024), 4)
+            co = v.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0.0)
+            d_["coexec_of_mfma_busy"] = round(co / max(v["SQ_VALU_MFMA_BUSY_CYCLES"], 1.0), 4)
+            d_["neither_pipe_issuing"] = round(max(0.0, 1.0 - d_["mfma_busy"] - d_["valu_busy"] + co / (cyc * 1024)), 4)
+        if "SQ_LDS_IDX_ACTIVE" in v:
+            d_["lds_busy"] = round(v["SQ_LDS_IDX_ACTIVE"] / (cyc * 256), 4)
+            d_["lds_bank_conflict_share"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v["SQ_LDS_IDX_ACTIVE"], 1.0), 4)
+        v["derived"] = d_
     json.dump({"csrc_sha16": h.hexdigest()[:16],
                "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --prof none "
                           "--no-cpu-baseline  (second pass: --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES); tools/collect_profiles.sh",
