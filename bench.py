@@ -583,9 +583,9 @@ def front_gather_roofline(device):
         torch.cuda.synchronize(device)
         tokens = B * L + 1
         t = ms.value * 1e-3 / max(n.value, 1)
-        # attribute rows: embed_fwd rebuilds them from the node id when the table has get_attributes' structure (attr_mode 1: ONE random
-        # row per token); front_fwd keeps reading them, as rows padded to one 128-byte fetch unit (csrc/attr_src.hpp)
-        attr_read = 0 if (cls == "embed_fwd" and clf._runtime().attr_mode == 1) else 4 * n_attr
+        # attribute rows: both kernels rebuild them from the node id when the table has get_attributes' structure (attr_mode 1: ONE random
+        # row per token; front_fwd2_kernel since round 6); any other table is read as rows padded to one 128-byte fetch unit (csrc/attr_src.hpp)
+        attr_read = 0 if clf._runtime().attr_mode == 1 else 4 * n_attr
         read = tokens * (8.0 + 4.0 * d + attr_read)
         written = tokens * 4.0 * d
         rec = dict(table=name, d=d, tokens_per_launch=tokens, resident="hbm", bound="hbm", kernel=cls, avg_launch_ms=round(t * 1e3, 4),

@@ -721,6 +721,89 @@ def g10_host_streams(M, U):
     print("G10", len(out), "arrays")
 
 
+class _RaggedNp:
+    """numpy for the reference's utils.np2tensor_hyper on mixed-k input (shim 2): np.asarray / np.array of a ragged list
+    falls back to a 1-D object array, which is what numpy < 1.24 returned there."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def _ragged(obj, *a, **kw):
+        try:
+            return np.asarray(obj, *a, **kw)
+        except ValueError:
+            arr = np.empty(len(obj), dtype=object)
+            for i, o in enumerate(obj):
+                arr[i] = o
+            return arr
+
+    asarray = _ragged
+    array = _ragged
+
+
+def sampler_stats_c3(M, U):
+    """Round 6: statistics of the reference's own generate_negative (main.py:361-459) at the layout of BASELINE configs[2] -- hg38 1 Mb (23
+    chromosomes), ONE mixed-k batch with k in {2..5} (ragged rows -> pad_sequence, size_list), min_dis 0 and 2, 2 000 positives per k,
+    neg_num 3: per k the histogram of the number of nodes a negative differs in, the histogram of WHICH position of the positive was
+    replaced, and the invariants of SURVEY.md 8 c3 asserted on the reference's output while the statistics are taken."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    cr = synth.chrom_range(num)
+    n2c = synth.node2chrom(num)
+    from pybloom_live import BloomFilter
+    out = {}
+    for min_dis in (0, 2):
+        rng = np.random.default_rng(30 + min_dis)
+        pos_by_k = {k: synth.make_edges_fast(rng, N, k, 4000) for k in (2, 3, 4, 5)}
+        if min_dis:
+            pos_by_k = {k: v[(np.diff(v, axis=1) > min_dis).all(axis=1)] for k, v in pos_by_k.items()}
+        dicts = [BloomFilter(10) for _ in range(6)]
+        for k, v in pos_by_k.items():
+            for r in v:
+                dicts[k].add(tuple(int(t) for t in r))
+        glb = dict(train_dict=dicts, test_dict=dicts, max_size=5, min_size=2, node2chrom={i: int(n2c[i]) for i in range(1, N + 1)},
+                   chrom_range=cr, min_dis=min_dis, task_mode="class", device=torch.device("cpu"), np=np, torch=torch,
+                   math=math, random=random, np2tensor_hyper=U.np2tensor_hyper, pad_sequence=torch.nn.utils.rnn.pad_sequence)
+        main_functions({"generate_negative", "neighbor_check"}, glb)
+        rows = [r for k in (2, 3, 4, 5) for r in pos_by_k[k][:2000]]
+        order = np.random.default_rng(77).permutation(len(rows))
+        batch = np.empty(len(rows), dtype=object)
+        for i, o in enumerate(order):
+            batch[i] = rows[o]
+        np.random.seed(6 + min_dis)
+        random.seed(6 + min_dis)
+        U.np = _RaggedNp()
+        try:
+            x, y, w, sizes = glb["generate_negative"](batch, "train_dict", np.ones(len(batch), dtype=np.float32), neg_num=3)
+        finally:
+            U.np = np
+        x = x.numpy()
+        P = len(batch)
+        assert x.shape == (4 * P, 5) and sizes.shape[0] == 4 * P
+        assert y[:P].min() == 1 and y[P:].max() == 0 and float(w[P:].min()) == 1.0
+        known = {k: {tuple(r) for r in v.tolist()} for k, v in pos_by_k.items()}
+        diff = {k: np.zeros(k + 1, dtype=np.int64) for k in (2, 3, 4, 5)}
+        posh = {k: np.zeros(k, dtype=np.int64) for k in (2, 3, 4, 5)}
+        for j in range(3 * P):
+            p = batch[j // 3]
+            k = len(p)
+            r = x[P + j]
+            assert (r[k:] == 0).all() and int(sizes[P + j]) == k and int(sizes[j // 3]) == k
+            r = r[:k]
+            assert (np.diff(r) > min_dis).all() and tuple(r.tolist()) not in known[k]
+            assert sorted(n2c[r].tolist()) == sorted(n2c[p].tolist())
+            gone = [i for i in range(k) if p[i] not in r]
+            diff[k][len(gone)] += 1
+            for i in gone:
+                posh[k][i] += 1
+        for k in (2, 3, 4, 5):
+            out[f"c3_d{min_dis}_diff_k{k}"] = diff[k]
+            out[f"c3_d{min_dis}_pos_k{k}"] = posh[k]
+            print("sampler c3 min_dis", min_dis, "k", k, "diff", diff[k], "positions", posh[k])
+    np.savez_compressed(os.path.join(HERE, "sampler_stats_c3.npz"), **out)
+
+
 def round6(M, U):
     K5, K8 = (2, 3, 4, 5), (2, 3, 4, 5, 6, 7, 8)
     g3_big(M, "hg38_table_d64_k5", synth.LAYOUTS["hg38_1mb"], 64, "table", 61, K5, 2304)     # 9 216 rows: ~1 100 half tiles
@@ -732,6 +815,7 @@ def round6(M, U):
     g3_big(M, "c1_table_d256_k8", synth.LAYOUTS["c1"], 256, "table", 67, K8, 300)            # 2 100 rows, L = 8 (configs[4]'s shape)
     g3_big(M, "c1_table_d64_k8_small", synth.LAYOUTS["c1"], 64, "table", 68, K8, 16)         # 112 rows: the small-batch kernels at ML = 8
     g10_host_streams(M, U)
+    sampler_stats_c3(M, U)
 
 
 def main():

@@ -103,3 +103,53 @@ def oracle_self_noise(name, layout, d, mode, seed, alpha, beta, tag, n_steps, pe
             n = key.split("/", 1)[1]
             pn[n] = float(np.abs(P[n].detach().numpy() - g[key]).max())
     return errs, pn
+
+
+def c3_sampler_case(min_dis):
+    """The positives sampler_stats_c3.npz was taken on (make_golden.py::sampler_stats_c3): hg38 1 Mb, 4 000 distinct hyperedges per k in
+    {2..5} (filtered to adjacent gaps > min_dis), the first 2 000 of each k as ONE shuffled mixed-k batch zero-padded to L = 5.
+    Returns (batch int64 [P, 5], known = {tuple without padding}, all known rows padded [M, 5])."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(30 + min_dis)
+    pos_by_k = {k: synth.make_edges_fast(rng, N, k, 4000) for k in (2, 3, 4, 5)}
+    if min_dis:
+        pos_by_k = {k: v[(np.diff(v, axis=1) > min_dis).all(axis=1)] for k, v in pos_by_k.items()}
+    rows = [np.pad(r, (0, 5 - k)) for k in (2, 3, 4, 5) for r in pos_by_k[k][:2000]]
+    order = np.random.default_rng(77).permutation(len(rows))
+    batch = np.stack([rows[o] for o in order]).astype(np.int64)
+    known_rows = np.concatenate([np.pad(v, ((0, 0), (0, 5 - k))) for k, v in pos_by_k.items()]).astype(np.int64)
+    known = {tuple(int(t) for t in r if t != 0) for r in known_rows}
+    return batch, known, known_rows
+
+
+def c3_sampler_statistics(batch, neg, known, n2c, min_dis):
+    """Per k: (histogram of the number of nodes a negative differs from its positive in, histogram of WHICH position of the positive was
+    replaced), with the invariants of main.py:383-428 asserted on every negative -- the statistics make_golden.py took on the reference."""
+    diff = {k: np.zeros(k + 1, dtype=np.int64) for k in (2, 3, 4, 5)}
+    posh = {k: np.zeros(k, dtype=np.int64) for k in (2, 3, 4, 5)}
+    for j in range(len(neg)):
+        p = batch[j // 3]
+        k = int((p != 0).sum())
+        r = neg[j]
+        assert (r[k:] == 0).all() and (r[:k] != 0).all()
+        p, r = p[:k], r[:k]
+        assert (np.diff(r) > min_dis).all() and tuple(r.tolist()) not in known
+        assert sorted(n2c[r].tolist()) == sorted(n2c[p].tolist())
+        rs = set(r.tolist())
+        gone = [i for i in range(k) if int(p[i]) not in rs]
+        diff[k][len(gone)] += 1
+        for i in gone:
+            posh[k][i] += 1
+    return diff, posh
+
+
+def c3_chi2_against_reference(diff, posh, min_dis):
+    """chi-square distances (per k) between the statistics above and the reference's own, tests/golden/sampler_stats_c3.npz."""
+    g = gold("sampler_stats_c3.npz")
+    out = {}
+    for k in (2, 3, 4, 5):
+        rd, rp = g[f"c3_d{min_dis}_diff_k{k}"].astype(np.float64), g[f"c3_d{min_dis}_pos_k{k}"].astype(np.float64)
+        assert diff[k].sum() == rd.sum()
+        out[k] = (float((((diff[k] - rd) ** 2) / np.maximum(rd + diff[k], 1.0))[1:].sum()), float((((posh[k] - rp) ** 2) / np.maximum(rp + posh[k], 1.0)).sum()))
+    return out

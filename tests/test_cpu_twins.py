@@ -5,7 +5,10 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 import torch
+
+from matcha_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -79,3 +82,26 @@ def test_hashset_twin():
     out = np.zeros(4, np.uint8)
     assert lib.matcha_hashset_contains_cpu(p(edges), C.c_int64(3), C.c_int32(4), p(rows), C.c_int64(4), C.c_int32(3), p(out)) == 0
     assert out.tolist() == [1, 0, 1, 0]                            # a prefix of a wider hyperedge is another hyperedge
+
+
+@pytest.mark.parametrize("min_dis", [0, 2])
+def test_oracle_sampler_distribution_vs_reference_at_the_c3_layout(min_dis):
+    """Round 6 fixture sampler_stats_c3.npz: the reference's own generate_negative (main.py:361-459) on ONE mixed-k batch (k in {2..5},
+    hg38 1 Mb, 23 chromosomes, neg_num 3, min_dis 0 / 2).  The oracle sampler draws from another random stream, so the comparison is
+    distributional: per k, the histogram of how many nodes a negative differs in and of which positions were replaced -- two-sample
+    chi-square, sum (a - b)^2 / (a + b), against 6 000 negatives per k (df <= 4: 30 is far in the tail) -- with every invariant of
+    main.py:383-428 asserted on the way.  """
+    from oracle import sampler as OS
+    from tests.helpers import c3_sampler_case, c3_sampler_statistics, gold
+    num = synth.LAYOUTS["hg38_1mb"]
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    batch, known, _ = c3_sampler_case(min_dis)
+    neg = OS.sample_negatives(batch, known, n2c, cr, 3, min_dis, seed=11)
+    diff, posh = c3_sampler_statistics(batch, neg, known, n2c, min_dis)
+    g = gold("sampler_stats_c3.npz")
+    for k in (2, 3, 4, 5):
+        rd, rp = g[f"c3_d{min_dis}_diff_k{k}"].astype(np.float64), g[f"c3_d{min_dis}_pos_k{k}"].astype(np.float64)
+        assert diff[k].sum() == rd.sum() == 6000 and diff[k][0] == 0
+        c_d = float((((diff[k] - rd) ** 2) / np.maximum(rd + diff[k], 1.0))[1:].sum())
+        c_p = float((((posh[k] - rp) ** 2) / np.maximum(rp + posh[k], 1.0)).sum())
+        assert c_d < 30.0 and c_p < 30.0, (k, diff[k], rd, posh[k], rp)

@@ -8,7 +8,7 @@ import torch
 from matcha_amd import synth
 from matcha_amd.sampler import HyperedgeSet, NegativeSampler
 from oracle import sampler as OS
-from tests.helpers import gold
+from tests.helpers import gold, c3_sampler_case, c3_sampler_statistics, c3_chi2_against_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -88,6 +88,24 @@ def test_sampler_invariants_and_distribution():
         ref = g[f"diff_hist_k{k}"].astype(np.float64)
         chi2 = (((hist - ref) ** 2) / np.maximum(ref, 1.0))[1:].sum()
         assert chi2 < 40.0, (k, hist, ref)
+
+
+@pytest.mark.parametrize("min_dis", [0, 2])
+def test_sampler_at_the_c3_layout_bit_exact_vs_oracle_and_distribution_vs_reference(min_dis):
+    """BASELINE configs[2]'s sampling problem -- hg38 1 Mb, ONE mixed-k batch of 8 000 positives with k in {2..5}, neg_num 3, min_dis 0 / 2 --
+    (a) bit for bit against the oracle sampler under the shared counter RNG (24 000 negatives), (b) distribution against the statistics
+    make_golden.py::sampler_stats_c3 took from the REFERENCE's generate_negative on the same positives (main.py:361-459): per k the number
+    of nodes a negative differs in and which positions were replaced, two-sample chi-square; every invariant of main.py:383-428 asserted."""
+    num = synth.LAYOUTS["hg38_1mb"]
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    batch, known, known_rows = c3_sampler_case(min_dis)
+    hs = HyperedgeSet(torch.from_numpy(known_rows).cuda())
+    smp = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=min_dis, seed=10)
+    neg = smp.sample(torch.from_numpy(batch).cuda()).cpu().numpy()
+    assert np.array_equal(neg, OS.sample_negatives(batch, known, n2c, cr, 3, min_dis, seed=11))
+    diff, posh = c3_sampler_statistics(batch, neg, known, n2c, min_dis)
+    for k, (c_d, c_p) in c3_chi2_against_reference(diff, posh, min_dis).items():
+        assert diff[k][0] == 0 and c_d < 30.0 and c_p < 30.0, (k, c_d, c_p, diff[k], posh[k])
 
 
 def test_sampler_phase1_quirk_empty_set():
