@@ -406,6 +406,16 @@ constexpr int kFwd2LdsFloats = (3 * kFPlane) / 2 + kAttrCols * 64 + 256 + 64;
 #ifndef FF2_ABL
 #define FF2_ABL 0
 #endif
+// the rows this kernel writes (X; x0 in a training forward) are read by another kernel later: -DFF2_NT=1 streams them past L2 (non-temporal),
+// as gather_rows_kernel does -- A/B'd on the 4 GiB table and in the training step
+#ifndef FF2_NT
+#define FF2_NT 0
+#endif
+#if FF2_NT
+#define FF2_STORE4(P, A, B, C, D) __builtin_nontemporal_store((f32x4){(A), (B), (C), (D)}, reinterpret_cast<f32x4*>(P))
+#else
+#define FF2_STORE4(P, A, B, C, D) (*reinterpret_cast<f32x4*>(P) = (f32x4){(A), (B), (C), (D)})
+#endif
 
 __device__ __forceinline__ Frag3 frag_row64(const short* __restrict__ p) {
   Frag3 f;
@@ -494,18 +504,29 @@ __global__ __launch_bounds__(256, 3) void front_fwd2_kernel(FrontFwdArgs g) {
   } while (0)
   int64_t idc;
   {
+    // prologue: the ids of the first three tiles in ONE round trip, the rows of the first two in the next (the loop's steady state has the
+    // rows of two tiles and the ids of a third in flight; issuing ids -> rows -> ids -> rows here was five dependent HBM round trips,
+    // a fifth of the kernel at 65 536 rows)
+    int64_t ia[4], ib[4];
     FF2_IDS_GLOAD(FF_TILE(0));
-    FF2_ROWS_GLOAD(FF_TILE(0));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qe[i] = pe[i];
+    for (int i = 0; i < 4; ++i) ia[i] = id_e[i];
     FF2_IDS_GLOAD(FF_TILE(1));
-    FF2_ROWS_GLOAD(FF_TILE(1));
-    FF2_IDS_GLOAD(FF_TILE(2));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const float4 t = pe[i]; pe[i] = qe[i]; qe[i] = t; }     // (pe, qe) = rows of the first and the second tile
-    __syncthreads();                                   // bnd is staged
-    if (wave == 0) { const int64_t id0 = FF2_ID_OF(FF_TILE(0)); FF2_DECODE(id0, 0); }
+    for (int i = 0; i < 4; ++i) ib[i] = id_e[i];
+    FF2_IDS_GLOAD(FF_TILE(2));
+    const int64_t id0 = FF2_ID_OF(FF_TILE(0));
     idc = FF2_ID_OF(FF_TILE(1));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t t0__ = (int64_t)FF_TILE(0) * 64 + srow + 16 * i, t1__ = (int64_t)FF_TILE(1) * 64 + srow + 16 * i;
+      const float* s0 = g.table ? g.table + ia[i] * 64 : g.dense + (t0__ < t_last ? t0__ : t_last) * 64;
+      const float* s1 = g.table ? g.table + ib[i] * 64 : g.dense + (t1__ < t_last ? t1__ : t_last) * 64;
+      pe[i] = *reinterpret_cast<const float4*>(s0 + sc4);
+      qe[i] = *reinterpret_cast<const float4*>(s1 + sc4);
+    }
+    __syncthreads();                                   // bnd is staged
+    if (wave == 0) FF2_DECODE(id0, 0);
   }
   for (int it = 0;; ++it) {
     const int tile = FF_TILE(it);
@@ -525,7 +546,7 @@ __global__ __launch_bounds__(256, 3) void front_fwd2_kernel(FrontFwdArgs g) {
         float4 v;
         v.x = (__builtin_fmaf(co, wl4.x, wc_.x) + ba4.x) + e.x; v.y = (__builtin_fmaf(co, wl4.y, wc_.y) + ba4.y) + e.y;
         v.z = (__builtin_fmaf(co, wl4.z, wc_.z) + ba4.z) + e.z; v.w = (__builtin_fmaf(co, wl4.w, wc_.w) + ba4.w) + e.w;
-        if (g.x0 && t_base + row < T) *reinterpret_cast<float4*>(g.x0 + (t_base + row) * 64 + sc4) = v;
+        if (g.x0 && t_base + row < T) FF2_STORE4(g.x0 + (t_base + row) * 64 + sc4, v.x, v.y, v.z, v.w);
         P3 p0, p1;
         if (FF2_ABL & 8) { p0 = P3{__float_as_uint(v.x), __float_as_uint(v.y), 0u}; p1 = P3{__float_as_uint(v.z), __float_as_uint(v.w), 0u}; }
         else { p0 = split2(v.x, v.y); p1 = split2(v.z, v.w); }
@@ -568,7 +589,7 @@ __global__ __launch_bounds__(256, 3) void front_fwd2_kernel(FrontFwdArgs g) {
         f32x4 o;
         if (FF2_ABL & 16) { o[0] = acc[tb][0] + bn4.x; o[1] = acc[tb][1] + bn4.y; o[2] = acc[tb][2] + bn4.z; o[3] = acc[tb][3] + bn4.w; }
         else { o[0] = fast_tanh(acc[tb][0] + bn4.x); o[1] = fast_tanh(acc[tb][1] + bn4.y); o[2] = fast_tanh(acc[tb][2] + bn4.z); o[3] = fast_tanh(acc[tb][3] + bn4.w); }
-        if (t < T && (!(FF2_ABL & 2) || o[0] == 12345.f)) *reinterpret_cast<f32x4*>(g.X + t * 64 + 16 * wave + 4 * kq) = o;
+        if (t < T && (!(FF2_ABL & 2) || o[0] == 12345.f)) FF2_STORE4(g.X + t * 64 + 16 * wave + 4 * kq, o[0], o[1], o[2], o[3]);
       }
     }
   }

@@ -105,3 +105,46 @@ def test_oracle_sampler_distribution_vs_reference_at_the_c3_layout(min_dis):
         c_d = float((((diff[k] - rd) ** 2) / np.maximum(rd + diff[k], 1.0))[1:].sum())
         c_p = float((((posh[k] - rp) ** 2) / np.maximum(rp + posh[k], 1.0)).sum())
         assert c_d < 30.0 and c_p < 30.0, (k, diff[k], rd, posh[k], rp)
+
+
+def _neg_sample_cpu(pos, known_rows, n2c, cr, neg_num, min_dis, seed):
+    lib = twins()
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    known_rows = np.ascontiguousarray(known_rows, dtype=np.int64)
+    P, L = pos.shape
+    neg = np.zeros((P * neg_num, L), dtype=np.int64)
+    status = np.zeros(4, dtype=np.int32)
+    n2c32 = np.ascontiguousarray(n2c, dtype=np.int32)
+    cr32 = np.ascontiguousarray(cr, dtype=np.int32)
+    sd = np.array([seed], dtype=np.uint64)
+    lib.matcha_neg_sample_cpu.restype = C.c_int
+    rc = lib.matcha_neg_sample_cpu(None, p(known_rows), C.c_int64(len(known_rows)), C.c_int32(known_rows.shape[1] if len(known_rows) else L), p(pos),
+                                   C.c_int64(P), C.c_int32(L), C.c_int32(neg_num), C.c_int32(min_dis), p(n2c32), C.c_int32(len(n2c32) - 1), p(cr32),
+                                   C.c_int32(len(cr32)), p(sd), p(neg), p(status))
+    assert rc == 0
+    return neg, status
+
+
+@pytest.mark.parametrize("layout,ks,min_dis", [("tiny", [2, 3], 0), ("c1", [2, 3, 4, 5], 0), ("c1", [3], 2), ("c1", [2, 5, 8], 1)])
+def test_neg_sample_cpu_twin_equals_the_python_restatement(layout, ks, min_dis):
+    """oracle/c/sampler_cpu.c (the C twin of matcha_neg_sample) against oracle/sampler.py, bit for bit: two independent
+    statements of main.py:361-459 on the shared counter RNG; plus the phase-1 quirk (empty set: negatives == positives, main.py:589)."""
+    from oracle import sampler as OS
+    num = synth.LAYOUTS[layout]
+    N = int(np.sum(num))
+    rng = np.random.default_rng(3)
+    L = max(ks)
+    pool = np.concatenate([np.pad(synth.make_edges_fast(rng, N, k, 150 if layout == "tiny" else 400), ((0, 0), (0, L - k))) for k in ks])
+    known = {tuple(int(v) for v in r if v) for r in pool}
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    pos = pool[np.random.default_rng(2).permutation(len(pool))[:200]]
+    fresh = np.pad(synth.make_edges_fast(np.random.default_rng(9), N, ks[0], 20), ((0, 0), (0, L - ks[0])))      # mostly non-members: returned unchanged
+    pos = np.concatenate([pos, fresh])
+    neg, status = _neg_sample_cpu(pos, pool, n2c, cr, 3, min_dis, 42)
+    assert np.array_equal(neg, OS.sample_negatives(pos, known, n2c, cr, 3, min_dis, seed=42))
+    # rows whose 65 536 trials were exhausted (two unchanged nodes of the positive closer than min_dis: every candidate is rejected) come back
+    # equal to their positive and are counted; the reference would loop forever there (main.py:392)
+    exhausted = sum(1 for n in range(len(neg)) if np.array_equal(neg[n], pos[n // 3]) and tuple(int(v) for v in pos[n // 3] if v) in known)
+    assert status[0] == 0 and status[1] == exhausted and (min_dis > 0 or exhausted == 0)
+    neg0, _ = _neg_sample_cpu(pos, pool[:0], n2c, cr, 3, min_dis, 42)
+    assert np.array_equal(neg0, np.repeat(pos, 3, axis=0))

@@ -108,6 +108,27 @@ def test_sampler_at_the_c3_layout_bit_exact_vs_oracle_and_distribution_vs_refere
         assert diff[k][0] == 0 and c_d < 30.0 and c_p < 30.0, (k, c_d, c_p, diff[k], posh[k])
 
 
+def test_sampler_bit_exact_vs_c_twin_at_the_bench_batch():
+    """The bench's sampling problem at full size -- hg38 1 Mb, 400 000 known hyperedges (100 000 per k in {2..5}), 16 384 mixed-k positives per
+    step, neg_num 3, min_dis 0 -- against oracle/c/sampler_cpu.c (the plain-C twin of matcha_neg_sample, pinned to oracle/sampler.py by
+    tests/test_cpu_twins.py): all 49 152 negatives bit for bit, for two consecutive seeds."""
+    from tests.test_cpu_twins import _neg_sample_cpu
+    num = synth.LAYOUTS["hg38_1mb"]
+    N = int(np.sum(num))
+    n2c, cr = synth.node2chrom(num), synth.chrom_range(num)
+    rng = np.random.default_rng(21)
+    pool = np.concatenate([np.pad(synth.make_edges_fast(rng, N, k, 100000), ((0, 0), (0, 5 - k))) for k in (2, 3, 4, 5)])
+    pos = pool[rng.permutation(len(pool))[:16384]]
+    hs = HyperedgeSet(torch.from_numpy(pool).cuda())
+    smp = NegativeSampler(hs, n2c, cr, neg_num=3, min_dis=0, seed=100)
+    for step in (1, 2):
+        neg = smp.sample(torch.from_numpy(pos).cuda()).cpu().numpy()
+        ref, status = _neg_sample_cpu(pos, pool, n2c, cr, 3, 0, 100 + step)
+        assert status[0] == 0 and status[1] == 0
+        assert np.array_equal(neg, ref), step
+        assert not np.array_equal(neg, np.repeat(pos, 3, axis=0))
+
+
 def test_sampler_phase1_quirk_empty_set():
     """Empty 'dict' (main.py:589) -> the while loop never runs -> negatives are copies of the positives."""
     num = synth.LAYOUTS["c1"]
