@@ -390,213 +390,138 @@ __global__ __launch_bounds__(256, 3) void front_fwd_kernel(FrontFwdArgs g) {
   }
 }
 
-// ---- round 6: the forward for attribute tables with get_attributes' structure (attr_mode 1; main.py:497-512) -------------------------------
+// ---- round 6: the forward for attribute tables with get_attributes' structure (attr_mode 1; main.py:497-512): front_fwd3_kernel --------------
 // A row of that table is one-hot(chromosome) || coordinate, so attribute_nn(row) = Wa[:, chrom] + coord * Wa[:, C] + ba: TWO fused multiply-adds
 // per output, not a K = 32 product -- and nothing to gather (one random row per token instead of two).  What is left of the
-// kernel's arithmetic, next_w (K = 64), runs on the bf16 matrix pipe as fp32-accurate plane products (bf16x3.hpp): the weights are split once
-// per workgroup into register fragments, the x0 tile is split ONCE by the thread that forms it (in the staging layout: 16 lanes x float4 per
-// row, where x0 = gathered row + the two attribute terms costs 12 vector instructions) and kept in LDS as planes only; x0 leaves for HBM from
-// the staging registers, X from the accumulators (16 bytes per lane: four lanes cover 64 contiguous bytes of a row).  Per 64-token tile: 48
-// bf16 MFMAs of 16 cycles on the matrix pipe instead of 48 f32 MFMAs of 64 cycles on the vector ALUs, two barriers instead of four, 40 KB of
-// LDS.  The in-step gather on a 4 GiB table: 0.22 -> see DESIGN.md 4.5 (the f32 products were 40 % of the kernel's time).
-constexpr int kFPS = 80;                 // bf16 per plane row (40 dwords: the 16-byte row-fragment reads are conflict-free, fused_bwd.hip)
-constexpr int kFPlane = 64 * kFPS;       // bf16 per plane of a 64-token tile
-constexpr int kFwd2LdsFloats = (3 * kFPlane) / 2 + kAttrCols * 64 + 256 + 64;
-// in-situ ablations (development builds, wrong results on purpose): -DFF2_ABL=<bits>  1: no decode, 2: no X stores, 4: no MFMAs, 8: no operand split, 16: no tanh
-#ifndef FF2_ABL
-#define FF2_ABL 0
-#endif
-// the rows this kernel writes (X; x0 in a training forward) are read by another kernel later: -DFF2_NT=1 streams them past L2 (non-temporal),
-// as gather_rows_kernel does -- A/B'd on the 4 GiB table and in the training step
-#ifndef FF2_NT
-#define FF2_NT 0
-#endif
-#if FF2_NT
-#define FF2_STORE4(P, A, B, C, D) __builtin_nontemporal_store((f32x4){(A), (B), (C), (D)}, reinterpret_cast<f32x4*>(P))
-#else
+// kernel's arithmetic, next_w (K = 64), runs on the bf16 matrix pipe as fp32-accurate plane products (bf16x3.hpp).
+// WAVE-INDEPENDENT (no barrier, no staged tile): one wavefront = 16 tokens per trip, its own loop.  Lane (c16, kq) gathers 64 bytes of token
+// c16's row -- features 32 s + 8 kq + {0..7}, s = 0, 1: exactly the eight contraction slots per step that v_mfma_f32_16x16x32_bf16 wants from
+// this lane as the B operand of X^T = Wn x0^T -- adds the two attribute terms from LDS, splits in registers, and multiplies against next_w's
+// planes read from LDS as A fragments (shared by all wavefronts, staged once per workgroup).  Nothing of the batch goes through LDS and
+// nothing synchronises: latency is hidden the way gather_rows_kernel hides it, by sixteen wavefronts per CU each with two trips of rows in
+// flight.  Two workgroup-tiled versions were built and measured first (64-token tiles, x0 planes in LDS, two barriers per tile; in the
+// history at `front_fwd2_kernel`): with two register row buffers 47-50 us on the 4 GiB table, and with a THREE-deep register prefetch no
+// better -- s_waitcnt vmcnt counts in order and hipcc's loop analysis merges the pending-load state at the loop header conservatively, so
+// every trip waited (vmcnt(8)) for the rows issued one trip earlier whatever the source said; a 64-bit id load whose upper half nobody read
+// even drew a vmcnt(0) into the middle of a tile (the allocator reused the dead half).  This version: 46 us there, 34-35 us in the step.
+constexpr int kFPS = 80;                 // bf16 per plane row of next_w (40 dwords: the 16-byte row-fragment reads are conflict-free, fused_bwd.hip)
 #define FF2_STORE4(P, A, B, C, D) (*reinterpret_cast<f32x4*>(P) = (f32x4){(A), (B), (C), (D)})
-#endif
+constexpr int kF3Lds = (3 * 64 * kFPS) / 2 + (kAttrCols + 2) * 64 + 64;      // next_w planes [3][64][kFPS] bf16 | WaT rows (+ Wa[:, C], + ba) | bounds
 
-__device__ __forceinline__ Frag3 frag_row64(const short* __restrict__ p) {
-  Frag3 f;
-  f.h = *reinterpret_cast<const u32x4*>(p); f.m = *reinterpret_cast<const u32x4*>(p + kFPlane); f.l = *reinterpret_cast<const u32x4*>(p + 2 * kFPlane);
-  return f;
-}
-
-__global__ __launch_bounds__(256, 3) void front_fwd2_kernel(FrontFwdArgs g) {
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 4) void front_fwd3_kernel(FrontFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nprep = g.nprep;
-  if ((int)blockIdx.x < nprep) {                        // block roles: the step's weight forms first (see front_fwd_kernel)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bool late = false;
+  if ((int)blockIdx.x < nprep) {
     const int b = blockIdx.x;
     prep_heads_role(g.prep, b % kPrepGridX, (b / kPrepGridX) % kPrepGridY, b / (kPrepGridX * kPrepGridY), lds);
     if (!g.prep_walks) return;
     __syncthreads();
+    late = true;
   }
-  const int nlate = g.prep_walks ? nprep : 0;
-  const int vb = (int)blockIdx.x - (nprep - nlate), Gf = (int)gridDim.x - (nprep - nlate);
-  short* Xp = reinterpret_cast<short*>(lds);                          // x0 as three bf16 planes [3][64][kFPS]
-  float* WaT = lds + (3 * kFPlane) / 2;                               // [n_attr][64]: row a < n_attr - 1 = attribute_nn.weight[:, a]; row n_attr - 1 = zeros
-  int* cinfo = reinterpret_cast<int*>(WaT + kAttrCols * 64);          // [2][64] x (row of WaT, coordinate): double-buffered, decoded one tile ahead
-  int* bnd = cinfo + 256;                                             // [n_attr] chromosome bounds 0, n_0, n_0 + n_1, ..., N
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  short* Wp = reinterpret_cast<short*>(lds);                          // next_w as three bf16 planes, row n = output feature
+  float* WaT = lds + (3 * 64 * kFPS) / 2;                             // row a < na - 1: attribute_nn.weight[:, a]; na - 1: zeros (padding / foreign ids); na: weight[:, C]; na + 1: bias
+  int* bnd = reinterpret_cast<int*>(WaT + (kAttrCols + 2) * 64);
   const int c16 = lane & 15, kq = lane >> 4;
-  const int srow = tid >> 4, sc4 = (tid & 15) * 4;
-  const int T = g.count[0];
-  const int ntiles = (T + 63) / 64;
-  const int q = ntiles / Gf, r_last = ntiles - q * Gf;
-  const int last_slot = vb >= nlate ? vb - nlate : vb - nlate + Gf;
-  const int tile_last = last_slot < r_last ? q * Gf + last_slot : 0x3FFFFFF;
   const int na = g.n_attr;
-  for (int i = tid; i < na * 64; i += 256) {
-    const int a = i >> 6, c = i & 63;
-    WaT[i] = a < na - 1 ? g.Wa[c * na + a] : 0.f;
-  }
-  if (tid < na) bnd[tid] = g.attr.bounds[tid];
-  // next_w as the A operand of X^T = Wn x0^T: wave w owns output features 16 w + {0..15}; lane (c16, kq), step s: Wn[16 w + c16][32 s + 8 kq + {0..7}]
-  Frag3 Wf[2];
   {
-    const float* wp = g.Wn + (16 * wave + c16) * 64 + 8 * kq;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = wp[32 * s2 + j];
-      Wf[s2] = split8(v);
-    }
-  }
-  const float4 bn4 = *reinterpret_cast<const float4*>(g.bn + 16 * wave + 4 * kq);
-  const float4 ba4 = *reinterpret_cast<const float4*>(g.ba + sc4);
-  const float4 wl4 = make_float4(g.Wa[(sc4 + 0) * na + na - 1], g.Wa[(sc4 + 1) * na + na - 1], g.Wa[(sc4 + 2) * na + na - 1], g.Wa[(sc4 + 3) * na + na - 1]);
-  const float scale = g.attr.scale;
-
-  int64_t id_e[4];
-  float4 pe[4], qe[4];
-  const int64_t t_last = (int64_t)T - 1;
-#define FF2_IDS_GLOAD(TILE)                                                                              \
-  do {                                                                                                   \
-    const int64_t tb__ = (int64_t)(TILE) * 64;                                                           \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                \
-      const int64_t t__ = tb__ + srow + 16 * i__;                                                        \
-      id_e[i__] = g.ids[t__ < t_last ? t__ : t_last];                                                    \
-    }                                                                                                    \
-  } while (0)
-#define FF2_ROWS_GLOAD(TILE)                                                                             \
-  do {                                                                                                   \
-    const int64_t tb__ = (int64_t)(TILE) * 64;                                                           \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                \
-      const int64_t t__ = tb__ + srow + 16 * i__;                                                        \
-      const float* src__ = g.table ? g.table + id_e[i__] * 64 : g.dense + (t__ < t_last ? t__ : t_last) * 64; \
-      pe[i__] = *reinterpret_cast<const float4*>(src__ + sc4);                                           \
-    }                                                                                                    \
-  } while (0)
-  // token `lane` of a tile -> (row of WaT, coordinate): a search over the <= 31 bounds in LDS and one correctly rounded division (attr_src.hpp)
-#define FF2_ID_OF(TILE) g.ids[((int64_t)(TILE) * 64 + lane) < t_last ? ((int64_t)(TILE) * 64 + lane) : t_last]
-#define FF2_DECODE(ID, BUF)                                                                              \
-  do {                                                                                                   \
-    const int nb__ = na - 1;                                                                             \
-    const int id__ = (int)(ID);                                                                          \
-    const int top__ = bnd[nb__];                                                                         \
-    const int idc__ = id__ < 1 ? 1 : (id__ > top__ ? top__ : id__);                                      \
-    const int c__ = attr_chrom(bnd, nb__, idc__);                                                        \
-    const bool real__ = id__ >= 1 && id__ <= top__;                                                      \
-    cinfo[(BUF) * 128 + 2 * lane] = real__ ? c__ : nb__;                                                 \
-    cinfo[(BUF) * 128 + 2 * lane + 1] = __float_as_int(real__ ? __fdiv_rn((float)(idc__ - bnd[c__] - 1), scale) : 0.f); \
-  } while (0)
-  int64_t idc;
-  {
-    // prologue: the ids of the first three tiles in ONE round trip, the rows of the first two in the next (the loop's steady state has the
-    // rows of two tiles and the ids of a third in flight; issuing ids -> rows -> ids -> rows here was five dependent HBM round trips,
-    // a fifth of the kernel at 65 536 rows)
-    int64_t ia[4], ib[4];
-    FF2_IDS_GLOAD(FF_TILE(0));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ia[i] = id_e[i];
-    FF2_IDS_GLOAD(FF_TILE(1));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ib[i] = id_e[i];
-    FF2_IDS_GLOAD(FF_TILE(2));
-    const int64_t id0 = FF2_ID_OF(FF_TILE(0));
-    idc = FF2_ID_OF(FF_TILE(1));
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t t0__ = (int64_t)FF_TILE(0) * 64 + srow + 16 * i, t1__ = (int64_t)FF_TILE(1) * 64 + srow + 16 * i;
-      const float* s0 = g.table ? g.table + ia[i] * 64 : g.dense + (t0__ < t_last ? t0__ : t_last) * 64;
-      const float* s1 = g.table ? g.table + ib[i] * 64 : g.dense + (t1__ < t_last ? t1__ : t_last) * 64;
-      pe[i] = *reinterpret_cast<const float4*>(s0 + sc4);
-      qe[i] = *reinterpret_cast<const float4*>(s1 + sc4);
+      const int n = srow + 16 * i;
+      const float4 w = *reinterpret_cast<const float4*>(g.Wn + n * 64 + sc4);
+      const P3 p0 = split2(w.x, w.y), p1 = split2(w.z, w.w);
+      short* d = Wp + n * kFPS + sc4;
+      *reinterpret_cast<u32x2*>(d) = (u32x2){p0.h, p1.h}; *reinterpret_cast<u32x2*>(d + 64 * kFPS) = (u32x2){p0.m, p1.m};
+      *reinterpret_cast<u32x2*>(d + 2 * 64 * kFPS) = (u32x2){p0.l, p1.l};
     }
-    __syncthreads();                                   // bnd is staged
-    if (wave == 0) FF2_DECODE(id0, 0);
+    for (int i = tid; i < (na + 2) * 64; i += 256) {
+      const int a = i >> 6, c = i & 63;
+      WaT[i] = a < na - 1 ? g.Wa[c * na + a] : (a == na - 1 ? 0.f : (a == na ? g.Wa[c * na + na - 1] : g.ba[c]));
+    }
+    if (tid < na) bnd[tid] = g.attr.bounds[tid];
   }
-  for (int it = 0;; ++it) {
-    const int tile = FF_TILE(it);
-    if (tile >= ntiles) break;
-    const int64_t t_base = (int64_t)tile * 64;
-    __syncthreads();                                   // the previous tile's fragment reads are done; this tile's (row, coordinate) pairs are visible
-    // ---- x0 = node row + Wa[:, chrom] + coord Wa[:, C] + ba in the staging layout -> HBM (training) and, split into planes, -> LDS ----
-    {
-      const int* ci = cinfo + (it & 1) * 128;
+  __syncthreads();
+  const int T = g.count[0];
+  const int64_t t_last = (int64_t)T - 1;
+  const int ngroups = (T + 15) / 16;
+  // group list: rounds over the wavefronts that are walking -- the role blocks join from round g.prep_walks - 1 on (they start late by about
+  // what the weight forms take)
+  const int W = (int)gridDim.x * 4, Wn_ = W - nprep * 4;               // all wavefronts / the ones without a role
+  const int r0 = g.prep_walks > 0 ? g.prep_walks - 1 : 0x3FFFFF;       // first round of the role blocks (never, when they do not walk: small batches)
+  const int wv = late ? (int)blockIdx.x * 4 + wave : ((int)blockIdx.x - nprep) * 4 + wave;      // role waves: index among all, others: among the role-free
+  const float scale = g.attr.scale;
+  const int* ids32 = reinterpret_cast<const int*>(g.ids);
+  const float4 bn4 = *reinterpret_cast<const float4*>(g.bn + 4 * kq);          // (+ 16 nb below)
+#define F3_GROUP(R) ((R) < r0 ? (late ? 0x3FFFFFF : (R) * Wn_ + wv) : r0 * Wn_ + ((R) - r0) * W + (late ? wv : nprep * 4 + wv))
+#define F3_LOAD(GRP, ID, E)                                                                              \
+  do {                                                                                                   \
+    const int64_t t__ = (int64_t)(GRP) * 16 + c16;                                                       \
+    const int64_t tc__ = t__ < t_last ? t__ : t_last;                                                    \
+    ID = ids32[2 * tc__];                                                                                \
+    const float* src__ = (g.table ? g.table + (int64_t)ID * 64 : g.dense + tc__ * 64) + 8 * kq;          \
+    E[0] = *reinterpret_cast<const float4*>(src__); E[1] = *reinterpret_cast<const float4*>(src__ + 4);   \
+    E[2] = *reinterpret_cast<const float4*>(src__ + 32); E[3] = *reinterpret_cast<const float4*>(src__ + 36); \
+  } while (0)
+  int idn = 0;
+  float4 en[4];
+  const int r_first = late ? r0 : 0;                   // (a role block's first round)
+  int grp = F3_GROUP(r_first);
+  if (grp < ngroups) F3_LOAD(grp, idn, en);
+  for (int r = r_first; grp < ngroups; ++r) {
+    const int id = idn;
+    float4 e[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = srow + 16 * i;
-        const int wr_ = ci[2 * row];
-        const float co = __int_as_float(ci[2 * row + 1]);
-        const float4 wc_ = *reinterpret_cast<const float4*>(&WaT[wr_ * 64 + sc4]);
-        const float4 e = pe[i];
-        float4 v;
-        v.x = (__builtin_fmaf(co, wl4.x, wc_.x) + ba4.x) + e.x; v.y = (__builtin_fmaf(co, wl4.y, wc_.y) + ba4.y) + e.y;
-        v.z = (__builtin_fmaf(co, wl4.z, wc_.z) + ba4.z) + e.z; v.w = (__builtin_fmaf(co, wl4.w, wc_.w) + ba4.w) + e.w;
-        if (g.x0 && t_base + row < T) FF2_STORE4(g.x0 + (t_base + row) * 64 + sc4, v.x, v.y, v.z, v.w);
-        P3 p0, p1;
-        if (FF2_ABL & 8) { p0 = P3{__float_as_uint(v.x), __float_as_uint(v.y), 0u}; p1 = P3{__float_as_uint(v.z), __float_as_uint(v.w), 0u}; }
-        else { p0 = split2(v.x, v.y); p1 = split2(v.z, v.w); }
-        short* d = Xp + row * kFPS + sc4;
-        *reinterpret_cast<u32x2*>(d) = (u32x2){p0.h, p1.h}; *reinterpret_cast<u32x2*>(d + kFPlane) = (u32x2){p0.m, p1.m};
-        *reinterpret_cast<u32x2*>(d + 2 * kFPlane) = (u32x2){p0.l, p1.l};
+    for (int i = 0; i < 4; ++i) e[i] = en[i];
+    const int gnext = F3_GROUP(r + 1);
+    if (gnext < ngroups) F3_LOAD(gnext, idn, en);        // the next trip's id and row: in flight during this trip
+    const int64_t t = (int64_t)grp * 16 + c16;
+    // (row of WaT, coordinate) of this lane's token: a search over the <= 31 bounds in LDS, one correctly rounded division (attr_src.hpp)
+    const int nb_ = na - 1, top = bnd[nb_];
+    const int idc = id < 1 ? 1 : (id > top ? top : id);
+    const int ch = attr_chrom(bnd, nb_, idc);
+    const bool real = id >= 1 && id <= top;
+    const int wrow = real ? ch : nb_;
+    const float co = real ? __fdiv_rn((float)(idc - bnd[ch] - 1), scale) : 0.f;
+    Frag3 xf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int k0 = 32 * s2 + 8 * kq;
+      float v[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const float4 wc_ = *reinterpret_cast<const float4*>(&WaT[wrow * 64 + k0 + 4 * hf]);
+        const float4 wl_ = *reinterpret_cast<const float4*>(&WaT[na * 64 + k0 + 4 * hf]);
+        const float4 ba_ = *reinterpret_cast<const float4*>(&WaT[(na + 1) * 64 + k0 + 4 * hf]);
+        const float4 ee = e[2 * s2 + hf];
+        v[4 * hf + 0] = (__builtin_fmaf(co, wl_.x, wc_.x) + ba_.x) + ee.x; v[4 * hf + 1] = (__builtin_fmaf(co, wl_.y, wc_.y) + ba_.y) + ee.y;
+        v[4 * hf + 2] = (__builtin_fmaf(co, wl_.z, wc_.z) + ba_.z) + ee.z; v[4 * hf + 3] = (__builtin_fmaf(co, wl_.w, wc_.w) + ba_.w) + ee.w;
+        if (TRAIN && t < T) FF2_STORE4(g.x0 + t * 64 + k0 + 4 * hf, v[4 * hf], v[4 * hf + 1], v[4 * hf + 2], v[4 * hf + 3]);
       }
+      xf[s2] = split8(v);
     }
-    // (pe) <- the tile after this one (in flight since the previous trip); its registers take the loads of the tile two ahead
-    {
-      float4 se[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) se[i] = qe[i];
-      FF2_ROWS_GLOAD(FF_TILE(it + 2));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { qe[i] = pe[i]; pe[i] = se[i]; }
-    }
-    FF2_IDS_GLOAD(FF_TILE(it + 3));
-    __syncthreads();
-    if (wave == 0 && !(FF2_ABL & 1)) FF2_DECODE(idc, (it + 1) & 1);      // the next tile's pairs (its ids arrived during the previous tile)
-    idc = FF2_ID_OF(FF_TILE(it + 2));
-    // ---- X^T = tanh(Wn x0^T + bn): lane (c16, kq) ends with token 16 tb + c16 and features 16 wave + 4 kq + {0..3} ----
-    {
-      const short* bp = Xp + c16 * kFPS + 8 * kq;
-      f32x4 acc[4];
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) acc[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // X^T = tanh(Wn x0^T + bn): lane (c16, kq) ends with token c16 and features 16 nb + 4 kq + {0..3}
+    // (not unrolled: with the four blocks' A fragments -- 96 registers -- hoisted in front of the MFMAs the kernel spilled; one block's 24 at a time)
+#pragma unroll 1
+    for (int nb = 0; nb < 4; ++nb) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const short* ap = Wp + (16 * nb + c16) * kFPS + 8 * kq;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-          const Frag3 b = frag_row64(bp + tb * 16 * kFPS + 32 * s2);
-          if (FF2_ABL & 4) { acc[tb][0] += __uint_as_float(b.h[0] ^ b.m[1] ^ b.l[2]); continue; }
-          acc[tb] = mma6(acc[tb], Wf[s2], b);
-        }
+        Frag3 a;
+        a.h = *reinterpret_cast<const u32x4*>(ap + 32 * s2); a.m = *reinterpret_cast<const u32x4*>(ap + 32 * s2 + 64 * kFPS);
+        a.l = *reinterpret_cast<const u32x4*>(ap + 32 * s2 + 2 * 64 * kFPS);
+        acc = mma6(acc, a, xf[s2]);
       }
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        const int64_t t = t_base + 16 * tb + c16;
-        f32x4 o;
-        if (FF2_ABL & 16) { o[0] = acc[tb][0] + bn4.x; o[1] = acc[tb][1] + bn4.y; o[2] = acc[tb][2] + bn4.z; o[3] = acc[tb][3] + bn4.w; }
-        else { o[0] = fast_tanh(acc[tb][0] + bn4.x); o[1] = fast_tanh(acc[tb][1] + bn4.y); o[2] = fast_tanh(acc[tb][2] + bn4.z); o[3] = fast_tanh(acc[tb][3] + bn4.w); }
-        if (t < T && (!(FF2_ABL & 2) || o[0] == 12345.f)) FF2_STORE4(g.X + t * 64 + 16 * wave + 4 * kq, o[0], o[1], o[2], o[3]);
-      }
+      const float4 bb = *reinterpret_cast<const float4*>(g.bn + 16 * nb + 4 * kq);
+      if (t < T) FF2_STORE4(g.X + t * 64 + 16 * nb + 4 * kq, fast_tanh(acc[0] + bb.x), fast_tanh(acc[1] + bb.y), fast_tanh(acc[2] + bb.z), fast_tanh(acc[3] + bb.w));
     }
+    grp = gnext;
   }
-#undef FF2_IDS_GLOAD
-#undef FF2_ROWS_GLOAD
-#undef FF2_ID_OF
-#undef FF2_DECODE
+#undef F3_GROUP
+#undef F3_LOAD
 }
 
 struct FrontReduceArgs {
@@ -650,15 +575,15 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   // around the loads and cost 20 % of front_bwd_kernel -- embed_fwd_kernel and the fused adj forward, one thread / one lane pair per row, do rebuild
   MATCHA_CHECK_ARG(f.attr_table, "front end: attr_table is required (also under attr_mode 1)");
   FrontFwdArgs g;
-  // attr_mode 1 (the table has get_attributes' structure): front_fwd2_kernel -- no attribute rows gathered, no attribute product; any other
+  // attr_mode 1 (the table has get_attributes' structure): front_fwd3_kernel -- no attribute rows gathered, no attribute product; any other
   // table: front_fwd_kernel gathers its rows (padded to one 128-byte unit when the caller padded them) for the K = 32 product
   const bool computed = f.attr_mode == 1 && f.attr_bounds && n_attr <= kAttrCols;
   g.ids = ids; g.table = table; g.dense = dense; g.attr = computed ? attr_src(f, n_attr) : attr_src_table_first(f, n_attr); g.n_attr = n_attr;
   g.Wa = p.attr_w; g.ba = p.attr_b; g.Wn = p.next_w; g.bn = p.next_b; g.count = rg.count; g.x0 = x0; g.X = X;
-  const int slots = front_grid() / 2 * 3;               // three workgroups per CU (44 / 40 KB of LDS each)
+  const int slots = front_grid() / 2 * 3;               // front_fwd_kernel: three workgroups per CU (44 KB of LDS each)
   const int64_t max_tiles = cdiv(tcap, 64);
-  const size_t lds = computed ? (size_t)kFwd2LdsFloats * sizeof(float) : ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
-  static_assert(((size_t)2 * kTile + 64 * kLdA) >= (size_t)kPrepLdsFloats && kFwd2LdsFloats >= kPrepLdsFloats, "the weight-form role needs its LDS inside the front end's");
+  const size_t lds = ((size_t)2 * kTile + 64 * kLdA) * sizeof(float);
+  static_assert(((size_t)2 * kTile + 64 * kLdA) >= (size_t)kPrepLdsFloats && kF3Lds >= kPrepLdsFloats, "the weight-form role needs its LDS inside the front end's");
   g.nprep = 0;
   if (prep) {
     prep_heads_args(*prep->p, prep->folded, prep->merged, prep->frag, g.prep);
@@ -674,8 +599,18 @@ int launch_front_fwd(const matcha_tensors& p, const int64_t* ids, const float* t
   // written (x0 == null: an inference forward -- nobody reads the pre-activation rows, they are not written)
   ProfScope ps(MATCHA_PROF_FRONT_FWD, (double)tcap * (8.0 + 256.0 + (computed ? 0.0 : 4.0 * n_attr) + (x0 ? 512.0 : 256.0)), st);
   if (computed) {
-    hipLaunchKernelGGL(front_fwd2_kernel, dim3((unsigned)grid), dim3(256), lds, st, g);
-    MATCHA_CHECK_LAUNCH("front_fwd2_kernel");
+    // wave-independent variant: four workgroups per CU, 16-token groups; the role blocks join from round prep_walks - 1 on
+    const int slots4 = front_grid() * 2;
+    const int64_t ngroups = cdiv(tcap, 16);
+    const int64_t rounds = cdiv(ngroups, (int64_t)slots4 * 4);
+    g.prep_walks = (g.nprep > 0 && rounds >= 4) ? 3 : 0;                       // (3: the role blocks skip the first two rounds)
+    int64_t grid3 = g.prep_walks ? slots4 : g.nprep + (cdiv(ngroups, 4) < slots4 ? cdiv(ngroups, 4) : slots4);
+    if (grid3 < g.nprep + 1) grid3 = g.nprep + 1;
+    const size_t lds3 = (size_t)kF3Lds * sizeof(float);
+    static_assert(kF3Lds >= kPrepLdsFloats, "the weight-form role needs its LDS inside the front end's");
+    if (x0) hipLaunchKernelGGL(front_fwd3_kernel<true>, dim3((unsigned)grid3), dim3(256), lds3, st, g);
+    else hipLaunchKernelGGL(front_fwd3_kernel<false>, dim3((unsigned)grid3), dim3(256), lds3, st, g);
+    MATCHA_CHECK_LAUNCH("front_fwd3_kernel");
   } else {
     hipLaunchKernelGGL(front_fwd_kernel, dim3((unsigned)grid), dim3(256), lds, st, g);
     MATCHA_CHECK_LAUNCH("front_fwd_kernel");

@@ -485,9 +485,9 @@ def test_g3g_elementwise_gradients_at_the_hg38_layout(name, mode, seed):
 # silently testing something else (round-5 review: the "bench configuration" test had moved onto the small-batch forward).
 _BIG64 = ({"fused_fwd32_kernel", "tail_bwd64_kernel", "fused_bwdh_kernel", "fbm_reduce_kernel", "fbm_chain_kernel"}, {"fused_fwd32h_kernel", "plan_small_kernel"})
 G3BIG_KERNELS = {
-    "hg38_table_d64_k5": (_BIG64[0] | {"front_fwd2_kernel", "front_bwd_kernel"}, _BIG64[1] | {"embed_fwd_kernel", "front_fwd_kernel"}),
+    "hg38_table_d64_k5": (_BIG64[0] | {"front_fwd3_kernel", "front_bwd_kernel"}, _BIG64[1] | {"embed_fwd_kernel", "front_fwd_kernel"}),
     "hg38_adj_d64_k5": (_BIG64[0] | {"adj_fused_fwd_kernel", "adj_recon_kernel", "adj_fused_bwd_kernel"}, _BIG64[1] | {"adj_encode_fwd_kernel"}),
-    "c23_table_d64_k8": (_BIG64[0] | {"front_fwd2_kernel", "front_bwd_kernel"}, _BIG64[1]),
+    "c23_table_d64_k8": (_BIG64[0] | {"front_fwd3_kernel", "front_bwd_kernel"}, _BIG64[1]),
     "c1_table_d64_k8_small": ({"fused_fwd32h_kernel", "plan_small_kernel", "fused_bwdh_kernel", "embed_fwd_kernel"}, {"fused_fwd32_kernel", "tail_bwd64_kernel"}),    # (n_attr = 5: the front end as separate kernels)
     "c1_table_d128_k5": ({"enc128_fwd_kernel", "enc128_bwd_kernel", "enc128_unfold_kernel"}, {"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"}),
     "c1_adj_d128_k5": ({"enc128_fwd_kernel", "enc128_bwd_kernel"}, {"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"}),

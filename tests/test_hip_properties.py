@@ -531,7 +531,7 @@ def test_trainer_fused_step_vs_oracle_bench_kernels_dropout(mode, layout, d, row
     else:
         assert {"enc128_fwd_kernel", "enc128_bwd_kernel"} <= ran and not ({"attn_fwd_wide_kernel", "attn_bwd_wide_kernel"} & ran), sorted(ran)
     if d == 64:
-        assert ("front_fwd2_kernel" in ran) if mode == "table" else ({"adj_fused_fwd_kernel", "adj_recon_kernel", "adj_fused_bwd_kernel"} <= ran), sorted(ran)
+        assert ("front_fwd3_kernel" in ran) if mode == "table" else ({"adj_fused_fwd_kernel", "adj_recon_kernel", "adj_fused_bwd_kernel"} <= ran), sorted(ran)
     seed = base_seed + 1                       # Trainer advances the device seed before every step
     T = x.size
     masks = {"fc1": torch.from_numpy(R.dropout_mask(seed, R.STREAM_DROP_FC1, O.P_DROP_FC1, T, d)),

@@ -49,7 +49,7 @@ def cls(n):
         return "fused_fwd"
     if "fused_bwd_kernel" in n or "fused_bwd8_kernel" in n or "fused_bwdm_kernel" in n or "fused_bwdh_kernel" in n:
         return "fused_bwd"
-    if "front_fwd_kernel" in n or "front_fwd2_kernel" in n:
+    if "front_fwd_kernel" in n or "front_fwd2_kernel" in n or "front_fwd3_kernel" in n:
         return "front_fwd"
     if "front_bwd_kernel" in n:
         return "front_bwd"
@@ -218,18 +218,19 @@ if grows and glob.glob(f"gpurun_out/{tag}_gather_fetch/*/*_counter_collection.cs
 # ---- the gather the model step executes on HBM-resident tables (tools/front_gather_bench.py = bench.py roofline_gather_in_step) ----
 frows = stats_md("front_stats", f"profiles/{rnd}_gather_in_step_kernel_stats.md", f"rocprofv3 --kernel-trace --stats of the in-step gather on HBM-resident tables ({rnd})",
                  "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/front_gather_bench.py  (front_fwd_kernel: d = 64, 16 M x 64 table, "
-                 "327 681 tokens per launch; embed_fwd_kernel<4>: d = 256, C5 table 1 M x 256, 131 073 tokens per launch)", n=8, must=("front_fwd_kernel", "front_fwd2_kernel", "embed_fwd_kernel"))
+                 "327 681 tokens per launch; embed_fwd_kernel<4>: d = 256, C5 table 1 M x 256, 131 073 tokens per launch)", n=8, must=("front_fwd_kernel", "front_fwd2_kernel", "front_fwd3_kernel", "embed_fwd_kernel"))
 ff = glob.glob(f"gpurun_out/{tag}_front_fetch/*/*_counter_collection.csv")
 if frows and ff:
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(ff[0])):
         if r["Counter_Name"] == "FETCH_SIZE":
-            for key in ("front_fwd2_kernel", "front_fwd_kernel", "embed_fwd_kernel"):
+            for key in ("front_fwd3_kernel", "front_fwd2_kernel", "front_fwd_kernel", "embed_fwd_kernel"):
                 if key in r["Kernel_Name"]:
                     acc[key].append(float(r["Counter_Value"]) * 1024 * 2)
     # round 4: embed_fwd rebuilds the attribute row from the node id (attr_mode 1: nothing read); front_fwd reads it as one 128-byte unit
     # (rows padded to 32 floats), of which 4 * 24 bytes are algorithmic
-    cases = {"front_fwd2_kernel": ("front_fwd2 (d = 64, attribute rows rebuilt from the id) on a 16 M x 64 table (4 GiB)", 327681, 8 + 256),
+    cases = {"front_fwd3_kernel": ("front_fwd3 (d = 64, wave-independent, attribute rows rebuilt from the id) on a 16 M x 64 table (4 GiB)", 327681, 8 + 256),
+             
              "front_fwd_kernel": ("front_fwd (d = 64) on a 16 M x 64 table (4 GiB)", 327681, 8 + 256 + 4 * 24),
              "embed_fwd_kernel": ("embed_fwd (d = 256) on the C5 table 1 M x 256 (1 GiB)", 131073, 8 + 1024)}
     res = []
