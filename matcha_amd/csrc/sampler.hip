@@ -14,8 +14,18 @@
 
 namespace matcha {
 
+// Set layout (round 6): 64 int32 header words (words 0..1 = capacity, a power of two), then `capacity` slots of 8 bytes: {int32 index of the
+// stored hyperedge in the edge list (-1 = empty), uint32 tag = upper 32 bits of the row's hash}.  A probe reads a WINDOW of eight consecutive
+// slots in one round trip (linear probing: the probe chain of a row lies inside its window with probability 1 - load^8) and compares tags;
+// only a tag match costs a second trip (the stored row itself: exactness does not rest on the tag).  Rounds 1-5 kept bare indices and loaded a
+// stored row per occupied slot: slot -> row -> next slot -> row ..., two dependent trips per probe, and the slowest lane of a wavefront paid
+// a chain of ~5 probes -- the negative sampler was a chain of 10+ global round trips (18.8 us for 288 negatives).
 constexpr int kSetHeader = 64;         // int32 words reserved in front of the slots (word 0..1 = capacity)
+constexpr int kSetWindow = 8;          // slots per probe window
 constexpr int kMaxTrials = 1 << 16;
+struct SetSlot { int32_t idx; uint32_t tag; };
+static_assert(sizeof(SetSlot) == 8, "a slot is one 8-byte word (inserted with a 64-bit compare-and-swap)");
+__device__ __forceinline__ uint32_t row_tag(uint64_t h) { return (uint32_t)(h >> 32); }
 
 __device__ __forceinline__ uint64_t row_hash(const int64_t* __restrict__ row, int L) {
   uint64_t h = 0x9E3779B97F4A7C15ull;
@@ -71,13 +81,24 @@ __device__ __forceinline__ bool rows_equal_reg(const int64_t* __restrict__ a, in
 __device__ __forceinline__ bool set_contains_reg(const int32_t* __restrict__ set, const int64_t* __restrict__ edges, int L_set,
                                                  const int64_t (&row)[MATCHA_MAX_L], int L) {
   const int64_t cap = reinterpret_cast<const int64_t*>(set)[0];
-  const int32_t* slots = set + kSetHeader;
-  uint64_t pos = row_hash_reg(row, L) & (uint64_t)(cap - 1);
-  for (int64_t probe = 0; probe < cap; ++probe) {
-    const int32_t idx = slots[pos];
-    if (idx < 0) return false;
-    if (rows_equal_reg(edges + (int64_t)idx * L_set, L_set, row, L)) return true;
-    pos = (pos + 1) & (uint64_t)(cap - 1);
+  const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(set + kSetHeader);
+  const uint64_t h = row_hash_reg(row, L);
+  const uint32_t tag = row_tag(h);
+  uint64_t pos = h & (uint64_t)(cap - 1);
+  for (int64_t probe = 0; probe < cap; probe += kSetWindow) {
+    unsigned long long w[kSetWindow];
+#pragma unroll
+    for (int i = 0; i < kSetWindow; ++i) w[i] = slots[(pos + (uint64_t)i) & (uint64_t)(cap - 1)];      // eight loads in flight: one round trip
+    bool open = true;                                    // no empty slot met yet
+#pragma unroll
+    for (int i = 0; i < kSetWindow; ++i) {
+      const int32_t idx = (int32_t)(uint32_t)(w[i] & 0xFFFFFFFFull);
+      const uint32_t t = (uint32_t)(w[i] >> 32);
+      if (open && idx < 0) open = false;
+      if (open && t == tag && rows_equal_reg(edges + (int64_t)idx * L_set, L_set, row, L)) return true;
+    }
+    if (!open) return false;
+    pos = (pos + kSetWindow) & (uint64_t)(cap - 1);
   }
   return false;
 }
@@ -85,20 +106,23 @@ __device__ __forceinline__ bool set_contains_reg(const int32_t* __restrict__ set
 __global__ void hashset_clear_kernel(int32_t* set, int64_t cap) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { reinterpret_cast<int64_t*>(set)[0] = cap; }
-  if (i < cap) set[kSetHeader + i] = -1;
+  if (i < cap) reinterpret_cast<unsigned long long*>(set + kSetHeader)[i] = ~0ull;        // idx = -1, tag = all ones
 }
 
 __global__ void hashset_insert_kernel(int32_t* set, const int64_t* __restrict__ edges, int64_t n, int L) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t cap = reinterpret_cast<const int64_t*>(set)[0];
-  int32_t* slots = set + kSetHeader;
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(set + kSetHeader);
   const int64_t* row = edges + i * L;
-  uint64_t pos = row_hash(row, L) & (uint64_t)(cap - 1);
+  const uint64_t h = row_hash(row, L);
+  const unsigned long long mine = ((unsigned long long)row_tag(h) << 32) | (unsigned long long)(uint32_t)(int32_t)i;
+  uint64_t pos = h & (uint64_t)(cap - 1);
   for (int64_t probe = 0; probe < cap; ++probe) {
-    const int32_t old = atomicCAS(&slots[pos], -1, (int32_t)i);
-    if (old == -1) return;                                         // inserted
-    if (rows_equal(edges + (int64_t)old * L, L, row, L)) return;   // duplicate row already present
+    const unsigned long long old = atomicCAS(&slots[pos], ~0ull, mine);
+    if (old == ~0ull) return;                                      // inserted
+    const int32_t oidx = (int32_t)(uint32_t)(old & 0xFFFFFFFFull);
+    if ((uint32_t)(old >> 32) == row_tag(h) && rows_equal(edges + (int64_t)oidx * L, L, row, L)) return;   // duplicate row already present
     pos = (pos + 1) & (uint64_t)(cap - 1);
   }
 }
@@ -106,12 +130,15 @@ __global__ void hashset_insert_kernel(int32_t* set, const int64_t* __restrict__ 
 __device__ __forceinline__ bool set_contains(const int32_t* __restrict__ set, const int64_t* __restrict__ edges, int L_set,
                                              const int64_t* row, int L) {
   const int64_t cap = reinterpret_cast<const int64_t*>(set)[0];
-  const int32_t* slots = set + kSetHeader;
-  uint64_t pos = row_hash(row, L) & (uint64_t)(cap - 1);
+  const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(set + kSetHeader);
+  const uint64_t h = row_hash(row, L);
+  const uint32_t tag = row_tag(h);
+  uint64_t pos = h & (uint64_t)(cap - 1);
   for (int64_t probe = 0; probe < cap; ++probe) {
-    const int32_t idx = slots[pos];
+    const unsigned long long w = slots[pos];
+    const int32_t idx = (int32_t)(uint32_t)(w & 0xFFFFFFFFull);
     if (idx < 0) return false;
-    if (rows_equal(edges + (int64_t)idx * L_set, L_set, row, L)) return true;
+    if ((uint32_t)(w >> 32) == tag && rows_equal(edges + (int64_t)idx * L_set, L_set, row, L)) return true;
     pos = (pos + 1) & (uint64_t)(cap - 1);
   }
   return false;
@@ -232,7 +259,7 @@ static int64_t set_capacity(int64_t n_edges) {
 }
 
 extern "C" size_t matcha_hashset_bytes(int64_t n_edges) {
-  return (size_t)(kSetHeader + set_capacity(n_edges < 0 ? 0 : n_edges)) * sizeof(int32_t);
+  return (size_t)kSetHeader * sizeof(int32_t) + (size_t)set_capacity(n_edges < 0 ? 0 : n_edges) * sizeof(SetSlot);
 }
 
 extern "C" int matcha_hashset_build(void* set, size_t set_bytes, const int64_t* edges, int64_t n_edges, int32_t L,
