@@ -212,8 +212,7 @@ struct FusedBwdHArgs {
   float* dxh; int64_t tcap;
   int dx_atomic;                                   // 1: every head adds into ONE [tcap][64] buffer with float atomics (zeroed by the launcher); 0: one slab per head
   float* wslab;                                    // [8][nchunks][kWgSlabM]
-  const float* rimg;                               // [nhalves][8][kImgRecH]: the forward's attention probabilities [32][8] per (half tile, head)
-  const float* mb;                                 // b_h [8][64] (launch_prep_heads): r = B_h x_hat + b_h is recomputed here, not read back
+  const float* rimg;                               // [nhalves][8][kImgRecH]: r rows (register images) + attention probabilities of the forward
 };
 constexpr size_t kBwdLdsBytes = (size_t)2 * kTileH * 4 + (size_t)4 * kPT * 2 + (64 + 256 + 256 + 32) * 4;
 
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int4 mn = tile_lo + 1 < tile_hi ? meta[tile_lo + 1] : mzero;
   float4 xn0, xn1, dn0, dn1;
   int tpn = 0;
-  f32x4 pn = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ri0, ri1, pn = {0.f, 0.f, 0.f, 0.f};
 #define FBH_ROW_GLOAD(I, M)                                                                              \
   do {                                                                                                   \
     const int row__ = srow + 16 * (I);                                                                   \
@@ -320,32 +319,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }                                                                                                    \
     cd0 += (f2){dm__.x, dm__.y}; cd1 += (f2){dm__.z, dm__.w};                                            \
   } while (0)
-  // the forward's record of this (half tile, head): the attention probabilities [32][8]
+  // the forward wavefront's register image: float4 index (wc * 4 + gq) * 64 + 32 h + r holds features 32 wc + 8 gq + 4 h + {0..3} of row r
 #define FBH_RIMG_GLOAD(HALF)                                                                             \
   do {                                                                                                   \
     const f32x4* r__ = reinterpret_cast<const f32x4*>(g.rimg + ((int64_t)(HALF) * MATCHA_N_HEAD + head) * kImgRecH);  \
-    if (tid < 64) pn = __builtin_nontemporal_load(r__ + tid);                                            \
+    if (tid < 64) pn = __builtin_nontemporal_load(r__ + 512 + tid);                                      \
+    ri0 = __builtin_nontemporal_load(r__ + tid); ri1 = __builtin_nontemporal_load(r__ + 256 + tid);      \
   } while (0)
   // B_h and M_h as register fragments for the whole walk: lane (c16, kq), step s holds W[32 s + 8 kq + {0..7}][fb + c16] -- the A operand of
   // dZ^T = M_h^T dDyn^T (rows = features) and the B operand of d x_hat = dR B_h (columns = features); three planes each
-  // ... and B_h once more with the OTHER index as the contraction index: Bt[s] = B_h[fb + c16][32 s + 8 kq + {0..7}], the A operand of
-  // r^T = B_h x_hat^T (round 6: the r rows are recomputed from the staged x_hat planes instead of read back from the forward's record)
-  Frag3 Mf[2], Bf[2], Bt[2];
-  f32x4 bh4;                                         // b_h[fb + 4 kq + {0..3}]: the accumulator rows of this lane
+  Frag3 Mf[2], Bf[2];
   {
     FBH_ROWS_GLOAD(mc);
     if (tile_lo < tile_hi) FBH_RIMG_GLOAD(tile_lo);
     const float* mp = g.mM + (int64_t)head * 4096 + (8 * kq) * 64 + fb + c16;
     const float* bp = g.mB + (int64_t)head * 4096 + (8 * kq) * 64 + fb + c16;
-    const float* tp = g.mB + (int64_t)head * 4096 + (fb + c16) * 64 + 8 * kq;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      float vm[8], vb[8], vt[8];
+      float vm[8], vb[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { vm[j] = mp[(32 * s + j) * 64]; vb[j] = bp[(32 * s + j) * 64]; vt[j] = tp[32 * s + j]; }
-      Mf[s] = split8(vm); Bf[s] = split8(vb); Bt[s] = split8(vt);
+      for (int j = 0; j < 8; ++j) { vm[j] = mp[(32 * s + j) * 64]; vb[j] = bp[(32 * s + j) * 64]; }
+      Mf[s] = split8(vm); Bf[s] = split8(vb);
     }
-    bh4 = *reinterpret_cast<const f32x4*>(g.mb + head * 64 + fb + 4 * kq);
   }
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
@@ -358,6 +353,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       FBH_ROW_STAGE(0); FBH_ROW_STAGE(1);
       if (tid < 32) tinfo[tid] = tid < n_real ? ((tid - (tpn & 255)) | (tpn & ~255)) : 0;
+      f32x4* d__ = reinterpret_cast<f32x4*>(&Rs[(lane & 31) * kLd + 8 * wave + 4 * (lane >> 5)]);
+      d__[0] = ri0; d__[8] = ri1;
       if (tid < 64) reinterpret_cast<f32x4*>(Ps)[tid] = pn;
     }
     __syncthreads();
@@ -381,18 +378,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       *reinterpret_cast<f32x4*>(&Fs[c16 * kLd + fb + 4 * kq]) = acc0;
       *reinterpret_cast<f32x4*>(&Fs[(16 + c16) * kLd + fb + 4 * kq]) = acc1;
-    }
-    // ---- r^T = B_h . x_hat^T + b_h (the attention's queries): the same lane map -- token c16 (+ 16), features fb + 4 kq + {0..3} ----
-    {
-      f32x4 r0 = bh4, r1 = bh4;
-      const short* xp = Xp + c16 * kPS + 8 * kq;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const Frag3 b0 = frag_row(xp + 32 * s), b1 = frag_row(xp + 16 * kPS + 32 * s);
-        r0 = mma6(r0, Bt[s], b0); r1 = mma6(r1, Bt[s], b1);
-      }
-      *reinterpret_cast<f32x4*>(&Rs[c16 * kLd + fb + 4 * kq]) = r0;
-      *reinterpret_cast<f32x4*>(&Rs[(16 + c16) * kLd + fb + 4 * kq]) = r1;
     }
     FB_T(1);
     __syncthreads();
@@ -812,7 +797,7 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
   {
     FusedBwdHArgs g;
     g.X = X; g.dDyn = dDyn; g.count = rg.count; g.half_meta = rg.half_meta; g.tok_pos = rg.tok_pos; g.L = L; g.nhalves = rg.nhalves; g.nchunks = nchunks;
-    g.mB = mv.B; g.mM = mv.M; g.mb = mv.bvec; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
+    g.mB = mv.B; g.mM = mv.M; g.dxh = dxh; g.tcap = tcap; g.dx_atomic = dx_atomic ? 1 : 0; g.wslab = wslab; g.rimg = rimg;
     const size_t lds = kBwdLdsBytes;
     auto launch = [&](auto kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -347,8 +347,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // (wave-uniform base + 32-bit lane offsets; two per-lane pointers held across the head loop were spill candidates)
   float* const img_base = g.qkv ? g.qkv + (int64_t)blockIdx.x * MATCHA_N_HEAD * kImgRecH : nullptr;
   const bool img_on = g.qkv != nullptr && real;
-  // (rounds 3-5 stored the r rows of every head here as well -- F32_IMG_STORE, 8 KB per (half tile, head); the backward recomputes them now)
-#define F32_IMG_STORE(ACC, HD, M) do { } while (0)
+#define F32_IMG_STORE(ACC, HD, M)                                                                        \
+  do {                                                                                                   \
+    if (img_on && !(F32_ABL & 2)) {                                                                      \
+      int l__ = lane;                                                                                    \
+      asm volatile("" : "+v"(l__));                                                                      \
+      f32x4* d__ = reinterpret_cast<f32x4*>(img_base + (HD) * kRec + (M) * 4096 + l__ * 4);             \
+      _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                              \
+        if (F32_ABL & 16) {                                                                              \
+          d__[g__ * 64] = (f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]};   \
+          d__[(4 + g__) * 64] = (f32x4){ACC.hi[4 * g__], ACC.hi[4 * g__ + 1], ACC.hi[4 * g__ + 2], ACC.hi[4 * g__ + 3]}; \
+        } else {                                                                                         \
+        __builtin_nontemporal_store((f32x4){ACC.lo[4 * g__], ACC.lo[4 * g__ + 1], ACC.lo[4 * g__ + 2], ACC.lo[4 * g__ + 3]}, d__ + g__ * 64); \
+        __builtin_nontemporal_store((f32x4){ACC.hi[4 * g__], ACC.hi[4 * g__ + 1], ACC.hi[4 * g__ + 2], ACC.hi[4 * g__ + 3]}, d__ + (4 + g__) * 64); \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
 
   const int n_pad = g.L - k;
   const float padf = (float)n_pad;
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (hpad) wv__[7] = p[ML];                                                                       \
         int l__ = lane;                                                                                  \
         asm volatile("" : "+v"(l__));                                                                    \
-        f32x4* dst__ = reinterpret_cast<f32x4*>(img_base + hd * kRec + (l__ & 31) * 8);          \
+        f32x4* dst__ = reinterpret_cast<f32x4*>(img_base + hd * kRec + 2048 + (l__ & 31) * 8);          \
         __builtin_nontemporal_store((f32x4){wv__[0], wv__[1], wv__[2], wv__[3]}, dst__);                 \
         __builtin_nontemporal_store((f32x4){wv__[4], wv__[5], wv__[6], wv__[7]}, dst__ + 1);             \
       }                                                                                                  \

@@ -172,9 +172,9 @@ int launch_fused_bwd_merged(const matcha_tensors& p, const float* folded, const 
                             bool dx_atomic, bool dx_zeroed = false,    // dx_zeroed: the caller already zeroed dxh[(B L + 1) x 64] on this stream
                             const struct TailReduceArgs* tail = nullptr);   // tail != null: the launch that sums this kernel's slabs also sums the forward's tail slabs (tail_reduce.hpp)
 size_t fused_qkv_floats(int64_t B, int L);         // what the training forward leaves for the fused backward, per (half tile, head):
-constexpr int kImgRecH = 256;                      // the attention probabilities [32][8] of the half tile's rows.  (Rounds 3-5 also kept the 32 r rows,
-                                                   // r = B_h x_hat + b_h, as the forward wavefront's register image: 8 KB more per (half tile, head), 570 MB written
-                                                   // and read back per 65 536-row step; round 6: fused_bwdh_kernel recomputes them -- 24 MFMAs on a pipe that was 24 % busy)
+constexpr int kImgRecH = 2048 + 256;               // 32 r rows (r = B_h x_hat + b_h; register images) + their attention probabilities [32][8].
+                                                   // (Round 6 measured the alternative -- the forward keeps only the probabilities, fused_bwdh_kernel recomputes r from its
+                                                   // staged x_hat planes, 24 more MFMAs per half tile: forward -19 us, backward +52 us on one box, same call: reverted.)
 
 const float* fused_bwd_dxpad(const float* ws);     // d x_hat of the shared padding token inside the fused backward's workspace
 

@@ -25,7 +25,9 @@
 
 namespace matcha {
 
-constexpr int kRowsPerBlock = 1024;
+constexpr int kRpt = 1;                      // rows per thread of the counting / filling passes (round 6: 1 -- four rows per thread left 64 workgroups for the
+                                             // bench's 65 536 rows, a quarter of the CUs, each thread a serial chain of ~56 scattered stores: 12.9 us; now 256 workgroups)
+constexpr int kRowsPerBlock = 256 * kRpt;
 
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds4, int* total) {
   // 256 threads: inclusive scan inside each wave, then the 4 wave totals
@@ -46,9 +48,9 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds4, int* t
 
 __global__ __launch_bounds__(256) void row_count_kernel(const int64_t* __restrict__ x, int64_t B, int L, int32_t* __restrict__ blk_sum) {
   __shared__ int lds4[4];
-  const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * 4;
+  const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * kRpt;
   int cnt = 0;
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kRpt; ++i)
     if (b0 + i < B)
       for (int l = 0; l < L; ++l) cnt += x[(b0 + i) * L + l] != 0 ? 1 : 0;
   int total;
@@ -95,12 +97,12 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
                                                        int32_t* __restrict__ tok_pos, int32_t* __restrict__ sb_first, int super_tok,
                                                        int32_t* __restrict__ tok_key, int64_t n_nodes, int32_t* __restrict__ status) {
   __shared__ int lds4[4];
-  const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * 4;
-  // this thread's four rows (and the row in front of them) in registers: ONE round of loads, all in flight together, on clamped
+  const int64_t b0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * kRpt;
+  // this thread's rows (and the row in front of them) in registers: ONE round of loads, all in flight together, on clamped
   // addresses with the masks applied to the values (the first version read x three times behind dependent waits)
-  int64_t v[4][MATCHA_MAX_L], vp[MATCHA_MAX_L];
+  int64_t v[kRpt][MATCHA_MAX_L], vp[MATCHA_MAX_L];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kRpt; ++i) {
     const int64_t bc = b0 + i < B ? b0 + i : B - 1;
 #pragma unroll
     for (int l = 0; l < MATCHA_MAX_L; ++l) v[i][l] = x[bc * L + (l < L ? l : L - 1)];
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
 #pragma unroll
     for (int l = 0; l < MATCHA_MAX_L; ++l) vp[l] = x[bp * L + (l < L ? l : L - 1)];
   }
-  int kk[4], cnt = 0;
+  int kk[kRpt], cnt = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kRpt; ++i) {
     int k = 0;
 #pragma unroll
     for (int l = 0; l < MATCHA_MAX_L; ++l) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void row_fill_kernel(const int64_t* __restrict
   for (int l = 0; l < MATCHA_MAX_L; ++l) kprev += (b0 > 0 && l < L && vp[l] != 0) ? 1 : 0;
   int pos = blk_base[blockIdx.x] + block_exclusive_scan_256(cnt, lds4, nullptr);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kRpt; ++i) {
     const int64_t b = b0 + i;
     if (b < B) {
       row_off[b] = pos;
