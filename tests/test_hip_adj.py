@@ -167,3 +167,46 @@ def test_recon_row_count_and_explicit_recon_gradient():
         grads.append(tr.gflat.clone())
     assert float(grads[0].abs().max()) > 0
     assert torch.equal(grads[0], grads[1])
+
+
+def test_unfused_adj_rows_through_the_fused_front_end_kernel():
+    """A caller may hand the adj front end feature rows padded to another unit than 64 floats (matcha_frozen.feat_row_pad, include/matcha_hip.h):
+    the fused adj kernels are then not eligible, the per-chromosome encoders run as separate kernels and their output rows enter
+    front_fwd3_kernel through its `dense` source (node row = row t of a [T, 64] buffer instead of table[id]) -- the one path of that kernel the
+    other tests do not reach.  One training step at embed_dim 64 against the oracle, kernel set asserted."""
+    from matcha_amd import _lib
+    from matcha_amd.engine import Trainer
+    from tests.test_hip_model import _trainer_grads
+    old = _lib.FEAT_ROW_PAD
+    _lib.FEAT_ROW_PAD = 128
+    try:
+        num = synth.LAYOUTS["c23"]
+        clf, _ = hip_model(num, 64, "adj", 27)
+        P, fe, _ = oracle_state(num, 64, "adj", 27, requires_grad=True)
+        for m in clf.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        clf.train()
+        x, y, w = synth.make_batch(np.random.default_rng(8), int(np.sum(num)), [2, 3, 4, 5], 300)
+        xt, yt, wt = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(w)
+        tr = Trainer(clf, lr=1e-3)
+        with _lib.launch_log() as log:
+            logits = tr.forward_backward(xt.cuda(), yt.cuda().reshape(-1), wt.cuda().reshape(-1), 1.0, 0.05, 2)
+            torch.cuda.synchronize()
+        ran = {k for k, n in log.counts.items() if n > 0}
+        assert {"front_fwd3_kernel", "adj_encode_fwd_kernel"} <= ran and "adj_fused_fwd_kernel" not in ran, sorted(ran)
+        _, bce, recon, lg_ref, g_ref = O.loss_and_grads(P, fe, xt, yt, wt, 1.0, 0.05, random_chrom=2)
+        assert logit_err(logits.cpu().numpy(), lg_ref.numpy()) < TOL
+        assert abs(float(tr.losses[1]) - float(recon[0])) <= TOL * max(1.0, abs(float(recon[0])))
+        mine = _trainer_grads(tr, clf)
+        checked = 0
+        for n, gref in g_ref.items():
+            if gref is None or n == GAUGE:
+                continue
+            assert mine[n] is not None, n
+            r = gref.numpy()
+            assert np.abs(mine[n].cpu().numpy() - r).max() <= TOL * max(np.abs(r).max(), 1e-3), n
+            checked += 1
+        assert checked >= 30
+    finally:
+        _lib.FEAT_ROW_PAD = old

@@ -97,22 +97,24 @@ def test_full_size_properties_table():
     assert float(g[~seen].abs().max()) == 0.0 and float(g[seen][1:].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
-def test_full_size_train_step_is_reproducible(deterministic):
+@pytest.mark.parametrize("deterministic,rows,runs", [(False, 16384, 4), (True, 16384, 4), (True, 65536, 8)])
+def test_full_size_train_step_is_reproducible(deterministic, rows, runs):
     """Two Trainers from identical weights fed the same batch produce the same loss and the same parameters: with
     Trainer(deterministic=True) EVERYTHING is bitwise equal, the table included (sorted embedding backward, csrc/table_grad.hip;
     per-head d x_hat slabs summed in a fixed order); with the default -- float atomics for the heads' d x_hat sum and for the table
     scatter -- what lies in FRONT of the encoder (table, next_w, attribute_nn) agrees up to the order of those additions and the
-    encoder and classifier parameters are bitwise equal."""
+    encoder and classifier parameters are bitwise equal.  This is also the run-time guard of the SLP-vectoriser finding (timing-dependent
+    dR rows in fused_bwdh_kernel<5> with two workgroups per CU, 15-125 of 512 workgroups per launch when it struck): the third case repeats the
+    bench's own batch -- 65 536 rows, every CU holding two workgroups for the whole launch -- eight times, six steps each."""
     from matcha_amd.engine import Trainer
     num = synth.LAYOUTS["hg38_1mb"]
     N = int(np.sum(num))
     rng = np.random.default_rng(1)
-    x = torch.from_numpy(_big_batch(N, 16384, rng)).cuda()
+    x = torch.from_numpy(_big_batch(N, rows, rng)).cuda()
     y = (torch.rand(len(x), device="cuda") < 0.25).float()
     w = torch.ones(len(x), device="cuda")
     outs = []
-    for _ in range(4):                                   # an intra-kernel race shows up in a fraction of the runs only: take several
+    for _ in range(runs):                                # an intra-kernel race shows up in a fraction of the runs only: take several
         clf, _ = hip_model(num, 64, "table", 3)
         clf.train()
         tr = Trainer(clf, base_seed=5, deterministic=deterministic)
