@@ -1,4 +1,4 @@
-"""The tile assignment of front_fwd_kernel (matcha_amd/csrc/front_fused.hip) restated on the CPU.
+"""The tile assignment of front_fwd_kernel and the group assignment of front_fwd3_kernel (matcha_amd/csrc/front_fused.hip) restated on the CPU.
 
 Round 5 put the blocks that build the encoder's per-step weight forms INSIDE the front end's launch (block roles).  For large
 batches the launch keeps one block per slot of the chip: the first `nprep` blocks build weight forms and then walk tiles like the others
@@ -74,3 +74,69 @@ def test_small_batches_add_the_role_blocks_to_one_block_per_tile():
     grid, walks, per_block = check(768, 72, 30, 23)           # the reference's 384-row step
     assert (grid, walks) == (72 + 30, 0)
     assert set(per_block) == set(range(72, 102)) and sum(per_block.values()) == 23
+
+
+# ---- front_fwd3_kernel (round 6): wave-independent, groups of 16 tokens, rounds over the wavefronts that are walking ----------------------------
+def launch_shape3(slots4, nprep, tcap):
+    """launch_front_fwd, attr_mode 1: (grid, prep_walks) -- prep_walks = 3: the role blocks join the group list from round 2 on."""
+    ngroups = -(-tcap // 16)
+    rounds = -(-ngroups // (slots4 * 4))
+    prep_walks = 3 if (nprep > 0 and rounds >= 4) else 0
+    grid = slots4 if prep_walks else nprep + min(-(-ngroups // 4), slots4)
+    return max(grid, nprep + 1), prep_walks
+
+
+def groups_of_wave(block, wave, grid, nprep, prep_walks, ngroups):
+    """front_fwd3_kernel: the 16-token groups wavefront `wave` of block `block` walks, in order (None: the block only has a role)."""
+    late = block < nprep
+    if late and not prep_walks:
+        return None
+    W, Wn = grid * 4, grid * 4 - nprep * 4
+    r0 = prep_walks - 1 if prep_walks > 0 else 0x3FFFFF
+    wv = block * 4 + wave if late else (block - nprep) * 4 + wave
+
+    def group(r):
+        if r < r0:
+            return BIG if late else r * Wn + wv
+        return r0 * Wn + (r - r0) * W + (wv if late else nprep * 4 + wv)
+
+    out, r = [], (r0 if late else 0)
+    while True:
+        g = group(r)
+        if g >= ngroups:
+            return out
+        out.append(g)
+        r += 1
+
+
+def check3(slots4, nprep, tcap, t_real):
+    grid, walks = launch_shape3(slots4, nprep, tcap)
+    ngroups = -(-t_real // 16)
+    seen, per_wave = [], {}
+    for b in range(grid):
+        for w in range(4):
+            g = groups_of_wave(b, w, grid, nprep, walks, ngroups)
+            if g is not None:
+                seen += g
+                per_wave[(b, w)] = len(g)
+    assert sorted(seen) == list(range(ngroups)), (slots4, nprep, tcap, t_real)
+    return grid, walks, per_wave
+
+
+def test_front_fwd3_every_group_is_walked_exactly_once():
+    for slots4, nprep in itertools.product((16, 1024), (0, 5, 72)):
+        if nprep >= slots4:
+            continue
+        for tcap in (1, 17, 64 * (slots4 - nprep), 64 * slots4 * 3 + 5, 64 * slots4 * 4, 64 * slots4 * 4 + 1, 64 * slots4 * 7 + 33):
+            # the kernel reads the token count from the plan (device memory): anything up to the launch-time bound
+            for t_real in sorted({1, tcap // 3 + 1, max(tcap - 1, 1), tcap}):
+                check3(slots4, nprep, tcap, t_real)
+
+
+def test_front_fwd3_role_blocks_start_two_rounds_late_at_the_bench_batch():
+    # the metric's batch: 65 536 x 5 + 1 token slots -> 20 481 groups bound, ~229 000 real tokens -> 14 313 groups on 1024 x 4 wavefronts
+    grid, walks, per_wave = check3(1024, 72, 65536 * 5 + 1, 229000)
+    assert (grid, walks) == (1024, 3)
+    role = [per_wave[(b, w)] for b in range(72) for w in range(4)]
+    rest = [per_wave[(b, w)] for b in range(72, 1024) for w in range(4)]
+    assert max(role) <= max(rest) - 2 + 1 and min(rest) >= 3 and max(rest) == 4      # (the role blocks' wavefronts skip the first two rounds)
