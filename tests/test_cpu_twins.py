@@ -148,3 +148,73 @@ def test_neg_sample_cpu_twin_equals_the_python_restatement(layout, ks, min_dis):
     assert status[0] == 0 and status[1] == exhausted and (min_dis > 0 or exhausted == 0)
     neg0, _ = _neg_sample_cpu(pos, pool[:0], n2c, cr, 3, min_dis, 42)
     assert np.array_equal(neg0, np.repeat(pos, 3, axis=0))
+
+
+def _forward_cpu(sd, num, d, x):
+    """matcha_forward_cpu (oracle/c/head_cpu.c) on a numpy state_dict of the table front end: the ABI structs of matcha_amd/_lib.py filled
+    with HOST pointers."""
+    from matcha_amd import _lib
+    lib = twins()
+    N = int(np.sum(num))
+    keep = []
+
+    def a(name, squeeze=False):
+        arr = np.ascontiguousarray(np.asarray(sd[name], dtype=np.float32))
+        if squeeze:
+            arr = np.ascontiguousarray(arr.reshape(arr.shape[0], -1))
+        keep.append(arr)
+        return arr.ctypes.data
+
+    t = _lib.Tensors()
+    pre, pp = "encode1.mul_head_attn.", "encode1.pff_n1."
+    for field, name, sq in (("table", "node_embedding.weight", False), ("attr_w", "attribute_nn.weight", False), ("attr_b", "attribute_nn.bias", False),
+                            ("next_w", "next_w.FF_Linear0.weight", False), ("next_b", "next_w.FF_Linear0.bias", False),
+                            ("ln_q_g", pre + "layer_norm1.weight", False), ("ln_q_b", pre + "layer_norm1.bias", False),
+                            ("ln_k_g", pre + "layer_norm2.weight", False), ("ln_k_b", pre + "layer_norm2.bias", False),
+                            ("ln_v_g", pre + "layer_norm3.weight", False), ("ln_v_b", pre + "layer_norm3.bias", False),
+                            ("w_q", pre + "w_qs.weight", False), ("w_k", pre + "w_ks.weight", False), ("w_v", pre + "w_vs.weight", False),
+                            ("fc1_w", pre + "fc1.weight", False), ("fc1_b", pre + "fc1.bias", False),
+                            ("pff0_w", pp + "PWF_Conv0.weight", True), ("pff0_b", pp + "PWF_Conv0.bias", False),
+                            ("pff1_w", pp + "PWF_Conv1.weight", True), ("pff1_b", pp + "PWF_Conv1.bias", False),
+                            ("pff_ln_g", pp + "layer_norm.weight", False), ("pff_ln_b", pp + "layer_norm.bias", False),
+                            ("ln1_g", "layer_norm1.weight", False), ("ln1_b", "layer_norm1.bias", False),
+                            ("ln2_g", "layer_norm2.weight", False), ("ln2_b", "layer_norm2.bias", False),
+                            ("cls_w", "pff_classifier.PWF_Conv0.weight", True), ("cls_b", "pff_classifier.PWF_Conv0.bias", False)):
+        setattr(t, field, a(name, sq))
+    fr = _lib.Frozen()
+    fr.attr_table = a("attribute_dict_embedding.weight")
+    shape = _lib.Shape(d, len(num) + 1, N, len(num), 0, max(num))
+    x = np.ascontiguousarray(x, dtype=np.int64)
+    out = np.zeros(len(x), dtype=np.float32)
+    lib.matcha_forward_cpu.restype = C.c_int
+    rc = lib.matcha_forward_cpu(C.byref(shape), C.byref(t), C.byref(fr), p(x), C.c_int64(len(x)), C.c_int32(x.shape[1]), p(out))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("name,layout,d,seed", [("tiny_table", "tiny", 16, 22), ("hg38_table_d64", "hg38_1mb", 64, 24)])
+def test_forward_cpu_twin_vs_reference_goldens(name, layout, d, seed):
+    """oracle/c/head_cpu.c (the plain-C twin of matcha_forward, table front end, eval mode) against the REAL reference's
+    eval logits (G2): uniform k = 2..5 at L = k and zero-padded to L = 5 (padding slots are attended: the two differ), and a mixed batch."""
+    from oracle import hypersagnn as O
+    from tests.helpers import gold, logit_err
+    g = gold(f"g2_{name}.npz")
+    num = synth.LAYOUTS[layout]
+    sd = synth.make_state_dict(np.random.default_rng(seed), num, d, "table", O.attribute_table(num))
+    for k in (2, 3, 4, 5):
+        xk = g[f"x_k{k}"]
+        assert logit_err(_forward_cpu(sd, num, d, xk), g[f"logits_k{k}"]) < 2e-5, k
+        assert logit_err(_forward_cpu(sd, num, d, np.pad(xk, ((0, 0), (0, 5 - k)))), g[f"logits_k{k}_L5"]) < 2e-5, k
+    assert logit_err(_forward_cpu(sd, num, d, g["x_mixed"]), g["logits_mixed"]) < 2e-5
+
+
+def test_forward_cpu_twin_vs_reference_at_embed_dim_256_and_k8():
+    """... and at configs[4]'s shape (embed_dim 256, k up to 8, L = 8): the eval logits of the g3big fixture."""
+    from oracle import hypersagnn as O
+    from tests.helpers import gold, logit_err, G3BIG
+    layout, d, mode, seed = G3BIG["c1_table_d256_k8"]
+    g = gold("g3big_c1_table_d256_k8.npz")
+    num = synth.LAYOUTS[layout]
+    sd = synth.make_state_dict(np.random.default_rng(seed), num, d, mode, O.attribute_table(num))
+    n = len(g["logits_eval"])
+    assert logit_err(_forward_cpu(sd, num, d, g["x0"][:n].astype(np.int64)), g["logits_eval"]) < 2e-5
