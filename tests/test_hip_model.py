@@ -582,17 +582,21 @@ def test_g3long_fifty_step_trajectory(name, mode, seed):
     assert np.abs(emb - ref).max() <= TOL * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("layout,d,ks,rows", [("hg38_1mb", 64, (2, 3, 4, 5), 1024), ("c1", 128, (2, 3, 4, 5, 6, 7, 8), 150), ("c1", 256, (2, 5, 8), 100)])
+@pytest.mark.parametrize("layout,d,ks,rows", [("hg38_1mb", 64, (2, 3, 4, 5), 1024), ("c1", 128, (2, 3, 4, 5, 6, 7, 8), 150), ("c1", 256, (2, 5, 8), 100),
+                                              # front_fwd3_kernel at the ends of the attribute widths it takes (n_attr = 4 and 32: 3 and 31 chromosomes)
+                                              ([40, 33, 27], 64, (2, 3, 5), 400), ([10] * 16 + [7] * 15, 64, (2, 4, 5), 400)])
 def test_eval_logits_vs_the_plain_c_forward_twin(layout, d, ks, rows):
     """model(x) in eval mode against oracle/c/head_cpu.c (matcha_forward_cpu: the plain-C statement of Classifier.forward for the table front
     end, pinned to the reference's G2 / g3big logits by tests/test_cpu_twins.py) on a few thousand mixed-k rows at embed_dim 64 / 128 / 256."""
     from tests.test_cpu_twins import _forward_cpu
-    num = synth.LAYOUTS[layout]
+    num = synth.LAYOUTS[layout] if isinstance(layout, str) else layout
     N = int(np.sum(num))
     clf, sd = hip_model(num, d, "table", 91)
     clf.eval()
     x, _, _ = synth.make_batch(np.random.default_rng(4), N, list(ks), rows)
-    with torch.no_grad():
+    with _lib.launch_log() as log, torch.no_grad():
         lg = clf(torch.from_numpy(x)).cpu().numpy().reshape(-1)
+    if d == 64 and (len(num) + 1) % 4 == 0:
+        assert log.counts.get("front_fwd3_kernel", 0) == 1, sorted(log.counts)
     ref = _forward_cpu(sd, num, d, x)
     assert logit_err(lg, ref) < TOL
